@@ -1,0 +1,27 @@
+/* ORACLE (test infrastructure only): precision-independent helpers. */
+#include <string.h>
+#include "oracle.h"
+
+int ora_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : 14; }
+int ora_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : 7; }
+
+/* reference defaults: config.cuh:24-61 (per plant), :78-136 (algorithm), plants/cost_arm.cuh:97-103 */
+void ora_default_cfg(ora_cfg *c, int plant) {
+    memset(c, 0, sizeof(*c));
+    c->plant = plant;
+    c->N = plant == 4 ? 64 : 128;
+    c->M = 4;
+    c->A = (plant == 3 || plant == 4) ? 16 : 32;
+    c->integrator = plant == 4 ? 1 : 3;
+    c->wafr_urdf = 0; c->mpc_mode = 0;
+    c->max_iter = 100;
+    c->ignore_max_rho_exit = 1;
+    c->cores = 0; c->spawn_threads = 1;
+    c->total_time = plant == 4 ? 0.5 : 4.0;
+    c->alpha_base = (plant == 3 || plant == 4) ? 0.5 : 0.75;
+    c->rho_init = plant == 4 ? 12.5 : (plant == 3 ? 1.0 : 10.0);
+    c->max_defect = plant == 2 ? 0.75 : 1.0;
+    c->tol_cost = 0.0001;
+    c->exp_red_min = 0.05; c->exp_red_max = 1.25;
+    c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
+}

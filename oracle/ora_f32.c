@@ -1,0 +1,7 @@
+/* ORACLE (test infrastructure only): algType = float instantiation (config.cuh:74). */
+typedef float real;
+#define ORA_SUF f32
+#define RSIN sinf
+#define RCOS cosf
+#define RABS fabsf
+#include "ora_impl.h"

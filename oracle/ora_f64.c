@@ -1,0 +1,7 @@
+/* ORACLE (test infrastructure only): algType = double instantiation (config.cuh:73). */
+typedef double real;
+#define ORA_SUF f64
+#define RSIN sin
+#define RCOS cos
+#define RABS fabs
+#include "ora_impl.h"

@@ -1,0 +1,98 @@
+/* ORACLE -- test infrastructure, NOT product code.
+ *
+ * A plain-C, CPU restatement of the reference's parallel DDP / iLQR hot path
+ * (plancherb1/parallel-DDP @ v1).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load it, and only as the checker / the reported CPU baseline.
+ * The product path (parallel-ddp_amd/) never includes, links or calls anything in oracle/.
+ *
+ * Pinning status: the reference's own tests hold no golden vectors for this path
+ * (SURVEY.md §4), and the reference cannot be compiled here without stand-in CUDA headers
+ * (it includes cuda.h / cuda_runtime.h / cublas_v2.h / cusolverDn.h, absent from this image),
+ * so no oracle/_ref build exists.  The oracle is pinned against the known answers recorded in
+ * SURVEY.md §8(c) / Appendix E (values the survey session measured from the reference's host
+ * instantiation): see tests/golden/survey_kat.json and tests/test_oracle_pins.py.
+ *
+ * Two instantiations are exported: suffix _f32 (algType float, config.cuh:74) and _f64.
+ */
+#ifndef PDDP_ORACLE_H
+#define PDDP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORA_MAX_ALPHA 64
+
+typedef struct ora_cfg {
+    int plant;          /* PLANT: 1 pendulum, 2 cart-pole, 3 quadrotor, 4 KUKA arm   config.cuh:21-61   */
+    int N;              /* NUM_TIME_STEPS                                            config.cuh:133-135 */
+    int M;              /* M_BLOCKS (= M_BLOCKS_B = M_BLOCKS_F)                      config.cuh:90-94   */
+    int A;              /* NUM_ALPHA                                                 config.cuh:113-115 */
+    int integrator;     /* INTEGRATOR 1 Euler, 2 midpoint, 3 RK3                     config.cuh:78-80   */
+    int wafr_urdf;      /* USE_WAFR_URDF (arm)                                       config.cuh:182-184 */
+    int mpc_mode;       /* MPC_MODE (arm gravity 0)                                  config.cuh:185-187 */
+    int max_iter;       /* MAX_ITER                                                  config.cuh:83      */
+    int ignore_max_rho_exit; /* IGNORE_MAX_ROX_EXIT                                  config.cuh:105-107 */
+    /* CPU-baseline thread structure (config.cuh:146-161); <=0 means "derive from cores like the reference" */
+    int cores;          /* value to use for CPU_CORES; <=0 -> sysconf                                    */
+    int spawn_threads;  /* 1: create/join pthreads per phase like the reference; 0: run the same partition serially */
+    int survey_int_minmax; /* PIN TEST ONLY: emulate the SURVEY harness artefact (integer min/max in the rho schedule) */
+    int survey_double_trig; /* PIN TEST ONLY: second artefact of that build -- sin/cos(float) bound to the double libm functions */
+    double total_time;  /* TOTAL_TIME                                                config.cuh:130-132 */
+    double alpha_base;  /* ALPHA_BASE                                                config.cuh:110-112 */
+    double rho_init;    /* RHO_INIT                                                  config.cuh:99-101  */
+    double max_defect;  /* MAX_DEFECT_SIZE                                           config.cuh:124-126 */
+    double tol_cost;    /* TOL_COST                                                  config.cuh:85-87   */
+    double exp_red_min, exp_red_max;    /*                                           config.cuh:117-122 */
+    double Q1, Q2, R, QF1, QF2;         /* arm joint-space cost weights  plants/cost_arm.cuh:97-103     */
+} ora_cfg;
+
+/* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */
+void ora_default_cfg(ora_cfg *c, int plant);
+int  ora_state_size(int plant);
+int  ora_control_size(int plant);
+
+/* result of a full solve */
+typedef struct ora_result {
+    int iters;              /* value of `iter` at exit (DDPWrappers.cuh:24,515-516) */
+    double t_total_ms, t_init_ms;
+} ora_result;
+
+#define ORA_DECL(SUF, REAL)                                                                                   \
+    /* plant-level entry points (G1) */                                                                       \
+    void ora_dynamics_##SUF(const ora_cfg *c, REAL *qdd, const REAL *x, const REAL *u);                       \
+    void ora_dynamics_gradient_##SUF(const ora_cfg *c, REAL *dqdd, REAL *qdd, const REAL *x, const REAL *u);  \
+    void ora_integrator_##SUF(const ora_cfg *c, REAL *xkp1, const REAL *x, const REAL *u);                    \
+    void ora_integrator_gradient_##SUF(const ora_cfg *c, REAL *ABk, const REAL *x, const REAL *u);            \
+    REAL ora_cost_func_##SUF(const ora_cfg *c, const REAL *xk, const REAL *uk, const REAL *xg, int k);        \
+    void ora_cost_grad_##SUF(const ora_cfg *c, REAL *Hk, REAL *gk, const REAL *xk, const REAL *uk,            \
+                             const REAL *xg, int k);                                                          \
+    /* phase-level entry points (G2); sem_gpu selects kernel (1) or host-thread (0) semantics */              \
+    int  ora_backward_pass_##SUF(const ora_cfg *c, int sem_gpu, const REAL *AB, REAL *P, REAL *p, REAL *Pp,   \
+                                 REAL *pp, REAL *H, REAL *g, REAL *KT, REAL *du, const REAL *d, REAL *ApBK,   \
+                                 REAL *Bdu, const REAL *x, const REAL *xp2, REAL rho, REAL *dJexp, int *err); \
+    void ora_forward_sweep_##SUF(const ora_cfg *c, REAL *x, const REAL *ApBK, const REAL *Bdu, const REAL *d, \
+                                 const REAL *xp, REAL alpha);                                                 \
+    void ora_forward_sim_##SUF(const ora_cfg *c, REAL *x, REAL *u, const REAL *KT, const REAL *du, REAL *d,   \
+                               REAL alpha, const REAL *xp);                                                   \
+    REAL ora_total_cost_##SUF(const ora_cfg *c, int sem_gpu, const REAL *x, const REAL *u, const REAL *xg);   \
+    REAL ora_max_defect_##SUF(const ora_cfg *c, int sem_gpu, const REAL *d);                                  \
+    void ora_next_iteration_setup_##SUF(const ora_cfg *c, const REAL *x, const REAL *u, const REAL *xg,       \
+                                        REAL *AB, REAL *H, REAL *g);                                          \
+    int  ora_line_search_gpu_##SUF(const ora_cfg *c, const REAL *J, const REAL *dmax, const REAL *dJexp,      \
+                                   REAL prevJ, int *ignore_defect, int *alphaIndex, REAL *dJ, REAL *z);       \
+    /* solver-level (G3/G4): x0 [n*N], u0 [m*N] in/out; KT_out [n*m*N] optional */                            \
+    int ora_run_ilqr_cpu_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,           \
+                               int *alphaOut, int rollout, int ignoreFirstDefect, REAL *KT_out,               \
+                               ora_result *res);                                                              \
+    int ora_run_ilqr_gpusem_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,        \
+                                  int *alphaOut, int rollout, int ignoreFirstDefect, REAL *KT_out,            \
+                                  ora_result *res);
+
+ORA_DECL(f32, float)
+ORA_DECL(f64, double)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,210 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (parallel-ddp_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+
+class OraCfg(C.Structure):
+    _fields_ = [
+        ("plant", C.c_int), ("N", C.c_int), ("M", C.c_int), ("A", C.c_int), ("integrator", C.c_int),
+        ("wafr_urdf", C.c_int), ("mpc_mode", C.c_int), ("max_iter", C.c_int), ("ignore_max_rho_exit", C.c_int),
+        ("cores", C.c_int), ("spawn_threads", C.c_int), ("survey_int_minmax", C.c_int), ("survey_double_trig", C.c_int),
+        ("total_time", C.c_double), ("alpha_base", C.c_double), ("rho_init", C.c_double), ("max_defect", C.c_double),
+        ("tol_cost", C.c_double), ("exp_red_min", C.c_double), ("exp_red_max", C.c_double),
+        ("Q1", C.c_double), ("Q2", C.c_double), ("R", C.c_double), ("QF1", C.c_double), ("QF2", C.c_double),
+    ]
+
+
+class OraResult(C.Structure):
+    _fields_ = [("iters", C.c_int), ("t_total_ms", C.c_double), ("t_init_ms", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ora_default_cfg.argtypes = [C.POINTER(OraCfg), C.c_int]
+        _LIB.ora_cost_func_f32.restype = C.c_float
+        _LIB.ora_cost_func_f64.restype = C.c_double
+        _LIB.ora_total_cost_f32.restype = C.c_float
+        _LIB.ora_total_cost_f64.restype = C.c_double
+        _LIB.ora_max_defect_f32.restype = C.c_float
+        _LIB.ora_max_defect_f64.restype = C.c_double
+    return _LIB
+
+
+PLANT_DIMS = {1: (1, 2, 1), 2: (2, 4, 1), 3: (6, 12, 4), 4: (7, 14, 7)}  # npos, n, m
+
+
+def default_cfg(plant, **kw):
+    c = OraCfg()
+    lib().ora_default_cfg(C.byref(c), plant)
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def _suf(dtype):
+    return "f32" if np.dtype(dtype) == np.float32 else "f64"
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _r(dtype, v):
+    return C.c_float(v) if np.dtype(dtype) == np.float32 else C.c_double(v)
+
+
+class Oracle:
+    """Thin, explicit wrapper: every array is a contiguous numpy array of `dtype`."""
+
+    def __init__(self, cfg, dtype=np.float32):
+        self.c = cfg
+        self.dtype = np.dtype(dtype)
+        self.suf = _suf(dtype)
+        self.npos, self.n, self.m = PLANT_DIMS[cfg.plant]
+
+    def _f(self, name):
+        return getattr(lib(), f"ora_{name}_{self.suf}")
+
+    def arr(self, a):
+        return np.ascontiguousarray(a, dtype=self.dtype)
+
+    # ---- plant level
+    def dynamics(self, x, u):
+        x, u = self.arr(x), self.arr(u)
+        qdd = np.zeros(self.npos, self.dtype)
+        self._f("dynamics")(C.byref(self.c), _p(qdd), _p(x), _p(u))
+        return qdd
+
+    def dynamics_gradient(self, x, u):
+        x, u = self.arr(x), self.arr(u)
+        qdd = np.zeros(self.npos, self.dtype)
+        dqdd = np.zeros(self.npos * (self.n + self.m), self.dtype)
+        self._f("dynamics_gradient")(C.byref(self.c), _p(dqdd), _p(qdd), _p(x), _p(u))
+        return dqdd, qdd
+
+    def integrator(self, x, u):
+        x, u = self.arr(x), self.arr(u)
+        xn = np.zeros(self.n, self.dtype)
+        self._f("integrator")(C.byref(self.c), _p(xn), _p(x), _p(u))
+        return xn
+
+    def integrator_gradient(self, x, u):
+        x, u = self.arr(x), self.arr(u)
+        AB = np.zeros(self.n * (self.n + self.m), self.dtype)
+        self._f("integrator_gradient")(C.byref(self.c), _p(AB), _p(x), _p(u))
+        return AB
+
+    def cost_func(self, x, u, xg, k):
+        x, u, xg = self.arr(x), self.arr(u), self.arr(xg)
+        return float(self._f("cost_func")(C.byref(self.c), _p(x), _p(u), _p(xg), int(k)))
+
+    def cost_grad(self, x, u, xg, k):
+        x, u, xg = self.arr(x), self.arr(u), self.arr(xg)
+        nm = self.n + self.m
+        H = np.zeros(nm * nm, self.dtype)
+        g = np.zeros(nm, self.dtype)
+        self._f("cost_grad")(C.byref(self.c), _p(H), _p(g), _p(x), _p(u), _p(xg), int(k))
+        return H, g
+
+    # ---- phase level (arrays are modified in place, like the reference)
+    def backward_pass(self, sem_gpu, AB, P, p, Pp, pp, H, g, KT, du, d, ApBK, Bdu, x, xp2, rho):
+        M = self.c.M
+        dJexp = np.zeros(2 * M, self.dtype)
+        err = np.zeros(M, np.int32)
+        fail = self._f("backward_pass")(C.byref(self.c), int(sem_gpu), _p(AB), _p(P), _p(p), _p(Pp), _p(pp), _p(H), _p(g),
+                                        _p(KT), _p(du), _p(d), _p(ApBK), _p(Bdu), _p(x), _p(xp2), _r(self.dtype, rho),
+                                        _p(dJexp), _p(err))
+        return int(fail), dJexp, err
+
+    def forward_sweep(self, x, ApBK, Bdu, d, xp, alpha):
+        self._f("forward_sweep")(C.byref(self.c), _p(x), _p(ApBK), _p(Bdu), _p(d), _p(xp), _r(self.dtype, alpha))
+
+    def forward_sim(self, x, u, KT, du, d, alpha, xp):
+        self._f("forward_sim")(C.byref(self.c), _p(x), _p(u), _p(KT), _p(du), _p(d), _r(self.dtype, alpha), _p(xp))
+
+    def total_cost(self, sem_gpu, x, u, xg):
+        return float(self._f("total_cost")(C.byref(self.c), int(sem_gpu), _p(x), _p(u), _p(xg)))
+
+    def max_defect(self, sem_gpu, d):
+        return float(self._f("max_defect")(C.byref(self.c), int(sem_gpu), _p(d)))
+
+    def next_iteration_setup(self, x, u, xg):
+        n, m, N = self.n, self.m, self.c.N
+        nm = n + m
+        AB = np.zeros(n * nm * N, self.dtype)
+        H = np.zeros(nm * nm * N, self.dtype)
+        g = np.zeros(nm * N, self.dtype)
+        self._f("next_iteration_setup")(C.byref(self.c), _p(x), _p(u), _p(xg), _p(AB), _p(H), _p(g))
+        return AB, H, g
+
+    def line_search_gpu(self, J, dmax, dJexp, prevJ, ignore_defect, alphaIndex):
+        J, dmax, dJexp = self.arr(J), self.arr(dmax), self.arr(dJexp)
+        ign, ai = C.c_int(ignore_defect), C.c_int(alphaIndex)
+        dJ = (C.c_float if self.suf == "f32" else C.c_double)(0)
+        z = (C.c_float if self.suf == "f32" else C.c_double)(0)
+        self._f("line_search_gpu")(C.byref(self.c), _p(J), _p(dmax), _p(dJexp), _r(self.dtype, prevJ), C.byref(ign),
+                                   C.byref(ai), C.byref(dJ), C.byref(z))
+        return ai.value, ign.value, dJ.value, z.value
+
+    # ---- solver level
+    def _run(self, which, x0, u0, xGoal, rollout=0, ignore_first_defect=1):
+        x0, u0, xGoal = self.arr(x0).copy(), self.arr(u0).copy(), self.arr(xGoal)
+        Jout = np.zeros(self.c.max_iter + 2, self.dtype)
+        aout = np.full(self.c.max_iter + 2, -99, np.int32)
+        KT = np.zeros(self.n * self.m * self.c.N, self.dtype)
+        res = OraResult()
+        self._f(which)(C.byref(self.c), _p(x0), _p(u0), _p(xGoal), _p(Jout), _p(aout), int(rollout),
+                       int(ignore_first_defect), _p(KT), C.byref(res))
+        return dict(x=x0, u=u0, KT=KT, Jout=Jout, alphaOut=aout, iters=res.iters, t_total_ms=res.t_total_ms,
+                    t_init_ms=res.t_init_ms)
+
+    def run_ilqr_cpu(self, x0, u0, xGoal, **kw):
+        return self._run("run_ilqr_cpu", x0, u0, xGoal, **kw)
+
+    def run_ilqr_gpusem(self, x0, u0, xGoal, **kw):
+        return self._run("run_ilqr_gpusem", x0, u0, xGoal, **kw)
+
+
+# ---- the reference example's inputs (examples/WAFR_iLQR_examples.cu:69-121), noise supplied by the caller
+def example_inputs(plant, N, dtype=np.float32, noise=None, wafr_urdf=1):
+    npos, n, m = PLANT_DIMS[plant]
+    x = np.zeros((N, n), np.float64)
+    u = np.zeros((N, m), np.float64)
+    if noise is None:
+        noise = np.zeros((N, n))
+    PI = 3.14159
+    if plant == 1:
+        x[:, 1] = noise[:, 1]; u[:] = 0.01; goal = [3.1416, 0.0]
+    elif plant == 2:
+        x[:, 2] = noise[:, 2]; x[:, 3] = noise[:, 3]; u[:] = 0.01; goal = [0.0, 3.1416, 0.0, 0.0]
+    elif plant == 3:
+        x[:, 2] = 0.5; x[:, 6:] = noise[:, 6:]; u[:] = 1.22625; goal = [7.0, 10.0, 0.5] + [0.0] * 9
+    else:
+        x[:, :7] = [-0.5 * PI, 0.25 * PI, 0.167 * PI, -0.167 * PI, 0.125 * PI, 0.167 * PI, 0.5 * PI]
+        x[:, 7:] = noise[:, 7:]
+        u[:] = ([0.0, -102.9832, 11.1968, 47.0724, 2.5993, -7.0290, -0.0907] if wafr_urdf else
+                [-0.0000000001, -62.282937, 4.172921, 21.513797, -0.088674, -0.890626, 0.0000000001])
+        goal = [0, 0, 0, -0.25 * PI, 0, 0.25 * PI, 0.5 * PI] + [0.0] * 7
+    return x.astype(dtype).ravel(), u.astype(dtype).ravel(), np.asarray(goal, dtype)

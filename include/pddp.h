@@ -1,0 +1,129 @@
+/* pddp.h -- C ABI of the MI355X-native parallel DDP / iLQR hot path (libpddp.so).
+ *
+ * The reference (plancherb1/parallel-DDP @ v1) has no binary interface: its hot path is a set of C++
+ * templates configured by preprocessor macros (config.cuh) and called from the examples as
+ *     allocateMemory_GPU<T>  (DDPHelpers/nisInitHelpers.cuh:768-861)
+ *     runiLQR_GPU<T>         (DDPHelpers/DDPWrappers.cuh:10-138)
+ *     freeMemory_GPU<T>      (DDPHelpers/nisInitHelpers.cuh:865-882)
+ * This header is what a binding of that path would call.  Each entry point names the reference
+ * interface it replaces.  Plain pointers and sizes only; element type is selected by pddp_config.dtype
+ * (0 = float, the reference's algType, config.cuh:74; 1 = double, config.cuh:73).
+ *
+ * All functions return 0 on success or a negative PDDP_E* code; pddp_last_error() gives the text.
+ * Nothing here ever calls exit() (the reference's gpuAssert does, utils/cudaUtils.cu:31-37).
+ * The library fails loudly (PDDP_ENODEVICE) when no HIP device is available: there is no CPU fallback.
+ */
+#ifndef PDDP_H
+#define PDDP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDDP_EINVAL     (-1)   /* bad argument / unsupported configuration */
+#define PDDP_ENODEVICE  (-2)   /* no HIP device, or HIP runtime error      */
+#define PDDP_ENOMEM     (-3)
+#define PDDP_ENUMERIC   (-4)   /* regulariser hit RHO_MAX (in-band in the reference: loop exit) */
+
+typedef struct pddp_solver* pddp_handle;
+
+/* The reference's compile-time configuration (config.cuh) as a run-time record. */
+typedef struct pddp_config {
+    int plant;            /* PLANT 1 pendulum, 2 cart-pole, 3 quadrotor, 4 KUKA iiwa14      config.cuh:21-61   */
+    int dtype;            /* 0 float, 1 double                                               config.cuh:72-74   */
+    int N;                /* NUM_TIME_STEPS (power of two, multiple of M)                    config.cuh:133-135 */
+    int M;                /* M_BLOCKS = M_BLOCKS_B = M_BLOCKS_F                               config.cuh:90-94   */
+    int A;                /* NUM_ALPHA                                                       config.cuh:113-115 */
+    int integrator;       /* INTEGRATOR 1 Euler, 2 midpoint, 3 RK3                           config.cuh:78-80   */
+    int batch;            /* independent problems solved concurrently (new: the reference solves one)           */
+    int max_iter;         /* MAX_ITER                                                        config.cuh:83      */
+    int wafr_urdf;        /* USE_WAFR_URDF (arm)                                             config.cuh:182-184 */
+    int mpc_mode;         /* MPC_MODE: gravity 0 (arm)                                       config.cuh:185-187 */
+    int ignore_max_rho_exit; /* IGNORE_MAX_ROX_EXIT                                          config.cuh:105-107 */
+    int device;           /* HIP device ordinal                                                                 */
+    int use_graph;        /* replay each DDP sweep from a hipGraph instead of four launches                     */
+    double total_time;    /* TOTAL_TIME                                                      config.cuh:130-132 */
+    double alpha_base;    /* ALPHA_BASE                                                      config.cuh:110-112 */
+    double rho_init;      /* RHO_INIT                                                        config.cuh:99-101  */
+    double max_defect;    /* MAX_DEFECT_SIZE                                                 config.cuh:124-126 */
+    double tol_cost;      /* TOL_COST                                                        config.cuh:85-87   */
+    double exp_red_min, exp_red_max;   /* EXP_RED_MIN / EXP_RED_MAX                          config.cuh:117-122 */
+    double Q1, Q2, R, QF1, QF2;        /* _Q1 _Q2 _R _QF1 _QF2 (arm joint cost)   plants/cost_arm.cuh:97-103   */
+} pddp_config;
+
+/* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */
+int pddp_default_config(pddp_config* cfg, int plant);
+int pddp_state_size(int plant);     /* STATE_SIZE   */
+int pddp_control_size(int plant);   /* CONTROL_SIZE */
+const char* pddp_last_error(void);
+
+/* allocateMemory_GPU (nisInitHelpers.cuh:768-861): all device buffers for `batch` problems, alpha[i] =
+ * ALPHA_BASE^i (:829), robot constants uploaded (:844-853).  freeMemory_GPU (:865-882). */
+int pddp_create(const pddp_config* cfg, pddp_handle* out);
+int pddp_destroy(pddp_handle h);
+
+/* loadVarsGPU (nisInitHelpers.cuh:596-652) + initAlgGPU (:355-397).
+ * x0 [batch][N][n], u0 [batch][N][m], xGoal [batch][n] on the HOST.  clear_vars: zero P,p,KT,d (the reference's
+ * clearVarsFlag = 1); otherwise they keep the values of the previous solve (warm start).
+ * After this call every input is resident in HBM; Jout[0] / alphaOut[0] are set. */
+int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xGoal, int clear_vars, int ignore_first_defect);
+
+/* The hot loop of runiLQR_GPU (DDPWrappers.cuh:52-114): `sweeps` x { backward pass, forward sweep+sim+cost,
+ * line search + accept/reject, next-iteration setup }, enqueued on the solver's stream with NO host
+ * synchronisation.  Problems that have met an exit condition idle through the remaining sweeps. */
+int pddp_iterate(pddp_handle h, int sweeps);
+int pddp_sync(pddp_handle h);
+/* done[b]: 0 running, 1 TOL_COST exit, 2 MAX_ITER exit, 3 RHO_MAX exit; iters[b]: reference `iter` at exit. */
+int pddp_status(pddp_handle h, int* done, int* iters);
+
+/* storeVarsGPU (nisInitHelpers.cuh:741-750): solution to the host.  Any pointer may be NULL.
+ * x [batch][N][n], u [batch][N][m], KT [batch][N][n*m], Jout/alphaOut [batch][max_iter+2], dmax [batch]. */
+int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax);
+
+/* runiLQR_GPU (DDPWrappers.cuh:10-138) for the whole batch: load, init, iterate until every problem exits, store.
+ * times_ms[0] = total, [1] = init (load+init+store), like *tTime / *initTime. */
+int pddp_solve(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal, void* Jout, int* alphaOut,
+               int clear_vars, int ignore_first_defect, double* times_ms);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+/* Runs `sweeps` sweeps bracketed by HIP events on the solver's stream; ms_total = elapsed, ms_phase[4] = summed
+ * durations of the four kernels (bp, fp, ls, nis) measured with per-launch events in a second pass. */
+int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase);
+/* Freeze / unfreeze the exit tests so a benchmark can time a fixed number of full-work sweeps. */
+int pddp_set_benchmark_mode(pddp_handle h, int on);
+
+/* ---- teacher-forced phase hooks (tests) ------------------------------------------------------------- */
+/* Named device arrays: xs us ds xb ucur dcur P p Pp pp AB H g KT du ApBK Bdu J dmax dJexp alpha xGoal Jout
+ * (element type = dtype), err alphaOut (int), state (see pddp_state below). */
+int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes);
+int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes);
+int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes);
+
+typedef struct pddp_state {      /* per problem, all scalars as double regardless of dtype */
+    double rho, drho, prevJ, dJ, z;
+    int iter, alphaIndex, ignore_defect, accepted, done, cur, cur2, bp_retries;
+} pddp_state;
+int pddp_get_state(pddp_handle h, pddp_state* out /* [batch] */);
+int pddp_set_state(pddp_handle h, const pddp_state* in /* [batch] */);
+
+#define PDDP_PHASE_BP        0   /* backPassKern                   bpHelpers.cuh:339-420            */
+#define PDDP_PHASE_FP        1   /* forwardSweepKern+forwardSimKern+costKern+defectKern  fpHelpers.cuh */
+#define PDDP_PHASE_LS        2   /* line search + acceptRejectTrajGPU                                */
+#define PDDP_PHASE_NIS       3   /* nextIterationSetupGPU          nisInitHelpers.cuh:247-279       */
+#define PDDP_PHASE_INIT_NIS  4   /* derivatives part of initAlgGPU nisInitHelpers.cuh:365-371       */
+#define PDDP_PHASE_INIT_COST 5   /* cost part of initAlgGPU        nisInitHelpers.cuh:385-395       */
+int pddp_run_phase(pddp_handle h, int phase);
+
+/* Plant plug-in evaluations on the device, `count` independent (x,u) pairs:
+ * what = 0 dynamics -> qdd[count][npos]                 (dynamics<T>,          plants/dynamics_*.cuh)
+ *        1 dynamicsGradient -> dqdd[count][npos*(n+m)]  (dynamicsGradient<T>)
+ *        2 _integrator -> xnext[count][n]               (utils/integrators.cuh)
+ *        3 _integratorGradient -> AB[count][n*(n+m)] */
+int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

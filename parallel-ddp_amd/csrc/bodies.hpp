@@ -1,0 +1,152 @@
+// Per-workgroup bodies of the sweep kernels, free of any HIP runtime dependency so that tests/hostsim can run the very
+// same code on the host with a 1-lane wave.  kernels.hpp wraps them into __global__ entry points.
+#pragma once
+
+#include "bp.hpp"
+#include "fp.hpp"
+#include "nis.hpp"
+#include "solver_state.hpp"
+
+namespace pddp {
+
+template <typename P, typename T>
+PDDP_HD void bp_body(const Wave& w, BpScratch<P, T>& s, const Buffers<T>& b, const Dims& dm, int blk, int pb) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    const int N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    if (st.done) return;
+    BpArgs<T> a;
+    a.AB = b.AB + (size_t)pb * N * NX * NM;
+    a.Pm = b.P + (size_t)pb * N * NX * NX;   a.pv = b.p + (size_t)pb * N * NX;
+    a.Pp = b.Pp + (size_t)pb * N * NX * NX;  a.pp = b.pp + (size_t)pb * N * NX;
+    a.H = b.H + (size_t)pb * N * NM * NM;    a.g = b.g + (size_t)pb * N * NM;
+    a.KT = b.KT + (size_t)pb * N * NX * NU;  a.du = b.du + (size_t)pb * N * NU;
+    a.dcur = b.dcur + (size_t)pb * N * NX;
+    a.ApBK = b.ApBK + (size_t)pb * N * NX * NX;  a.Bdu = b.Bdu + (size_t)pb * N * NX;
+    a.xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX;
+    a.xprev2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
+    a.dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
+    a.err = b.err + (size_t)pb * dm.M;
+    a.rho = st.rho;
+    if (bp_block<P, T>(w, s, dm, blk, a)) { if (w.lane == 0) a.err[blk] = 1; }
+}
+
+// true when the forward pass of this sweep has to run for problem pb
+template <typename T>
+PDDP_HD bool fp_active(const Buffers<T>& b, const Dims& dm, int pb) {
+    if (b.state[pb].done) return false;
+    const int* err = b.err + (size_t)pb * dm.M;
+    for (int i = 0; i < dm.M; i++) if (err[i]) return false;   // backward pass failed: this sweep only raises rho
+    return true;
+}
+template <typename P, typename T>
+PDDP_HD FpArgs<T> fp_args(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T dt, T* segx, T* dnorm) {
+    constexpr int NX = P::NX, NU = P::NU;
+    const int N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    FpArgs<T> a;
+    const size_t slot = (size_t)pb * dm.A + a_idx;
+    a.x = b.xs + slot * N * NX; a.u = b.us + slot * N * NU; a.d = b.ds + slot * N * NX;
+    a.xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX;
+    a.ucur = b.ucur + (size_t)pb * N * NU; a.dcur = b.dcur + (size_t)pb * N * NX;
+    a.KT = b.KT + (size_t)pb * N * NX * NU; a.du = b.du + (size_t)pb * N * NU;
+    a.ApBK = b.ApBK + (size_t)pb * N * NX * NX; a.Bdu = b.Bdu + (size_t)pb * N * NX;
+    a.alpha = b.alpha[a_idx]; a.dt = dt; a.segx = segx; a.dnorm = dnorm;
+    return a;
+}
+// cost tree-sum and defect max of one candidate, by one wave
+template <typename T>
+PDDP_HD void fp_reduce(const Wave& w, const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T* cost_k, const T* dnorm) {
+    const T J = tree_sum<T>(w, cost_k, dm.N);
+    if (w.lane == 0) {
+        T mx = 0;
+        for (int i = 0; i < dm.M; i++) mx = tmax(mx, dnorm[i]);
+        const size_t slot = (size_t)pb * dm.A + a_idx;
+        b.J[slot] = J; b.dmax[slot] = mx;
+    }
+}
+
+template <typename T>
+PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp, int pb, int freeze_exit) {
+    SolverState<T> st = b.state[pb];
+    if (st.done) return;
+    const int* err = b.err + (size_t)pb * dm.M;
+    int any = 0;
+    for (int i = 0; i < dm.M; i++) any |= err[i];
+    const size_t ho = (size_t)pb * (sp.max_iter + 2);
+    if (freeze_exit) {   // benchmark mode: never exit, keep writing the same Jout slot
+        SolverParams sp2 = sp; sp2.tol_cost = -1e300; sp2.ignore_max_rho_exit = 1;
+        const int it = st.iter;
+        line_search_accept<T>(st, sp2, dm, any, b.alpha, b.J + (size_t)pb * dm.A, b.dmax + (size_t)pb * dm.A,
+                              b.dJexp + (size_t)pb * 2 * dm.M, b.Jout + ho, b.alphaOut + ho);
+        st.done = 0; st.iter = it;
+    } else {
+        line_search_accept<T>(st, sp, dm, any, b.alpha, b.J + (size_t)pb * dm.A, b.dmax + (size_t)pb * dm.A,
+                              b.dJexp + (size_t)pb * 2 * dm.M, b.Jout + ho, b.alphaOut + ho);
+    }
+    b.state[pb] = st;
+}
+
+// knot k of problem pb.
+//   accepted: winner candidate -> current trajectory (x into the other half of xb, u, d), then AB_k, H_k, g_k there;
+//   rejected: trajectory and derivatives are unchanged (the reference recomputes identical values);
+//   always (unless the backward pass failed): boundary cost-to-go P,p -> Pp,pp (only block-boundary slots are ever read).
+// mode 1 = initAlgGPU derivatives (no copies).
+template <typename P, int INTEG, typename T>
+PDDP_HD void nis_body(const Wave& w, NisScratch<P, INTEG, T>& s, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt,
+                      int mode, int k, int pb) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    const int N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    T* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX + (size_t)k * NX;
+    T* uc = b.ucur + ((size_t)pb * N + k) * NU;
+    if (mode == 0) {
+        if (st.accepted < 0) return;                           // backward pass failed: nothing moved
+        if (dm.M > 1 && dm.on_defect_boundary(k)) {            // Pp <- P, pp <- p at the slots the next backward pass reads
+            const size_t o = ((size_t)pb * N + k);
+            PDDP_FOR(e, NX * NX) b.Pp[o * NX * NX + e] = b.P[o * NX * NX + e];
+            PDDP_FOR(e, NX) b.pp[o * NX + e] = b.p[o * NX + e];
+        }
+        if (st.accepted != 1) return;
+        const size_t slot = (size_t)pb * dm.A + st.alphaIndex;
+        const T* xw = b.xs + (slot * N + k) * NX; const T* uw = b.us + (slot * N + k) * NU;
+        PDDP_FOR(i, NX) xc[i] = xw[i];
+        PDDP_FOR(i, NU) uc[i] = uw[i];
+        if (dm.M > 1 && dm.on_defect_boundary(k)) {
+            const T* dw = b.ds + (slot * N + k) * NX; T* dc = b.dcur + ((size_t)pb * N + k) * NX;
+            PDDP_FOR(i, NX) dc[i] = dw[i];
+        }
+        if (st.done) return;                                   // final accepted step: solution copied, no derivatives needed
+        wsync();
+    }
+    P::load_model(w, s.plant, reinterpret_cast<const typename P::Model*>(b.model));
+    nis_knot<P, INTEG, T>(w, s, dm, k, xc, uc, b.xGoal + (size_t)pb * NX, cw, dt,
+                          b.AB + ((size_t)pb * N + k) * NX * NM, b.H + ((size_t)pb * N + k) * NM * NM, b.g + ((size_t)pb * N + k) * NM);
+}
+
+// cost of the loaded trajectory, prevJ = J + 2 TOL_COST, Jout[0], alphaOut[0], fresh solver state
+// (initAlgGPU, nisInitHelpers.cuh:363,385-395, and the locals of runiLQR_GPU, DDPWrappers.cuh:24).
+template <typename P, typename T>
+PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw,
+                            const SolverParams& sp, int ignore_first_defect, int rollout, int pb) {
+    constexpr int NX = P::NX, NU = P::NU;
+    const int N = dm.N;
+    const T* x = b.xb + ((size_t)pb * 2 + 0) * N * NX; const T* u = b.ucur + (size_t)pb * N * NU;
+    const T* xg = b.xGoal + (size_t)pb * NX;
+    PDDP_FOR(k, N) cost_k[k] = P::cost(cw, x + (size_t)k * NX, u + (size_t)k * NU, xg, k, N);
+    wsync();
+    const T J = tree_sum<T>(w, cost_k, N);
+    if (w.lane == 0) {
+        SolverState<T> st;
+        st.rho = T(sp.rho_init); st.drho = T(1.0); st.dJ = 0; st.z = 0;
+        st.prevJ = J + T(2 * sp.tol_cost);
+        st.iter = 1; st.alphaIndex = 0; st.ignore_defect = ignore_first_defect; st.accepted = 1; st.done = 0;
+        st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.pad = 0;
+        b.state[pb] = st;
+        const size_t ho = (size_t)pb * (sp.max_iter + 2);
+        b.Jout[ho] = st.prevJ - T(2 * sp.tol_cost);
+        b.alphaOut[ho] = rollout ? 0 : -1;
+    }
+}
+
+}  // namespace pddp

@@ -1,0 +1,125 @@
+// Discrete-time step x+ = f_d(x,u) and its Jacobian AB = [A B] for Euler / midpoint / RK3, wave-cooperative.
+// Replaces _integrator / _integratorGradient (utils/integrators.cuh:24-53 Euler, :56-120 midpoint, :123-233 RK3),
+// including the two behaviours of the reference that change results: the midpoint rule's final update uses the START
+// velocity for the position rows (:78), and the RK3 Jacobian builds its stage states from positions where the
+// integrator uses velocities (:182,:190-191).
+#pragma once
+
+#include "plants.hpp"
+
+namespace pddp {
+
+template <typename P, typename T>
+struct IntegScratch {                 // per-wave LDS
+    T qdd[P::NPOS], qdd2[P::NPOS], qdd3[P::NPOS];
+    T x2[P::NX], x3[P::NX];
+};
+
+template <typename P, int INTEG, typename T>
+struct IntegGradScratch {             // per-wave LDS; stage arrays only exist for the integrators that use them
+    static constexpr int ND = P::NPOS * (P::NX + P::NU), NAB = P::NX * (P::NX + P::NU);
+    T qdd1[P::NPOS], qdd2[P::NPOS], qdd3[P::NPOS];
+    T d1[ND], d2[INTEG >= 2 ? ND : 1], d3[INTEG == 3 ? ND : 1];
+    T xm1[INTEG >= 2 ? P::NX : 1], xm2[INTEG == 3 ? P::NX : 1];
+    T T1[INTEG == 3 ? NAB : 1], T2[INTEG == 3 ? NAB : 1];
+};
+
+// d(xdot)/d(x,u) entry (r,c) from dqdd:  x = [q; qd]  ->  [0 I 0; dqdd]     (integrators.cuh:17)
+template <int NPOS, typename T>
+PDDP_HD T dxd(const T* dqdd, int r, int c) {
+    return r < NPOS ? T(r + NPOS == c ? 1 : 0) : dqdd[c * NPOS + (r - NPOS)];
+}
+
+// xkp1, x, u in LDS (or host memory).  xkp1 must not alias x.
+template <typename P, int INTEG, typename T>
+PDDP_HD void integrator_step(const Wave& w, typename P::Scratch& ps, IntegScratch<P, T>& s, T* xkp1, const T* x, const T* u, T dt) {
+    constexpr int NP = P::NPOS;
+    P::dynamics(w, ps, s.qdd, x, u);
+    if constexpr (INTEG == 1) {
+        PDDP_FOR(i, NP) { xkp1[i] = x[i] + dt * x[i + NP]; xkp1[i + NP] = x[i + NP] + dt * s.qdd[i]; }
+        wsync();
+    } else if constexpr (INTEG == 2) {
+        PDDP_FOR(i, NP) { s.x2[i] = x[i] + T(0.5) * dt * x[i + NP]; s.x2[i + NP] = x[i + NP] + T(0.5) * dt * s.qdd[i]; }
+        wsync();
+        P::dynamics(w, ps, s.qdd, s.x2, u);
+        PDDP_FOR(i, NP) { xkp1[i] = x[i] + dt * x[i + NP]; xkp1[i + NP] = x[i + NP] + dt * s.qdd[i]; }
+        wsync();
+    } else {
+        PDDP_FOR(i, NP) { s.x2[i] = x[i] + T(0.5) * dt * x[i + NP]; s.x2[i + NP] = x[i + NP] + T(0.5) * dt * s.qdd[i]; }
+        wsync();
+        P::dynamics(w, ps, s.qdd2, s.x2, u);
+        PDDP_FOR(i, NP) {
+            s.x3[i] = x[i] + dt * (T(2) * s.x2[i + NP] - x[i + NP]);
+            s.x3[i + NP] = x[i + NP] + dt * (T(2) * s.qdd2[i] - s.qdd[i]);
+        }
+        wsync();
+        P::dynamics(w, ps, s.qdd3, s.x3, u);
+        PDDP_FOR(i, NP) {
+            xkp1[i] = x[i] + (dt / T(6)) * (x[i + NP] + T(4) * s.x2[i + NP] + s.x3[i + NP]);
+            xkp1[i + NP] = x[i + NP] + (dt / T(6)) * (s.qdd[i] + T(4) * s.qdd2[i] + s.qdd3[i]);
+        }
+        wsync();
+    }
+}
+
+// ABk: NX x (NX+NU) column-major with leading dimension NX, written to `ABk` (global or LDS).
+template <typename P, int INTEG, typename T>
+PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typename P::GradScratch& pg, IntegGradScratch<P, INTEG, T>& s,
+                                 T* ABk, const T* x, const T* u, T dt) {
+    constexpr int NP = P::NPOS, NX = P::NX, NM = P::NX + P::NU;
+    P::gradient(w, ps, pg, s.d1, s.qdd1, x, u);
+    if constexpr (INTEG == 1) {
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            ABk[e] = T(ky == kx ? 1 : 0) + dt * dxd<NP>(s.d1, kx, ky);
+        }
+        wsync();
+    } else if constexpr (INTEG == 2) {
+        PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i + NP] + T(0.5) * dt * s.qdd1[i]; }
+        wsync();
+        P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            T val = 0;
+            for (int i = 0; i < NX; i++) {
+                const T A2 = T(kx == i ? 1 : 0) + T(0.5) * dt * dxd<NP>(s.d2, kx, i);
+                const T AB1 = T(ky == i ? 1 : 0) + T(0.5) * dt * dxd<NP>(s.d1, i, ky);
+                val += A2 * AB1;
+            }
+            ABk[e] = val + (ky < NX ? T(0) : T(0.5) * dt * dxd<NP>(s.d2, kx, ky));
+        }
+        wsync();
+    } else {
+        PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
+        wsync();
+        P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
+        PDDP_FOR(i, NP) {
+            s.xm2[i] = x[i] + dt * x[i + NP] + T(2) * dt * s.xm1[i + NP];
+            s.xm2[i + NP] = x[i] + dt * s.qdd1[i] + T(2) * dt * s.qdd2[i];
+        }
+        wsync();
+        P::gradient(w, ps, pg, s.d3, s.qdd3, s.xm2, u);
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            T val = 0;
+            for (int i = 0; i < NX; i++) val += dxd<NP>(s.d2, kx, i) * (T(0.5) * dt * dxd<NP>(s.d1, i, ky) + T(ky == i ? 1 : 0));
+            s.T1[e] = val + (ky < NX ? T(0) : dxd<NP>(s.d2, kx, ky));
+        }
+        wsync();
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            T val = 0;
+            for (int i = 0; i < NX; i++)
+                val += dxd<NP>(s.d3, kx, i) * (T(2) * dt * s.T1[ky * NX + i] - dt * dxd<NP>(s.d1, i, ky) + T(ky == i ? 1 : 0));
+            s.T2[e] = val + (ky < NX ? T(0) : dxd<NP>(s.d3, kx, ky));
+        }
+        wsync();
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            ABk[e] = (dt / T(6)) * dxd<NP>(s.d1, kx, ky) + (T(2) * dt / T(3)) * s.T1[e] + (dt / T(6)) * s.T2[e] + T(kx == ky ? 1 : 0);
+        }
+        wsync();
+    }
+}
+
+}  // namespace pddp

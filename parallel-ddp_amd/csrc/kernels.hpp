@@ -1,0 +1,98 @@
+// __global__ entry points: one DDP sweep = k_bp -> k_fp -> k_ls -> k_nis on one stream, no host sync.
+// grid.y indexes the independent problems of the batch; every workgroup is made of whole 64-lane waves, each wave
+// owning one unit of work (see pddp_common.hpp).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "bodies.hpp"
+
+namespace pddp {
+
+// backward pass: grid (M, B), block 64.  Replaces backPassKern<<<M_BLOCKS_B,(8,7)>>> (bpHelpers.cuh:492).
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_bp(Buffers<T> b, Dims dm) {
+    __shared__ BpScratch<P, T> s;
+    bp_body<P, T>(this_wave(), s, b, dm, blockIdx.x, blockIdx.y);
+}
+
+// forward pass: grid (A, B), block M*64, dynamic LDS.  One workgroup per (candidate alpha, problem): wave 0 runs the
+// linear sweep, then wave b rolls out segment b, then wave 0 reduces cost and defect.  Replaces forwardSweepKern<<<A,14>>>,
+// forwardSimKern<<<(M,A),(8,7)>>>, costKern<<<A,N>>> and defectKern<<<A,N>>> (DDPWrappers.cuh:73, fpHelpers.cuh:366,383,388).
+template <typename P, typename T>
+struct FpLds {
+    static PDDP_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+    static size_t bytes(int M, int N) {
+        return align16(sizeof(SweepScratch<P, T>)) + (size_t)M * align16(sizeof(SimScratch<P, T>)) +
+               align16(sizeof(T) * (size_t)N) + align16(sizeof(T) * (size_t)M * P::NX) + align16(sizeof(T) * (size_t)M);
+    }
+};
+
+template <typename P, int INTEG, typename T>
+__global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int a_idx = blockIdx.x, pb = blockIdx.y, M = dm.M;
+    if (!fp_active<T>(b, dm, pb)) return;
+    using L = FpLds<P, T>;
+    unsigned char* ptr = lds_raw;
+    SweepScratch<P, T>& sw = *reinterpret_cast<SweepScratch<P, T>*>(ptr); ptr += L::align16(sizeof(SweepScratch<P, T>));
+    const int wave_id = threadIdx.x / kWave;
+    SimScratch<P, T>& sim = *reinterpret_cast<SimScratch<P, T>*>(ptr + (size_t)wave_id * L::align16(sizeof(SimScratch<P, T>)));
+    ptr += (size_t)M * L::align16(sizeof(SimScratch<P, T>));
+    T* cost_k = reinterpret_cast<T*>(ptr); ptr += L::align16(sizeof(T) * (size_t)dm.N);
+    T* segx = reinterpret_cast<T*>(ptr); ptr += L::align16(sizeof(T) * (size_t)M * P::NX);
+    T* dnorm = reinterpret_cast<T*>(ptr);
+    const Wave w = this_wave();
+    const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm);
+    if (M > 1) {
+        if (wave_id == 0) forward_sweep<P, T>(w, sw, dm, a);
+        __syncthreads();
+    }
+    P::load_model(w, sim.plant, reinterpret_cast<const typename P::Model*>(b.model));
+    forward_sim_segment<P, INTEG, T>(w, sim, dm, a, wave_id, cw, b.xGoal + (size_t)pb * P::NX, cost_k);
+    __syncthreads();
+    if (wave_id == 0) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm);
+}
+
+// line search + accept/reject: grid (B), block 64; one lane takes the decision the reference takes on the host
+// (fpHelpers.cuh:395-408, nisInitHelpers.cuh:489-518).
+template <typename T>
+__global__ __launch_bounds__(64) void k_ls(Buffers<T> b, Dims dm, SolverParams sp, int freeze_exit) {
+    if (threadIdx.x == 0) ls_body<T>(b, dm, sp, blockIdx.x, freeze_exit);
+}
+
+// next-iteration setup: grid (N, B), block 64 (see nis_body).
+template <typename P, int INTEG, typename T>
+__global__ __launch_bounds__(64) void k_nis(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode) {
+    __shared__ NisScratch<P, INTEG, T> s;
+    nis_body<P, INTEG, T>(this_wave(), s, b, dm, cw, dt, mode, blockIdx.x, blockIdx.y);
+}
+
+// initial cost + solver state: grid (B), block 64, dynamic LDS N*sizeof(T).
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_init_cost(Buffers<T> b, Dims dm, CostWeights<T> cw, SolverParams sp, int ignore_first_defect, int rollout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    init_cost_body<P, T>(this_wave(), reinterpret_cast<T*>(lds_raw), b, dm, cw, sp, ignore_first_defect, rollout, blockIdx.x);
+}
+// ---------------------------------------------------------------------------------------------- plant evaluation (tests / tools)
+template <typename P, int INTEG, typename T>
+__global__ __launch_bounds__(64) void k_plant_eval(const void* model, int what, int count, const T* x, const T* u, T* out, T dt) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU, NP = P::NPOS;
+    __shared__ NisScratch<P, INTEG, T> s;
+    __shared__ IntegScratch<P, T> is;
+    __shared__ T xn[NX], qdd[NP], dq[NP * NM];
+    const Wave w = this_wave();
+    P::load_model(w, s.plant, reinterpret_cast<const typename P::Model*>(model));
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        PDDP_FOR(e, NX) s.x[e] = x[(size_t)i * NX + e];
+        PDDP_FOR(e, NU) s.u[e] = u[(size_t)i * NU + e];
+        wsync();
+        if (what == 0) { P::dynamics(w, s.plant, qdd, s.x, s.u); PDDP_FOR(e, NP) out[(size_t)i * NP + e] = qdd[e]; }
+        else if (what == 1) { P::gradient(w, s.plant, s.pgrad, dq, qdd, s.x, s.u); PDDP_FOR(e, NP * NM) out[(size_t)i * NP * NM + e] = dq[e]; }
+        else if (what == 2) { integrator_step<P, INTEG, T>(w, s.plant, is, xn, s.x, s.u, dt); PDDP_FOR(e, NX) out[(size_t)i * NX + e] = xn[e]; }
+        else { integrator_gradient<P, INTEG, T>(w, s.plant, s.pgrad, s.integ, out + (size_t)i * NX * NM, s.x, s.u, dt); }
+        wsync();
+    }
+}
+
+}  // namespace pddp

@@ -1,0 +1,34 @@
+// Next-iteration setup for one knot: dynamics/cost derivatives at the current trajectory.
+//
+// Replaces integratorGradientKern (DDPHelpers/nisInitHelpers.cuh:205-221) and costGradientHessianKern (:46-93, the
+// joint-cost branch, one THREAD per knot writing a strided 21x21 block) with one wavefront per knot that writes
+// AB_k, H_k, g_k coalesced.  The copies the reference issues around them (memcpyCurrAKern x3, P->Pp, p->pp,
+// winner -> xp/up/dp, :266-276) are folded into the same launch: see kernels.hip.
+#pragma once
+
+#include "integrators.hpp"
+
+namespace pddp {
+
+template <typename P, int INTEG, typename T>
+struct NisScratch {
+    typename P::Scratch plant;
+    typename P::GradScratch pgrad;
+    IntegGradScratch<P, INTEG, T> integ;
+    T x[P::NX], u[P::NU];
+};
+
+// xk/uk: the knot's state and control (global).  Writes ABk (k < N-1), Hk, gk (global).
+template <typename P, int INTEG, typename T>
+PDDP_HD void nis_knot(const Wave& w, NisScratch<P, INTEG, T>& s, const Dims& dm, int k, const T* xk, const T* uk, const T* xg,
+                      const CostWeights<T>& cw, T dt, T* ABk, T* Hk, T* gk) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    PDDP_FOR(i, NX) s.x[i] = xk[i];
+    PDDP_FOR(i, NU) s.u[i] = uk[i];
+    wsync();
+    PDDP_FOR(e, NM * NM) { const int i = e / NM, j = e % NM; Hk[e] = (i == j) ? P::weight(cw, i, k, dm.N) : T(0); }
+    PDDP_FOR(i, NM) gk[i] = P::weight(cw, i, k, dm.N) * (i < NX ? (s.x[i] - xg[i]) : s.u[i - NX]);
+    if (k < dm.N - 1) integrator_gradient<P, INTEG>(w, s.plant, s.pgrad, s.integ, ABk, s.x, s.u, dt);
+}
+
+}  // namespace pddp

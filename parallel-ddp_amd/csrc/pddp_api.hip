@@ -1,0 +1,375 @@
+// libpddp.so: host side of the C ABI declared in include/pddp.h.  gfx950 only; no CPU fallback.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <sys/time.h>
+#include <vector>
+
+#include "../../include/pddp.h"
+#include "iiwa14_model_data.h"
+#include "kernels.hpp"
+
+using namespace pddp;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return fail(PDDP_ENODEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* pddp_last_error(void) { return g_err.c_str(); }
+extern "C" int pddp_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 4 ? 14 : -1; }
+extern "C" int pddp_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 4 ? 7 : -1; }
+
+// Reference defaults: config.cuh:24-61 per plant, :78-136 algorithm, plants/cost_arm.cuh:97-103 weights.
+extern "C" int pddp_default_config(pddp_config* c, int plant) {
+    if (!c || plant < 1 || plant > 4) return fail(PDDP_EINVAL, "plant must be 1..4");
+    std::memset(c, 0, sizeof(*c));
+    c->plant = plant; c->dtype = 0;
+    c->N = plant == 4 ? 64 : 128; c->M = 4;
+    c->A = (plant == 3 || plant == 4) ? 16 : 32;
+    c->integrator = plant == 4 ? 1 : 3;
+    c->batch = 1; c->max_iter = 100; c->ignore_max_rho_exit = 1;
+    c->total_time = plant == 4 ? 0.5 : 4.0;
+    c->alpha_base = (plant == 3 || plant == 4) ? 0.5 : 0.75;
+    c->rho_init = plant == 4 ? 12.5 : (plant == 3 ? 1.0 : 10.0);
+    c->max_defect = plant == 2 ? 0.75 : 1.0;
+    c->tol_cost = 0.0001; c->exp_red_min = 0.05; c->exp_red_max = 1.25;
+    c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
+    return 0;
+}
+
+static double now_ms() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
+
+struct SolverBase {
+    pddp_config cfg;
+    virtual ~SolverBase() {}
+    virtual int init() = 0;
+    virtual int load(const void* x0, const void* u0, const void* xg, int clear, int ignore_first_defect) = 0;
+    virtual int iterate(int sweeps) = 0;
+    virtual int sync() = 0;
+    virtual int status(int* done, int* iters) = 0;
+    virtual int store(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) = 0;
+    virtual int time_sweeps(int sweeps, float* ms_total, float* ms_phase) = 0;
+    virtual int array(const char* name, void** ptr, size_t* bytes) = 0;
+    virtual int get_state(pddp_state* out) = 0;
+    virtual int set_state(const pddp_state* in) = 0;
+    virtual int run_phase(int phase) = 0;
+    virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
+    int bench_mode = 0;
+    hipStream_t stream = nullptr;
+};
+struct pddp_solver { SolverBase* impl; };
+
+template <typename T> static void fill_model(ArmModel<T>& m, const pddp_config& c) {
+    const int v = c.wafr_urdf ? 1 : 0;
+    for (int b = 0; b < 7; b++) {
+        for (int i = 0; i < 36; i++) m.I[36 * b + i] = (T)IIWA14_SPATIAL_INERTIA[v][b][i];
+        for (int i = 0; i < 16; i++) m.F[16 * b + i] = (T)IIWA14_JOINT_FRAME[v][b][i];
+    }
+    m.grav = (T)(c.mpc_mode ? 0.0 : 9.81);   // plants/dynamics_arm.cuh:42-46
+}
+static void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
+
+template <typename P, int INTEG, typename T>
+struct Solver : SolverBase {
+    static constexpr int NX = P::NX, NU = P::NU, NM = NX + NU, NP = P::NPOS;
+    Buffers<T> b{};
+    Dims dm{};
+    SolverParams sp{};
+    CostWeights<T> cw{};
+    T dt{};
+    std::map<std::string, std::pair<void*, size_t>> arrays;
+    std::vector<void*> allocs;
+    hipGraphExec_t graph = nullptr;
+    int graph_mode = -1;
+    size_t fp_lds = 0;
+
+    ~Solver() override {
+        if (graph) hipGraphExecDestroy(graph);
+        for (void* p : allocs) hipFree(p);
+        if (stream) hipStreamDestroy(stream);
+    }
+    template <typename U> int alloc(const char* name, U** out, size_t count) {
+        void* p = nullptr;
+        if (hipMalloc(&p, count * sizeof(U)) != hipSuccess) return fail(PDDP_ENOMEM, std::string("hipMalloc failed for ") + name);
+        if (hipMemset(p, 0, count * sizeof(U)) != hipSuccess) return fail(PDDP_ENODEVICE, "hipMemset failed");
+        allocs.push_back(p); arrays[name] = {p, count * sizeof(U)}; *out = (U*)p;
+        return 0;
+    }
+    int init() override {
+        const pddp_config& c = cfg;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device)
+            return fail(PDDP_ENODEVICE, "no HIP device available: libpddp has no CPU fallback");
+        HIPCHK(hipSetDevice(c.device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
+        sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
+        sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;
+        cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
+        dt = (T)(c.total_time / (c.N - 1));                       // TIME_STEP, config.cuh:136
+        const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
+        int rc = 0;
+#define AL(name, count) if ((rc = alloc(#name, &b.name, (count)))) return rc
+        AL(xs, B * A * N * NX); AL(us, B * A * N * NU); AL(ds, B * A * N * NX);
+        AL(xb, B * 2 * N * NX); AL(ucur, B * N * NU); AL(dcur, B * N * NX);
+        AL(P, B * N * NX * NX); AL(p, B * N * NX); AL(Pp, B * N * NX * NX); AL(pp, B * N * NX);
+        AL(AB, B * N * NX * NM); AL(H, B * N * NM * NM); AL(g, B * N * NM);
+        AL(KT, B * N * NX * NU); AL(du, B * N * NU); AL(ApBK, B * N * NX * NX); AL(Bdu, B * N * NX);
+        AL(J, B * A); AL(dmax, B * A); AL(dJexp, B * 2 * M); AL(alpha, A); AL(xGoal, B * NX);
+        AL(Jout, B * (c.max_iter + 2)); AL(err, B * M); AL(alphaOut, B * (c.max_iter + 2)); AL(state, B);
+#undef AL
+        std::vector<T> al(A);
+        for (size_t i = 0; i < A; i++) al[i] = (T)std::pow(c.alpha_base, (double)i);   // nisInitHelpers.cuh:829
+        HIPCHK(hipMemcpy(b.alpha, al.data(), A * sizeof(T), hipMemcpyHostToDevice));
+        typename P::Model hm; fill_model(hm, c);
+        void* dmodel = nullptr;
+        HIPCHK(hipMalloc(&dmodel, sizeof(hm))); allocs.push_back(dmodel);
+        HIPCHK(hipMemcpy(dmodel, &hm, sizeof(hm), hipMemcpyHostToDevice));
+        b.model = dmodel;
+        fp_lds = FpLds<P, T>::bytes(c.M, c.N);
+        if (fp_lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint exceeds 160 KiB: reduce M");
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp<P, INTEG, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp_lds));
+        HIPCHK(hipDeviceSynchronize());
+        return 0;
+    }
+    int load(const void* x0, const void* u0, const void* xg, int clear, int ignore_first_defect) override {
+        const size_t B = cfg.batch, N = cfg.N;
+        // current trajectory goes to half 0 of xb (state.cur = 0 after init)
+        for (size_t pb = 0; pb < B; pb++)
+            HIPCHK(hipMemcpyAsync(b.xb + pb * 2 * N * NX, (const T*)x0 + pb * N * NX, N * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(b.ucur, u0, B * N * NU * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(b.xGoal, xg, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (clear) {                                                 // clearVarsFlag, nisInitHelpers.cuh:612-619
+            HIPCHK(hipMemsetAsync(b.P, 0, B * N * NX * NX * sizeof(T), stream)); HIPCHK(hipMemsetAsync(b.Pp, 0, B * N * NX * NX * sizeof(T), stream));
+            HIPCHK(hipMemsetAsync(b.p, 0, B * N * NX * sizeof(T), stream)); HIPCHK(hipMemsetAsync(b.pp, 0, B * N * NX * sizeof(T), stream));
+            HIPCHK(hipMemsetAsync(b.KT, 0, B * N * NX * NU * sizeof(T), stream)); HIPCHK(hipMemsetAsync(b.dcur, 0, B * N * NX * sizeof(T), stream));
+        }
+        HIPCHK(hipMemsetAsync(b.du, 0, B * N * NU * sizeof(T), stream));   // always (:630-632)
+        HIPCHK(hipMemsetAsync(b.err, 0, B * cfg.M * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(b.dmax, 0, B * cfg.A * sizeof(T), stream));
+        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, 0);
+        hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(N, B), dim3(64), 0, stream, b, dm, cw, dt, 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    void launch_sweep(hipStream_t s, int only = -1) {
+        const unsigned B = cfg.batch;
+        if (only < 0 || only == PDDP_PHASE_BP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
+        if (only < 0 || only == PDDP_PHASE_FP) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt);
+        if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
+        if (only < 0 || only == PDDP_PHASE_NIS) hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, 0);
+    }
+    int iterate(int sweeps) override {
+        if (cfg.use_graph) {
+            if (!graph || graph_mode != bench_mode) {
+                if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+                hipGraph_t gr;
+                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                launch_sweep(stream);
+                HIPCHK(hipStreamEndCapture(stream, &gr));
+                HIPCHK(hipGraphInstantiate(&graph, gr, nullptr, nullptr, 0));
+                HIPCHK(hipGraphDestroy(gr));
+                graph_mode = bench_mode;
+            }
+            for (int i = 0; i < sweeps; i++) HIPCHK(hipGraphLaunch(graph, stream));
+        } else {
+            for (int i = 0; i < sweeps; i++) launch_sweep(stream);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int sync() override { HIPCHK(hipStreamSynchronize(stream)); return 0; }
+    int status(int* done, int* iters) override {
+        std::vector<SolverState<T>> st(cfg.batch);
+        HIPCHK(hipMemcpyAsync(st.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = st[i].done; if (iters) iters[i] = st[i].iter; }
+        return 0;
+    }
+    int store(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) override {
+        const size_t B = cfg.batch, N = cfg.N;
+        std::vector<SolverState<T>> st(B);
+        HIPCHK(hipMemcpyAsync(st.data(), b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (size_t pb = 0; pb < B; pb++) {
+            if (x) HIPCHK(hipMemcpyAsync((T*)x + pb * N * NX, b.xb + (pb * 2 + st[pb].cur) * N * NX, N * NX * sizeof(T), hipMemcpyDeviceToHost, stream));
+            if (dmax) HIPCHK(hipMemcpyAsync((T*)dmax + pb, b.dmax + pb * cfg.A + st[pb].alphaIndex, sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
+        if (u) HIPCHK(hipMemcpyAsync(u, b.ucur, B * N * NU * sizeof(T), hipMemcpyDeviceToHost, stream));
+        if (KT) HIPCHK(hipMemcpyAsync(KT, b.KT, B * N * NX * NU * sizeof(T), hipMemcpyDeviceToHost, stream));
+        if (Jout) HIPCHK(hipMemcpyAsync(Jout, b.Jout, B * (cfg.max_iter + 2) * sizeof(T), hipMemcpyDeviceToHost, stream));
+        if (alphaOut) HIPCHK(hipMemcpyAsync(alphaOut, b.alphaOut, B * (cfg.max_iter + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int time_sweeps(int sweeps, float* ms_total, float* ms_phase) override {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipEventRecord(e0, stream));
+        int rc = iterate(sweeps);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(e1, stream));
+        HIPCHK(hipEventSynchronize(e1));
+        if (ms_total) HIPCHK(hipEventElapsedTime(ms_total, e0, e1));
+        if (ms_phase) {   // second pass: an event pair around every launch of each of the four kernels
+            std::vector<hipEvent_t> ev(5 * (size_t)sweeps);
+            for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+            for (int i = 0; i < sweeps; i++)
+                for (int ph = 0; ph < 4; ph++) {
+                    if (ph == 0) HIPCHK(hipEventRecord(ev[5 * i], stream));
+                    launch_sweep(stream, ph);
+                    HIPCHK(hipEventRecord(ev[5 * i + ph + 1], stream));
+                }
+            HIPCHK(hipStreamSynchronize(stream));
+            for (int ph = 0; ph < 4; ph++) ms_phase[ph] = 0;
+            for (int i = 0; i < sweeps; i++)
+                for (int ph = 0; ph < 4; ph++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[5 * i + ph], ev[5 * i + ph + 1])); ms_phase[ph] += ms; }
+            for (auto& e : ev) hipEventDestroy(e);
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        return 0;
+    }
+    int array(const char* name, void** ptr, size_t* bytes) override {
+        auto it = arrays.find(name);
+        if (it == arrays.end()) return fail(PDDP_EINVAL, std::string("unknown array ") + name);
+        *ptr = it->second.first; *bytes = it->second.second;
+        return 0;
+    }
+    int get_state(pddp_state* out) override {
+        std::vector<SolverState<T>> st(cfg.batch);
+        HIPCHK(hipMemcpy(st.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost));
+        for (int i = 0; i < cfg.batch; i++) {
+            const auto& s = st[i]; pddp_state& o = out[i];
+            o.rho = s.rho; o.drho = s.drho; o.prevJ = s.prevJ; o.dJ = s.dJ; o.z = s.z; o.iter = s.iter; o.alphaIndex = s.alphaIndex;
+            o.ignore_defect = s.ignore_defect; o.accepted = s.accepted; o.done = s.done; o.cur = s.cur; o.cur2 = s.cur2; o.bp_retries = s.bp_retries;
+        }
+        return 0;
+    }
+    int set_state(const pddp_state* in) override {
+        std::vector<SolverState<T>> st(cfg.batch);
+        for (int i = 0; i < cfg.batch; i++) {
+            auto& s = st[i]; const pddp_state& o = in[i];
+            s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
+            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.pad = 0;
+        }
+        HIPCHK(hipMemcpy(b.state, st.data(), cfg.batch * sizeof(SolverState<T>), hipMemcpyHostToDevice));
+        return 0;
+    }
+    int run_phase(int phase) override {
+        const unsigned B = cfg.batch;
+        if (phase >= 0 && phase <= 3) launch_sweep(stream, phase);
+        else if (phase == PDDP_PHASE_INIT_NIS) hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, stream, b, dm, cw, dt, 1);
+        else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0);
+        else return fail(PDDP_EINVAL, "unknown phase");
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
+        if (what < 0 || what > 3 || count <= 0) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
+        const size_t osz = (what == 0 ? NP : what == 1 ? NP * NM : what == 2 ? NX : NX * NM);
+        T *dx, *du_, *dout;
+        HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&du_, (size_t)count * NU * sizeof(T)));
+        HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
+        HIPCHK(hipMemcpy(dx, x, (size_t)count * NX * sizeof(T), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
+        const int grid = count < 4096 ? count : 4096;
+        hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipMemcpy(out, dout, (size_t)count * osz * sizeof(T), hipMemcpyDeviceToHost));
+        hipFree(dx); hipFree(du_); hipFree(dout);
+        return 0;
+    }
+};
+
+template <template <typename> class PT, typename T>
+static SolverBase* make_integ(int integ) {
+    switch (integ) {
+    case 1: return new Solver<PT<T>, 1, T>();
+    case 2: return new Solver<PT<T>, 2, T>();
+    case 3: return new Solver<PT<T>, 3, T>();
+    }
+    return nullptr;
+}
+template <typename T>
+static SolverBase* make_plant(const pddp_config& c) {
+    switch (c.plant) {
+    case 1: return make_integ<PendPlant, T>(c.integrator);
+    case 2: return make_integ<CartPlant, T>(c.integrator);
+    case 3: return make_integ<QuadPlant, T>(c.integrator);
+    case 4: return c.integrator == 1 ? new Solver<ArmPlant<T>, 1, T>() : nullptr;   // the arm is Euler-only, as config.cuh:58
+    }
+    return nullptr;
+}
+
+extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
+    if (!cfg || !out) return fail(PDDP_EINVAL, "null argument");
+    const pddp_config& c = *cfg;
+    if (c.plant < 1 || c.plant > 4) return fail(PDDP_EINVAL, "plant must be 1..4");
+    if (c.N < 4 || (c.N & (c.N - 1)) || c.N > 1024) return fail(PDDP_EINVAL, "N must be a power of two in [4,1024] (the reference's tree reductions assume it)");
+    if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
+    if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
+    SolverBase* s = c.dtype == 0 ? make_plant<float>(c) : c.dtype == 1 ? make_plant<double>(c) : nullptr;
+    if (!s) return fail(PDDP_EINVAL, "unsupported plant / integrator / dtype combination (the arm supports Euler only)");
+    s->cfg = c;
+    int rc = s->init();
+    if (rc) { delete s; return rc; }
+    *out = new pddp_solver{s};
+    return 0;
+}
+extern "C" int pddp_destroy(pddp_handle h) { if (h) { delete h->impl; delete h; } return 0; }
+#define IMPL(h) if (!(h)) return fail(PDDP_EINVAL, "null handle"); SolverBase* s = (h)->impl
+extern "C" int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xg, int clear, int ifd) { IMPL(h); return s->load(x0, u0, xg, clear, ifd); }
+extern "C" int pddp_iterate(pddp_handle h, int sweeps) { IMPL(h); return s->iterate(sweeps); }
+extern "C" int pddp_sync(pddp_handle h) { IMPL(h); return s->sync(); }
+extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); return s->status(done, iters); }
+extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { IMPL(h); return s->store(x, u, KT, Jout, alphaOut, dmax); }
+extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
+extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { IMPL(h); s->bench_mode = on ? 1 : 0; return 0; }
+extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { IMPL(h); void* p; return s->array(name, &p, bytes); }
+extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes) {
+    IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
+    if (bytes > cap) return fail(PDDP_EINVAL, "set_array: too many bytes");
+    HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice)); return 0;
+}
+extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes) {
+    IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
+    if (bytes > cap) return fail(PDDP_EINVAL, "get_array: too many bytes");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost)); return 0;
+}
+extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { IMPL(h); return s->get_state(out); }
+extern "C" int pddp_set_state(pddp_handle h, const pddp_state* in) { IMPL(h); return s->set_state(in); }
+extern "C" int pddp_run_phase(pddp_handle h, int phase) { IMPL(h); return s->run_phase(phase); }
+extern "C" int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out) { IMPL(h); return s->plant_eval(what, count, x, u, out); }
+
+// runiLQR_GPU (DDPWrappers.cuh:10-138) for the batch.
+extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
+    IMPL(h);
+    const double t0 = now_ms();
+    int rc = s->load(x0, u0, xGoal, clear, ifd);
+    if (rc) return rc;
+    double t_init = now_ms() - t0;
+    std::vector<int> done(s->cfg.batch);
+    const int chunk = 8;                                       // sweeps enqueued between two polls of the exit flags
+    for (int guard = 0; guard < 1000000; guard++) {
+        if ((rc = s->iterate(chunk))) return rc;
+        if ((rc = s->status(done.data(), nullptr))) return rc;
+        bool all = true;
+        for (int d : done) all &= (d != 0);
+        if (all) break;
+    }
+    const double t1 = now_ms();
+    if ((rc = s->store(x0, u0, nullptr, Jout, alphaOut, nullptr))) return rc;
+    const double t2 = now_ms();
+    if (times_ms) { times_ms[0] = t2 - t0; times_ms[1] = t_init + (t2 - t1); }
+    return 0;
+}

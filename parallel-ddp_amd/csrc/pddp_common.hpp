@@ -1,0 +1,110 @@
+// parallel-ddp_amd: common device/host scaffolding for the wave-cooperative kernels (gfx950).
+//
+// Execution model.  Every unit of work of the DDP hot path (one backward-pass block, one forward
+// shooting segment, one knot's derivatives) is owned by ONE 64-lane wavefront.  The reference assigns
+// a 56-thread block with __syncthreads() between micro-stages (DDPWrappers.cuh:27-29); on CDNA4 that
+// whole block fits one wave, so stage boundaries become wave-local LDS fences (no s_barrier traffic)
+// and a workgroup can hold several independent waves whose loops have different trip counts.
+//
+// Code is written as a sequence of STAGES.  Inside a stage every lane writes disjoint LDS/registers and
+// reads only what earlier stages produced; stages are separated by wsync().  The same source compiles
+// for the host with a 1-lane "wave" (lane loops run serially), which is how tests/hostsim checks the
+// kernel arithmetic on a machine without a GPU.  The product library never uses that mode.
+#pragma once
+
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PDDP_HD __host__ __device__ __forceinline__
+#define PDDP_D __device__ __forceinline__
+#else
+#define PDDP_HD inline
+#define PDDP_D inline
+#endif
+
+namespace pddp {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+struct Wave {
+    int lane;    // first index this lane handles
+    int nlanes;  // stride between indices (64 on the GPU, 1 in host emulation)
+};
+
+PDDP_HD Wave this_wave() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return Wave{static_cast<int>(threadIdx.x) & (kWave - 1), kWave};
+#else
+    return Wave{0, 1};
+#endif
+}
+// Wave-local stage boundary: LDS operations of one wave are issued and retired in order, so only the
+// compiler has to be stopped from moving LDS traffic across the boundary.
+PDDP_HD void wsync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+#define PDDP_FOR(i, n) for (int i = w.lane; i < (n); i += w.nlanes)
+
+template <typename T> PDDP_HD T tsin(T v);
+template <typename T> PDDP_HD T tcos(T v);
+template <> PDDP_HD float tsin<float>(float v) { return sinf(v); }
+template <> PDDP_HD float tcos<float>(float v) { return cosf(v); }
+template <> PDDP_HD double tsin<double>(double v) { return sin(v); }
+template <> PDDP_HD double tcos<double>(double v) { return cos(v); }
+template <typename T> PDDP_HD T tabs(T v) { return v < T(0) ? -v : v; }
+template <typename T> PDDP_HD T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> PDDP_HD T tmin(T a, T b) { return a < b ? a : b; }
+
+// ---- spatial 6-vector helpers ([angular; linear]) on register arrays -----------------------------
+template <typename T> PDDP_HD void cross3(T* o, const T* a, const T* b) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// o = crm(a) b   (spatial motion cross product)
+template <typename T> PDDP_HD void crm_mul(T* o, const T* a, const T* b) {
+    T t[3];
+    cross3(o, a, b);
+    cross3(o + 3, a, b + 3);
+    cross3(t, a + 3, b);
+    o[3] += t[0]; o[4] += t[1]; o[5] += t[2];
+}
+// o = crf(a) f   (spatial force cross product, crf = -crm^T)
+template <typename T> PDDP_HD void crf_mul(T* o, const T* a, const T* f) {
+    T t[3];
+    cross3(o, a, f);
+    cross3(t, a + 3, f + 3);
+    o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
+    cross3(o + 3, a, f + 3);
+}
+// o = A v, A column-major 6x6
+template <typename T> PDDP_HD void mat6_mul(T* o, const T* A, const T* v) {
+    for (int r = 0; r < 6; r++) {
+        T s = 0;
+        for (int c = 0; c < 6; c++) s += A[r + 6 * c] * v[c];
+        o[r] = s;
+    }
+}
+template <typename T> PDDP_HD T dot6(const T* a, const T* b) {
+    T s = 0;
+    for (int i = 0; i < 6; i++) s += a[i] * b[i];
+    return s;
+}
+
+// Problem dimensions shared by every kernel.  Runtime values (the reference fixes them at compile time,
+// config.cuh:90-94,113-115,133-136).
+struct Dims {
+    int N;   // knots (NUM_TIME_STEPS)
+    int M;   // shooting segments == backward blocks (M_BLOCKS_F == M_BLOCKS_B)
+    int A;   // line-search step sizes (NUM_ALPHA)
+    int NB;  // knots per block, N / M
+    PDDP_HD bool on_defect_boundary(int k) const { return (((k + 1) % NB) == 0) && (k < N - 1); }  // config.cuh:127
+};
+
+}  // namespace pddp

@@ -1,0 +1,136 @@
+// Plant plug-in surface of the kernels.  A plant is a policy struct (compile-time, like the reference's
+// `#define PLANT` + config.cuh:240-252 include switch) providing
+//     dims NPOS/NX/NU, Model (device constants), Scratch/GradScratch (per-wave LDS),
+//     dynamics(), gradient()   -- wave-cooperative, the whole wave is inside the call (the reference's plug-ins
+//                                 run with the whole thread block inside them),
+//     cost(), cost_grad()      -- single-lane, per knot.
+// Plants: 1 pendulum, 2 cart-pole, 3 quadrotor, 4 KUKA iiwa14 (reference PLANT codes, config.cuh:21-61).
+#pragma once
+
+#include "plant_arm.hpp"
+#include "plant_closed_form.hpp"
+
+namespace pddp {
+
+template <typename T>
+struct CostWeights {   // arm joint-space weights (plants/cost_arm.cuh:97-103); other plants use fixed macros
+    T Q1, Q2, R, QF1, QF2;
+};
+
+struct EmptyModel { int unused; };
+template <typename T> struct EmptyScratch { T unused; };
+
+// ---- older 4-argument diagonal costs of pend / cart / quad (plants/cost_{pend,cart,quad}.cuh) ------------
+// weight(i): running weight of state/control index i; QF: final weight.  pow(T,int) promotes to double on the
+// host path the oracle restates; we keep the square in double for both precisions.
+template <typename P, typename T>
+PDDP_HD T diag_cost(const T* xk, const T* uk, const T* xg, int k, int N) {
+    T cost = 0.0;
+    for (int i = 0; i < P::NX; i++) { const double dl = xk[i] - xg[i]; cost += (T)(k == N - 1 ? P::QF(N) : P::QR(i, N)) * (dl * dl); }
+    if (k != N - 1) for (int i = 0; i < P::NU; i++) { const double uu = uk[i]; cost += (T)P::Rw(N) * (uu * uu); }
+    return 0.5 * cost;
+}
+template <typename P, typename T>
+PDDP_HD void diag_cost_grad(T* Hk, T* gk, const T* xk, const T* uk, const T* xg, int k, int N) {
+    constexpr int NM = P::NX + P::NU;
+    for (int i = 0; i < NM; i++) for (int j = 0; j < NM; j++)
+        Hk[i * NM + j] = (T)(i != j ? 0.0 : (k == N - 1 ? (i < P::NX ? P::QF(N) : 0.0) : P::QR(i, N)));
+    for (int i = 0; i < P::NX; i++) gk[i] = (T)(k == N - 1 ? P::QF(N) : P::QR(i, N)) * (xk[i] - xg[i]);
+    for (int i = 0; i < P::NU; i++) gk[i + P::NX] = (T)(k == N - 1 ? 0.0 : P::Rw(N)) * uk[i];
+}
+
+#define PDDP_CLOSED_FORM_PLANT(NAME, CODE, NP, NUv, EVAL, GRAD)                                                          \
+    template <typename T>                                                                                                \
+    struct NAME {                                                                                                        \
+        static constexpr int PLANT = CODE, NPOS = NP, NX = 2 * NP, NU = NUv;                                             \
+        using Model = EmptyModel;                                                                                        \
+        using Scratch = EmptyScratch<T>;                                                                                 \
+        using GradScratch = EmptyScratch<T>;                                                                             \
+        static PDDP_HD void load_model(const Wave&, Scratch&, const Model*) {}                                           \
+        static PDDP_HD void dynamics(const Wave& w, Scratch&, T* qdd, const T* x, const T* u) {                          \
+            if (w.lane == 0) EVAL<T>(qdd, x, u);                                                                         \
+            wsync();                                                                                                     \
+        }                                                                                                                \
+        static PDDP_HD void gradient(const Wave& w, Scratch&, GradScratch&, T* dqdd, T* qdd, const T* x, const T* u) {   \
+            if (w.lane == 0) GRAD<T>(dqdd, qdd, x, u);                                                                   \
+            wsync();                                                                                                     \
+        }                                                                                                                \
+        static PDDP_HD T cost(const CostWeights<T>&, const T* xk, const T* uk, const T* xg, int k, int N) {              \
+            return diag_cost<NAME<T>, T>(xk, uk, xg, k, N);                                                              \
+        }                                                                                                                \
+        static PDDP_HD void cost_grad(const CostWeights<T>&, T* Hk, T* gk, const T* xk, const T* uk, const T* xg, int k, \
+                                      int N) {                                                                           \
+            diag_cost_grad<NAME<T>, T>(Hk, gk, xk, uk, xg, k, N);                                                        \
+        }                                                                                                                \
+        /* diagonal weight of state/control index i at knot k (H_k = diag(weight), g_k = weight .* [x-xg; u]) */          \
+        static PDDP_HD T weight(const CostWeights<T>&, int i, int k, int N) {                                            \
+            return (T)(k == N - 1 ? (i < NX ? QF(N) : 0.0) : QR(i, N));                                                  \
+        }                                                                                                                \
+        static PDDP_HD double QR(int i, int N);                                                                          \
+        static PDDP_HD double Rw(int N);                                                                                 \
+        static PDDP_HD double QF(int N);                                                                                 \
+    };
+
+PDDP_CLOSED_FORM_PLANT(PendPlant, 1, 1, 1, pend_dynamics_eval, pend_gradient_eval)
+PDDP_CLOSED_FORM_PLANT(CartPlant, 2, 2, 1, cart_dynamics_eval, cart_gradient_eval)
+PDDP_CLOSED_FORM_PLANT(QuadPlant, 3, 6, 4, quad_dynamics_eval, quad_gradient_eval)
+#undef PDDP_CLOSED_FORM_PLANT
+
+// cost_pend.cuh:19-24 (QR(1) falls through to R, QR(2) is the control's Q2)
+template <typename T> PDDP_HD double PendPlant<T>::QR(int i, int) { return i == 0 ? 1.0 : (i == 2 ? 0.1 : 0.1); }
+template <typename T> PDDP_HD double PendPlant<T>::Rw(int) { return 0.1; }
+template <typename T> PDDP_HD double PendPlant<T>::QF(int) { return 1000.0; }
+// cost_cart.cuh:19-38 (weights depend on the horizon length)
+template <typename T> PDDP_HD double CartPlant<T>::QR(int i, int N) {
+    if (N == 512) return i == 0 ? 0.01 : (i == 1 ? 0.01 : (i < 4 ? 0.01 : 0.001));
+    return i == 0 ? 0.01 : (i == 1 ? 0.01 : (i < 4 ? 0.001 : 0.0001));
+}
+template <typename T> PDDP_HD double CartPlant<T>::Rw(int N) { return N == 512 ? 0.001 : 0.0001; }
+template <typename T> PDDP_HD double CartPlant<T>::QF(int N) { return N == 512 ? 100000.0 : 1000.0; }
+// cost_quad.cuh:19-25
+template <typename T> PDDP_HD double QuadPlant<T>::QR(int i, int) { return i < 3 ? 0.01 : (i < 6 ? 0.001 : (i < 9 ? 2.0 : (i < 12 ? 2.0 : 5.0))); }
+template <typename T> PDDP_HD double QuadPlant<T>::Rw(int) { return 5.0; }
+template <typename T> PDDP_HD double QuadPlant<T>::QF(int) { return 1000.0; }
+
+// ---- KUKA arm, joint-space cost (plants/cost_arm.cuh:130-153, 158-202) --------------------------------------
+template <typename T>
+struct ArmPlant {
+    static constexpr int PLANT = 4, NPOS = 7, NX = 14, NU = 7;
+    using Model = ArmModel<T>;
+    using Scratch = ArmScratch<T>;
+    using GradScratch = ArmGradScratch<T>;
+    static PDDP_HD void load_model(const Wave& w, Scratch& s, const Model* m) { arm_load_model(w, s, m); }
+    static PDDP_HD void dynamics(const Wave& w, Scratch& s, T* qdd, const T* x, const T* u) { arm_dynamics(w, s, qdd, x, u); }
+    static PDDP_HD void gradient(const Wave& w, Scratch& s, GradScratch& g, T* dqdd, T* qdd, const T* x, const T* u) {
+        arm_dynamics_gradient(w, s, g, dqdd, qdd, x, u);
+    }
+    static PDDP_HD T weight(const CostWeights<T>& cw, int i, int k, int N) {
+        if (k == N - 1) return i < NPOS ? cw.QF1 : (i < NX ? cw.QF2 : T(0));
+        return i < NPOS ? cw.Q1 : (i < NX ? cw.Q2 : cw.R);
+    }
+    static PDDP_HD T cost(const CostWeights<T>& cw, const T* xk, const T* uk, const T* xg, int k, int N) {
+        T cost = 0;
+        if (k == N - 1) {
+            for (int i = 0; i < NX; i++) { const T dl = xk[i] - xg[i]; cost += (i < NPOS ? cw.QF1 : cw.QF2) * dl * dl; }
+        } else {
+            for (int i = 0; i < NX; i++) { const T dl = xk[i] - xg[i]; cost += (i < NPOS ? cw.Q1 : cw.Q2) * dl * dl; }
+            for (int i = 0; i < NU; i++) cost += cw.R * uk[i] * uk[i];
+        }
+        return T(0.5) * cost;
+    }
+    // H_k is (NX+NU)^2 column-major; at the final knot only the NX x NX block and g are defined
+    // (cost_arm.cuh:159-174) -- we still write zeros to the rest so the buffer is deterministic.
+    static PDDP_HD void cost_grad(const CostWeights<T>& cw, T* Hk, T* gk, const T* xk, const T* uk, const T* xg, int k, int N) {
+        constexpr int NM = NX + NU;
+        const bool fin = (k == N - 1);
+        for (int i = 0; i < NM; i++) for (int j = 0; j < NM; j++) {
+            T v = 0;
+            if (i == j) v = fin ? (i < NPOS ? cw.QF1 : (i < NX ? cw.QF2 : T(0))) : (i < NPOS ? cw.Q1 : (i < NX ? cw.Q2 : cw.R));
+            Hk[i * NM + j] = v;
+        }
+        for (int i = 0; i < NX; i++) gk[i] = (fin ? (i < NPOS ? cw.QF1 : cw.QF2) : (i < NPOS ? cw.Q1 : cw.Q2)) * (xk[i] - xg[i]);
+        for (int i = 0; i < NU; i++) gk[i + NX] = fin ? T(0) : cw.R * uk[i];
+    }
+};
+
+}  // namespace pddp

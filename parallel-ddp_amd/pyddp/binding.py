@@ -1,0 +1,183 @@
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PLANT_DIMS = {1: (1, 2, 1), 2: (2, 4, 1), 3: (6, 12, 4), 4: (7, 14, 7)}  # npos, n, m (config.cuh:24-46)
+PHASE_BP, PHASE_FP, PHASE_LS, PHASE_NIS, PHASE_INIT_NIS, PHASE_INIT_COST = range(6)
+
+
+class PddpError(RuntimeError):
+    pass
+
+
+class PddpConfig(C.Structure):
+    """pddp_config (include/pddp.h): the reference's config.cuh macros as a run-time record."""
+    _fields_ = [
+        ("plant", C.c_int), ("dtype", C.c_int), ("N", C.c_int), ("M", C.c_int), ("A", C.c_int), ("integrator", C.c_int),
+        ("batch", C.c_int), ("max_iter", C.c_int), ("wafr_urdf", C.c_int), ("mpc_mode", C.c_int),
+        ("ignore_max_rho_exit", C.c_int), ("device", C.c_int), ("use_graph", C.c_int),
+        ("total_time", C.c_double), ("alpha_base", C.c_double), ("rho_init", C.c_double), ("max_defect", C.c_double),
+        ("tol_cost", C.c_double), ("exp_red_min", C.c_double), ("exp_red_max", C.c_double),
+        ("Q1", C.c_double), ("Q2", C.c_double), ("R", C.c_double), ("QF1", C.c_double), ("QF2", C.c_double),
+    ]
+
+
+class PddpState(C.Structure):
+    _fields_ = [("rho", C.c_double), ("drho", C.c_double), ("prevJ", C.c_double), ("dJ", C.c_double), ("z", C.c_double),
+                ("iter", C.c_int), ("alphaIndex", C.c_int), ("ignore_defect", C.c_int), ("accepted", C.c_int),
+                ("done", C.c_int), ("cur", C.c_int), ("cur2", C.c_int), ("bp_retries", C.c_int)]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(_HERE), "lib", "libpddp.so")
+
+
+_LIBS = {}
+
+
+def _load(path):
+    if path not in _LIBS:
+        if not os.path.exists(path):
+            raise PddpError(f"{path} not found: build it with `make -C parallel-ddp_amd` (there is no CPU fallback)")
+        lib = C.CDLL(path)
+        lib.pddp_last_error.restype = C.c_char_p
+        _LIBS[path] = lib
+    return _LIBS[path]
+
+
+def default_config(plant, _lib_path=None, **kw):
+    lib = _load(_lib_path or library_path())
+    c = PddpConfig()
+    rc = lib.pddp_default_config(C.byref(c), int(plant))
+    if rc:
+        raise PddpError(lib.pddp_last_error().decode())
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Solver:
+    """One pddp handle = the buffers of allocateMemory_GPU for `batch` problems + the solver kernels."""
+
+    def __init__(self, cfg, _lib_path=None):
+        self.path = _lib_path or library_path()
+        if _lib_path is None and "hostsim" in self.path:
+            raise PddpError("the product binding never loads the host emulation")
+        self.lib = _load(self.path)
+        self.cfg = cfg
+        self.dtype = np.dtype(np.float32 if cfg.dtype == 0 else np.float64)
+        self.npos, self.n, self.m = PLANT_DIMS[cfg.plant]
+        self.h = C.c_void_p()
+        self._chk(self.lib.pddp_create(C.byref(cfg), C.byref(self.h)))
+
+    def _chk(self, rc):
+        if rc:
+            raise PddpError(f"pddp error {rc}: {self.lib.pddp_last_error().decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.pddp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def arr(self, a):
+        return np.ascontiguousarray(a, dtype=self.dtype)
+
+    # ---- runiLQR_GPU pieces
+    def load(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1):
+        B, N = self.cfg.batch, self.cfg.N
+        x0, u0, xGoal = self.arr(x0), self.arr(u0), self.arr(xGoal)
+        assert x0.size == B * N * self.n and u0.size == B * N * self.m and xGoal.size == B * self.n
+        self._chk(self.lib.pddp_load(self.h, _p(x0), _p(u0), _p(xGoal), int(clear_vars), int(ignore_first_defect)))
+
+    def iterate(self, sweeps=1):
+        self._chk(self.lib.pddp_iterate(self.h, int(sweeps)))
+
+    def sync(self):
+        self._chk(self.lib.pddp_sync(self.h))
+
+    def status(self):
+        B = self.cfg.batch
+        done, iters = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        self._chk(self.lib.pddp_status(self.h, _p(done), _p(iters)))
+        return done, iters
+
+    def store(self):
+        B, N, n, m, mi = self.cfg.batch, self.cfg.N, self.n, self.m, self.cfg.max_iter
+        out = dict(x=np.zeros((B, N, n), self.dtype), u=np.zeros((B, N, m), self.dtype), KT=np.zeros((B, N, m, n), self.dtype),
+                   Jout=np.zeros((B, mi + 2), self.dtype), alphaOut=np.zeros((B, mi + 2), np.int32), dmax=np.zeros(B, self.dtype))
+        self._chk(self.lib.pddp_store(self.h, _p(out["x"]), _p(out["u"]), _p(out["KT"]), _p(out["Jout"]), _p(out["alphaOut"]), _p(out["dmax"])))
+        return out
+
+    def solve(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1, max_sweeps=None, chunk=8):
+        """load -> iterate until every problem has exited -> store (the shape of runiLQR_GPU)."""
+        self.load(x0, u0, xGoal, clear_vars, ignore_first_defect)
+        limit = max_sweeps if max_sweeps is not None else 4 * (self.cfg.max_iter + 2) + 250
+        sweeps = 0
+        while sweeps < limit:
+            self.iterate(chunk)
+            sweeps += chunk
+            done, iters = self.status()
+            if done.all():
+                break
+        out = self.store()
+        out["done"], out["iters"], out["sweeps"] = done, iters, sweeps
+        return out
+
+    # ---- measurement
+    def set_benchmark_mode(self, on):
+        self._chk(self.lib.pddp_set_benchmark_mode(self.h, int(on)))
+
+    def time_sweeps(self, sweeps, phases=False):
+        tot = C.c_float(0)
+        ph = (C.c_float * 4)()
+        self._chk(self.lib.pddp_time_sweeps(self.h, int(sweeps), C.byref(tot), ph if phases else None))
+        return tot.value, [v for v in ph]
+
+    # ---- teacher-forced hooks
+    def _adtype(self, name):
+        return np.int32 if name in ("err", "alphaOut") else self.dtype
+
+    def get(self, name):
+        nb = C.c_size_t(0)
+        self._chk(self.lib.pddp_array_bytes(self.h, name.encode(), C.byref(nb)))
+        a = np.zeros(nb.value // np.dtype(self._adtype(name)).itemsize, self._adtype(name))
+        self._chk(self.lib.pddp_get_array(self.h, name.encode(), _p(a), C.c_size_t(nb.value)))
+        return a
+
+    def set(self, name, a):
+        a = np.ascontiguousarray(a, dtype=self._adtype(name)).ravel()
+        self._chk(self.lib.pddp_set_array(self.h, name.encode(), _p(a), C.c_size_t(a.nbytes)))
+
+    def get_state(self):
+        st = (PddpState * self.cfg.batch)()
+        self._chk(self.lib.pddp_get_state(self.h, st))
+        return st
+
+    def set_state(self, st):
+        self._chk(self.lib.pddp_set_state(self.h, st))
+
+    def run_phase(self, phase):
+        self._chk(self.lib.pddp_run_phase(self.h, int(phase)))
+
+    def plant_eval(self, what, x, u):
+        x, u = self.arr(x).reshape(-1, self.n), self.arr(u).reshape(-1, self.m)
+        count = x.shape[0]
+        nm = self.n + self.m
+        osz = [self.npos, self.npos * nm, self.n, self.n * nm][what]
+        out = np.zeros((count, osz), self.dtype)
+        self._chk(self.lib.pddp_plant_eval(self.h, int(what), count, _p(x), _p(u), _p(out)))
+        return out

@@ -1,0 +1,247 @@
+// TEST TOOL -- NOT PRODUCT CODE.
+// libpddp_hostsim.so: the C ABI of include/pddp.h implemented by running the kernel BODIES (parallel-ddp_amd/csrc/
+// bodies.hpp and below, the very headers the HIP kernels are compiled from) on the host with a 1-lane "wave".
+// It exists so that the arithmetic and indexing of the kernels can be checked against the oracle on a machine
+// without a GPU (`pytest -m "not gpu"`).  It cannot detect cross-lane races; the GPU tests do that.
+// Only tests/ loads it; the product binding (parallel-ddp_amd/pyddp) refuses to.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pddp.h"
+#include "../../parallel-ddp_amd/csrc/bodies.hpp"
+#include "../../parallel-ddp_amd/csrc/iiwa14_model_data.h"
+
+using namespace pddp;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+extern "C" const char* pddp_last_error(void) { return g_err.c_str(); }
+extern "C" int pddp_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 4 ? 14 : -1; }
+extern "C" int pddp_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 4 ? 7 : -1; }
+extern "C" int pddp_default_config(pddp_config* c, int plant) {
+    std::memset(c, 0, sizeof(*c));
+    c->plant = plant; c->N = plant == 4 ? 64 : 128; c->M = 4; c->A = (plant == 3 || plant == 4) ? 16 : 32;
+    c->integrator = plant == 4 ? 1 : 3; c->batch = 1; c->max_iter = 100; c->ignore_max_rho_exit = 1;
+    c->total_time = plant == 4 ? 0.5 : 4.0; c->alpha_base = (plant == 3 || plant == 4) ? 0.5 : 0.75;
+    c->rho_init = plant == 4 ? 12.5 : (plant == 3 ? 1.0 : 10.0); c->max_defect = plant == 2 ? 0.75 : 1.0;
+    c->tol_cost = 0.0001; c->exp_red_min = 0.05; c->exp_red_max = 1.25;
+    c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
+    return 0;
+}
+
+struct Base {
+    pddp_config cfg; int bench = 0;
+    virtual ~Base() {}
+    virtual int load(const void*, const void*, const void*, int, int) = 0;
+    virtual int iterate(int) = 0;
+    virtual int status(int*, int*) = 0;
+    virtual int store(void*, void*, void*, void*, int*, void*) = 0;
+    virtual int array(const char*, void**, size_t*) = 0;
+    virtual int get_state(pddp_state*) = 0;
+    virtual int set_state(const pddp_state*) = 0;
+    virtual int run_phase(int) = 0;
+    virtual int plant_eval(int, int, const void*, const void*, void*) = 0;
+};
+struct pddp_solver { Base* impl; };
+
+template <typename T> static void fill_model(ArmModel<T>& m, const pddp_config& c) {
+    const int v = c.wafr_urdf ? 1 : 0;
+    for (int b = 0; b < 7; b++) { for (int i = 0; i < 36; i++) m.I[36 * b + i] = (T)IIWA14_SPATIAL_INERTIA[v][b][i];
+                                  for (int i = 0; i < 16; i++) m.F[16 * b + i] = (T)IIWA14_JOINT_FRAME[v][b][i]; }
+    m.grav = (T)(c.mpc_mode ? 0.0 : 9.81);
+}
+static void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
+
+template <typename P, int INTEG, typename T>
+struct Sim : Base {
+    static constexpr int NX = P::NX, NU = P::NU, NM = NX + NU, NP = P::NPOS;
+    Buffers<T> b{}; Dims dm{}; SolverParams sp{}; CostWeights<T> cw{}; T dt{};
+    typename P::Model model;
+    std::map<std::string, std::pair<void*, size_t>> arrays;
+    std::vector<void*> allocs;
+    ~Sim() override { for (void* p : allocs) std::free(p); }
+    template <typename U> void al(const char* name, U** out, size_t count) {
+        void* p = std::calloc(count, sizeof(U)); allocs.push_back(p); arrays[name] = {p, count * sizeof(U)}; *out = (U*)p;
+    }
+    void init() {
+        const pddp_config& c = cfg;
+        dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
+        sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
+        sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;
+        cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
+        dt = (T)(c.total_time / (c.N - 1));
+        const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
+#define AL(name, count) al(#name, &b.name, (count))
+        AL(xs, B * A * N * NX); AL(us, B * A * N * NU); AL(ds, B * A * N * NX);
+        AL(xb, B * 2 * N * NX); AL(ucur, B * N * NU); AL(dcur, B * N * NX);
+        AL(P, B * N * NX * NX); AL(p, B * N * NX); AL(Pp, B * N * NX * NX); AL(pp, B * N * NX);
+        AL(AB, B * N * NX * NM); AL(H, B * N * NM * NM); AL(g, B * N * NM);
+        AL(KT, B * N * NX * NU); AL(du, B * N * NU); AL(ApBK, B * N * NX * NX); AL(Bdu, B * N * NX);
+        AL(J, B * A); AL(dmax, B * A); AL(dJexp, B * 2 * M); AL(alpha, A); AL(xGoal, B * NX);
+        AL(Jout, B * (c.max_iter + 2)); AL(err, B * M); AL(alphaOut, B * (c.max_iter + 2)); AL(state, B);
+#undef AL
+        for (size_t i = 0; i < A; i++) b.alpha[i] = (T)std::pow(c.alpha_base, (double)i);
+        fill_model(model, c); b.model = &model;
+    }
+    void phase(int ph) {
+        const int B = cfg.batch; const Wave w = this_wave();
+        if (ph == PDDP_PHASE_BP) {
+            static BpScratch<P, T> s;
+            for (int pb = 0; pb < B; pb++) for (int blk = 0; blk < cfg.M; blk++) bp_body<P, T>(w, s, b, dm, blk, pb);
+        } else if (ph == PDDP_PHASE_FP) {
+            static SweepScratch<P, T> sw; static SimScratch<P, T> sim;
+            std::vector<T> cost_k(cfg.N), segx(cfg.M * NX), dnorm(cfg.M);
+            for (int pb = 0; pb < B; pb++) {
+                if (!fp_active<T>(b, dm, pb)) continue;
+                for (int a = 0; a < cfg.A; a++) {
+                    const FpArgs<T> fa = fp_args<P, T>(b, dm, pb, a, dt, segx.data(), dnorm.data());
+                    if (cfg.M > 1) forward_sweep<P, T>(w, sw, dm, fa);
+                    P::load_model(w, sim.plant, &model);
+                    for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + (size_t)pb * NX, cost_k.data());
+                    fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data());
+                }
+            }
+        } else if (ph == PDDP_PHASE_LS) {
+            for (int pb = 0; pb < B; pb++) ls_body<T>(b, dm, sp, pb, bench);
+        } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
+            static NisScratch<P, INTEG, T> s;
+            for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) nis_body<P, INTEG, T>(w, s, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+        } else if (ph == PDDP_PHASE_INIT_COST) {
+            std::vector<T> cost_k(cfg.N);
+            for (int pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, 1, 0, pb);
+        }
+    }
+    int load(const void* x0, const void* u0, const void* xg, int clear, int ifd) override {
+        const size_t B = cfg.batch, N = cfg.N;
+        for (size_t pb = 0; pb < B; pb++) std::memcpy(b.xb + pb * 2 * N * NX, (const T*)x0 + pb * N * NX, N * NX * sizeof(T));
+        std::memcpy(b.ucur, u0, B * N * NU * sizeof(T)); std::memcpy(b.xGoal, xg, B * NX * sizeof(T));
+        if (clear) {
+            std::memset(b.P, 0, B * N * NX * NX * sizeof(T)); std::memset(b.Pp, 0, B * N * NX * NX * sizeof(T));
+            std::memset(b.p, 0, B * N * NX * sizeof(T)); std::memset(b.pp, 0, B * N * NX * sizeof(T));
+            std::memset(b.KT, 0, B * N * NX * NU * sizeof(T)); std::memset(b.dcur, 0, B * N * NX * sizeof(T));
+        }
+        std::memset(b.du, 0, B * N * NU * sizeof(T)); std::memset(b.err, 0, B * cfg.M * sizeof(int)); std::memset(b.dmax, 0, B * cfg.A * sizeof(T));
+        std::vector<T> cost_k(cfg.N); const Wave w = this_wave();
+        for (size_t pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 0, (int)pb);
+        phase(PDDP_PHASE_INIT_NIS);
+        return 0;
+    }
+    int iterate(int sweeps) override { for (int i = 0; i < sweeps; i++) for (int ph = 0; ph < 4; ph++) phase(ph); return 0; }
+    int status(int* done, int* iters) override {
+        for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = b.state[i].done; if (iters) iters[i] = b.state[i].iter; }
+        return 0;
+    }
+    int store(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) override {
+        const size_t B = cfg.batch, N = cfg.N;
+        for (size_t pb = 0; pb < B; pb++) {
+            if (x) std::memcpy((T*)x + pb * N * NX, b.xb + (pb * 2 + b.state[pb].cur) * N * NX, N * NX * sizeof(T));
+            if (dmax) ((T*)dmax)[pb] = b.dmax[pb * cfg.A + b.state[pb].alphaIndex];
+        }
+        if (u) std::memcpy(u, b.ucur, B * N * NU * sizeof(T));
+        if (KT) std::memcpy(KT, b.KT, B * N * NX * NU * sizeof(T));
+        if (Jout) std::memcpy(Jout, b.Jout, B * (cfg.max_iter + 2) * sizeof(T));
+        if (alphaOut) std::memcpy(alphaOut, b.alphaOut, B * (cfg.max_iter + 2) * sizeof(int));
+        return 0;
+    }
+    int array(const char* name, void** ptr, size_t* bytes) override {
+        auto it = arrays.find(name);
+        if (it == arrays.end()) return fail(PDDP_EINVAL, std::string("unknown array ") + name);
+        *ptr = it->second.first; *bytes = it->second.second; return 0;
+    }
+    int get_state(pddp_state* out) override {
+        for (int i = 0; i < cfg.batch; i++) {
+            const auto& s = b.state[i]; pddp_state& o = out[i];
+            o.rho = s.rho; o.drho = s.drho; o.prevJ = s.prevJ; o.dJ = s.dJ; o.z = s.z; o.iter = s.iter; o.alphaIndex = s.alphaIndex;
+            o.ignore_defect = s.ignore_defect; o.accepted = s.accepted; o.done = s.done; o.cur = s.cur; o.cur2 = s.cur2; o.bp_retries = s.bp_retries;
+        }
+        return 0;
+    }
+    int set_state(const pddp_state* in) override {
+        for (int i = 0; i < cfg.batch; i++) {
+            auto& s = b.state[i]; const pddp_state& o = in[i];
+            s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
+            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.pad = 0;
+        }
+        return 0;
+    }
+    int run_phase(int ph) override { if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase"); phase(ph); return 0; }
+    int plant_eval(int what, int count, const void* xv, const void* uv, void* outv) override {
+        static NisScratch<P, INTEG, T> s; static IntegScratch<P, T> is;
+        const T* x = (const T*)xv; const T* u = (const T*)uv; T* out = (T*)outv; const Wave w = this_wave();
+        P::load_model(w, s.plant, &model);
+        T qdd[NP], dq[NP * NM], xn[NX];
+        for (int i = 0; i < count; i++) {
+            const T* xi = x + (size_t)i * NX; const T* ui = u + (size_t)i * NU;
+            if (what == 0) { P::dynamics(w, s.plant, qdd, xi, ui); std::memcpy(out + (size_t)i * NP, qdd, sizeof(qdd)); }
+            else if (what == 1) { P::gradient(w, s.plant, s.pgrad, dq, qdd, xi, ui); std::memcpy(out + (size_t)i * NP * NM, dq, sizeof(dq)); }
+            else if (what == 2) { integrator_step<P, INTEG, T>(w, s.plant, is, xn, xi, ui, dt); std::memcpy(out + (size_t)i * NX, xn, sizeof(xn)); }
+            else integrator_gradient<P, INTEG, T>(w, s.plant, s.pgrad, s.integ, out + (size_t)i * NX * NM, xi, ui, dt);
+        }
+        return 0;
+    }
+};
+
+template <template <typename> class PT, typename T> static Base* mk_integ(const pddp_config& c) {
+    Base* r = nullptr;
+    if (c.integrator == 1) { auto* s = new Sim<PT<T>, 1, T>(); s->cfg = c; s->init(); r = s; }
+    else if (c.integrator == 2) { auto* s = new Sim<PT<T>, 2, T>(); s->cfg = c; s->init(); r = s; }
+    else if (c.integrator == 3) { auto* s = new Sim<PT<T>, 3, T>(); s->cfg = c; s->init(); r = s; }
+    return r;
+}
+template <typename T> static Base* mk(const pddp_config& c) {
+    switch (c.plant) {
+    case 1: return mk_integ<PendPlant, T>(c);
+    case 2: return mk_integ<CartPlant, T>(c);
+    case 3: return mk_integ<QuadPlant, T>(c);
+    case 4: if (c.integrator == 1) { auto* s = new Sim<ArmPlant<T>, 1, T>(); s->cfg = c; s->init(); return s; } return nullptr;
+    }
+    return nullptr;
+}
+extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
+    const pddp_config& c = *cfg;
+    if (c.plant < 1 || c.plant > 4) return fail(PDDP_EINVAL, "plant must be 1..4");
+    if (c.N < 4 || (c.N & (c.N - 1)) || c.N > 1024) return fail(PDDP_EINVAL, "N must be a power of two in [4,1024]");
+    if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
+    if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
+    Base* s = c.dtype == 0 ? mk<float>(c) : c.dtype == 1 ? mk<double>(c) : nullptr;
+    if (!s) return fail(PDDP_EINVAL, "unsupported plant / integrator / dtype combination");
+    *out = new pddp_solver{s};
+    return 0;
+}
+extern "C" int pddp_destroy(pddp_handle h) { if (h) { delete h->impl; delete h; } return 0; }
+extern "C" int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xg, int clear, int ifd) { return h->impl->load(x0, u0, xg, clear, ifd); }
+extern "C" int pddp_iterate(pddp_handle h, int sweeps) { return h->impl->iterate(sweeps); }
+extern "C" int pddp_sync(pddp_handle) { return 0; }
+extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { return h->impl->status(done, iters); }
+extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { return h->impl->store(x, u, KT, Jout, alphaOut, dmax); }
+extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* t, float* ph) { h->impl->iterate(sweeps); if (t) *t = 0; if (ph) for (int i = 0; i < 4; i++) ph[i] = 0; return 0; }
+extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { h->impl->bench = on ? 1 : 0; return 0; }
+extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { void* p; return h->impl->array(name, &p, bytes); }
+extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes) {
+    void* p; size_t cap; int rc = h->impl->array(name, &p, &cap); if (rc) return rc;
+    if (bytes > cap) return fail(PDDP_EINVAL, "too many bytes"); std::memcpy(p, host, bytes); return 0;
+}
+extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes) {
+    void* p; size_t cap; int rc = h->impl->array(name, &p, &cap); if (rc) return rc;
+    if (bytes > cap) return fail(PDDP_EINVAL, "too many bytes"); std::memcpy(host, p, bytes); return 0;
+}
+extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { return h->impl->get_state(out); }
+extern "C" int pddp_set_state(pddp_handle h, const pddp_state* in) { return h->impl->set_state(in); }
+extern "C" int pddp_run_phase(pddp_handle h, int phase) { return h->impl->run_phase(phase); }
+extern "C" int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out) { return h->impl->plant_eval(what, count, x, u, out); }
+extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
+    Base* s = h->impl; s->load(x0, u0, xGoal, clear, ifd);
+    std::vector<int> done(s->cfg.batch);
+    for (int guard = 0; guard < 100000; guard++) {
+        s->iterate(1); s->status(done.data(), nullptr);
+        bool all = true; for (int d : done) all &= (d != 0);
+        if (all) break;
+    }
+    s->store(x0, u0, nullptr, Jout, alphaOut, nullptr);
+    if (times_ms) { times_ms[0] = 0; times_ms[1] = 0; }
+    return 0;
+}

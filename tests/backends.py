@@ -1,0 +1,35 @@
+"""Backends the parity tests run against.
+
+  "hip"     : the product, parallel-ddp_amd/lib/libpddp.so through its C ABI on a real MI355X  (-m gpu)
+  "hostsim" : TEST TOOL -- the same kernel bodies compiled for the host with a 1-lane wave
+              (tests/hostsim), used by the CPU suite to check kernel arithmetic and indexing without a GPU.
+"""
+import os
+import subprocess
+
+import pytest
+
+import pyddp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOSTSIM = os.path.join(ROOT, "tests", "hostsim", "libpddp_hostsim.so")
+
+
+def hostsim_path():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "-s"])
+    return HOSTSIM
+
+
+def lib_path(backend):
+    if backend == "hip":
+        return pyddp.library_path()
+    return hostsim_path()
+
+
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def make_solver(backend, plant, **kw):
+    path = lib_path(backend)
+    cfg = pyddp.default_config(plant, _lib_path=path, **kw)
+    return pyddp.Solver(cfg, _lib_path=path)

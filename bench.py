@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- DDP iterations/s of the HIP hot path on BASELINE.json's headline configuration.
+
+Workload (config.workload): BASELINE configs[2] -- KUKA iiwa14 (n=14, m=7), N=128 knots, 8 line-search alphas x 4
+multiple-shooting segments, Euler, float (algType, config.cuh:74), joint-space cost, inputs of
+examples/WAFR_iLQR_examples.cu:69-121 with a seeded N(0, 0.001) velocity noise per problem.
+
+A "step" is one DDP sweep (backward pass -> forward sweep+rollout+cost for every alpha -> line search + accept/reject
+-> next-iteration setup) over the rank's batch of independent problems.  All inputs are resident in HBM before the
+timed region starts (pddp_load is untimed); the exit tests are live (TOL_COST 0, MAX_ITER >= warmup+steps like
+the example's TOL_COST 0 / MAX_ITER 100), nothing is cached or skipped.
+
+value = problems x sweeps / second summed over all ranks (weak scaling: the per-GPU batch is fixed).  The single-
+problem latency figures the reference reports (iterations/s of ONE solve, ms to convergence) are in "latency".
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the batch axis is sharded, the solves are
+independent, and the only exchange is one all-gather of the per-problem cost per poll (pyddp.shard).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd"))
+
+import pyddp  # noqa: E402
+from pyddp import shard  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
+KERNELS = ("k_bp", "k_fp", "k_ls", "k_nis")
+
+
+def example_inputs(N, rng, count):
+    """examples/WAFR_iLQR_examples.cu:34-53,80-82,93-94,117 (arm, USE_WAFR_URDF): x0,u0,xGoal for `count` problems."""
+    PI = 3.14159
+    x = np.zeros((count, N, 14), np.float32)
+    x[:, :, :7] = np.asarray([-0.5 * PI, 0.25 * PI, 0.167 * PI, -0.167 * PI, 0.125 * PI, 0.167 * PI, 0.5 * PI], np.float32)
+    x[:, :, 7:] = rng.normal(0, 0.001, (count, N, 7)).astype(np.float32)
+    u = np.zeros((count, N, 7), np.float32)
+    u[:] = np.asarray([0.0, -102.9832, 11.1968, 47.0724, 2.5993, -7.0290, -0.0907], np.float32)
+    g = np.zeros((count, 14), np.float32)
+    g[:, :7] = np.asarray([0, 0, 0, -0.25 * PI, 0, 0.25 * PI, 0.5 * PI], np.float32)
+    return x, u, g
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's runiLQR_CPU restatement (reference thread-per-phase structure) timed on this host's cores on a
+    bounded sample of the same workload.  The oracle is the CHECKER/baseline only -- never the measured product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import Oracle, default_cfg, example_inputs as ora_inputs
+    cores = os.cpu_count() or 1
+    o = Oracle(default_cfg(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=30, cores=cores, spawn_threads=1),
+               np.float32)
+    rng = np.random.default_rng(99)
+    iters, ms, solves = 0, 0.0, 0
+    t0 = time.time()
+    while time.time() - t0 < budget_s:
+        x0, u0, xg = ora_inputs(4, 128, np.float32, noise=rng.normal(0, 0.001, (128, 14)))
+        r = o.run_ilqr_cpu(x0, u0, xg)
+        iters += r["iters"]; ms += r["t_total_ms"] - r["t_init_ms"]; solves += 1
+    return {"value": round(iters / (ms * 1e-3), 2), "unit": "DDP iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{solves} solves x 30 iterations of the same Kuka N=128 A=8 M=4 problem (runiLQR_CPU semantics, "
+                      f"BP/FSIM threads=min(M,cores), COST/INT threads=cores/2, pthreads created per phase like the reference)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2048, help="independent problems per GPU")
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
+    args = ap.parse_args()
+
+    ctx = shard.init_from_env(args.gpus)              # rank, world, local_rank; torch.distributed if world > 1
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    torch.cuda.set_device(ctx.local_rank)
+    K, W, B = args.steps, args.warmup, args.batch
+    N, M, A, n, m = 128, 4, 8, 14, 7
+
+    cfg = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B,
+                               max_iter=max(100, K + W + 1), device=ctx.local_rank, use_graph=args.graph)
+    s = pyddp.Solver(cfg)
+    rng = np.random.default_rng(1234 + ctx.rank)      # every rank owns different problems
+    x0, u0, xg = example_inputs(N, rng, B)
+    s.load(x0, u0, xg)                                # untimed: inputs are in HBM from here on
+
+    s.iterate(W); s.sync()
+    shard.barrier(ctx); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.iterate(K)
+    s.sync(); torch.cuda.synchronize()
+    shard.barrier(ctx); torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    t = shard.max_over_ranks(ctx, t_local)
+
+    # ---- what happened in the timed sweeps (honesty: accepted / rejected iterations, decrease of J)
+    out = s.store()
+    done, iters = s.status()
+    acc = np.mean([(out["alphaOut"][b][W + 1: W + K + 1] >= 0).mean() for b in range(min(B, 64))])
+    J_all = shard.allgather_costs(ctx, s.device_array("Jout"), B, cfg.max_iter + 2, int(iters.min()))   # RCCL exchange
+
+    # ---- per-kernel durations with HIP events on the solver's own stream (second pass, same state machine)
+    ms_tot, ms_phase = s.time_sweeps(min(K, 20), phases=True)
+    nsw = min(K, 20)
+    per_launch_ms = [v / nsw for v in ms_phase]
+    dom = int(np.argmax(per_launch_ms))
+    alg = pyddp.algorithmic_bytes(n, m, N, A, M, 4)
+    bytes_launch = alg[KERNELS[dom]] * B
+    achieved = bytes_launch / (per_launch_ms[dom] * 1e-3) / 1e9
+    sweep_bytes = sum(alg.values()) * B
+    roof = {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": args.traffic_bytes,
+            "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": round(per_launch_ms[dom], 5),
+            "per_kernel_ms": {k: round(v, 5) for k, v in zip(KERNELS, per_launch_ms)},
+            "whole_sweep_GBs": round(sweep_bytes / (t_local / K) / 1e9, 2)}
+
+    line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
+            "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Kuka iiwa14 RBD (n=14,m=7), N=128, 8 alphas x 4 shooting segments, Euler, fp32, "
+                                   "joint cost, T=0.5 s, WAFR example inputs + N(0,1e-3) velocity noise",
+                       "problems_per_gpu": B, "problems_total": ctx.world * B, "hipgraph": bool(args.graph), "sharding": "batch axis, no data-path collective"},
+            "accepted_fraction_in_timed_sweeps": round(float(acc), 3),
+            "J_first_last_mean": [round(float(J_all[:, 0].mean()), 3), round(float(J_all[:, -1].mean()), 3)],
+            "roofline": roof}
+
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
+        line["latency"] = latency_single_problem(ctx.local_rank)
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    elif ctx.rank == 0:
+        line["cpu_baseline"] = None
+    if ctx.rank == 0:
+        print(json.dumps(line), flush=True)
+    s.close()
+    shard.finalize(ctx)
+
+
+def latency_single_problem(device):
+    """The reference's own figures of merit for ONE problem (examples/WAFR_iLQR_examples.cu:141-187): iterations/s of a
+    solve = iter / (tTime - initTime), and ms to convergence with the default TOL_COST 1e-4 (config.cuh:85-87)."""
+    res = {}
+    rng = np.random.default_rng(4321)
+    for name, tol, max_iter in (("fixed_100_iterations", 0.0, 100), ("to_convergence_tol_1e-4", 1e-4, 100)):
+        cfg = pyddp.default_config(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=tol, total_time=0.5, batch=1, max_iter=max_iter,
+                                   device=device, use_graph=1)
+        s = pyddp.Solver(cfg)
+        its, mss, Js = [], [], []
+        for rep in range(21):
+            x0, u0, xg = example_inputs(128, rng, 1)
+            r = s.solve_timed(x0, u0, xg)
+            if rep == 0:
+                continue                           # first solve instantiates the graph
+            its.append(r["iters"]); mss.append(r["ms_loop"]); Js.append(r["J_final"])
+        res[name] = {"median_iterations": float(np.median(its)), "median_ms": round(float(np.median(mss)), 3),
+                     "iterations_per_s": round(float(np.median(np.asarray(its) / (np.asarray(mss) * 1e-3))), 1),
+                     "median_J_final": round(float(np.median(Js)), 3), "solves": len(its)}
+        s.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,9 @@ int pddp_set_benchmark_mode(pddp_handle h, int on);
 int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes);
 int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes);
 int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes);
+/* Device address of a named array (the reference hands its callers the raw device buffers, nisInitHelpers.cuh:768-772);
+ * lets the host layer run an RCCL collective on the cost table without staging it through the host. */
+int pddp_array_ptr(pddp_handle h, const char* name, void** device_ptr, size_t* bytes);
 
 typedef struct pddp_state {      /* per problem, all scalars as double regardless of dtype */
     double rho, drho, prevJ, dJ, z;

@@ -335,6 +335,7 @@ extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout,
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { IMPL(h); s->bench_mode = on ? 1 : 0; return 0; }
 extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { IMPL(h); void* p; return s->array(name, &p, bytes); }
+extern "C" int pddp_array_ptr(pddp_handle h, const char* name, void** ptr, size_t* bytes) { IMPL(h); if (!ptr || !bytes) return fail(PDDP_EINVAL, "null argument"); return s->array(name, ptr, bytes); }
 extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes) {
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
     if (bytes > cap) return fail(PDDP_EINVAL, "set_array: too many bytes");

@@ -30,6 +30,27 @@ class PddpState(C.Structure):
                 ("done", C.c_int), ("cur", C.c_int), ("cur2", C.c_int), ("bp_retries", C.c_int)]
 
 
+class DeviceArray:
+    """A 1-D device buffer owned by a Solver (valid until Solver.close())."""
+
+    def __init__(self, ptr, count, dtype):
+        self.ptr, self.count, self.dtype = ptr, count, dtype
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": dtype.str, "data": (ptr, False), "version": 2}
+
+
+def algorithmic_bytes(n, m, N, A, M, s):
+    """Algorithmic HBM bytes of ONE problem per launch of each sweep kernel: every array read/written once per phase
+    that consumes/produces it, in the reference's phase decomposition (DESIGN.md "roofline").
+    k_fp = sweep + rollout + cost of all A candidates (the three reference kernels it fuses)."""
+    nm = n + m
+    bp = (n * nm + nm * nm + nm) * (N - 1) + n * n + n + (M - 1) * (n * n + 4 * n) + (2 * n * n + n * m + 2 * n + m) * (N - 1)
+    sweep = ((n * n + n) * (N - 1) + 3 * n * N + n * (M - 1)) if M > 1 else 0
+    sim = (n * m + m) * (N - 1) + 3 * n * N + 2 * m * (N - 1) + n * (M - 1)
+    cost = n * N + m * (N - 1)
+    nis = 2 * (n * N + m * (N - 1)) + n * nm * (N - 1) + (nm * nm + nm) * N + 2 * (n * n + n) * N + A * (2 * n + m) * N + (2 * n + m) * N + n * N
+    return {"k_bp": bp * s, "k_fp": A * (sweep + sim + cost) * s, "k_ls": (3 * A + 2 * M + 16) * s, "k_nis": nis * s}
+
+
 def library_path():
     return os.path.join(os.path.dirname(_HERE), "lib", "libpddp.so")
 
@@ -137,6 +158,19 @@ class Solver:
         out["done"], out["iters"], out["sweeps"] = done, iters, sweeps
         return out
 
+    def solve_timed(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1):
+        """pddp_solve: the whole runiLQR_GPU call in C (load, init, sweeps until every problem exits, store), with the
+        reference's two timers: ms_total (*tTime) and ms_init (*initTime); ms_loop = their difference."""
+        B, mi = self.cfg.batch, self.cfg.max_iter
+        x0, u0, xGoal = self.arr(x0).copy(), self.arr(u0).copy(), self.arr(xGoal)
+        Jout, aout = np.zeros((B, mi + 2), self.dtype), np.zeros((B, mi + 2), np.int32)
+        times = (C.c_double * 2)()
+        self._chk(self.lib.pddp_solve(self.h, _p(x0), _p(u0), _p(xGoal), _p(Jout), _p(aout), int(clear_vars), int(ignore_first_defect), times))
+        done, iters = self.status()
+        return dict(x=x0.reshape(B, self.cfg.N, self.n), u=u0.reshape(B, self.cfg.N, self.m), Jout=Jout, alphaOut=aout, done=done,
+                    iters=int(iters[0]) if B == 1 else iters, ms_total=times[0], ms_init=times[1], ms_loop=times[0] - times[1],
+                    J_final=float(Jout[0][iters[0]]))
+
     # ---- measurement
     def set_benchmark_mode(self, on):
         self._chk(self.lib.pddp_set_benchmark_mode(self.h, int(on)))
@@ -161,6 +195,13 @@ class Solver:
     def set(self, name, a):
         a = np.ascontiguousarray(a, dtype=self._adtype(name)).ravel()
         self._chk(self.lib.pddp_set_array(self.h, name.encode(), _p(a), C.c_size_t(a.nbytes)))
+
+    def device_array(self, name):
+        """Zero-copy view of a solver array in HBM for torch (`torch.as_tensor(view, device="cuda")`), via
+        __cuda_array_interface__; used for the RCCL exchange of the cost table."""
+        ptr, nb = C.c_void_p(), C.c_size_t(0)
+        self._chk(self.lib.pddp_array_ptr(self.h, name.encode(), C.byref(ptr), C.byref(nb)))
+        return DeviceArray(ptr.value, nb.value // np.dtype(self._adtype(name)).itemsize, np.dtype(self._adtype(name)))
 
     def get_state(self):
         st = (PddpState * self.cfg.batch)()

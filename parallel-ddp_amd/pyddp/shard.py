@@ -1,0 +1,113 @@
+"""Batch-axis sharding of independent iLQR problems over the GPUs of one node (one process per GPU).
+
+The reference has no multi-GPU path (no NCCL/MPI anywhere); its natural shard axis is the batch of
+independent problems (MPC rollouts, BASELINE configs[3]).  Every rank owns problems {r : r % world == rank} with all
+A alphas and all M segments local, so a DDP sweep needs NO collective.  The only exchanges are per POLL, not per sweep:
+  * allgather_costs   -- the per-problem cost trace column(s), so every rank can select the globally best rollout;
+  * all_done          -- "has every problem on every rank exited?" (a max-reduce of one integer).
+torch.distributed is plumbing here: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in the CPU tests.
+"""
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class ShardCtx:
+    rank: int = 0
+    world: int = 1
+    local_rank: int = 0
+    backend: str = ""
+
+
+def owned_problems(total, rank, world):
+    """Round-robin ownership (mode R): global problem ids of `rank`."""
+    return list(range(rank, total, world))
+
+
+def init_from_env(n_gpus_flag=1, backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run; a bare `python bench.py` is world 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return ShardCtx(0, 1, local_rank, "")
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return ShardCtx(rank, world, local_rank, backend)
+
+
+def _dev(ctx):
+    import torch
+    return torch.device("cuda", ctx.local_rank) if ctx.backend == "nccl" else torch.device("cpu")
+
+
+def barrier(ctx):
+    if ctx.world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(ctx, value):
+    if ctx.world == 1:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_dev(ctx))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_done(ctx, done_local):
+    """True when every problem on every rank has met an exit condition."""
+    flag = 0 if bool(np.all(np.asarray(done_local) != 0)) else 1
+    if ctx.world == 1:
+        return flag == 0
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([flag], dtype=torch.int32, device=_dev(ctx))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item()) == 0
+
+
+def allgather_costs(ctx, jout, batch, stride, last_col):
+    """Gather columns 0 and `last_col` of every rank's cost trace Jout[batch][stride] -> array [world*batch][2] in GLOBAL
+    problem order (problem g lives on rank g % world at local index g // world).
+    `jout` is a pyddp DeviceArray (HBM, zero-copy through __cuda_array_interface__) or a host numpy array (gloo tests)."""
+    import torch
+    if isinstance(jout, np.ndarray):
+        local = torch.from_numpy(np.ascontiguousarray(jout)).reshape(batch, stride)
+    else:
+        local = torch.as_tensor(jout, device=_dev(ctx) if ctx.world > 1 else torch.device("cuda", ctx.local_rank)).reshape(batch, stride)
+    cols = local[:, [0, last_col]].contiguous()
+    if ctx.world == 1:
+        return cols.cpu().numpy()
+    import torch.distributed as dist
+    cols = cols.to(_dev(ctx))
+    gathered = torch.empty((ctx.world,) + tuple(cols.shape), dtype=cols.dtype, device=cols.device)
+    dist.all_gather_into_tensor(gathered, cols)
+    # [rank][local][2] -> global order g = local * world + rank
+    return gathered.permute(1, 0, 2).reshape(ctx.world * batch, 2).cpu().numpy()
+
+
+def best_rollout(costs_global):
+    """Index (global problem id) and cost of the best rollout -- what an MPC caller picks its control from."""
+    final = np.asarray(costs_global)[:, -1]
+    g = int(np.argmin(final))
+    return g, float(final[g])
+
+
+def finalize(ctx):
+    if ctx.world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()

@@ -221,6 +221,7 @@ extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout,
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* t, float* ph) { h->impl->iterate(sweeps); if (t) *t = 0; if (ph) for (int i = 0; i < 4; i++) ph[i] = 0; return 0; }
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { h->impl->bench = on ? 1 : 0; return 0; }
 extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { void* p; return h->impl->array(name, &p, bytes); }
+extern "C" int pddp_array_ptr(pddp_handle h, const char* name, void** ptr, size_t* bytes) { return h->impl->array(name, ptr, bytes); }
 extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes) {
     void* p; size_t cap; int rc = h->impl->array(name, &p, &cap); if (rc) return rc;
     if (bytes > cap) return fail(PDDP_EINVAL, "too many bytes"); std::memcpy(p, host, bytes); return 0;

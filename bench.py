@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative libpddp build (measurement of build variants only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()
@@ -89,8 +90,8 @@ def main():
     N, M, A, n, m = 128, 4, 8, 14, 7
 
     cfg = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B,
-                               max_iter=max(100, K + W + 1), device=ctx.local_rank, use_graph=args.graph)
-    s = pyddp.Solver(cfg)
+                               max_iter=max(100, K + W + 1), device=ctx.local_rank, use_graph=args.graph, _lib_path=args.lib)
+    s = pyddp.Solver(cfg, _lib_path=args.lib)
     rng = np.random.default_rng(1234 + ctx.rank)      # every rank owns different problems
     x0, u0, xg = example_inputs(N, rng, B)
     s.load(x0, u0, xg)                                # untimed: inputs are in HBM from here on
@@ -108,7 +109,7 @@ def main():
     out = s.store()
     done, iters = s.status()
     acc = np.mean([(out["alphaOut"][b][W + 1: W + K + 1] >= 0).mean() for b in range(min(B, 64))])
-    J_all = shard.allgather_costs(ctx, s.device_array("Jout"), B, cfg.max_iter + 2, int(iters.min()))   # RCCL exchange
+    J_all = shard.allgather_costs(ctx, s.device_array("Jout"), B, cfg.max_iter + 2, int(iters.min()) - 1)   # RCCL exchange
 
     # ---- per-kernel durations with HIP events on the solver's own stream (second pass, same state machine)
     ms_tot, ms_phase = s.time_sweeps(min(K, 20), phases=True)

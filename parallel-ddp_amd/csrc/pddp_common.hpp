@@ -53,8 +53,24 @@ PDDP_HD void wsync() {
 
 template <typename T> PDDP_HD T tsin(T v);
 template <typename T> PDDP_HD T tcos(T v);
-template <> PDDP_HD float tsin<float>(float v) { return sinf(v); }
-template <> PDDP_HD float tcos<float>(float v) { return cosf(v); }
+// float sin/cos: the reference's host instantiation calls glibc sinf/cosf, which return the correctly rounded float
+// in all but a vanishing fraction of arguments; ocml's device sinf/cosf are 1-2 ulp functions, and the mass-matrix
+// solve behind them amplifies that to ~5e-5 in qdd.  On the device we therefore evaluate in double and round once
+// (7 lanes x 2 calls per dynamics evaluation -- not on any critical resource).
+template <> PDDP_HD float tsin<float>(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<float>(sin(static_cast<double>(v)));
+#else
+    return sinf(v);
+#endif
+}
+template <> PDDP_HD float tcos<float>(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<float>(cos(static_cast<double>(v)));
+#else
+    return cosf(v);
+#endif
+}
 template <> PDDP_HD double tsin<double>(double v) { return sin(v); }
 template <> PDDP_HD double tcos<double>(double v) { return cos(v); }
 template <typename T> PDDP_HD T tabs(T v) { return v < T(0) ? -v : v; }

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--lib", default=None, help="alternative libpddp build (measurement of build variants only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
+    ap.add_argument("--calibrate-hbm", action="store_true", help="also launch the known-byte-count copy kernel (for --pmc passes)")
     args = ap.parse_args()
 
     ctx = shard.init_from_env(args.gpus)              # rank, world, local_rank; torch.distributed if world > 1
@@ -95,6 +96,8 @@ def main():
     rng = np.random.default_rng(1234 + ctx.rank)      # every rank owns different problems
     x0, u0, xg = example_inputs(N, rng, B)
     s.load(x0, u0, xg)                                # untimed: inputs are in HBM from here on
+    if args.calibrate_hbm:
+        s.hbm_calibration(1 << 30, 3)
 
     s.iterate(W); s.sync()
     shard.barrier(ctx); torch.cuda.synchronize()

@@ -94,6 +94,10 @@ int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase
 /* Freeze / unfreeze the exit tests so a benchmark can time a fixed number of full-work sweeps. */
 int pddp_set_benchmark_mode(pddp_handle h, int on);
 
+/* Profiling aid: `reps` launches of k_hbm_calib_dword copying `bytes` (use > 256 MiB, the Infinity Cache size) with the
+ * sweep kernels' access width, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count. */
+int pddp_hbm_calibration(int device, size_t bytes, int reps);
+
 /* ---- teacher-forced phase hooks (tests) ------------------------------------------------------------- */
 /* Named device arrays: xs us ds xb ucur dcur P p Pp pp AB H g KT du ApBK Bdu J dmax dJexp alpha xGoal Jout
  * (element type = dtype), err alphaOut (int), state (see pddp_state below). */

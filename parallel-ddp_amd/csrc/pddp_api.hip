@@ -352,6 +352,18 @@ extern "C" int pddp_set_state(pddp_handle h, const pddp_state* in) { IMPL(h); re
 extern "C" int pddp_run_phase(pddp_handle h, int phase) { IMPL(h); return s->run_phase(phase); }
 extern "C" int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out) { IMPL(h); return s->plant_eval(what, count, x, u, out); }
 
+extern "C" int pddp_hbm_calibration(int device, size_t bytes, int reps) {
+    if (bytes < 4096 || reps < 1) return fail(PDDP_EINVAL, "hbm_calibration: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    float *a = nullptr, *b2 = nullptr;
+    HIPCHK(hipMalloc((void**)&a, bytes)); HIPCHK(hipMalloc((void**)&b2, bytes));
+    HIPCHK(hipMemset(a, 1, bytes)); HIPCHK(hipMemset(b2, 0, bytes));
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_hbm_calib_dword, dim3(256 * 16), dim3(256), 0, 0, a, b2, bytes / sizeof(float));
+    HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+    hipFree(a); hipFree(b2);
+    return 0;
+}
+
 // runiLQR_GPU (DDPWrappers.cuh:10-138) for the batch.
 extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
     IMPL(h);

@@ -175,6 +175,10 @@ class Solver:
     def set_benchmark_mode(self, on):
         self._chk(self.lib.pddp_set_benchmark_mode(self.h, int(on)))
 
+    def hbm_calibration(self, nbytes, reps):
+        self.lib.pddp_hbm_calibration.argtypes = [C.c_int, C.c_size_t, C.c_int]
+        self._chk(self.lib.pddp_hbm_calibration(self.cfg.device, nbytes, reps))
+
     def time_sweeps(self, sweeps, phases=False):
         tot = C.c_float(0)
         ph = (C.c_float * 4)()

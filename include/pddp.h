@@ -70,6 +70,14 @@ int pddp_destroy(pddp_handle h);
  * After this call every input is resident in HBM; Jout[0] / alphaOut[0] are set. */
 int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xGoal, int clear_vars, int ignore_first_defect);
 
+/* The same with every option of the reference call: warm-start arrays, used when clear_vars == 0 (KT0 [batch][N][n*m],
+ * P0 [batch][N][n*n], p0 [batch][N][n], d0 [batch][N][n]; P0/p0 also seed Pp/pp, nisInitHelpers.cuh:621-628; a NULL array
+ * keeps the device values of the previous solve), and forward_rollout = the reference's forwardRolloutFlag (:642-648):
+ * every shooting segment is first rolled out from x0[b*N/M] with u0 (and K from KT0), and the result -- with its boundary
+ * defects -- becomes the initial trajectory; alphaOut[0] is then 0 instead of -1 (:363). */
+int pddp_load_ex(pddp_handle h, const void* x0, const void* u0, const void* xGoal, const void* KT0, const void* P0, const void* p0,
+                 const void* d0, int forward_rollout, int clear_vars, int ignore_first_defect);
+
 /* The hot loop of runiLQR_GPU (DDPWrappers.cuh:52-114): `sweeps` x { backward pass, forward sweep+sim+cost,
  * line search + accept/reject, next-iteration setup }, enqueued on the solver's stream with NO host
  * synchronisation.  Problems that have met an exit condition idle through the remaining sweeps. */
@@ -86,6 +94,17 @@ int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alpha
  * times_ms[0] = total, [1] = init (load+init+store), like *tTime / *initTime. */
 int pddp_solve(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal, void* Jout, int* alphaOut,
                int clear_vars, int ignore_first_defect, double* times_ms);
+
+/* The full reference call.  Warm-start arrays / forward_rollout as in pddp_load_ex.  phase_ms, when not NULL, is
+ * [4][max_iter+2] doubles (bp, sweep+sim, line search+accept/reject, next-iteration setup): the duration of each kernel of
+ * sweep i measured with HIP events on the solver's stream -- what the reference's bpTime[], sweepTime[]+simTime[], nisTime[]
+ * report (DDPWrappers.cuh:54-105).  With phase_ms the sweeps are launched kernel by kernel instead of as a graph; in
+ * both modes the loop never synchronises with the host except to poll the exit flags every `poll_every` sweeps. */
+int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal, const void* KT0, const void* P0, const void* p0,
+                  const void* d0, void* Jout, int* alphaOut, int forward_rollout, int clear_vars, int ignore_first_defect,
+                  int poll_every, double* times_ms, double* phase_ms, int* sweeps_out);
+/* The HIP stream every kernel of this handle is enqueued on (a hipStream_t). */
+int pddp_stream(pddp_handle h, void** hip_stream);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* Runs `sweeps` sweeps bracketed by HIP events on the solver's stream; ms_total = elapsed, ms_phase[4] = summed

@@ -65,6 +65,13 @@ PDDP_HD void forward_sweep(const Wave& w, SweepScratch<P, T>& s, const Dims& dm,
     }
 }
 
+// Initial rollout (forwardRolloutFlag, nisInitHelpers.cuh:642-648): no sweep, segment bInd starts from the loaded state.
+template <typename P, typename T>
+PDDP_HD void rollout_seed_segment(const Wave& w, const Dims& dm, const FpArgs<T>& a, int bInd) {
+    constexpr int NX = P::NX;
+    PDDP_FOR(i, NX) { const T v = a.xcur[NX * bInd * dm.NB + i]; a.segx[NX * bInd + i] = v; a.x[NX * bInd * dm.NB + i] = v; }
+}
+
 // Nonlinear rollout of segment bInd.  Start state: a.segx[bInd] (from the sweep), or xcur[0] for segment 0.
 // Writes x[k+1], u[k] for the segment's knots and the boundary defect.  cost_k (optional, LDS [N]) receives the
 // per-knot cost of every knot this segment owns.

@@ -28,11 +28,13 @@ struct FpLds {
     }
 };
 
+// init_rollout = 1: the optional initial rollout of loadVarsGPU (forwardRolloutFlag, nisInitHelpers.cuh:642-648): launched with
+// grid (1, B); no sweep, every segment starts from the loaded state x0[b*NB], alpha = alpha[0], candidate slot 0.
 template <typename P, int INTEG, typename T>
-__global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt) {
+__global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int a_idx = blockIdx.x, pb = blockIdx.y, M = dm.M;
-    if (!fp_active<T>(b, dm, pb)) return;
+    if (!init_rollout && !fp_active<T>(b, dm, pb)) return;
     using L = FpLds<P, T>;
     unsigned char* ptr = lds_raw;
     SweepScratch<P, T>& sw = *reinterpret_cast<SweepScratch<P, T>*>(ptr); ptr += L::align16(sizeof(SweepScratch<P, T>));
@@ -44,7 +46,10 @@ __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt) {
     T* dnorm = reinterpret_cast<T*>(ptr);
     const Wave w = this_wave();
     const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm);
-    if (M > 1) {
+    if (init_rollout) {
+        rollout_seed_segment<P, T>(w, dm, a, wave_id);
+        __syncthreads();
+    } else if (M > 1) {
         if (wave_id == 0) forward_sweep<P, T>(w, sw, dm, a);
         __syncthreads();
     }
@@ -66,6 +71,19 @@ template <typename P, int INTEG, typename T>
 __global__ __launch_bounds__(64) void k_nis(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode) {
     __shared__ NisScratch<P, INTEG, T> s;
     nis_body<P, INTEG, T>(this_wave(), s, b, dm, cw, dt, mode, blockIdx.x, blockIdx.y);
+}
+
+// after the initial rollout: candidate slot 0 becomes the current trajectory (initAlgGPU copies slot 0 to xp, up, dp,
+// nisInitHelpers.cuh:378-381).  grid (N, B), block 64.
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
+    constexpr int NX = P::NX, NU = P::NU;
+    const int k = blockIdx.x, pb = blockIdx.y, N = dm.N;
+    const Wave w = this_wave();
+    const size_t slot = (size_t)pb * dm.A;
+    PDDP_FOR(i, NX) b.xb[((size_t)pb * 2 * N + k) * NX + i] = b.xs[(slot * N + k) * NX + i];
+    PDDP_FOR(i, NU) b.ucur[((size_t)pb * N + k) * NU + i] = b.us[(slot * N + k) * NU + i];
+    PDDP_FOR(i, NX) b.dcur[((size_t)pb * N + k) * NX + i] = b.ds[(slot * N + k) * NX + i];
 }
 
 // initial cost + solver state: grid (B), block 64, dynamic LDS N*sizeof(T).

@@ -1,4 +1,5 @@
 // libpddp.so: host side of the C ABI declared in include/pddp.h.  gfx950 only; no CPU fallback.
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -48,7 +49,7 @@ struct SolverBase {
     pddp_config cfg;
     virtual ~SolverBase() {}
     virtual int init() = 0;
-    virtual int load(const void* x0, const void* u0, const void* xg, int clear, int ignore_first_defect) = 0;
+    virtual int load(const void* x0, const void* u0, const void* xg, const void* KT0, const void* P0, const void* p0, const void* d0, int rollout, int clear, int ignore_first_defect) = 0;
     virtual int iterate(int sweeps) = 0;
     virtual int sync() = 0;
     virtual int status(int* done, int* iters) = 0;
@@ -59,6 +60,7 @@ struct SolverBase {
     virtual int set_state(const pddp_state* in) = 0;
     virtual int run_phase(int phase) = 0;
     virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
+    virtual int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) = 0;
     int bench_mode = 0;
     hipStream_t stream = nullptr;
 };
@@ -93,6 +95,11 @@ struct Solver : SolverBase {
         for (void* p : allocs) hipFree(p);
         if (stream) hipStreamDestroy(stream);
     }
+    void register_model(void* dmodel, const ArmModel<T>&) {
+        arrays["model_I"] = {dmodel, sizeof(T) * kArmNB * 36};
+        arrays["model_F"] = {(char*)dmodel + offsetof(ArmModel<T>, F), sizeof(T) * kArmNB * 16};
+    }
+    void register_model(void*, const EmptyModel&) {}
     template <typename U> int alloc(const char* name, U** out, size_t count) {
         void* p = nullptr;
         if (hipMalloc(&p, count * sizeof(U)) != hipSuccess) return fail(PDDP_ENOMEM, std::string("hipMalloc failed for ") + name);
@@ -131,28 +138,48 @@ struct Solver : SolverBase {
         HIPCHK(hipMalloc(&dmodel, sizeof(hm))); allocs.push_back(dmodel);
         HIPCHK(hipMemcpy(dmodel, &hm, sizeof(hm), hipMemcpyHostToDevice));
         b.model = dmodel;
+        register_model(dmodel, hm);
+        // device tables of per-alpha pointers, the reference's d_x / d_u / d_d (nisInitHelpers.cuh:777-789,808-813)
+        void** tab[3]; const char* tn[3] = {"xs_ptrs", "us_ptrs", "ds_ptrs"};
+        T* base[3] = {b.xs, b.us, b.ds}; const size_t per[3] = {N * NX, N * NU, N * NX};
+        for (int t = 0; t < 3; t++) {
+            if ((rc = alloc(tn[t], &tab[t], B * A))) return rc;
+            std::vector<void*> hp(B * A);
+            for (size_t i = 0; i < B * A; i++) hp[i] = base[t] + i * per[t];
+            HIPCHK(hipMemcpy(tab[t], hp.data(), B * A * sizeof(void*), hipMemcpyHostToDevice));
+        }
         fp_lds = FpLds<P, T>::bytes(c.M, c.N);
         if (fp_lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint exceeds 160 KiB: reduce M");
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp<P, INTEG, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp_lds));
         HIPCHK(hipDeviceSynchronize());
         return 0;
     }
-    int load(const void* x0, const void* u0, const void* xg, int clear, int ignore_first_defect) override {
+    int load(const void* x0, const void* u0, const void* xg, const void* KT0, const void* P0, const void* p0, const void* d0, int rollout, int clear,
+             int ignore_first_defect) override {
         const size_t B = cfg.batch, N = cfg.N;
-        // current trajectory goes to half 0 of xb (state.cur = 0 after init)
-        for (size_t pb = 0; pb < B; pb++)
-            HIPCHK(hipMemcpyAsync(b.xb + pb * 2 * N * NX, (const T*)x0 + pb * N * NX, N * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        // current trajectory goes to half 0 of xb (state.cur = 0 after init): one strided copy for the whole batch
+        HIPCHK(hipMemcpy2DAsync(b.xb, 2 * N * NX * sizeof(T), x0, N * NX * sizeof(T), N * NX * sizeof(T), B, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(b.ucur, u0, B * N * NU * sizeof(T), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(b.xGoal, xg, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
         if (clear) {                                                 // clearVarsFlag, nisInitHelpers.cuh:612-619
             HIPCHK(hipMemsetAsync(b.P, 0, B * N * NX * NX * sizeof(T), stream)); HIPCHK(hipMemsetAsync(b.Pp, 0, B * N * NX * NX * sizeof(T), stream));
             HIPCHK(hipMemsetAsync(b.p, 0, B * N * NX * sizeof(T), stream)); HIPCHK(hipMemsetAsync(b.pp, 0, B * N * NX * sizeof(T), stream));
             HIPCHK(hipMemsetAsync(b.KT, 0, B * N * NX * NU * sizeof(T), stream)); HIPCHK(hipMemsetAsync(b.dcur, 0, B * N * NX * sizeof(T), stream));
+        } else {                                                     // warm start (:621-628); a NULL array keeps the device values
+            if (P0) { HIPCHK(hipMemcpyAsync(b.P, P0, B * N * NX * NX * sizeof(T), hipMemcpyHostToDevice, stream)); HIPCHK(hipMemcpyAsync(b.Pp, P0, B * N * NX * NX * sizeof(T), hipMemcpyHostToDevice, stream)); }
+            if (p0) { HIPCHK(hipMemcpyAsync(b.p, p0, B * N * NX * sizeof(T), hipMemcpyHostToDevice, stream)); HIPCHK(hipMemcpyAsync(b.pp, p0, B * N * NX * sizeof(T), hipMemcpyHostToDevice, stream)); }
+            if (KT0) HIPCHK(hipMemcpyAsync(b.KT, KT0, B * N * NX * NU * sizeof(T), hipMemcpyHostToDevice, stream));
+            if (d0) HIPCHK(hipMemcpyAsync(b.dcur, d0, B * N * NX * sizeof(T), hipMemcpyHostToDevice, stream));
         }
         HIPCHK(hipMemsetAsync(b.du, 0, B * N * NU * sizeof(T), stream));   // always (:630-632)
         HIPCHK(hipMemsetAsync(b.err, 0, B * cfg.M * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(b.dmax, 0, B * cfg.A * sizeof(T), stream));
-        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, 0);
+        if (rollout) {                                               // forwardRolloutFlag (:642-648)
+            hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, 1);   // state.cur = 0
+            hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(1, B), dim3(64 * cfg.M), fp_lds, stream, b, dm, cw, dt, 1);
+            hipLaunchKernelGGL((k_adopt_slot0<P, T>), dim3(N, B), dim3(64), 0, stream, b, dm);
+        }
+        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, rollout);
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(N, B), dim3(64), 0, stream, b, dm, cw, dt, 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -161,7 +188,7 @@ struct Solver : SolverBase {
     void launch_sweep(hipStream_t s, int only = -1) {
         const unsigned B = cfg.batch;
         if (only < 0 || only == PDDP_PHASE_BP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
-        if (only < 0 || only == PDDP_PHASE_FP) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt);
+        if (only < 0 || only == PDDP_PHASE_FP) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, 0);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
         if (only < 0 || only == PDDP_PHASE_NIS) hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, 0);
     }
@@ -182,6 +209,24 @@ struct Solver : SolverBase {
             for (int i = 0; i < sweeps; i++) launch_sweep(stream);
         }
         HIPCHK(hipGetLastError());
+        return 0;
+    }
+    // `sweeps` sweeps, kernel by kernel, an event after every launch; phase_ms[ph*stride + first_sweep + i] = duration of kernel ph
+    std::vector<hipEvent_t> trace_ev;
+    int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) override {
+        const size_t need = 5 * (size_t)sweeps;
+        while (trace_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); trace_ev.push_back(e); }
+        for (int i = 0; i < sweeps; i++) {
+            HIPCHK(hipEventRecord(trace_ev[5 * i], stream));
+            for (int ph = 0; ph < 4; ph++) { launch_sweep(stream, ph); HIPCHK(hipEventRecord(trace_ev[5 * i + ph + 1], stream)); }
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int i = 0; i < sweeps; i++)
+            for (int ph = 0; ph < 4; ph++) {
+                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, trace_ev[5 * i + ph], trace_ev[5 * i + ph + 1]));
+                if (first_sweep + i < stride) phase_ms[(size_t)ph * stride + first_sweep + i] = ms;
+            }
         return 0;
     }
     int sync() override { HIPCHK(hipStreamSynchronize(stream)); return 0; }
@@ -327,7 +372,13 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
 }
 extern "C" int pddp_destroy(pddp_handle h) { if (h) { delete h->impl; delete h; } return 0; }
 #define IMPL(h) if (!(h)) return fail(PDDP_EINVAL, "null handle"); SolverBase* s = (h)->impl
-extern "C" int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xg, int clear, int ifd) { IMPL(h); return s->load(x0, u0, xg, clear, ifd); }
+extern "C" int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xg, int clear, int ifd) { IMPL(h); return s->load(x0, u0, xg, nullptr, nullptr, nullptr, nullptr, 0, clear, ifd); }
+extern "C" int pddp_load_ex(pddp_handle h, const void* x0, const void* u0, const void* xg, const void* KT0, const void* P0, const void* p0, const void* d0,
+                            int rollout, int clear, int ifd) {
+    IMPL(h);
+    if (!x0 || !u0 || !xg) return fail(PDDP_EINVAL, "pddp_load: null trajectory or goal");
+    return s->load(x0, u0, xg, KT0, P0, p0, d0, rollout, clear, ifd);
+}
 extern "C" int pddp_iterate(pddp_handle h, int sweeps) { IMPL(h); return s->iterate(sweeps); }
 extern "C" int pddp_sync(pddp_handle h) { IMPL(h); return s->sync(); }
 extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); return s->status(done, iters); }
@@ -364,17 +415,25 @@ extern "C" int pddp_hbm_calibration(int device, size_t bytes, int reps) {
     return 0;
 }
 
+extern "C" int pddp_stream(pddp_handle h, void** hip_stream) { IMPL(h); if (!hip_stream) return fail(PDDP_EINVAL, "null argument"); *hip_stream = (void*)s->stream; return 0; }
+
 // runiLQR_GPU (DDPWrappers.cuh:10-138) for the batch.
-extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
+extern "C" int pddp_solve_ex(pddp_handle h, void* x0, void* u0, const void* xGoal, const void* KT0, const void* P0, const void* p0, const void* d0,
+                             void* Jout, int* alphaOut, int rollout, int clear, int ifd, int poll_every, double* times_ms, double* phase_ms,
+                             int* sweeps_out) {
     IMPL(h);
+    if (!x0 || !u0 || !xGoal) return fail(PDDP_EINVAL, "pddp_solve: null trajectory or goal");
     const double t0 = now_ms();
-    int rc = s->load(x0, u0, xGoal, clear, ifd);
+    int rc = s->load(x0, u0, xGoal, KT0, P0, p0, d0, rollout, clear, ifd);
     if (rc) return rc;
     double t_init = now_ms() - t0;
     std::vector<int> done(s->cfg.batch);
-    const int chunk = 8;                                       // sweeps enqueued between two polls of the exit flags
+    const int chunk = poll_every > 0 ? poll_every : 8;         // sweeps enqueued between two polls of the exit flags
+    const int stride = s->cfg.max_iter + 2;
+    int sweeps = 0;
     for (int guard = 0; guard < 1000000; guard++) {
-        if ((rc = s->iterate(chunk))) return rc;
+        if ((rc = phase_ms ? s->iterate_traced(chunk, phase_ms, sweeps, stride) : s->iterate(chunk))) return rc;
+        sweeps += chunk;
         if ((rc = s->status(done.data(), nullptr))) return rc;
         bool all = true;
         for (int d : done) all &= (d != 0);
@@ -384,5 +443,9 @@ extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, 
     if ((rc = s->store(x0, u0, nullptr, Jout, alphaOut, nullptr))) return rc;
     const double t2 = now_ms();
     if (times_ms) { times_ms[0] = t2 - t0; times_ms[1] = t_init + (t2 - t1); }
+    if (sweeps_out) *sweeps_out = sweeps;
     return 0;
+}
+extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
+    return pddp_solve_ex(h, x0, u0, xGoal, nullptr, nullptr, nullptr, nullptr, Jout, alphaOut, 0, clear, ifd, 8, times_ms, nullptr, nullptr);
 }

@@ -1,0 +1,202 @@
+// DDPWrappers.hpp -- the reference's solver entry points, same names and argument order, over libpddp.so.
+//
+//   allocateMemory_GPU<T>   DDPHelpers/nisInitHelpers.cuh:768-861
+//   runiLQR_GPU<T>          DDPHelpers/DDPWrappers.cuh:10-138
+//   freeMemory_GPU<T>       DDPHelpers/nisInitHelpers.cuh:865-882
+//
+// so that a caller written against the reference (examples/WAFR_iLQR_examples.cu:303-361, `testGPU`) recompiles after
+// replacing `#include "config.cuh"` by `#include "hostapi/config.hpp"` and `cudaStream_t` by `pddpStream_t`.
+//
+// What the arguments mean here.  The reference makes the CALLER hold every device buffer and hands them back on each
+// call.  This implementation keeps one solver handle (include/pddp.h) behind them: allocateMemory_GPU creates the handle
+// and fills the caller's variables with the handle's own device arrays, runiLQR_GPU finds the handle back from `d_P`.
+// Buffers with the reference's layout and meaning (readable/writable by the caller between solves, e.g. for warm starts
+// or an MPC shift): d_P d_p d_Pp d_pp d_AB d_H d_g d_KT d_du d_ApBK d_Bdu d_JT d_dJexp d_err d_alpha d_xGoal d_up d_dp
+// and the per-alpha tables d_x/h_d_x, d_u/h_d_u, d_d/h_d_d.  Differences, all consequences of copies the reference makes
+// and this design does not:
+//   * d_xp / d_xp2 are the two halves of one double buffer whose roles (current trajectory / trajectory the stored
+//     boundary cost-to-go belongs to) alternate with every accepted iteration instead of being copied;
+//   * the per-alpha slots are pure outputs of the forward pass: after a solve h_d_x[*alphaIndex] holds the winner, the
+//     other slots hold the other candidates of the LAST line search (the reference overwrites them with the winner);
+//   * d_I / d_Tbody point to the library's robot constants (spatial inertias / fixed joint frames), not to the
+//     reference's 36-float-per-link scratch layout; treat them as opaque;
+//   * `streams` has NUM_STREAMS entries that all alias the solver's single stream (one stream is all it needs).
+// Errors: like the reference's gpuErrchk (utils/cudaUtils.cu:31-37), a device/runtime error prints and exit()s; numerical
+// failure stays in band (alphaOut[iter] = -1, loop exit on RHO_MAX unless IGNORE_MAX_ROX_EXIT).
+#ifndef PDDP_HOSTAPI_DDPWRAPPERS_HPP
+#define PDDP_HOSTAPI_DDPWRAPPERS_HPP
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <type_traits>
+#include <vector>
+
+#ifndef PDDP_PHASE_TIMERS
+#define PDDP_PHASE_TIMERS 1   // fill bpTime/simTime/nisTime per iteration (HIP events; sweeps are then not replayed from a hipGraph)
+#endif
+#ifndef PDDP_POLL_EVERY
+#define PDDP_POLL_EVERY 8     // sweeps enqueued between two polls of the device-side exit flags
+#endif
+#ifndef PDDP_DEVICE
+#define PDDP_DEVICE 0
+#endif
+
+namespace pddp_hostapi {
+
+struct Context {
+    pddp_handle h;
+    std::vector<double> phase;    // [4][MAX_ITER+2]
+    std::vector<char> Jtmp;       // [MAX_ITER+2] elements of T
+    std::vector<int> atmp;
+};
+inline std::map<const void*, Context*>& registry() { static std::map<const void*, Context*> r; return r; }
+
+inline void check(int rc, const char* what) {
+    if (rc == 0) return;
+    std::fprintf(stderr, "GPUassert: %s: %s (code %d)\n", what, pddp_last_error(), rc);
+    std::exit(rc < 0 ? -rc : rc);
+}
+template <typename T> T* dev(pddp_handle h, const char* name) {
+    void* p = nullptr; size_t nb = 0;
+    check(pddp_array_ptr(h, name, &p, &nb), name);
+    return static_cast<T*>(p);
+}
+inline Context* find(const void* d_P) {
+    auto it = registry().find(d_P);
+    if (it == registry().end()) { std::fprintf(stderr, "GPUassert: buffers were not obtained from allocateMemory_GPU\n"); std::exit(1); }
+    return it->second;
+}
+
+}  // namespace pddp_hostapi
+
+template <typename T>
+void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T*** h_d_u, T** d_up, T** d_xGoal, T** xGoal, T** d_P, T** d_Pp,
+                        T** d_p, T** d_pp, T** d_AB, T** d_H, T** d_g, T** d_KT, T** d_du, T*** d_d, T*** h_d_d, T** d_dp, T** d_dT, T** d_dM,
+                        T** d, T** d_ApBK, T** d_Bdu, T** d_JT, T** J, T** d_dJexp, T** dJexp, T** alpha, T** d_alpha, int** alphaIndex,
+                        int** d_err, int** err, int* ld_x, int* ld_u, int* ld_P, int* ld_p, int* ld_AB, int* ld_H, int* ld_g, int* ld_KT,
+                        int* ld_du, int* ld_d, int* ld_A, pddpStream_t** streams, T** d_I = nullptr, T** d_Tbody = nullptr) {
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "algType must be float or double");
+    using namespace pddp_hostapi;
+    pddp_config c;
+    check(pddp_default_config(&c, PLANT), "pddp_default_config");
+    c.dtype = std::is_same<T, double>::value ? 1 : 0;
+    c.N = NUM_TIME_STEPS; c.M = M_BLOCKS; c.A = NUM_ALPHA; c.integrator = INTEGRATOR; c.batch = 1; c.max_iter = MAX_ITER;
+    c.wafr_urdf = USE_WAFR_URDF; c.mpc_mode = MPC_MODE; c.ignore_max_rho_exit = IGNORE_MAX_ROX_EXIT; c.device = PDDP_DEVICE;
+    c.use_graph = PDDP_PHASE_TIMERS ? 0 : 1;
+    c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
+    c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX;
+    c.Q1 = _Q1; c.Q2 = _Q2; c.R = _R; c.QF1 = _QF1; c.QF2 = _QF2;
+    Context* ctx = new Context();
+    check(pddp_create(&c, &ctx->h), "allocateMemory_GPU");
+    pddp_handle h = ctx->h;
+    ctx->phase.assign(4 * (MAX_ITER + 2), 0.0);
+    ctx->Jtmp.assign(sizeof(T) * (MAX_ITER + 2), 0);
+    ctx->atmp.assign(MAX_ITER + 2, 0);
+
+    *ld_x = DIM_x_r; *ld_u = DIM_u_r; *ld_P = DIM_P_r; *ld_p = DIM_p_r; *ld_AB = DIM_AB_r; *ld_H = DIM_H_r; *ld_g = DIM_g_r;
+    *ld_KT = DIM_KT_r; *ld_du = DIM_du_r; *ld_d = DIM_d_r; *ld_A = DIM_A_r;
+    const size_t N = NUM_TIME_STEPS;
+    T* xs = dev<T>(h, "xs"); T* us = dev<T>(h, "us"); T* ds = dev<T>(h, "ds");
+    *h_d_x = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*)));
+    *h_d_u = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*)));
+    *h_d_d = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*)));
+    for (int a = 0; a < NUM_ALPHA; a++) {
+        (*h_d_x)[a] = xs + a * N * STATE_SIZE; (*h_d_u)[a] = us + a * N * CONTROL_SIZE; (*h_d_d)[a] = ds + a * N * STATE_SIZE;
+    }
+    *d_x = reinterpret_cast<T**>(dev<void*>(h, "xs_ptrs")); *d_u = reinterpret_cast<T**>(dev<void*>(h, "us_ptrs"));
+    *d_d = reinterpret_cast<T**>(dev<void*>(h, "ds_ptrs"));
+    *d_xp = dev<T>(h, "xb"); *d_xp2 = dev<T>(h, "xb") + N * STATE_SIZE; *d_up = dev<T>(h, "ucur"); *d_dp = dev<T>(h, "dcur");
+    *d_xGoal = dev<T>(h, "xGoal"); *xGoal = static_cast<T*>(std::calloc(STATE_SIZE, sizeof(T)));
+    *d_P = dev<T>(h, "P"); *d_Pp = dev<T>(h, "Pp"); *d_p = dev<T>(h, "p"); *d_pp = dev<T>(h, "pp");
+    *d_AB = dev<T>(h, "AB"); *d_H = dev<T>(h, "H"); *d_g = dev<T>(h, "g"); *d_KT = dev<T>(h, "KT"); *d_du = dev<T>(h, "du");
+    *d_dT = dev<T>(h, "dmax"); *d_dM = dev<T>(h, "dmax"); *d = static_cast<T*>(std::calloc(NUM_ALPHA, sizeof(T)));
+    *d_ApBK = dev<T>(h, "ApBK"); *d_Bdu = dev<T>(h, "Bdu");
+    *d_JT = dev<T>(h, "J"); *J = static_cast<T*>(std::calloc(NUM_ALPHA, sizeof(T)));
+    *d_dJexp = dev<T>(h, "dJexp"); *dJexp = static_cast<T*>(std::calloc(2 * M_BLOCKS_B, sizeof(T)));
+    *d_alpha = dev<T>(h, "alpha"); *alpha = static_cast<T*>(std::calloc(NUM_ALPHA, sizeof(T)));
+    check(pddp_get_array(h, "alpha", *alpha, NUM_ALPHA * sizeof(T)), "alpha");      // alpha[i] = ALPHA_BASE^i (:829)
+    *alphaIndex = static_cast<int*>(std::calloc(1, sizeof(int)));
+    *d_err = dev<int>(h, "err"); *err = static_cast<int*>(std::calloc(M_BLOCKS_B, sizeof(int)));
+    void* st = nullptr;
+    check(pddp_stream(h, &st), "pddp_stream");
+    *streams = static_cast<pddpStream_t*>(std::malloc(NUM_STREAMS * sizeof(pddpStream_t)));
+    for (int i = 0; i < NUM_STREAMS; i++) (*streams)[i] = static_cast<pddpStream_t>(st);
+    if (d_I) *d_I = (PLANT == 4) ? dev<T>(h, "model_I") : nullptr;
+    if (d_Tbody) *d_Tbody = (PLANT == 4) ? dev<T>(h, "model_F") : nullptr;
+    registry()[*d_P] = ctx;
+}
+
+template <typename T>
+void runiLQR_GPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag,
+                 int ignoreFirstDefectFlag, double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime, double* initTime,
+                 pddpStream_t* streams, T** d_x, T** h_d_x, T* d_xp, T* d_xp2, T** d_u, T** h_d_u, T* d_up, T* d_P, T* d_p, T* d_Pp, T* d_pp, T* d_AB,
+                 T* d_H, T* d_g, T* d_KT, T* d_du, T** d_d, T** h_d_d, T* d_dp, T* d_dT, T* d, T* d_ApBK, T* d_Bdu, T* d_dM, T* alpha, T* d_alpha,
+                 int* alphaIndex, T* d_JT, T* J, T* dJexp, T* d_dJexp, T* d_xGoal, int* err, int* d_err, int ld_x, int ld_u, int ld_P, int ld_p,
+                 int ld_AB, int ld_H, int ld_g, int ld_KT, int ld_du, int ld_d, int ld_A, T* d_I = nullptr, T* d_Tbody = nullptr,
+                 T Q_EE1 = _Q_EE1, T Q_EE2 = _Q_EE2, T QF_EE1 = _QF_EE1, T QF_EE2 = _QF_EE2, T Q_EEV1 = _Q_EEV1, T Q_EEV2 = _Q_EEV2,
+                 T QF_EEV1 = _QF_EEV1, T QF_EEV2 = _QF_EEV2, T R_EE = _R_EE, T Q_xdEE = _Q_xdEE, T QF_xdEE = _QF_xdEE, T Q_xEE = _Q_xEE,
+                 T QF_xEE = _QF_xEE, T Q1 = _Q1, T Q2 = _Q2, T R = _R, T QF1 = _QF1, T QF2 = _QF2) {
+    using namespace pddp_hostapi;
+    (void)streams; (void)d_x; (void)h_d_x; (void)d_xp; (void)d_xp2; (void)d_u; (void)h_d_u; (void)d_up; (void)d_p; (void)d_Pp; (void)d_pp;
+    (void)d_AB; (void)d_H; (void)d_g; (void)d_KT; (void)d_du; (void)d_d; (void)h_d_d; (void)d_dp; (void)d_dT; (void)d_ApBK; (void)d_Bdu; (void)d_dM;
+    (void)alpha; (void)d_alpha; (void)d_JT; (void)d_dJexp; (void)d_xGoal; (void)d_err; (void)ld_x; (void)ld_u; (void)ld_P; (void)ld_p; (void)ld_AB;
+    (void)ld_H; (void)ld_g; (void)ld_KT; (void)ld_du; (void)ld_d; (void)ld_A; (void)d_I; (void)d_Tbody;
+    (void)Q_EE1; (void)Q_EE2; (void)QF_EE1; (void)QF_EE2; (void)Q_EEV1; (void)Q_EEV2; (void)QF_EEV1; (void)QF_EEV2; (void)R_EE; (void)Q_xdEE;
+    (void)QF_xdEE; (void)Q_xEE; (void)QF_xEE;
+    Context* ctx = find(d_P);
+    pddp_handle h = ctx->h;
+    if (Q1 != (T)_Q1 || Q2 != (T)_Q2 || R != (T)_R || QF1 != (T)_QF1 || QF2 != (T)_QF2) {
+        std::fprintf(stderr, "GPUassert: cost weights are fixed at allocateMemory_GPU time (define _Q1.._QF2 before the include)\n");
+        std::exit(1);
+    }
+    double times[2] = {0, 0};
+    int sweeps = 0;
+    T* Jtmp = reinterpret_cast<T*>(ctx->Jtmp.data());
+    check(pddp_solve_ex(h, x0, u0, xGoal, KT0, P0, p0, d0, Jtmp, ctx->atmp.data(), forwardRolloutFlag, clearVarsFlag, ignoreFirstDefectFlag,
+                        PDDP_POLL_EVERY, times, PDDP_PHASE_TIMERS ? ctx->phase.data() : nullptr, &sweeps), "runiLQR_GPU");
+    std::memcpy(Jout, Jtmp, (MAX_ITER + 1) * sizeof(T));                 // the reference's arrays hold MAX_ITER+1 entries
+    std::memcpy(alphaOut, ctx->atmp.data(), (MAX_ITER + 1) * sizeof(int));
+    pddp_state st;
+    check(pddp_get_state(h, &st), "pddp_get_state");
+    const int iter = st.iter;
+    *alphaIndex = st.alphaIndex;
+    check(pddp_get_array(h, "J", J, NUM_ALPHA * sizeof(T)), "J");
+    check(pddp_get_array(h, "dmax", d, NUM_ALPHA * sizeof(T)), "dmax");
+    check(pddp_get_array(h, "dJexp", dJexp, 2 * M_BLOCKS_B * sizeof(T)), "dJexp");
+    check(pddp_get_array(h, "err", err, M_BLOCKS_B * sizeof(int)), "err");
+    if (tTime) *tTime = times[0];
+    if (initTime) *initTime = times[1];
+    const int stride = MAX_ITER + 2;
+    for (int k = 0; k < iter && k < MAX_ITER; k++) {                      // bpTime[iter-1] ... (DDPWrappers.cuh:65,78,89,100)
+        const double* ph = ctx->phase.data();
+        if (bpTime) bpTime[k] = PDDP_PHASE_TIMERS ? ph[0 * stride + k] : 0.0;
+        if (sweepTime) sweepTime[k] = 0.0;                                // the sweep is fused into the forward-pass kernel
+        if (simTime) simTime[k] = PDDP_PHASE_TIMERS ? ph[1 * stride + k] + ph[2 * stride + k] : 0.0;
+        if (nisTime) nisTime[k] = PDDP_PHASE_TIMERS ? ph[3 * stride + k] : 0.0;
+    }
+    std::printf("GPU (MI355X) Parallel blocks:[%d] t:[%f] with FP[%f], FS[%f], BP[%f], NIU[%f] Xf:[%.4f, %.4f] iters:[%d] cost:[%f] max_d[%f]\n",
+                M_BLOCKS_B, times[0], simTime ? *simTime : 0.0, sweepTime ? *sweepTime : 0.0, bpTime ? *bpTime : 0.0, nisTime ? *nisTime : 0.0,
+                (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1)], (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1) + 1], iter, st.prevJ,
+                (double)d[st.alphaIndex]);
+}
+
+template <typename T>
+void freeMemory_GPU(T** d_x, T** h_d_x, T* d_xp, T* d_xp2, T** d_u, T** h_d_u, T* d_up, T* xGoal, T* d_xGoal, T* d_P, T* d_Pp, T* d_p, T* d_pp,
+                    T* d_AB, T* d_H, T* d_g, T* d_KT, T* d_du, T** d_d, T** h_d_d, T* d_dp, T* d_dM, T* d_dT, T* d, T* d_ApBK, T* d_Bdu, T* d_JT,
+                    T* J, T* d_dJexp, T* dJexp, T* alpha, T* d_alpha, int* alphaIndex, int* d_err, int* err, pddpStream_t* streams,
+                    T* d_I = nullptr, T* d_Tbody = nullptr) {
+    using namespace pddp_hostapi;
+    (void)d_x; (void)d_xp; (void)d_xp2; (void)d_u; (void)d_up; (void)d_xGoal; (void)d_Pp; (void)d_p; (void)d_pp; (void)d_AB; (void)d_H; (void)d_g;
+    (void)d_KT; (void)d_du; (void)d_d; (void)d_dp; (void)d_dM; (void)d_dT; (void)d_ApBK; (void)d_Bdu; (void)d_JT; (void)d_dJexp; (void)d_alpha;
+    (void)d_err; (void)d_I; (void)d_Tbody;
+    Context* ctx = find(d_P);
+    registry().erase(d_P);
+    check(pddp_destroy(ctx->h), "freeMemory_GPU");
+    delete ctx;
+    std::free(h_d_x); std::free(h_d_u); std::free(h_d_d); std::free(xGoal); std::free(d); std::free(J); std::free(dJexp); std::free(alpha);
+    std::free(alphaIndex); std::free(err); std::free(streams);
+}
+
+#endif

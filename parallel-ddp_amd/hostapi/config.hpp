@@ -1,0 +1,205 @@
+// config.hpp -- the compile-time configuration surface of the reference (config.cuh) for the MI355X-native solver.
+//
+// A caller of the reference defines macros and then includes "config.cuh" (config.cuh:10-12); a caller of this
+// package defines THE SAME macros and includes "hostapi/config.hpp".  Macro names, meanings and defaults follow
+// config.cuh (line numbers below); the only differences are
+//   * every macro is #ifndef-guarded: NUM_ALPHA, ALPHA_BASE, INTEGRATOR, RHO_INIT, MAX_DEFECT_SIZE (unconditional in the
+//     per-plant blocks, config.cuh:24-58) and M_BLOCKS, MAX_ITER (:83,:90) can be overridden without editing the file;
+//   * algType can be switched with -DPDDP_ALGTYPE_DOUBLE (the reference edits a typedef, :72-74);
+//   * the macros configure a run-time record (pddp_config, include/pddp.h) instead of template code: the kernels live in
+//     libpddp.so.
+// Host-only C++11: compiles with g++ or hipcc; link with -lpddp.
+#ifndef PDDP_HOSTAPI_CONFIG_HPP
+#define PDDP_HOSTAPI_CONFIG_HPP
+
+#include <sys/time.h>
+
+#include "../../include/pddp.h"
+
+#ifndef PLANT
+#define PLANT 4                       // 1 pendulum, 2 cart-pole, 3 quadrotor, 4 KUKA iiwa14      config.cuh:21-23
+#endif
+#if PLANT == 1                        //                                                          config.cuh:24-28
+#define NUM_POS 1
+#define CONTROL_SIZE 1
+#ifndef RHO_INIT
+#define RHO_INIT 10.0
+#endif
+#elif PLANT == 2                      //                                                          config.cuh:29-34
+#define NUM_POS 2
+#define CONTROL_SIZE 1
+#ifndef MAX_DEFECT_SIZE
+#define MAX_DEFECT_SIZE 0.75
+#endif
+#ifndef RHO_INIT
+#define RHO_INIT 10.0
+#endif
+#elif PLANT == 3                      //                                                          config.cuh:35-42
+#define NUM_POS 6
+#define CONTROL_SIZE 4
+#ifndef ALPHA_BASE
+#define ALPHA_BASE 0.5
+#endif
+#ifndef NUM_ALPHA
+#define NUM_ALPHA 16
+#endif
+#ifndef RHO_INIT
+#define RHO_INIT 1.0
+#endif
+#elif PLANT == 4                      //                                                          config.cuh:43-58
+#define NUM_POS 7
+#define CONTROL_SIZE 7
+#ifndef TOTAL_TIME
+#define TOTAL_TIME 0.5
+#endif
+#ifndef NUM_TIME_STEPS
+#define NUM_TIME_STEPS 64
+#endif
+#ifndef ALPHA_BASE
+#define ALPHA_BASE 0.5
+#endif
+#ifndef NUM_ALPHA
+#define NUM_ALPHA 16
+#endif
+#ifndef RHO_INIT
+#define RHO_INIT 12.5
+#endif
+#ifndef INTEGRATOR
+#define INTEGRATOR 1                  // the arm's dynamics are only provided for Euler, as upstream (README.md:33)
+#endif
+#else
+#error "PLANT must be 1 (pendulum), 2 (cart-pole), 3 (quadrotor) or 4 (KUKA iiwa14)"
+#endif
+#define STATE_SIZE (2 * NUM_POS)
+
+#ifdef PDDP_ALGTYPE_DOUBLE
+typedef double algType;               //                                                          config.cuh:73
+#else
+typedef float algType;                //                                                          config.cuh:74
+#endif
+
+#ifndef INTEGRATOR
+#define INTEGRATOR 3                  // 1 Euler, 2 midpoint, 3 RK3                               config.cuh:78-80
+#endif
+#ifndef MAX_ITER
+#define MAX_ITER 100                  //                                                          config.cuh:83
+#endif
+#ifndef TOL_COST
+#define TOL_COST 0.0001               //                                                          config.cuh:85-87
+#endif
+#ifndef M_BLOCKS
+#define M_BLOCKS 4                    //                                                          config.cuh:90
+#endif
+#define M_BLOCKS_B M_BLOCKS           //                                                          config.cuh:91-94
+#define M_BLOCKS_F M_BLOCKS
+#define N_BLOCKS_B (NUM_TIME_STEPS / M_BLOCKS_B)
+#define N_BLOCKS_F (NUM_TIME_STEPS / M_BLOCKS_F)
+#ifndef RHO_INIT
+#define RHO_INIT 1.0                  //                                                          config.cuh:99-101
+#endif
+#ifndef IGNORE_MAX_ROX_EXIT
+#define IGNORE_MAX_ROX_EXIT 1         //                                                          config.cuh:105-107
+#endif
+#ifndef ALPHA_BASE
+#define ALPHA_BASE 0.75               //                                                          config.cuh:110-112
+#endif
+#ifndef NUM_ALPHA
+#define NUM_ALPHA 32                  //                                                          config.cuh:113-115
+#endif
+#ifndef EXP_RED_MIN
+#define EXP_RED_MIN 0.05              //                                                          config.cuh:117-119
+#endif
+#ifndef EXP_RED_MAX
+#define EXP_RED_MAX 1.25              //                                                          config.cuh:120-122
+#endif
+#ifndef MAX_DEFECT_SIZE
+#define MAX_DEFECT_SIZE 1.0           //                                                          config.cuh:124-126
+#endif
+#define onDefectBoundary(k) ((((k + 1) % N_BLOCKS_F) == 0) && (k < NUM_TIME_STEPS - 1))   //      config.cuh:127
+#ifndef TOTAL_TIME
+#define TOTAL_TIME 4.0                //                                                          config.cuh:130-132
+#endif
+#ifndef NUM_TIME_STEPS
+#define NUM_TIME_STEPS 128            //                                                          config.cuh:133-135
+#endif
+#define TIME_STEP (TOTAL_TIME / (NUM_TIME_STEPS - 1))
+#define NUM_STREAMS ((18 > 4 + NUM_ALPHA) ? 18 : (4 + NUM_ALPHA))   //                            config.cuh:144
+#ifndef USE_WAFR_URDF
+#define USE_WAFR_URDF 0               //                                                          config.cuh:182-184
+#endif
+#ifndef MPC_MODE
+#define MPC_MODE 0                    //                                                          config.cuh:185-187
+#endif
+#ifndef EE_COST
+#define EE_COST 0                     //                                                          config.cuh:165-167
+#endif
+#if EE_COST
+#error "the end-effector cost family (plants/cost_arm.cuh:206-389) is not provided yet (SURVEY.md section 8f, row N2)"
+#endif
+// joint-space cost weights (plants/cost_arm.cuh:97-103); the pendulum / cart-pole / quadrotor weights are fixed inside
+// the library exactly as plants/cost_{pend,cart,quad}.cuh fix them
+#ifndef _Q1
+#define _Q1 0.1
+#endif
+#ifndef _Q2
+#define _Q2 0.001
+#endif
+#ifndef _R
+#define _R 0.0001
+#endif
+#ifndef _QF1
+#define _QF1 1000.0
+#endif
+#ifndef _QF2
+#define _QF2 1000.0
+#endif
+// the end-effector weights exist only so that call sites that pass them keep compiling
+#define _Q_EE1 0.0
+#define _Q_EE2 0.0
+#define _QF_EE1 0.0
+#define _QF_EE2 0.0
+#define _Q_EEV1 0.0
+#define _Q_EEV2 0.0
+#define _QF_EEV1 0.0
+#define _QF_EEV2 0.0
+#define _R_EE 0.0
+#define _Q_xdEE 0.0
+#define _QF_xdEE 0.0
+#define _Q_xEE 0.0
+#define _QF_xEE 0.0
+
+// matrix dimensions (config.cuh:195-236), column-major, leading dimension = rows
+#define DIM_x_r STATE_SIZE
+#define DIM_u_r CONTROL_SIZE
+#define DIM_d_r STATE_SIZE
+#define DIM_AB_r STATE_SIZE
+#define DIM_AB_c (STATE_SIZE + CONTROL_SIZE)
+#define DIM_A_r STATE_SIZE
+#define DIM_A_c STATE_SIZE
+#define DIM_H_r (STATE_SIZE + CONTROL_SIZE)
+#define DIM_H_c (STATE_SIZE + CONTROL_SIZE)
+#define DIM_g_r (STATE_SIZE + CONTROL_SIZE)
+#define DIM_P_r STATE_SIZE
+#define DIM_P_c STATE_SIZE
+#define DIM_p_r STATE_SIZE
+#define DIM_K_r CONTROL_SIZE
+#define DIM_K_c STATE_SIZE
+#define DIM_KT_r DIM_K_c
+#define DIM_KT_c DIM_K_r
+#define DIM_du_r CONTROL_SIZE
+#define OFFSET_HXU (DIM_x_r * (DIM_x_r + DIM_u_r))
+#define OFFSET_HUU (OFFSET_HXU + DIM_x_r)
+#define OFFSET_HUX_GU DIM_x_r
+#define OFFSET_B (DIM_AB_r * DIM_x_r)
+
+#define get_time_us(time) (static_cast<double>(time.tv_sec * 1000000.0 + time.tv_usec))    //      config.cuh:137-141
+#define get_time_ms(time) (get_time_us(time) / 1000.0)
+#define time_delta_us(start, end) (static_cast<double>(get_time_us(end) - get_time_us(start)))
+#define time_delta_ms(start, end) (time_delta_us(start, end) / 1000.0)
+
+// A HIP stream handle (identical to hipStream_t when <hip/hip_runtime.h> is also included).
+typedef struct ihipStream_t* pddpStream_t;
+
+#include "DDPWrappers.hpp"
+
+#endif

@@ -118,11 +118,14 @@ class Solver:
         return np.ascontiguousarray(a, dtype=self.dtype)
 
     # ---- runiLQR_GPU pieces
-    def load(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1):
+    def load(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1, forward_rollout=0, KT0=None, P0=None, p0=None, d0=None):
+        """loadVarsGPU + initAlgGPU (pddp_load_ex): warm-start arrays are used when clear_vars == 0."""
         B, N = self.cfg.batch, self.cfg.N
         x0, u0, xGoal = self.arr(x0), self.arr(u0), self.arr(xGoal)
         assert x0.size == B * N * self.n and u0.size == B * N * self.m and xGoal.size == B * self.n
-        self._chk(self.lib.pddp_load(self.h, _p(x0), _p(u0), _p(xGoal), int(clear_vars), int(ignore_first_defect)))
+        ws = [None if a is None else self.arr(a) for a in (KT0, P0, p0, d0)]
+        self._chk(self.lib.pddp_load_ex(self.h, _p(x0), _p(u0), _p(xGoal), _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]),
+                                        int(forward_rollout), int(clear_vars), int(ignore_first_defect)))
 
     def iterate(self, sweeps=1):
         self._chk(self.lib.pddp_iterate(self.h, int(sweeps)))
@@ -143,9 +146,9 @@ class Solver:
         self._chk(self.lib.pddp_store(self.h, _p(out["x"]), _p(out["u"]), _p(out["KT"]), _p(out["Jout"]), _p(out["alphaOut"]), _p(out["dmax"])))
         return out
 
-    def solve(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1, max_sweeps=None, chunk=8):
+    def solve(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1, max_sweeps=None, chunk=8, **load_kw):
         """load -> iterate until every problem has exited -> store (the shape of runiLQR_GPU)."""
-        self.load(x0, u0, xGoal, clear_vars, ignore_first_defect)
+        self.load(x0, u0, xGoal, clear_vars, ignore_first_defect, **load_kw)
         limit = max_sweeps if max_sweeps is not None else 4 * (self.cfg.max_iter + 2) + 250
         sweeps = 0
         while sweeps < limit:

@@ -93,8 +93,9 @@ def allgather_costs(ctx, jout, batch, stride, last_col):
         return cols.cpu().numpy()
     import torch.distributed as dist
     cols = cols.to(_dev(ctx))
-    gathered = torch.empty((ctx.world,) + tuple(cols.shape), dtype=cols.dtype, device=cols.device)
+    gathered = torch.empty((ctx.world * batch, 2), dtype=cols.dtype, device=cols.device)     # rank-major concatenation
     dist.all_gather_into_tensor(gathered, cols)
+    gathered = gathered.reshape(ctx.world, batch, 2)
     # [rank][local][2] -> global order g = local * world + rank
     return gathered.permute(1, 0, 2).reshape(ctx.world * batch, 2).cpu().numpy()
 
@@ -111,3 +112,33 @@ def finalize(ctx):
         import torch.distributed as dist
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def solve_sharded(ctx, make_solver, x0_all, u0_all, xg_all, poll_every=8, max_sweeps=100000, **load_kw):
+    """MPC-rollout mode (BASELINE configs[3]): `total` independent problems, rank g solves {r : r % world == g} with a solver
+    created by make_solver(batch); sweeps run with no collective; every `poll_every` sweeps the ranks agree on "all done?"
+    (one max-reduce) and at the end exchange the cost table (one all-gather).
+    Returns dict(costs [total][2] = (J_initial, J_final) in global order, best = (problem id, cost), local = the rank's store())."""
+    import numpy as np
+    total = len(x0_all)
+    mine = owned_problems(total, ctx.rank, ctx.world)
+    per_rank = (total + ctx.world - 1) // ctx.world
+    if total % ctx.world:
+        raise ValueError("the number of problems must be a multiple of the number of ranks (pad the batch)")
+    s = make_solver(per_rank)
+    s.load(np.stack([x0_all[i] for i in mine]), np.stack([u0_all[i] for i in mine]), np.stack([xg_all[i] for i in mine]), **load_kw)
+    sweeps = 0
+    while sweeps < max_sweeps:
+        s.iterate(poll_every)
+        sweeps += poll_every
+        done, iters = s.status()
+        if all_done(ctx, done):
+            break
+    out = s.store()
+    done, iters = s.status()
+    stride = s.cfg.max_iter + 2
+    J = out["Jout"].reshape(per_rank, stride)
+    first_last = np.stack([J[:, 0], J[np.arange(per_rank), iters]], axis=1).astype(np.float64)
+    padded = np.zeros((per_rank, stride)); padded[:, 0] = first_last[:, 0]; padded[:, 1] = first_last[:, 1]
+    costs = allgather_costs(ctx, padded, per_rank, stride, 1)
+    return dict(costs=costs, best=best_rollout(costs), local=out, sweeps=sweeps, iters=iters)

@@ -36,7 +36,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
 struct Base {
     pddp_config cfg; int bench = 0;
     virtual ~Base() {}
-    virtual int load(const void*, const void*, const void*, int, int) = 0;
+    virtual int load(const void*, const void*, const void*, const void*, const void*, const void*, const void*, int, int, int) = 0;
     virtual int iterate(int) = 0;
     virtual int status(int*, int*) = 0;
     virtual int store(void*, void*, void*, void*, int*, void*) = 0;
@@ -115,7 +115,7 @@ struct Sim : Base {
             for (int pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, 1, 0, pb);
         }
     }
-    int load(const void* x0, const void* u0, const void* xg, int clear, int ifd) override {
+    int load(const void* x0, const void* u0, const void* xg, const void* KT0, const void* P0, const void* p0, const void* d0, int rollout, int clear, int ifd) override {
         const size_t B = cfg.batch, N = cfg.N;
         for (size_t pb = 0; pb < B; pb++) std::memcpy(b.xb + pb * 2 * N * NX, (const T*)x0 + pb * N * NX, N * NX * sizeof(T));
         std::memcpy(b.ucur, u0, B * N * NU * sizeof(T)); std::memcpy(b.xGoal, xg, B * NX * sizeof(T));
@@ -123,10 +123,30 @@ struct Sim : Base {
             std::memset(b.P, 0, B * N * NX * NX * sizeof(T)); std::memset(b.Pp, 0, B * N * NX * NX * sizeof(T));
             std::memset(b.p, 0, B * N * NX * sizeof(T)); std::memset(b.pp, 0, B * N * NX * sizeof(T));
             std::memset(b.KT, 0, B * N * NX * NU * sizeof(T)); std::memset(b.dcur, 0, B * N * NX * sizeof(T));
+        } else {
+            if (P0) { std::memcpy(b.P, P0, B * N * NX * NX * sizeof(T)); std::memcpy(b.Pp, P0, B * N * NX * NX * sizeof(T)); }
+            if (p0) { std::memcpy(b.p, p0, B * N * NX * sizeof(T)); std::memcpy(b.pp, p0, B * N * NX * sizeof(T)); }
+            if (KT0) std::memcpy(b.KT, KT0, B * N * NX * NU * sizeof(T));
+            if (d0) std::memcpy(b.dcur, d0, B * N * NX * sizeof(T));
         }
         std::memset(b.du, 0, B * N * NU * sizeof(T)); std::memset(b.err, 0, B * cfg.M * sizeof(int)); std::memset(b.dmax, 0, B * cfg.A * sizeof(T));
         std::vector<T> cost_k(cfg.N); const Wave w = this_wave();
-        for (size_t pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 0, (int)pb);
+        if (rollout) {
+            static SimScratch<P, T> sim; std::vector<T> segx(cfg.M * NX), dnorm(cfg.M);
+            for (size_t pb = 0; pb < B; pb++) {
+                init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 1, (int)pb);
+                const FpArgs<T> fa = fp_args<P, T>(b, dm, (int)pb, 0, dt, segx.data(), dnorm.data());
+                for (int sg = 0; sg < cfg.M; sg++) rollout_seed_segment<P, T>(w, dm, fa, sg);
+                P::load_model(w, sim.plant, &model);
+                for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + pb * NX, cost_k.data());
+                fp_reduce<T>(w, b, dm, (int)pb, 0, cost_k.data(), dnorm.data());
+                const size_t slot = pb * cfg.A;
+                std::memcpy(b.xb + pb * 2 * N * NX, b.xs + slot * N * NX, N * NX * sizeof(T));
+                std::memcpy(b.ucur + pb * N * NU, b.us + slot * N * NU, N * NU * sizeof(T));
+                std::memcpy(b.dcur + pb * N * NX, b.ds + slot * N * NX, N * NX * sizeof(T));
+            }
+        }
+        for (size_t pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, rollout, (int)pb);
         phase(PDDP_PHASE_INIT_NIS);
         return 0;
     }
@@ -213,7 +233,11 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     return 0;
 }
 extern "C" int pddp_destroy(pddp_handle h) { if (h) { delete h->impl; delete h; } return 0; }
-extern "C" int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xg, int clear, int ifd) { return h->impl->load(x0, u0, xg, clear, ifd); }
+extern "C" int pddp_load(pddp_handle h, const void* x0, const void* u0, const void* xg, int clear, int ifd) { return h->impl->load(x0, u0, xg, nullptr, nullptr, nullptr, nullptr, 0, clear, ifd); }
+extern "C" int pddp_load_ex(pddp_handle h, const void* x0, const void* u0, const void* xg, const void* KT0, const void* P0, const void* p0, const void* d0, int rollout, int clear, int ifd) {
+    return h->impl->load(x0, u0, xg, KT0, P0, p0, d0, rollout, clear, ifd);
+}
+extern "C" int pddp_hbm_calibration(int, size_t, int) { return fail(PDDP_ENODEVICE, "host emulation has no HBM"); }
 extern "C" int pddp_iterate(pddp_handle h, int sweeps) { return h->impl->iterate(sweeps); }
 extern "C" int pddp_sync(pddp_handle) { return 0; }
 extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { return h->impl->status(done, iters); }
@@ -234,15 +258,23 @@ extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { return h->impl->
 extern "C" int pddp_set_state(pddp_handle h, const pddp_state* in) { return h->impl->set_state(in); }
 extern "C" int pddp_run_phase(pddp_handle h, int phase) { return h->impl->run_phase(phase); }
 extern "C" int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out) { return h->impl->plant_eval(what, count, x, u, out); }
-extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
-    Base* s = h->impl; s->load(x0, u0, xGoal, clear, ifd);
+extern "C" int pddp_solve_ex(pddp_handle h, void* x0, void* u0, const void* xGoal, const void* KT0, const void* P0, const void* p0, const void* d0,
+                             void* Jout, int* alphaOut, int rollout, int clear, int ifd, int, double* times_ms, double* phase_ms, int* sweeps_out) {
+    Base* s = h->impl; s->load(x0, u0, xGoal, KT0, P0, p0, d0, rollout, clear, ifd);
     std::vector<int> done(s->cfg.batch);
+    int sweeps = 0;
     for (int guard = 0; guard < 100000; guard++) {
-        s->iterate(1); s->status(done.data(), nullptr);
+        s->iterate(1); sweeps++; s->status(done.data(), nullptr);
         bool all = true; for (int d : done) all &= (d != 0);
         if (all) break;
     }
     s->store(x0, u0, nullptr, Jout, alphaOut, nullptr);
     if (times_ms) { times_ms[0] = 0; times_ms[1] = 0; }
+    if (phase_ms) std::memset(phase_ms, 0, sizeof(double) * 4 * (s->cfg.max_iter + 2));
+    if (sweeps_out) *sweeps_out = sweeps;
     return 0;
 }
+extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
+    return pddp_solve_ex(h, x0, u0, xGoal, nullptr, nullptr, nullptr, nullptr, Jout, alphaOut, 0, clear, ifd, 1, times_ms, nullptr, nullptr);
+}
+extern "C" int pddp_stream(pddp_handle, void** st) { if (st) *st = nullptr; return 0; }

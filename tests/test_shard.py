@@ -1,0 +1,68 @@
+"""Multi-GPU path on CPU: world_size 2, gloo.  The per-rank solver is the host emulation of the kernels (test tool); what is
+under test is the host logic of pyddp.shard -- round-robin ownership, no collective per sweep, the exit-flag reduce, the
+cost all-gather in global problem order and the best-rollout pick -- against a single-process solve of the same batch."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, os.path.join(%(root)r, "parallel-ddp_amd"))
+import pyddp
+from pyddp import shard
+from backends import hostsim_path
+from oracle_binding import example_inputs
+ctx = shard.init_from_env(2, backend="gloo")
+assert ctx.world == 2 and ctx.backend == "gloo"
+kw = dict(N=32, M=4, A=4, wafr_urdf=1, tol_cost=1e-3, total_time=0.5, max_iter=12)
+rng = np.random.default_rng(3)
+total = 6
+xs, us, gs = [], [], []
+for b in range(total):
+    x0, u0, xg = example_inputs(4, 32, np.float32, noise=rng.normal(0, 0.01 * (b + 1), (32, 14)))
+    xs.append(x0); us.append(u0); gs.append(xg)
+path = hostsim_path()
+mk = lambda batch: pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=batch, **kw), _lib_path=path)
+res = shard.solve_sharded(ctx, mk, xs, us, gs, poll_every=3)
+tmax = shard.max_over_ranks(ctx, 1.0 + ctx.rank)
+assert tmax == 2.0
+assert shard.owned_problems(total, ctx.rank, 2) == list(range(ctx.rank, total, 2))
+if ctx.rank == 0:
+    json.dump(dict(costs=res["costs"].tolist(), best=res["best"], sweeps=res["sweeps"]), open(sys.argv[1], "w"))
+shard.finalize(ctx)
+'''
+
+
+def test_world_size_2_gloo_matches_single_process(tmp_path):
+    out = tmp_path / "res.json"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29613", str(script), str(out)], env=env, timeout=600)
+    import json
+    res = json.load(open(out))
+    # single-process reference: all 6 problems in one handle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pyddp
+    from backends import hostsim_path
+    from oracle_binding import example_inputs
+    kw = dict(N=32, M=4, A=4, wafr_urdf=1, tol_cost=1e-3, total_time=0.5, max_iter=12)
+    rng = np.random.default_rng(3)
+    xs, us, gs = [], [], []
+    for b in range(6):
+        x0, u0, xg = example_inputs(4, 32, np.float32, noise=rng.normal(0, 0.01 * (b + 1), (32, 14)))
+        xs.append(x0); us.append(u0); gs.append(xg)
+    path = hostsim_path()
+    s = pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=6, **kw), _lib_path=path)
+    one = s.solve(np.stack(xs), np.stack(us), np.stack(gs))
+    J0 = one["Jout"][:, 0]; Jf = one["Jout"][np.arange(6), one["iters"]]
+    costs = np.asarray(res["costs"])
+    assert np.array_equal(costs[:, 0].astype(np.float32), J0) and np.array_equal(costs[:, 1].astype(np.float32), Jf)
+    assert res["best"][0] == int(np.argmin(Jf))
+    assert res["sweeps"] % 3 == 0

@@ -134,3 +134,43 @@ def test_full_size_properties(backend):
     nonb = [k for k in range(128) if not (((k + 1) % 32 == 0) and k < 127)]
     assert not ds[:, nonb].any()
     assert (out["dmax"] >= 0).all()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("plant,kw", [
+    (4, dict(N=64, M=4, A=8, wafr_urdf=1, total_time=0.5, max_iter=8)),
+    (2, dict(N=64, M=2, A=8, integrator=3, total_time=2.0, max_iter=8)),
+])
+def test_forward_rollout_flag(backend, plant, kw):
+    """forwardRolloutFlag = 1 (nisInitHelpers.cuh:642-648): the loaded trajectory is first rolled out segment by segment;
+    alphaOut[0] = 0, and the whole solve follows the oracle's GPU-semantics driver with rollout = 1."""
+    dtype = np.float64
+    s = make_solver(backend, plant, dtype=1, tol_cost=0.0, **kw)
+    o = Oracle(default_cfg(plant, cores=8, spawn_threads=0, tol_cost=0.0, **kw), dtype)
+    x0, u0, xg = example_inputs(plant, kw["N"], dtype, noise=RNG.normal(0, 0.001, (kw["N"], o.n)))
+    r = o.run_ilqr_gpusem(x0, u0, xg, rollout=1)
+    out = s.solve(x0, u0, xg, forward_rollout=1)
+    it = r["iters"]
+    assert out["alphaOut"][0][0] == 0 and r["alphaOut"][0] == 0
+    assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-8)
+    np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-8 * max(np.abs(r["x"]).max(), 1))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_warm_start_arrays(backend):
+    """clearVarsFlag = 0 (nisInitHelpers.cuh:621-628): KT0, P0, p0, d0 handed back by the caller give exactly the solve that
+    keeping the device values gives, and differ from a cold start (the boundary cost-to-go enters the first backward pass)."""
+    kw = dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=6)
+    x0, u0, xg = example_inputs(4, 64, np.float32, noise=RNG.normal(0, 0.001, (64, 14)))
+    s = make_solver(backend, 4, **kw)
+    first = s.solve(x0, u0, xg)
+    warm = dict(KT0=s.get("KT"), P0=s.get("P"), p0=s.get("p"), d0=s.get("dcur"))
+    x1, u1 = first["x"][0].ravel(), first["u"][0].ravel()
+    kept = s.solve(x1, u1, xg, clear_vars=0)                       # device values kept
+    s2 = make_solver(backend, 4, **kw)
+    given = s2.solve(x1, u1, xg, clear_vars=0, **warm)              # same values handed over the boundary
+    cold = make_solver(backend, 4, **kw).solve(x1, u1, xg, clear_vars=1)
+    assert np.array_equal(kept["Jout"][0], given["Jout"][0]) and np.array_equal(kept["alphaOut"][0], given["alphaOut"][0])
+    assert np.array_equal(kept["x"][0], given["x"][0])
+    assert not np.array_equal(kept["Jout"][0][1:], cold["Jout"][0][1:])

@@ -146,7 +146,8 @@ int pddp_run_phase(pddp_handle h, int phase);
  * what = 0 dynamics -> qdd[count][npos]                 (dynamics<T>,          plants/dynamics_*.cuh)
  *        1 dynamicsGradient -> dqdd[count][npos*(n+m)]  (dynamicsGradient<T>)
  *        2 _integrator -> xnext[count][n]               (utils/integrators.cuh)
- *        3 _integratorGradient -> AB[count][n*(n+m)] */
+ *        3 _integratorGradient -> AB[count][n*(n+m)]
+ *        4 dynamics on lane groups (KUKA arm only; the forward pass's code path) -> qdd[count][npos] */
 int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);
 
 #ifdef __cplusplus

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bodies.hpp"
+#include "fp_lg.hpp"
 
 namespace pddp {
 
@@ -57,6 +58,53 @@ __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_ro
     forward_sim_segment<P, INTEG, T>(w, sim, dm, a, wave_id, cw, b.xGoal + (size_t)pb * P::NX, cost_k);
     __syncthreads();
     if (wave_id == 0) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm);
+}
+
+// ---------------------------------------------------------------------------------------------- KUKA arm: lane-group forward pass
+// (fp_lg.hpp).  k_sweep_lg: grid (ceil(A/8), B), block 64 -- one 8-lane group per candidate alpha.
+template <typename T>
+__global__ __launch_bounds__(64) void k_sweep_lg(Buffers<T> b, Dims dm, T dt) {
+    const int pb = blockIdx.y, a_idx = blockIdx.x * kLgPerWave + (threadIdx.x >> 3);
+    if (!fp_active<T>(b, dm, pb) || a_idx >= dm.A) return;
+    const FpArgs<T> a = fp_args<ArmPlant<T>, T>(b, dm, pb, a_idx, dt, nullptr, nullptr);
+    arm_lg_forward_sweep<LgDevice<T>, T>(dm, a);
+}
+// k_fp_lg: grid (B), block 64 * ceil(A*M/8): group i of the block rolls out segment i / A of candidate i % A (the 8 groups
+// of a wave are 8 candidates of one segment: they read the same gains, which the memory pipeline coalesces); per-knot
+// costs meet in LDS and are tree-summed per candidate in the reference's pairing.  Dynamic LDS: A*(N+M) elements.
+template <typename T, int MAXT>
+__global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1)) void k_fp_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int pb = blockIdx.x;
+    if (!init_rollout && !fp_active<T>(b, dm, pb)) return;
+    const int A_eff = init_rollout ? 1 : dm.A, n_inst = A_eff * dm.M;
+    T* cost_k = reinterpret_cast<T*>(lds_raw);              // [A_eff][N]
+    T* dnorm = cost_k + (size_t)A_eff * dm.N;               // [A_eff][M]
+    const int inst = threadIdx.x >> 3;
+    if (inst < n_inst) {
+        const int a_idx = inst % A_eff, seg = inst / A_eff;
+        ArmLgConst<LgDevice<T>> c;
+        arm_lg_load_const<LgDevice<T>, T>(c, reinterpret_cast<const ArmModel<T>*>(b.model));
+        const FpArgs<T> a = fp_args<ArmPlant<T>, T>(b, dm, pb, a_idx, dt, nullptr, dnorm + a_idx * dm.M);
+        arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, b.xGoal + (size_t)pb * 14, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
+    }
+    __syncthreads();
+    const Wave w = this_wave();
+    const int wave_id = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+    for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M);
+}
+// forward dynamics of `count` (x,u) samples, one lane group each (tests): out qdd[count][7]
+template <typename T>
+__global__ __launch_bounds__(64) void k_plant_eval_lg(const void* model, int count, const T* x, const T* u, T* out) {
+    using L = LgDevice<T>;
+    ArmLgConst<L> c;
+    arm_lg_load_const<L, T>(c, reinterpret_cast<const ArmModel<T>*>(model));
+    ArmLgState<L> st;
+    for (int i = blockIdx.x * kLgPerWave + (threadIdx.x >> 3); i < count; i += gridDim.x * kLgPerWave) {
+        const T q = x[(size_t)i * 14 + L::link()], qd = x[(size_t)i * 14 + 7 + L::link()], uu = u[(size_t)i * 7 + L::link()];
+        const T qdd = arm_lg_dynamics<L>(c, st, q, qd, uu);
+        if (L::lane() < 7) out[(size_t)i * 7 + L::lane()] = qdd;
+    }
 }
 
 // line search + accept/reject: grid (B), block 64; one lane takes the decision the reference takes on the host

@@ -1,0 +1,134 @@
+// Lane groups: 8 consecutive lanes of a 64-lane wavefront cooperate on ONE instance (one rollout, one knot, ...), so a
+// wave carries 8 independent instances and every value lives in registers.
+//
+// Why.  The wave-cooperative kernels (plant_arm.hpp, fp.hpp) give a whole wave to one instance: most stages keep 7..49
+// of the 64 lanes busy and every stage boundary is an LDS round trip, so a forward-dynamics evaluation costs ~19 k
+// cycles for ~25 kflop.  The KUKA arm has 7 links: with lane l of a group owning link l (lane 7 shadows lane 6), the
+// per-link quantities (transforms, 6x6 inertias, twists, wrenches, one row of [M | I]) are per-lane REGISTER arrays, the
+// recursions over links become nearest-neighbour moves (DPP row_shr/row_shl: an operand modifier, no LDS), and the few
+// all-to-one accesses (joint axes for the mass matrix, pivot rows of the Gauss-Jordan) are intra-group broadcasts
+// (ds_swizzle: the LDS crossbar without touching LDS memory).  No LDS, no barriers, 8 instances per wave.
+//
+// The code using this header is written ONCE against a policy L:
+//     L::V            one value per lane of the group (device: T itself; host: Vec8<T>)
+//     L::M            one predicate per lane
+//     L::lane_is(j), lane_lt(j), lane_ge(j)      predicates on the lane-in-group index
+//     L::sel(m,a,b)   per-lane select
+//     L::up(v)        value of lane-1 (0 in lane 0);   L::down(v)  value of lane+1 (0 in lanes 6 and 7)
+//     L::bcast<j>(v)  value of lane j of the group
+//     L::gather(p, f) p[f(lane)] per lane,  L::scatter(p, f, v, m)
+// LgDevice<T> is the gfx950 implementation; LgHost<T> runs the 8 lanes of one group in lock step on the CPU (TEST TOOL
+// path used by tests/hostsim -- the product never instantiates it).  Arithmetic is identical operation by operation in
+// both, which is what makes the float32 results of the two comparable bit for bit.
+#pragma once
+
+#include "pddp_common.hpp"
+
+namespace pddp {
+
+constexpr int kLg = 8;          // lanes per group
+constexpr int kLgPerWave = 8;   // groups per 64-lane wave
+
+// ------------------------------------------------------------------------------------------------ host: 8 lanes in lock step
+template <typename T>
+struct Vec8 {
+    T l[kLg];
+    Vec8() {}
+    Vec8(T s) { for (int i = 0; i < kLg; i++) l[i] = s; }
+};
+struct Mask8 { bool l[kLg]; };
+#define PDDP_V8_BIN(op)                                                                                                         \
+    template <typename T> inline Vec8<T> operator op(const Vec8<T>& a, const Vec8<T>& b) { Vec8<T> r; for (int i = 0; i < kLg; i++) r.l[i] = a.l[i] op b.l[i]; return r; } \
+    template <typename T> inline Vec8<T> operator op(const Vec8<T>& a, T b) { Vec8<T> r; for (int i = 0; i < kLg; i++) r.l[i] = a.l[i] op b; return r; }               \
+    template <typename T> inline Vec8<T> operator op(T a, const Vec8<T>& b) { Vec8<T> r; for (int i = 0; i < kLg; i++) r.l[i] = a op b.l[i]; return r; }
+PDDP_V8_BIN(+) PDDP_V8_BIN(-) PDDP_V8_BIN(*) PDDP_V8_BIN(/)
+#undef PDDP_V8_BIN
+template <typename T> inline Vec8<T> operator-(const Vec8<T>& a) { Vec8<T> r; for (int i = 0; i < kLg; i++) r.l[i] = -a.l[i]; return r; }
+template <typename T> inline Vec8<T>& operator+=(Vec8<T>& a, const Vec8<T>& b) { for (int i = 0; i < kLg; i++) a.l[i] = a.l[i] + b.l[i]; return a; }
+template <typename T> inline Vec8<T>& operator-=(Vec8<T>& a, const Vec8<T>& b) { for (int i = 0; i < kLg; i++) a.l[i] = a.l[i] - b.l[i]; return a; }
+template <typename T> inline Vec8<T>& operator*=(Vec8<T>& a, const Vec8<T>& b) { for (int i = 0; i < kLg; i++) a.l[i] = a.l[i] * b.l[i]; return a; }
+
+template <typename T>
+struct LgHost {
+    using V = Vec8<T>;
+    using M = Mask8;
+    using Scalar = T;
+    static constexpr bool kDevice = false;
+    static M lane_is(int j) { M m; for (int i = 0; i < kLg; i++) m.l[i] = (i == j); return m; }
+    static M lane_lt(int j) { M m; for (int i = 0; i < kLg; i++) m.l[i] = (i < j); return m; }
+    static M lane_ge(int j) { M m; for (int i = 0; i < kLg; i++) m.l[i] = (i >= j); return m; }
+    static V sel(const M& m, const V& a, const V& b) { V r; for (int i = 0; i < kLg; i++) r.l[i] = m.l[i] ? a.l[i] : b.l[i]; return r; }
+    static V up(const V& v) { V r; r.l[0] = T(0); for (int i = 1; i < kLg; i++) r.l[i] = v.l[i - 1]; return r; }
+    static V down(const V& v) { V r; for (int i = 0; i < 6; i++) r.l[i] = v.l[i + 1]; r.l[6] = T(0); r.l[7] = T(0); return r; }
+    template <int J> static V bcast(const V& v) { return V(v.l[J]); }
+    static V bcast_dyn(const V& v, int j) { return V(v.l[j]); }
+    template <typename F> static V gather(const T* p, F f) { V r; for (int i = 0; i < kLg; i++) r.l[i] = p[f(i < 7 ? i : 6)]; return r; }
+    template <typename F> static void scatter(T* p, F f, const V& v, const M& m) { for (int i = 0; i < 7; i++) if (m.l[i]) p[f(i)] = v.l[i]; }
+    template <typename F> static V make(F f) { V r; for (int i = 0; i < kLg; i++) r.l[i] = f(i < 7 ? i : 6); return r; }
+    static V vsin(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tsin<T>(v.l[i]); return r; }
+    static V vcos(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tcos<T>(v.l[i]); return r; }
+    static V vabs(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tabs(v.l[i]); return r; }
+    static T lane_value(const V& v, int j) { return v.l[j]; }     // host-side extraction (tests)
+    static M all_true() { M m; for (int i = 0; i < kLg; i++) m.l[i] = true; return m; }
+};
+
+// ------------------------------------------------------------------------------------------------ device: gfx950
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+template <typename T>
+struct LgDevice {
+    using V = T;
+    using M = bool;
+    using Scalar = T;
+    static constexpr bool kDevice = true;
+    static __device__ __forceinline__ int lane() { return static_cast<int>(threadIdx.x) & (kLg - 1); }
+    static __device__ __forceinline__ int link() { const int l = lane(); return l < 7 ? l : 6; }   // lane 7 shadows lane 6
+    static __device__ __forceinline__ M lane_is(int j) { return lane() == j; }
+    static __device__ __forceinline__ M lane_lt(int j) { return lane() < j; }
+    static __device__ __forceinline__ M lane_ge(int j) { return lane() >= j; }
+    static __device__ __forceinline__ V sel(M m, V a, V b) { return m ? a : b; }
+
+    // nearest-neighbour moves inside a DPP row (16 lanes = two groups); the select kills what crosses a group boundary
+    static __device__ __forceinline__ float dpp_shr1(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));   // row_shr:1
+    }
+    static __device__ __forceinline__ float dpp_shl1(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));   // row_shl:1
+    }
+    static __device__ __forceinline__ double dpp_shr1(double v) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x111, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, true);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    static __device__ __forceinline__ double dpp_shl1(double v) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x101, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, true);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    static __device__ __forceinline__ V up(V v) { const V t = dpp_shr1(v); return lane() == 0 ? V(0) : t; }
+    static __device__ __forceinline__ V down(V v) { const V t = dpp_shl1(v); return lane() >= 6 ? V(0) : t; }
+
+    // intra-group broadcast of lane J: ds_swizzle bit mode, lane' = (lane & 0x18) | J inside each half-wave
+    template <int J> static __device__ __forceinline__ float swz(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (J << 5)));
+    }
+    template <int J> static __device__ __forceinline__ double swz(double v) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffLL), 0x18 | (J << 5));
+        const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x18 | (J << 5));
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    template <int J> static __device__ __forceinline__ V bcast(V v) { return swz<J>(v); }
+    static __device__ __forceinline__ V bcast_dyn(V v, int j) { return __shfl(v, j, kLg); }
+    template <typename F> static __device__ __forceinline__ V gather(const T* p, F f) { return p[f(link())]; }
+    template <typename F> static __device__ __forceinline__ void scatter(T* p, F f, V v, M m) { if (m && lane() < 7) p[f(lane())] = v; }
+    template <typename F> static __device__ __forceinline__ V make(F f) { return f(link()); }
+    static __device__ __forceinline__ V vsin(V v) { return tsin<T>(v); }
+    static __device__ __forceinline__ V vcos(V v) { return tcos<T>(v); }
+    static __device__ __forceinline__ V vabs(V v) { return tabs(v); }
+    static __device__ __forceinline__ M all_true() { return true; }
+};
+#endif
+
+}  // namespace pddp

@@ -176,7 +176,7 @@ struct Solver : SolverBase {
         HIPCHK(hipMemsetAsync(b.dmax, 0, B * cfg.A * sizeof(T), stream));
         if (rollout) {                                               // forwardRolloutFlag (:642-648)
             hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, 1);   // state.cur = 0
-            hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(1, B), dim3(64 * cfg.M), fp_lds, stream, b, dm, cw, dt, 1);
+            launch_fp(stream, 1);
             hipLaunchKernelGGL((k_adopt_slot0<P, T>), dim3(N, B), dim3(64), 0, stream, b, dm);
         }
         hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, rollout);
@@ -185,10 +185,25 @@ struct Solver : SolverBase {
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
     }
+    // forward pass: the arm runs on lane groups (fp_lg.hpp), the closed-form plants on the wave-cooperative kernel
+    void launch_fp(hipStream_t s, int init_rollout) {
+        const unsigned B = cfg.batch;
+        if constexpr (P::PLANT == 4) {
+            const int A_eff = init_rollout ? 1 : cfg.A;
+            const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
+            if (!init_rollout && cfg.M > 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
+            const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
+            if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            else hipLaunchKernelGGL((k_fp_lg<T, 1024>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+        } else {
+            hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
+        }
+    }
     void launch_sweep(hipStream_t s, int only = -1) {
         const unsigned B = cfg.batch;
         if (only < 0 || only == PDDP_PHASE_BP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
-        if (only < 0 || only == PDDP_PHASE_FP) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, 0);
+        if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
         if (only < 0 || only == PDDP_PHASE_NIS) hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, 0);
     }
@@ -318,15 +333,16 @@ struct Solver : SolverBase {
         return 0;
     }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
-        if (what < 0 || what > 3 || count <= 0) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
-        const size_t osz = (what == 0 ? NP : what == 1 ? NP * NM : what == 2 ? NX : NX * NM);
+        if (what < 0 || what > 4 || count <= 0 || (what == 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
+        const size_t osz = (what == 0 || what == 4 ? NP : what == 1 ? NP * NM : what == 2 ? NX : NX * NM);
         T *dx, *du_, *dout;
         HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&du_, (size_t)count * NU * sizeof(T)));
         HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
         HIPCHK(hipMemcpy(dx, x, (size_t)count * NX * sizeof(T), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
         const int grid = count < 4096 ? count : 4096;
-        hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
+        if (what == 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout); }
+        else hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(out, dout, (size_t)count * osz * sizeof(T), hipMemcpyDeviceToHost));
@@ -362,6 +378,7 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.N < 4 || (c.N & (c.N - 1)) || c.N > 1024) return fail(PDDP_EINVAL, "N must be a power of two in [4,1024] (the reference's tree reductions assume it)");
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
+    if (c.plant == 4 && c.A * c.M > 128) return fail(PDDP_EINVAL, "KUKA arm: A * M must not exceed 128 (one workgroup rolls out all candidates of a problem)");
     SolverBase* s = c.dtype == 0 ? make_plant<float>(c) : c.dtype == 1 ? make_plant<double>(c) : nullptr;
     if (!s) return fail(PDDP_EINVAL, "unsupported plant / integrator / dtype combination (the arm supports Euler only)");
     s->cfg = c;

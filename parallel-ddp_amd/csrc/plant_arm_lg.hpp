@@ -1,0 +1,279 @@
+// KUKA iiwa14 forward dynamics on a LANE GROUP: lane l of an 8-lane group owns link l, everything is in registers.
+//
+// Same algorithm and the same floating-point operations, in the same order per output element, as arm_dynamics()
+// (plant_arm.hpp), which restates the reference's dynamics<T> (plants/dynamics_arm.cuh:2097-2163): world-frame link
+// transforms, Pluecker transforms, world inertias Iw = TA' (I TA), composite inertias, twists, velocity-product
+// accelerations, body / net wrenches, mass matrix M_ij = S_min . (Ic_max S_max), unpivoted Gauss-Jordan on [M | I],
+// qdd = Minv tau.  Terms that multiply a structural zero of TA (its upper-right 3x3 block) or the constant last row
+// (0 0 0 1) of a homogeneous transform are dropped: adding an exact zero does not change a sum.
+//
+// What changes is WHERE things live (lanegroup.hpp): per-link data = per-lane registers; the chain recursions
+// (T_i = T_{i-1} Tb_i, v_i, JdotV_i forwards; Ic_i, net wrench backwards) are written as 6 sweeps of "own + neighbour"
+// (after sweep s the first/last s+1 links hold their final value, computed from final neighbours -- the same additions
+// in the same order as the serial loop); row r of [M | I] lives in lane r.
+#pragma once
+
+#include "lanegroup.hpp"
+#include "plant_arm.hpp"
+
+namespace pddp {
+
+// Robot constants of one group: lane l holds I_l (36) and the upper 3 rows of F_l (12).
+template <typename L>
+struct ArmLgConst {
+    typename L::V I[36];
+    typename L::V F[12];      // F[3*col + r], r < 3   (row 3 of every frame is 0 0 0 1)
+    typename L::Scalar grav;
+};
+
+template <typename L, typename T>
+PDDP_HD void arm_lg_load_const(ArmLgConst<L>& c, const ArmModel<T>* mdl) {
+#pragma unroll
+    for (int e = 0; e < 36; e++) c.I[e] = L::gather(mdl->I, [e](int b) { return 36 * b + e; });
+#pragma unroll
+    for (int col = 0; col < 4; col++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) c.F[3 * col + r] = L::gather(mdl->F, [col, r](int b) { return 16 * b + 4 * col + r; });
+    c.grav = mdl->grav;
+}
+
+// o = a x b on 3-vectors of per-lane values
+template <typename V> PDDP_HD void lg_cross3(V* o, const V* a, const V* b) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename V> PDDP_HD V lg_dot6(const V* a, const V* b) {
+    V s = a[0] * b[0];            // 0 + a0 b0 is exact
+    s = s + a[1] * b[1]; s = s + a[2] * b[2]; s = s + a[3] * b[3]; s = s + a[4] * b[4]; s = s + a[5] * b[5];
+    return s;
+}
+// o = A v, A column-major 6x6 in registers
+template <typename V> PDDP_HD void lg_mat6_mul(V* o, const V* A, const V* v) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        V s = A[r] * v[0];
+#pragma unroll
+        for (int c = 1; c < 6; c++) s = s + A[r + 6 * c] * v[c];
+        o[r] = s;
+    }
+}
+
+// Working set that outlives arm_lg_dynamics() (the gradient needs it); all per lane = per link.
+template <typename L>
+struct ArmLgState {
+    typename L::V S[6], v[6], JdV[6], t1[6], t2[6], Fj[6], Wn[6];
+    typename L::V Iw[36], Ic[36];
+    typename L::V Minv[7];        // row `lane` of M^-1
+};
+
+// q, qd, u: this lane's joint position, velocity, torque.  Returns this lane's qdd.
+template <typename L>
+PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st, typename L::V q, typename L::V qd, typename L::V u) {
+    using V = typename L::V;
+    using T = typename L::Scalar;
+    const V sn = L::vsin(q), cs = L::vcos(q);
+    // ---- link transform Tb = F Rz(q), rows 0..2, col-major index 3*col + r
+    V Tb[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        Tb[r] = cs * c.F[r] + sn * c.F[3 + r];
+        Tb[3 + r] = -sn * c.F[r] + cs * c.F[3 + r];
+        Tb[6 + r] = c.F[6 + r];
+        Tb[9 + r] = c.F[9 + r];
+    }
+    // ---- world transforms T_i = T_{i-1} Tb_i : sweep s finalises link s
+    V Tw[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) Tw[e] = Tb[e];
+#pragma unroll
+    for (int s = 1; s < 7; s++) {
+        V P[12];
+#pragma unroll
+        for (int e = 0; e < 12; e++) P[e] = L::up(Tw[e]);
+        const typename L::M me = L::lane_is(s);
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                V val = P[kx] * Tb[3 * ky];
+                val = val + P[kx + 3] * Tb[3 * ky + 1];
+                val = val + P[kx + 6] * Tb[3 * ky + 2];
+                if (ky == 3) val = val + P[kx + 9];
+                Tw[3 * ky + kx] = L::sel(me, val, Tw[3 * ky + kx]);
+            }
+    }
+    // R(row, col) = Tw[3*col + row]; p = Tw[9..11]
+    // ---- Pluecker transform TA = [R' 0; K R'],  K = skew(-R'p) R'   (Rt[row][col] = R(col,row); Kb[row][col])
+    V tt[3];
+    // indexing: the cooperative code reads a 4x4 column-major Tw4[4*col + row]; here Tw[3*col + row] (rows 0..2), so
+    //   t[k] = -(Tw4[4k] Tw4[12] + Tw4[4k+1] Tw4[13] + Tw4[4k+2] Tw4[14]) = -(R(0,k) p0 + R(1,k) p1 + R(2,k) p2), R(j,k) = Tw[3k + j]
+#pragma unroll
+    for (int k = 0; k < 3; k++) tt[k] = -((Tw[3 * k] * Tw[9] + Tw[3 * k + 1] * Tw[10]) + Tw[3 * k + 2] * Tw[11]);
+    V Rt[9], Kb[9];               // [3*col + row]
+#pragma unroll
+    for (int col = 0; col < 3; col++)
+#pragma unroll
+        for (int row = 0; row < 3; row++) {
+            const int i1 = (row + 1) % 3, i2 = (row + 2) % 3;
+            Rt[3 * col + row] = Tw[3 * row + col];                                   // Tw4[col + 4 row]
+            Kb[3 * col + row] = -tt[i2] * Tw[3 * i1 + col] + tt[i1] * Tw[3 * i2 + col];
+        }
+    // joint axis S = [z; p x z]
+    {
+        V z[3] = {Tw[6], Tw[7], Tw[8]}, p[3] = {Tw[9], Tw[10], Tw[11]};
+        st.S[0] = z[0]; st.S[1] = z[1]; st.S[2] = z[2];
+        lg_cross3(st.S + 3, p, z);
+    }
+    // TA column cc (6 entries): cc < 3: [Rt[.][cc]; Kb[.][cc]] ; cc >= 3: [0; Rt[.][cc-3]]
+    // ---- ITA = I TA   (col-major 6x6: ITA[6*cc + r])
+    V ITA[36];
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++)
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            V val;
+            if (cc < 3) {
+                val = c.I[r] * Rt[3 * cc];
+                val = val + c.I[r + 6] * Rt[3 * cc + 1];
+                val = val + c.I[r + 12] * Rt[3 * cc + 2];
+                val = val + c.I[r + 18] * Kb[3 * cc];
+                val = val + c.I[r + 24] * Kb[3 * cc + 1];
+                val = val + c.I[r + 30] * Kb[3 * cc + 2];
+            } else {
+                val = c.I[r + 18] * Rt[3 * (cc - 3)];
+                val = val + c.I[r + 24] * Rt[3 * (cc - 3) + 1];
+                val = val + c.I[r + 30] * Rt[3 * (cc - 3) + 2];
+            }
+            ITA[6 * cc + r] = val;
+        }
+    // ---- twists v_i = S_i qd_i + v_{i-1}
+    {
+        V sq[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { sq[e] = st.S[e] * qd; st.v[e] = sq[e]; }
+#pragma unroll
+        for (int s = 1; s < 7; s++)
+#pragma unroll
+            for (int e = 0; e < 6; e++) st.v[e] = sq[e] + L::up(st.v[e]);
+    }
+    // ---- world inertia Iw = TA' ITA :  Iw[6*cc + r] = sum_i TA[6*r + i] ITA[6*cc + i]
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++)
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            V val;
+            if (r < 3) {
+                val = Rt[3 * r] * ITA[6 * cc];
+                val = val + Rt[3 * r + 1] * ITA[6 * cc + 1];
+                val = val + Rt[3 * r + 2] * ITA[6 * cc + 2];
+                val = val + Kb[3 * r] * ITA[6 * cc + 3];
+                val = val + Kb[3 * r + 1] * ITA[6 * cc + 4];
+                val = val + Kb[3 * r + 2] * ITA[6 * cc + 5];
+            } else {
+                val = Rt[3 * (r - 3)] * ITA[6 * cc + 3];
+                val = val + Rt[3 * (r - 3) + 1] * ITA[6 * cc + 4];
+                val = val + Rt[3 * (r - 3) + 2] * ITA[6 * cc + 5];
+            }
+            st.Iw[6 * cc + r] = val;
+        }
+    // ---- velocity-product acceleration of this link: qd (crm(v) S)
+    V cvs[6];
+    {
+        V o[6], t3[3];
+        lg_cross3(o, st.v, st.S);
+        lg_cross3(o + 3, st.v, st.S + 3);
+        lg_cross3(t3, st.v + 3, st.S);
+        o[3] = o[3] + t3[0]; o[4] = o[4] + t3[1]; o[5] = o[5] + t3[2];
+#pragma unroll
+        for (int e = 0; e < 6; e++) cvs[e] = qd * o[e];
+    }
+    // ---- composite inertias Ic_i = Ic_{i+1} + Iw_i, JdotV_i = cvs_i + JdotV_{i-1}
+#pragma unroll
+    for (int e = 0; e < 36; e++) st.Ic[e] = st.Iw[e];
+#pragma unroll
+    for (int s = 1; s < 7; s++)
+#pragma unroll
+        for (int e = 0; e < 36; e++) st.Ic[e] = L::down(st.Ic[e]) + st.Iw[e];
+#pragma unroll
+    for (int e = 0; e < 6; e++) st.JdV[e] = cvs[e];
+#pragma unroll
+    for (int s = 1; s < 7; s++)
+#pragma unroll
+        for (int e = 0; e < 6; e++) st.JdV[e] = cvs[e] + L::up(st.JdV[e]);
+    // ---- Iw v, Iw (JdotV + g), Ic S
+    {
+        V ag[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) ag[e] = e == 5 ? st.JdV[e] + V(c.grav) : st.JdV[e];
+        lg_mat6_mul(st.t1, st.Iw, st.v);
+        lg_mat6_mul(st.t2, st.Iw, ag);
+        lg_mat6_mul(st.Fj, st.Ic, st.S);
+    }
+    // ---- body wrench Wb = crf(v) (Iw v) + Iw (JdotV + g); net wrench Wn_i = Wn_{i+1} + Wb_i
+    V Wb[6];
+    {
+        V o[6], t3[3];
+        lg_cross3(o, st.v, st.t1);
+        lg_cross3(t3, st.v + 3, st.t1 + 3);
+        o[0] = o[0] + t3[0]; o[1] = o[1] + t3[1]; o[2] = o[2] + t3[2];
+        lg_cross3(o + 3, st.v, st.t1 + 3);
+#pragma unroll
+        for (int e = 0; e < 6; e++) Wb[e] = o[e] + st.t2[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) st.Wn[e] = Wb[e];
+#pragma unroll
+    for (int s = 1; s < 7; s++)
+#pragma unroll
+        for (int e = 0; e < 6; e++) st.Wn[e] = L::down(st.Wn[e]) + Wb[e];
+    // ---- mass matrix row of this lane: M(l, k) = S_min(l,k) . Fj_max(l,k)
+    V A[14];                       // row `lane` of [M | I]
+    {
+        V Lw[7];                   // Lw[k] = S_k . Fj_lane  (meaningful for k <= lane)
+#define PDDP_LG_ROW(K)                                                                                      \
+        { V Sk[6]; _Pragma("unroll") for (int e = 0; e < 6; e++) Sk[e] = L::template bcast<K>(st.S[e]); Lw[K] = lg_dot6(Sk, st.Fj); }
+        PDDP_LG_ROW(0) PDDP_LG_ROW(1) PDDP_LG_ROW(2) PDDP_LG_ROW(3) PDDP_LG_ROW(4) PDDP_LG_ROW(5) PDDP_LG_ROW(6)
+#undef PDDP_LG_ROW
+        // upper part: M(l, k) for k > l is lane k's Lw[l]
+#define PDDP_LG_COL(K)                                                                                      \
+        {                                                                                                   \
+            V up_val = Lw[K];                                                                               \
+            _Pragma("unroll") for (int j = 0; j < K; j++) { const V cand = L::template bcast<K>(Lw[j]); up_val = L::sel(L::lane_is(j), cand, up_val); } \
+            A[K] = up_val;                                                                                  \
+        }
+        PDDP_LG_COL(0) PDDP_LG_COL(1) PDDP_LG_COL(2) PDDP_LG_COL(3) PDDP_LG_COL(4) PDDP_LG_COL(5) PDDP_LG_COL(6)
+#undef PDDP_LG_COL
+#pragma unroll
+        for (int k = 0; k < 7; k++) A[7 + k] = L::sel(L::lane_is(k), V(T(1)), V(T(0)));
+    }
+    // ---- joint torques tau = u - (S . Wn + 0.5 qd)
+    const V tau = u - (lg_dot6(st.S, st.Wn) + V(T(0.5)) * qd);
+    // ---- unpivoted Gauss-Jordan on [M | I]
+#define PDDP_LG_PIV(PV)                                                                                     \
+    {                                                                                                       \
+        V rowp[8];                                                                                          \
+        _Pragma("unroll") for (int kc = 0; kc < 8; kc++) rowp[kc] = L::template bcast<PV>(A[PV + kc]);      \
+        const V colp = A[PV];                                                                               \
+        const V inv = V(T(1)) / rowp[0];                                                                    \
+        const typename L::M isp = L::lane_is(PV);                                                           \
+        _Pragma("unroll") for (int kc = 0; kc < 8; kc++) A[PV + kc] = L::sel(isp, A[PV + kc] * inv, A[PV + kc] - colp * inv * rowp[kc]); \
+    }
+    PDDP_LG_PIV(0) PDDP_LG_PIV(1) PDDP_LG_PIV(2) PDDP_LG_PIV(3) PDDP_LG_PIV(4) PDDP_LG_PIV(5) PDDP_LG_PIV(6)
+#undef PDDP_LG_PIV
+#pragma unroll
+    for (int k = 0; k < 7; k++) st.Minv[k] = A[7 + k];
+    // ---- qdd_l = sum_i Minv(l,i) tau_i
+    V qdd;
+    {
+        V tk[7];
+        tk[0] = L::template bcast<0>(tau); tk[1] = L::template bcast<1>(tau); tk[2] = L::template bcast<2>(tau); tk[3] = L::template bcast<3>(tau);
+        tk[4] = L::template bcast<4>(tau); tk[5] = L::template bcast<5>(tau); tk[6] = L::template bcast<6>(tau);
+        qdd = st.Minv[0] * tk[0];
+#pragma unroll
+        for (int i = 1; i < 7; i++) qdd = qdd + st.Minv[i] * tk[i];
+    }
+    return qdd;
+}
+
+}  // namespace pddp

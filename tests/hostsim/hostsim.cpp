@@ -13,6 +13,7 @@
 
 #include "../../include/pddp.h"
 #include "../../parallel-ddp_amd/csrc/bodies.hpp"
+#include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/iiwa14_model_data.h"
 
 using namespace pddp;
@@ -99,6 +100,14 @@ struct Sim : Base {
                 if (!fp_active<T>(b, dm, pb)) continue;
                 for (int a = 0; a < cfg.A; a++) {
                     const FpArgs<T> fa = fp_args<P, T>(b, dm, pb, a, dt, segx.data(), dnorm.data());
+                    if constexpr (P::PLANT == 4) {          // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
+                        using L = LgHost<T>;
+                        ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
+                        if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, fa);
+                        for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, fa, sg, cw, b.xGoal + (size_t)pb * NX, cost_k.data(), false);
+                        fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data());
+                        continue;
+                    }
                     if (cfg.M > 1) forward_sweep<P, T>(w, sw, dm, fa);
                     P::load_model(w, sim.plant, &model);
                     for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + (size_t)pb * NX, cost_k.data());
@@ -136,9 +145,15 @@ struct Sim : Base {
             for (size_t pb = 0; pb < B; pb++) {
                 init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 1, (int)pb);
                 const FpArgs<T> fa = fp_args<P, T>(b, dm, (int)pb, 0, dt, segx.data(), dnorm.data());
-                for (int sg = 0; sg < cfg.M; sg++) rollout_seed_segment<P, T>(w, dm, fa, sg);
-                P::load_model(w, sim.plant, &model);
-                for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + pb * NX, cost_k.data());
+                if constexpr (P::PLANT == 4) {
+                    using L = LgHost<T>;
+                    ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
+                    for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, fa, sg, cw, b.xGoal + pb * NX, cost_k.data(), true);
+                } else {
+                    for (int sg = 0; sg < cfg.M; sg++) rollout_seed_segment<P, T>(w, dm, fa, sg);
+                    P::load_model(w, sim.plant, &model);
+                    for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + pb * NX, cost_k.data());
+                }
                 fp_reduce<T>(w, b, dm, (int)pb, 0, cost_k.data(), dnorm.data());
                 const size_t slot = pb * cfg.A;
                 std::memcpy(b.xb + pb * 2 * N * NX, b.xs + slot * N * NX, N * NX * sizeof(T));
@@ -196,7 +211,15 @@ struct Sim : Base {
         T qdd[NP], dq[NP * NM], xn[NX];
         for (int i = 0; i < count; i++) {
             const T* xi = x + (size_t)i * NX; const T* ui = u + (size_t)i * NU;
-            if (what == 0) { P::dynamics(w, s.plant, qdd, xi, ui); std::memcpy(out + (size_t)i * NP, qdd, sizeof(qdd)); }
+            if (what == 4) {
+                if constexpr (P::PLANT == 4) {
+                    using L = LgHost<T>;
+                    ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model); ArmLgState<L> st;
+                    const auto r = arm_lg_dynamics<L>(c, st, L::gather(xi, [](int l) { return l; }), L::gather(xi, [](int l) { return l + 7; }), L::gather(ui, [](int l) { return l; }));
+                    for (int e = 0; e < 7; e++) out[(size_t)i * NP + e] = r.l[e];
+                }
+            }
+            else if (what == 0) { P::dynamics(w, s.plant, qdd, xi, ui); std::memcpy(out + (size_t)i * NP, qdd, sizeof(qdd)); }
             else if (what == 1) { P::gradient(w, s.plant, s.pgrad, dq, qdd, xi, ui); std::memcpy(out + (size_t)i * NP * NM, dq, sizeof(dq)); }
             else if (what == 2) { integrator_step<P, INTEG, T>(w, s.plant, is, xn, xi, ui, dt); std::memcpy(out + (size_t)i * NX, xn, sizeof(xn)); }
             else integrator_gradient<P, INTEG, T>(w, s.plant, s.pgrad, s.integ, out + (size_t)i * NX * NM, xi, ui, dt);

@@ -65,7 +65,7 @@ __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_ro
 template <typename T>
 __global__ __launch_bounds__(64) void k_sweep_lg(Buffers<T> b, Dims dm, T dt) {
     const int pb = blockIdx.y, a_idx = blockIdx.x * kLgPerWave + (threadIdx.x >> 3);
-    if (!fp_active<T>(b, dm, pb) || a_idx >= dm.A) return;
+    if (!fp_active<T>(b, dm, pb) || a_idx >= dm.A || LgDevice<T>::lane() == 7) return;   // lane 7 of every group stays inactive (lanegroup.hpp)
     const FpArgs<T> a = fp_args<ArmPlant<T>, T>(b, dm, pb, a_idx, dt, nullptr, nullptr);
     arm_lg_forward_sweep<LgDevice<T>, T>(dm, a);
 }
@@ -78,13 +78,19 @@ __global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1)) void k_fp_lg(Buffers<T
     const int pb = blockIdx.x;
     if (!init_rollout && !fp_active<T>(b, dm, pb)) return;
     const int A_eff = init_rollout ? 1 : dm.A, n_inst = A_eff * dm.M;
+    __shared__ ArmModel<T> lds_model;
     T* cost_k = reinterpret_cast<T*>(lds_raw);              // [A_eff][N]
     T* dnorm = cost_k + (size_t)A_eff * dm.N;               // [A_eff][M]
+    {
+        const T* src = reinterpret_cast<const T*>(b.model); T* dst = reinterpret_cast<T*>(&lds_model);
+        for (int e = threadIdx.x; e < (int)(sizeof(ArmModel<T>) / sizeof(T)); e += blockDim.x) dst[e] = src[e];
+    }
+    __syncthreads();
     const int inst = threadIdx.x >> 3;
-    if (inst < n_inst) {
+    if (inst < n_inst && LgDevice<T>::lane() < 7) {        // lane 7 of every group stays inactive (lanegroup.hpp)
         const int a_idx = inst % A_eff, seg = inst / A_eff;
         ArmLgConst<LgDevice<T>> c;
-        arm_lg_load_const<LgDevice<T>, T>(c, reinterpret_cast<const ArmModel<T>*>(b.model));
+        arm_lg_load_const<LgDevice<T>, T>(c, &lds_model);
         const FpArgs<T> a = fp_args<ArmPlant<T>, T>(b, dm, pb, a_idx, dt, nullptr, dnorm + a_idx * dm.M);
         arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, b.xGoal + (size_t)pb * 14, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
     }
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(64) void k_plant_eval_lg(const void* model, int cou
     ArmLgConst<L> c;
     arm_lg_load_const<L, T>(c, reinterpret_cast<const ArmModel<T>*>(model));
     ArmLgState<L> st;
+    if (L::lane() == 7) return;                              // lane 7 of every group stays inactive (lanegroup.hpp)
     for (int i = blockIdx.x * kLgPerWave + (threadIdx.x >> 3); i < count; i += gridDim.x * kLgPerWave) {
         const T q = x[(size_t)i * 14 + L::link()], qd = x[(size_t)i * 14 + 7 + L::link()], uu = u[(size_t)i * 7 + L::link()];
         const T qdd = arm_lg_dynamics<L>(c, st, q, qd, uu);

@@ -7,7 +7,7 @@
 // per-link quantities (transforms, 6x6 inertias, twists, wrenches, one row of [M | I]) are per-lane REGISTER arrays, the
 // recursions over links become nearest-neighbour moves (DPP row_shr/row_shl: an operand modifier, no LDS), and the few
 // all-to-one accesses (joint axes for the mass matrix, pivot rows of the Gauss-Jordan) are intra-group broadcasts
-// (ds_swizzle: the LDS crossbar without touching LDS memory).  No LDS, no barriers, 8 instances per wave.
+// (two or three DPP moves: quad_perm, then row_shr/shl:4 under a bank mask).  No LDS, no barriers, 8 instances per wave.
 //
 // The code using this header is written ONCE against a policy L:
 //     L::V            one value per lane of the group (device: T itself; host: Vec8<T>)
@@ -67,6 +67,7 @@ struct LgHost {
     template <typename F> static V make(F f) { V r; for (int i = 0; i < kLg; i++) r.l[i] = f(i < 7 ? i : 6); return r; }
     static V vsin(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tsin<T>(v.l[i]); return r; }
     static V vcos(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tcos<T>(v.l[i]); return r; }
+    static void vsincos(const V& v, V& sn, V& cs) { sn = vsin(v); cs = vcos(v); }
     static V vabs(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tabs(v.l[i]); return r; }
     static T lane_value(const V& v, int j) { return v.l[j]; }     // host-side extraction (tests)
     static M all_true() { M m; for (int i = 0; i < kLg; i++) m.l[i] = true; return m; }
@@ -87,45 +88,55 @@ struct LgDevice {
     static __device__ __forceinline__ M lane_ge(int j) { return lane() >= j; }
     static __device__ __forceinline__ V sel(M m, V a, V b) { return m ? a : b; }
 
-    // nearest-neighbour moves inside a DPP row (16 lanes = two groups); the select kills what crosses a group boundary
-    static __device__ __forceinline__ float dpp_shr1(float v) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));   // row_shr:1
+    // PRECONDITION of every cross-lane function below: lane 7 of each group is INACTIVE (EXEC = 0) -- the kernels run all
+    // group code inside `if (LgDevice<T>::lane() < 7)`.  A DPP read whose source lane is out of the 16-lane row or
+    // disabled returns 0 when bound_ctrl is set (verified on gfx950: tools/probes/dpp_probe.hip), so
+    //   up(v):   row_shr:1 -- lane 0 of the first group of a row reads out of the row, lane 0 of the second group reads
+    //            the disabled lane 7 of the first: both get the 0 the recursions start from;
+    //   down(v): row_shl:1 -- lane 6 reads the disabled lane 7: 0.
+    // One DPP operand modifier each: no select, no LDS.
+    static __device__ __forceinline__ int dpp32(int v, int ctrl) {
+        return ctrl == 0x111 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true);
     }
-    static __device__ __forceinline__ float dpp_shl1(float v) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));   // row_shl:1
+    template <int CTRL> static __device__ __forceinline__ float dppv(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
     }
-    static __device__ __forceinline__ double dpp_shr1(double v) {
+    template <int CTRL> static __device__ __forceinline__ double dppv(double v) {
         const long long b = __builtin_bit_cast(long long, v);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x111, 0xF, 0xF, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, true);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
         return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
-    static __device__ __forceinline__ double dpp_shl1(double v) {
-        const long long b = __builtin_bit_cast(long long, v);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x101, 0xF, 0xF, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, true);
-        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-    }
-    static __device__ __forceinline__ V up(V v) { const V t = dpp_shr1(v); return lane() == 0 ? V(0) : t; }
-    static __device__ __forceinline__ V down(V v) { const V t = dpp_shl1(v); return lane() >= 6 ? V(0) : t; }
+    static __device__ __forceinline__ V up(V v) { return dppv<0x111>(v); }      // row_shr:1
+    static __device__ __forceinline__ V down(V v) { return dppv<0x101>(v); }    // row_shl:1
 
-    // intra-group broadcast of lane J: ds_swizzle bit mode, lane' = (lane & 0x18) | J inside each half-wave
-    template <int J> static __device__ __forceinline__ float swz(float v) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x18 | (J << 5)));
+    // intra-group broadcast of lane J (J <= 6) in DPP moves (no LDS crossbar):
+    //   1. quad_perm: every lane takes lane (J % 4) of its own quad -- correct in the quad that contains J;
+    //   2. row_shr:4 / row_shl:4 restricted by bank_mask to the OTHER quad of each group copies it across;
+    //   3. J >= 4 only: lane 3 would have to read the disabled lane 7 in step 2 (it keeps its old value): it takes lane 2's.
+    template <int J> static __device__ __forceinline__ int bc32(int v) {
+        constexpr int q = J & 3;
+        const int t = __builtin_amdgcn_update_dpp(0, v, q * 0x55, 0xF, 0xF, false);                   // quad_perm:[q,q,q,q]
+        if constexpr (J < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false);        // banks 1,3 <- lane-4
+        else {
+            const int r = __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false);                  // banks 0,2 <- lane+4
+            return __builtin_amdgcn_update_dpp(r, r, 0xA4, 0xF, 0x5, false);                          // quad_perm:[0,1,2,2] in banks 0,2
+        }
     }
-    template <int J> static __device__ __forceinline__ double swz(double v) {
+    template <int J> static __device__ __forceinline__ float bcv(float v) { return __builtin_bit_cast(float, bc32<J>(__builtin_bit_cast(int, v))); }
+    template <int J> static __device__ __forceinline__ double bcv(double v) {
         const long long b = __builtin_bit_cast(long long, v);
-        const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffLL), 0x18 | (J << 5));
-        const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x18 | (J << 5));
+        const int lo = bc32<J>((int)(b & 0xffffffffLL)), hi = bc32<J>((int)(b >> 32));
         return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
-    template <int J> static __device__ __forceinline__ V bcast(V v) { return swz<J>(v); }
+    template <int J> static __device__ __forceinline__ V bcast(V v) { return bcv<J>(v); }
     static __device__ __forceinline__ V bcast_dyn(V v, int j) { return __shfl(v, j, kLg); }
     template <typename F> static __device__ __forceinline__ V gather(const T* p, F f) { return p[f(link())]; }
     template <typename F> static __device__ __forceinline__ void scatter(T* p, F f, V v, M m) { if (m && lane() < 7) p[f(lane())] = v; }
     template <typename F> static __device__ __forceinline__ V make(F f) { return f(link()); }
     static __device__ __forceinline__ V vsin(V v) { return tsin<T>(v); }
     static __device__ __forceinline__ V vcos(V v) { return tcos<T>(v); }
+    static __device__ __forceinline__ void vsincos(V v, V& sn, V& cs) { double s_, c_; sincos(static_cast<double>(v), &s_, &c_); sn = static_cast<T>(s_); cs = static_cast<T>(c_); }
     static __device__ __forceinline__ V vabs(V v) { return tabs(v); }
     static __device__ __forceinline__ M all_true() { return true; }
 };

@@ -1,6 +1,7 @@
 // libpddp.so: host side of the C ABI declared in include/pddp.h.  gfx950 only; no CPU fallback.
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -340,7 +341,8 @@ struct Solver : SolverBase {
         HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
         HIPCHK(hipMemcpy(dx, x, (size_t)count * NX * sizeof(T), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
-        const int grid = count < 4096 ? count : 4096;
+        int grid = count < 4096 ? count : 4096;
+        if (const char* g = std::getenv("PDDP_EVAL_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;   // micro-benchmarks (tools/)
         if (what == 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout); }
         else hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
         HIPCHK(hipGetLastError());

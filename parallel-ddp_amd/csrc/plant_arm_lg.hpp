@@ -18,24 +18,19 @@
 
 namespace pddp {
 
-// Robot constants of one group: lane l holds I_l (36) and the upper 3 rows of F_l (12).
+// Robot constants: pointers to the model tables (in LDS inside the kernels -- lane l reads I[36 l + e], 7 distinct banks,
+// the 8 groups of a wave read the same addresses = broadcast -- so that they do not pin 48 VGPRs for a whole rollout).
 template <typename L>
 struct ArmLgConst {
-    typename L::V I[36];
-    typename L::V F[12];      // F[3*col + r], r < 3   (row 3 of every frame is 0 0 0 1)
+    const typename L::Scalar* Itab;    // [7][36] link spatial inertias
+    const typename L::Scalar* Ftab;    // [7][16] fixed joint frames (row 3 of every frame is 0 0 0 1)
     typename L::Scalar grav;
+    PDDP_HD typename L::V I(int e) const { return L::gather(Itab, [e](int b) { return 36 * b + e; }); }
+    PDDP_HD typename L::V F(int col, int r) const { return L::gather(Ftab, [col, r](int b) { return 16 * b + 4 * col + r; }); }
 };
 
 template <typename L, typename T>
-PDDP_HD void arm_lg_load_const(ArmLgConst<L>& c, const ArmModel<T>* mdl) {
-#pragma unroll
-    for (int e = 0; e < 36; e++) c.I[e] = L::gather(mdl->I, [e](int b) { return 36 * b + e; });
-#pragma unroll
-    for (int col = 0; col < 4; col++)
-#pragma unroll
-        for (int r = 0; r < 3; r++) c.F[3 * col + r] = L::gather(mdl->F, [col, r](int b) { return 16 * b + 4 * col + r; });
-    c.grav = mdl->grav;
-}
+PDDP_HD void arm_lg_load_const(ArmLgConst<L>& c, const ArmModel<T>* mdl) { c.Itab = mdl->I; c.Ftab = mdl->F; c.grav = mdl->grav; }
 
 // o = a x b on 3-vectors of per-lane values
 template <typename V> PDDP_HD void lg_cross3(V* o, const V* a, const V* b) {
@@ -72,26 +67,31 @@ template <typename L>
 PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st, typename L::V q, typename L::V qd, typename L::V u) {
     using V = typename L::V;
     using T = typename L::Scalar;
-    const V sn = L::vsin(q), cs = L::vcos(q);
+    V sn, cs;
+    L::vsincos(q, sn, cs);
     // ---- link transform Tb = F Rz(q), rows 0..2, col-major index 3*col + r
     V Tb[12];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        Tb[r] = cs * c.F[r] + sn * c.F[3 + r];
-        Tb[3 + r] = -sn * c.F[r] + cs * c.F[3 + r];
-        Tb[6 + r] = c.F[6 + r];
-        Tb[9 + r] = c.F[9 + r];
+        const V f0 = c.F(0, r), f1 = c.F(1, r);
+        Tb[r] = cs * f0 + sn * f1;
+        Tb[3 + r] = -sn * f0 + cs * f1;
+        Tb[6 + r] = c.F(2, r);
+        Tb[9 + r] = c.F(3, r);
     }
-    // ---- world transforms T_i = T_{i-1} Tb_i : sweep s finalises link s
+    // ---- world transforms T_i = T_{i-1} Tb_i.  Every sweep EVERY lane recomputes from its predecessor's current value: lanes
+    // below s already hold (and reproduce, bit for bit) their final value, lane s becomes final in sweep s.  Lane 0's
+    // predecessor is the identity (up() gives 0, the diagonal gets +1), and I * Tb_0 = Tb_0 exactly.
     V Tw[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) Tw[e] = Tb[e];
+    const V e0 = L::sel(L::lane_is(0), V(T(1)), V(T(0)));
 #pragma unroll
     for (int s = 1; s < 7; s++) {
         V P[12];
 #pragma unroll
         for (int e = 0; e < 12; e++) P[e] = L::up(Tw[e]);
-        const typename L::M me = L::lane_is(s);
+        P[0] = P[0] + e0; P[4] = P[4] + e0; P[8] = P[8] + e0;
 #pragma unroll
         for (int ky = 0; ky < 4; ky++)
 #pragma unroll
@@ -100,7 +100,7 @@ PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st,
                 val = val + P[kx + 3] * Tb[3 * ky + 1];
                 val = val + P[kx + 6] * Tb[3 * ky + 2];
                 if (ky == 3) val = val + P[kx + 9];
-                Tw[3 * ky + kx] = L::sel(me, val, Tw[3 * ky + kx]);
+                Tw[3 * ky + kx] = val;
             }
     }
     // R(row, col) = Tw[3*col + row]; p = Tw[9..11]
@@ -134,16 +134,16 @@ PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st,
         for (int r = 0; r < 6; r++) {
             V val;
             if (cc < 3) {
-                val = c.I[r] * Rt[3 * cc];
-                val = val + c.I[r + 6] * Rt[3 * cc + 1];
-                val = val + c.I[r + 12] * Rt[3 * cc + 2];
-                val = val + c.I[r + 18] * Kb[3 * cc];
-                val = val + c.I[r + 24] * Kb[3 * cc + 1];
-                val = val + c.I[r + 30] * Kb[3 * cc + 2];
+                val = c.I(r) * Rt[3 * cc];
+                val = val + c.I(r + 6) * Rt[3 * cc + 1];
+                val = val + c.I(r + 12) * Rt[3 * cc + 2];
+                val = val + c.I(r + 18) * Kb[3 * cc];
+                val = val + c.I(r + 24) * Kb[3 * cc + 1];
+                val = val + c.I(r + 30) * Kb[3 * cc + 2];
             } else {
-                val = c.I[r + 18] * Rt[3 * (cc - 3)];
-                val = val + c.I[r + 24] * Rt[3 * (cc - 3) + 1];
-                val = val + c.I[r + 30] * Rt[3 * (cc - 3) + 2];
+                val = c.I(r + 18) * Rt[3 * (cc - 3)];
+                val = val + c.I(r + 24) * Rt[3 * (cc - 3) + 1];
+                val = val + c.I(r + 30) * Rt[3 * (cc - 3) + 2];
             }
             ITA[6 * cc + r] = val;
         }

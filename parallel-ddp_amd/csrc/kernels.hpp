@@ -7,6 +7,7 @@
 
 #include "bodies.hpp"
 #include "fp_lg.hpp"
+#include "nis_lg.hpp"
 
 namespace pddp {
 
@@ -99,18 +100,36 @@ __global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1)) void k_fp_lg(Buffers<T
     const int wave_id = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
     for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M);
 }
-// forward dynamics of `count` (x,u) samples, one lane group each (tests): out qdd[count][7]
+// k_nis_lg: grid (ceil(N/32), B), block 256 -- one 8-lane group per knot, 32 knots per workgroup (nis_lg.hpp).
 template <typename T>
-__global__ __launch_bounds__(64) void k_plant_eval_lg(const void* model, int count, const T* x, const T* u, T* out) {
+__global__ __launch_bounds__(256, 2) void k_nis_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode) {
+    __shared__ ArmModel<T> lds_model;
+    {
+        const T* src = reinterpret_cast<const T*>(b.model); T* dst = reinterpret_cast<T*>(&lds_model);
+        for (int e = threadIdx.x; e < (int)(sizeof(ArmModel<T>) / sizeof(T)); e += blockDim.x) dst[e] = src[e];
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 32 + (threadIdx.x >> 3), pb = blockIdx.y;
+    if (k >= dm.N || LgDevice<T>::lane() == 7) return;       // lane 7 of every group stays inactive (lanegroup.hpp)
+    ArmLgConst<LgDevice<T>> c;
+    arm_lg_load_const<LgDevice<T>, T>(c, &lds_model);
+    arm_lg_nis_body<LgDevice<T>, T>(c, b, dm, cw, dt, mode, k, pb);
+}
+
+// forward dynamics (grad = 0: out qdd[count][7]) or its gradient (grad = 1: out dqdd[count][7*21]) of `count` (x,u) samples,
+// one lane group each (tests, micro-benchmarks)
+template <typename T>
+__global__ __launch_bounds__(64) void k_plant_eval_lg(const void* model, int count, const T* x, const T* u, T* out, int grad) {
     using L = LgDevice<T>;
     ArmLgConst<L> c;
     arm_lg_load_const<L, T>(c, reinterpret_cast<const ArmModel<T>*>(model));
     ArmLgState<L> st;
     if (L::lane() == 7) return;                              // lane 7 of every group stays inactive (lanegroup.hpp)
     for (int i = blockIdx.x * kLgPerWave + (threadIdx.x >> 3); i < count; i += gridDim.x * kLgPerWave) {
-        const T q = x[(size_t)i * 14 + L::link()], qd = x[(size_t)i * 14 + 7 + L::link()], uu = u[(size_t)i * 7 + L::link()];
+        const T q = x[(size_t)i * 14 + L::lane()], qd = x[(size_t)i * 14 + 7 + L::lane()], uu = u[(size_t)i * 7 + L::lane()];
         const T qdd = arm_lg_dynamics<L>(c, st, q, qd, uu);
-        if (L::lane() < 7) out[(size_t)i * 7 + L::lane()] = qdd;
+        if (!grad) out[(size_t)i * 7 + L::lane()] = qdd;
+        else { T* o = out + (size_t)i * 147 + L::lane(); arm_lg_gradient<L>(c, st, qd, qdd, [o](int jj, T val) { o[7 * jj] = val; }); }
     }
 }
 

@@ -181,7 +181,7 @@ struct Solver : SolverBase {
             hipLaunchKernelGGL((k_adopt_slot0<P, T>), dim3(N, B), dim3(64), 0, stream, b, dm);
         }
         hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, rollout);
-        hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(N, B), dim3(64), 0, stream, b, dm, cw, dt, 1);
+        launch_nis(stream, 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
@@ -201,12 +201,17 @@ struct Solver : SolverBase {
             hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
         }
     }
+    void launch_nis(hipStream_t s, int mode) {
+        const unsigned B = cfg.batch;
+        if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
+        else hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
+    }
     void launch_sweep(hipStream_t s, int only = -1) {
         const unsigned B = cfg.batch;
         if (only < 0 || only == PDDP_PHASE_BP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
         if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
-        if (only < 0 || only == PDDP_PHASE_NIS) hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, 0);
+        if (only < 0 || only == PDDP_PHASE_NIS) launch_nis(s, 0);
     }
     int iterate(int sweeps) override {
         if (cfg.use_graph) {
@@ -326,7 +331,7 @@ struct Solver : SolverBase {
     int run_phase(int phase) override {
         const unsigned B = cfg.batch;
         if (phase >= 0 && phase <= 3) launch_sweep(stream, phase);
-        else if (phase == PDDP_PHASE_INIT_NIS) hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, stream, b, dm, cw, dt, 1);
+        else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);
         else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0);
         else return fail(PDDP_EINVAL, "unknown phase");
         HIPCHK(hipGetLastError());
@@ -334,8 +339,8 @@ struct Solver : SolverBase {
         return 0;
     }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
-        if (what < 0 || what > 4 || count <= 0 || (what == 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
-        const size_t osz = (what == 0 || what == 4 ? NP : what == 1 ? NP * NM : what == 2 ? NX : NX * NM);
+        if (what < 0 || what > 5 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
+        const size_t osz = (what == 0 || what == 4 ? NP : (what == 1 || what == 5) ? NP * NM : what == 2 ? NX : NX * NM);
         T *dx, *du_, *dout;
         HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&du_, (size_t)count * NU * sizeof(T)));
         HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
@@ -343,7 +348,7 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
         int grid = count < 4096 ? count : 4096;
         if (const char* g = std::getenv("PDDP_EVAL_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;   // micro-benchmarks (tools/)
-        if (what == 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout); }
+        if (what >= 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout, what == 5); }
         else hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));

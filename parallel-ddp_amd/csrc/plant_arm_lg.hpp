@@ -276,4 +276,178 @@ PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st,
     return qdd;
 }
 
+
+// ------------------------------------------------------------------------------------------------ gradient on a lane group
+// o = crm(a) b and o = crf(a) f on per-lane 6-vectors, operation order of crm_mul / crf_mul (pddp_common.hpp)
+template <typename V> PDDP_HD void lg_crm_mul(V* o, const V* a, const V* b) {
+    V t[3];
+    lg_cross3(o, a, b);
+    lg_cross3(o + 3, a, b + 3);
+    lg_cross3(t, a + 3, b);
+    o[3] = o[3] + t[0]; o[4] = o[4] + t[1]; o[5] = o[5] + t[2];
+}
+template <typename V> PDDP_HD void lg_crf_mul(V* o, const V* a, const V* f) {
+    V t[3];
+    lg_cross3(o, a, f);
+    lg_cross3(t, a + 3, f + 3);
+    o[0] = o[0] + t[0]; o[1] = o[1] + t[1]; o[2] = o[2] + t[2];
+    lg_cross3(o + 3, a, f + 3);
+}
+
+// Analytic gradient of the forward dynamics, same derivation and the same operations per output element as
+// arm_dynamics_gradient() (plant_arm.hpp, stages G1..G7).  Lane i owns link i = row i of every Jacobian column; the loop runs
+// over the derivative index k (q_k and qd_k together), so only one column's worth of pair quantities is live:
+//     from lane k:   S_k, v_k, Ic_k                                  (dynamic intra-group broadcasts)
+//     own:           dS_i/dq_k, dv_i/dq_k, tmpM_ik, d(JdotV)/d(q,qd)_k (prefix chain), dWb (suffix chain)
+//     dM/dq_k:       lane i builds its lower-triangular row entries (c <= i) from lane c's dS_c/dq_k and S_c; the upper
+//                    ones are the transposed entries of the lanes above (dM is symmetric by construction, bit for bit)
+// st must hold the state arm_lg_dynamics() left for (q, qd, u); qdd is this lane's acceleration.
+// emit(jj, val): column jj (0..6 d/dq, 7..13 d/dqd, 14..20 d/du) of dqdd, row = lane.
+template <typename L, typename Emit>
+PDDP_HD void arm_lg_gradient(const ArmLgConst<L>& c, const ArmLgState<L>& st, typename L::V qd, typename L::V qdd, Emit emit) {
+    using V = typename L::V;
+    using T = typename L::Scalar;
+    const V zero = V(T(0));
+    // loop-invariant broadcasts: every joint axis and every acceleration
+    V Sall[7][6], qddall[7];
+#define PDDP_LG_ALL(K) { _Pragma("unroll") for (int e = 0; e < 6; e++) Sall[K][e] = L::template bcast<K>(st.S[e]); qddall[K] = L::template bcast<K>(qdd); }
+    PDDP_LG_ALL(0) PDDP_LG_ALL(1) PDDP_LG_ALL(2) PDDP_LG_ALL(3) PDDP_LG_ALL(4) PDDP_LG_ALL(5) PDDP_LG_ALL(6)
+#undef PDDP_LG_ALL
+    V ag[6];                                                  // JdotV + g
+#pragma unroll
+    for (int e = 0; e < 6; e++) ag[e] = e == 5 ? st.JdV[e] + V(c.grav) : st.JdV[e];
+
+    for (int k = 0; k < 7; k++) {
+        const typename L::M below = L::lane_lt(k);            // i <  k
+        const typename L::M above = L::lane_ge(k + 1);        // i >  k   (k < i)
+        V Sk[6], vk[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { Sk[e] = L::bcast_dyn(st.S[e], k); vk[e] = L::bcast_dyn(st.v[e], k); }
+        // ---- G1
+        V dS[6], dvq[6], tmpM[6];
+        {
+            V t6[6], dlt[6];
+            lg_crm_mul(t6, Sk, st.S);
+#pragma unroll
+            for (int e = 0; e < 6; e++) { dS[e] = L::sel(above, t6[e], zero); dlt[e] = st.v[e] - vk[e]; }
+            lg_crm_mul(t6, Sk, dlt);
+#pragma unroll
+            for (int e = 0; e < 6; e++) dvq[e] = L::sel(above, t6[e], zero);
+            // k <= i: crf(S_k) F_i ;  k > i: crf(S_k)(Ic_k S_i) - Ic_k (crm(S_k) S_i)
+            V lo[6], hi[6], Ick[36], a6[6], b6[6], c6[6];
+            lg_crf_mul(lo, Sk, st.Fj);
+#pragma unroll
+            for (int e = 0; e < 36; e++) Ick[e] = L::bcast_dyn(st.Ic[e], k);
+            lg_mat6_mul(a6, Ick, st.S);
+            lg_crf_mul(hi, Sk, a6);
+            lg_crm_mul(b6, Sk, st.S);
+            lg_mat6_mul(c6, Ick, b6);
+#pragma unroll
+            for (int e = 0; e < 6; e++) tmpM[e] = L::sel(below, hi[e] - c6[e], lo[e]);
+        }
+        // ---- G2: increment of d(JdotV)/dq_k and closed form d(JdotV)/dqd_k
+        V term[6], dJq[6];
+        {
+            V a6[6], b6[6];
+            lg_crm_mul(a6, dvq, st.S);
+            lg_crm_mul(b6, st.v, dS);
+#pragma unroll
+            for (int e = 0; e < 6; e++) term[e] = L::sel(above, (a6[e] + b6[e]) * qd, zero);
+            lg_crm_mul(a6, vk, Sk);
+#pragma unroll
+            for (int e = 0; e < 6; e++) dJq[e] = L::sel(below, zero, dvq[e] + a6[e]);
+        }
+        // ---- G3: prefix over links
+        {
+            V inc[6];
+#pragma unroll
+            for (int e = 0; e < 6; e++) inc[e] = term[e];
+#pragma unroll
+            for (int s = 1; s < 7; s++)
+#pragma unroll
+                for (int e = 0; e < 6; e++) term[e] = L::up(term[e]) + inc[e];
+        }
+        // ---- G4: body-wrench derivatives (zero for links below k)
+        V dWq[6], dWv[6];
+        {
+            V t6[6], r1[6], r2[6], r3[6], r4[6], in1[6], in2[6];
+            lg_crm_mul(t6, Sk, ag);
+#pragma unroll
+            for (int e = 0; e < 6; e++) t6[e] = term[e] - t6[e];
+            lg_mat6_mul(r1, st.Iw, t6);
+            lg_crf_mul(r2, Sk, st.t2);
+            lg_crf_mul(r3, dvq, st.t1);
+            lg_crm_mul(t6, Sk, st.v);
+#pragma unroll
+            for (int e = 0; e < 6; e++) t6[e] = dvq[e] - t6[e];
+            lg_mat6_mul(in1, st.Iw, t6);
+            lg_crf_mul(in2, Sk, st.t1);
+#pragma unroll
+            for (int e = 0; e < 6; e++) in1[e] = in1[e] + in2[e];
+            lg_crf_mul(r4, st.v, in1);
+#pragma unroll
+            for (int e = 0; e < 6; e++) dWq[e] = L::sel(below, zero, r1[e] + r2[e] + r3[e] + r4[e]);
+            lg_mat6_mul(r1, st.Iw, dJq);
+            // r2 of the qd column is crf(S_k)(Iw v) = in2
+            lg_mat6_mul(t6, st.Iw, Sk);
+            lg_crf_mul(r3, st.v, t6);
+#pragma unroll
+            for (int e = 0; e < 6; e++) dWv[e] = L::sel(below, zero, r1[e] + in2[e] + r3[e]);
+        }
+        // ---- G5: suffix over links (net-wrench derivatives)
+        {
+            V iq[6], iv[6];
+#pragma unroll
+            for (int e = 0; e < 6; e++) { iq[e] = dWq[e]; iv[e] = dWv[e]; }
+#pragma unroll
+            for (int s = 1; s < 7; s++)
+#pragma unroll
+                for (int e = 0; e < 6; e++) { dWq[e] = L::down(dWq[e]) + iq[e]; dWv[e] = L::down(dWv[e]) + iv[e]; }
+        }
+        // ---- dM/dq_k row of this lane and (dM/dq_k) qdd
+        V mq;
+        {
+            V Lw[7];
+#define PDDP_LG_DM(C)                                                                                                     \
+            { V dSc[6]; _Pragma("unroll") for (int e = 0; e < 6; e++) dSc[e] = L::template bcast<C>(dS[e]);              \
+              Lw[C] = lg_dot6(dSc, st.Fj) + lg_dot6(Sall[C], tmpM); }
+            PDDP_LG_DM(0) PDDP_LG_DM(1) PDDP_LG_DM(2) PDDP_LG_DM(3) PDDP_LG_DM(4) PDDP_LG_DM(5) PDDP_LG_DM(6)
+#undef PDDP_LG_DM
+            V row[7];
+#define PDDP_LG_DMT(C)                                                                                                    \
+            { V uv = Lw[C]; _Pragma("unroll") for (int j = 0; j < C; j++) { const V cand = L::template bcast<C>(Lw[j]); uv = L::sel(L::lane_is(j), cand, uv); } row[C] = uv; }
+            PDDP_LG_DMT(0) PDDP_LG_DMT(1) PDDP_LG_DMT(2) PDDP_LG_DMT(3) PDDP_LG_DMT(4) PDDP_LG_DMT(5) PDDP_LG_DMT(6)
+#undef PDDP_LG_DMT
+            mq = row[0] * qddall[0];
+#pragma unroll
+            for (int cc = 1; cc < 7; cc++) mq = mq + row[cc] * qddall[cc];
+        }
+        // ---- G6: dtau columns
+        V tq, tv;
+        {
+            V val = lg_dot6(st.S, dWq);
+            val = val + lg_dot6(dS, st.Wn);
+            tq = -val - mq;                                    // -(val + 0) - mq
+            const V val2 = lg_dot6(st.S, dWv);
+            tv = -(val2 + L::sel(L::lane_is(k), V(T(0.5)), zero));
+        }
+        // ---- G7: dqdd columns = Minv dtau
+        V oq, ov;
+        {
+            V bq[7], bv[7];
+            bq[0] = L::template bcast<0>(tq); bq[1] = L::template bcast<1>(tq); bq[2] = L::template bcast<2>(tq); bq[3] = L::template bcast<3>(tq);
+            bq[4] = L::template bcast<4>(tq); bq[5] = L::template bcast<5>(tq); bq[6] = L::template bcast<6>(tq);
+            bv[0] = L::template bcast<0>(tv); bv[1] = L::template bcast<1>(tv); bv[2] = L::template bcast<2>(tv); bv[3] = L::template bcast<3>(tv);
+            bv[4] = L::template bcast<4>(tv); bv[5] = L::template bcast<5>(tv); bv[6] = L::template bcast<6>(tv);
+            oq = st.Minv[0] * bq[0]; ov = st.Minv[0] * bv[0];
+#pragma unroll
+            for (int i = 1; i < 7; i++) { oq = oq + st.Minv[i] * bq[i]; ov = ov + st.Minv[i] * bv[i]; }
+        }
+        emit(k, oq);
+        emit(7 + k, ov);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 7; cc++) emit(14 + cc, st.Minv[cc]);
+}
+
 }  // namespace pddp

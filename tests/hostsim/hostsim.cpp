@@ -14,6 +14,7 @@
 #include "../../include/pddp.h"
 #include "../../parallel-ddp_amd/csrc/bodies.hpp"
 #include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
+#include "../../parallel-ddp_amd/csrc/nis_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/iiwa14_model_data.h"
 
 using namespace pddp;
@@ -117,8 +118,14 @@ struct Sim : Base {
         } else if (ph == PDDP_PHASE_LS) {
             for (int pb = 0; pb < B; pb++) ls_body<T>(b, dm, sp, pb, bench);
         } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
-            static NisScratch<P, INTEG, T> s;
-            for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) nis_body<P, INTEG, T>(w, s, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+            if constexpr (P::PLANT == 4) {                    // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
+                using L = LgHost<T>;
+                ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
+                for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) arm_lg_nis_body<L, T>(c, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+            } else {
+                static NisScratch<P, INTEG, T> s;
+                for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) nis_body<P, INTEG, T>(w, s, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+            }
         } else if (ph == PDDP_PHASE_INIT_COST) {
             std::vector<T> cost_k(cfg.N);
             for (int pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, 1, 0, pb);
@@ -211,12 +218,14 @@ struct Sim : Base {
         T qdd[NP], dq[NP * NM], xn[NX];
         for (int i = 0; i < count; i++) {
             const T* xi = x + (size_t)i * NX; const T* ui = u + (size_t)i * NU;
-            if (what == 4) {
+            if (what >= 4) {
                 if constexpr (P::PLANT == 4) {
                     using L = LgHost<T>;
                     ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model); ArmLgState<L> st;
-                    const auto r = arm_lg_dynamics<L>(c, st, L::gather(xi, [](int l) { return l; }), L::gather(xi, [](int l) { return l + 7; }), L::gather(ui, [](int l) { return l; }));
-                    for (int e = 0; e < 7; e++) out[(size_t)i * NP + e] = r.l[e];
+                    const auto qdv = L::gather(xi, [](int l) { return l + 7; });
+                    const auto r = arm_lg_dynamics<L>(c, st, L::gather(xi, [](int l) { return l; }), qdv, L::gather(ui, [](int l) { return l; }));
+                    if (what == 4) for (int e = 0; e < 7; e++) out[(size_t)i * NP + e] = r.l[e];
+                    else { T* o = out + (size_t)i * NP * NM; arm_lg_gradient<L>(c, st, qdv, r, [o](int jj, const Vec8<T>& val) { for (int e = 0; e < 7; e++) o[7 * jj + e] = val.l[e]; }); }
                 }
             }
             else if (what == 0) { P::dynamics(w, s.plant, qdd, xi, ui); std::memcpy(out + (size_t)i * NP, qdd, sizeof(qdd)); }

@@ -140,6 +140,8 @@ int pddp_set_state(pddp_handle h, const pddp_state* in /* [batch] */);
 #define PDDP_PHASE_NIS       3   /* nextIterationSetupGPU          nisInitHelpers.cuh:247-279       */
 #define PDDP_PHASE_INIT_NIS  4   /* derivatives part of initAlgGPU nisInitHelpers.cuh:365-371       */
 #define PDDP_PHASE_INIT_COST 5   /* cost part of initAlgGPU        nisInitHelpers.cuh:385-395       */
+#define PDDP_PHASE_BP_COOP   6   /* the wave-cooperative backward pass (all plants); for the KUKA arm PDDP_PHASE_BP is the lane-group
+                                    kernel and this one exists so that tests can require the two to agree bit for bit */
 int pddp_run_phase(pddp_handle h, int phase);
 
 /* Plant plug-in evaluations on the device, `count` independent (x,u) pairs:

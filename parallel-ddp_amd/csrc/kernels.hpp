@@ -8,6 +8,7 @@
 #include "bodies.hpp"
 #include "fp_lg.hpp"
 #include "nis_lg.hpp"
+#include "bp_lg.hpp"
 
 namespace pddp {
 
@@ -100,6 +101,15 @@ __global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1)) void k_fp_lg(Buffers<T
     const int wave_id = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
     for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M);
 }
+// k_bp_lg: grid (ceil(B*M/8)), block 64 -- one 8-lane group per (problem, block of knots) (bp_lg.hpp); 8 x 3.2 KB of LDS.
+template <typename T>
+__global__ __launch_bounds__(64) void k_bp_lg(Buffers<T> b, Dims dm, int batch) {
+    __shared__ __attribute__((aligned(16))) T lds[kLgPerWave * kBpLgFloats];
+    const int inst = blockIdx.x * kLgPerWave + (threadIdx.x >> 3);
+    if (inst >= batch * dm.M || LgDevice<T>::lane() == 7) return;    // lane 7 of every group stays inactive (lanegroup.hpp)
+    arm_lg_bp_body<LgDevice<T>, T>(lds + (threadIdx.x >> 3) * kBpLgFloats, b, dm, inst % dm.M, inst / dm.M, LgDevice<T>::lane() == 6);
+}
+
 // k_nis_lg: grid (ceil(N/32), B), block 256 -- one 8-lane group per knot, 32 knots per workgroup (nis_lg.hpp).
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_nis_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode) {

@@ -208,7 +208,10 @@ struct Solver : SolverBase {
     }
     void launch_sweep(hipStream_t s, int only = -1) {
         const unsigned B = cfg.batch;
-        if (only < 0 || only == PDDP_PHASE_BP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
+        if (only < 0 || only == PDDP_PHASE_BP) {
+            if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B);
+            else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
+        }
         if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
         if (only < 0 || only == PDDP_PHASE_NIS) launch_nis(s, 0);
@@ -331,6 +334,7 @@ struct Solver : SolverBase {
     int run_phase(int phase) override {
         const unsigned B = cfg.batch;
         if (phase >= 0 && phase <= 3) launch_sweep(stream, phase);
+        else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);
         else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);
         else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0);
         else return fail(PDDP_EINVAL, "unknown phase");

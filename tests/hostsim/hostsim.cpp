@@ -15,6 +15,7 @@
 #include "../../parallel-ddp_amd/csrc/bodies.hpp"
 #include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/nis_lg.hpp"
+#include "../../parallel-ddp_amd/csrc/bp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/iiwa14_model_data.h"
 
 using namespace pddp;
@@ -36,7 +37,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
 }
 
 struct Base {
-    pddp_config cfg; int bench = 0;
+    pddp_config cfg; int bench = 0; int bp_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
     virtual ~Base() {}
     virtual int load(const void*, const void*, const void*, const void*, const void*, const void*, const void*, int, int, int) = 0;
     virtual int iterate(int) = 0;
@@ -92,6 +93,13 @@ struct Sim : Base {
     void phase(int ph) {
         const int B = cfg.batch; const Wave w = this_wave();
         if (ph == PDDP_PHASE_BP) {
+            if constexpr (P::PLANT == 4) {                    // the arm's backward pass runs on lane groups (bp_lg.hpp)
+                if (!bp_coop) {
+                    static T lds[kBpLgFloats];
+                    for (int pb = 0; pb < B; pb++) for (int blk = 0; blk < cfg.M; blk++) arm_lg_bp_body<LgHost<T>, T>(lds, b, dm, blk, pb, true);
+                    return;
+                }
+            }
             static BpScratch<P, T> s;
             for (int pb = 0; pb < B; pb++) for (int blk = 0; blk < cfg.M; blk++) bp_body<P, T>(w, s, b, dm, blk, pb);
         } else if (ph == PDDP_PHASE_FP) {
@@ -210,7 +218,10 @@ struct Sim : Base {
         }
         return 0;
     }
-    int run_phase(int ph) override { if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase"); phase(ph); return 0; }
+    int run_phase(int ph) override {
+        if (ph == PDDP_PHASE_BP_COOP) { bp_coop = 1; phase(PDDP_PHASE_BP); bp_coop = 0; return 0; }
+        if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase"); phase(ph); return 0;
+    }
     int plant_eval(int what, int count, const void* xv, const void* uv, void* outv) override {
         static NisScratch<P, INTEG, T> s; static IntegScratch<P, T> is;
         const T* x = (const T*)xv; const T* u = (const T*)uv; T* out = (T*)outv; const Wave w = this_wave();

@@ -31,3 +31,46 @@ def test_lane_group_gradient_bit_identical_to_cooperative(backend, dtype):
     coop, lg = s.plant_eval(1, x, u), s.plant_eval(5, x, u)
     assert np.isfinite(coop).all() and np.abs(coop).max() > 0
     assert np.array_equal(coop, lg)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("N,M", [(32, 4), (16, 1), (64, 8)])
+def test_lane_group_backward_pass_bit_identical_to_cooperative(backend, dtype, N, M):
+    """k_bp_lg (PHASE_BP for the arm) against the wave-cooperative k_bp (PHASE_BP_COOP) from identical inputs: boundary
+    cost-to-go, defects, shifted trajectory, regulariser, arbitrary (non-diagonal) cost Hessians."""
+    import pyddp
+    from oracle_binding import example_inputs
+    n, m, nm = 14, 7, 21
+    s = make_solver(backend, 4, dtype=0 if dtype == np.float32 else 1, N=N, M=M, A=2, wafr_urdf=1, total_time=0.5, batch=3)
+    rng = np.random.default_rng(5)
+    xs, us, gs = [], [], []
+    for b in range(3):
+        x, u, xg = example_inputs(4, N, dtype, noise=rng.normal(0, 0.01, (N, n)))
+        xs.append(x); us.append(u); gs.append(xg)
+    s.load(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    NB = N // M
+    H = s.get("H").reshape(3, N, nm, nm).copy()
+    H += (rng.normal(0, 1e-3, H.shape)).astype(dtype)                  # break the diagonal structure
+    Pp, pp, d = np.zeros((3, N, n, n), dtype), np.zeros((3, N, n), dtype), np.zeros((3, N, n), dtype)
+    for pb in range(3):
+        for b in range(M - 1):
+            k = NB * (b + 1) - 1
+            Q = rng.normal(0, 1, (n, n)); Pp[pb, k] = (Q @ Q.T / n + np.eye(n)) * 10; pp[pb, k] = rng.normal(0, 1, n); d[pb, k] = rng.normal(0, 0.01, n)
+    xb = s.get("xb").reshape(3, 2, N, n).copy()
+    xb[:, 1] = xb[:, 0] + rng.normal(0, 0.005, (3, N, n)).astype(dtype)
+    st = s.get_state()
+    for pb in range(3):
+        st[pb].rho = 3.5 + pb; st[pb].cur = 0; st[pb].cur2 = 1
+    outs = {}
+    for phase in (pyddp.PHASE_BP_COOP, pyddp.PHASE_BP):
+        s.set("H", H); s.set("Pp", Pp); s.set("pp", pp); s.set("dcur", d); s.set("xb", xb); s.set_state(st)
+        for name in ("P", "p", "KT", "du", "ApBK", "Bdu", "dJexp"):
+            s.set(name, np.zeros_like(s.get(name)))
+        s.set("err", np.ones(3 * M, np.int32))
+        s.run_phase(phase)
+        outs[phase] = {name: s.get(name).copy() for name in ("P", "p", "KT", "du", "ApBK", "Bdu", "dJexp", "err")}
+    ref, lg = outs[pyddp.PHASE_BP_COOP], outs[pyddp.PHASE_BP]
+    assert np.abs(ref["KT"]).max() > 0 and np.isfinite(ref["P"]).all()
+    for name in ref:
+        assert np.array_equal(ref[name], lg[name]), name

@@ -21,14 +21,26 @@
 
 namespace pddp {
 
-constexpr int kBpLgAB = 0, kBpLgP = 294, kBpLgp = 490, kBpLgW = 504, kBpLgGu = 798, kBpLgDu = 805, kBpLgFloats = 816;
-// W region (294): AB2[ky*21 + kx] while H is formed; then K[ky + 7 kx] at +0 (98), Huu[j + 7 ky] at +98 (49), Hux[j + 7 kx] at +147 (98)
+constexpr int kBpLgAB = 0, kBpLgP = 296, kBpLgp = 492, kBpLgW = 508, kBpLgGu = 844, kBpLgDu = 852, kBpLgFloats = 860;
+// W region (336): AB2 row-contiguous, AB2(kx,ky) at [kx*16 + ky] (21 rows of 14, padded to 16) while H is formed;
+// then K[ky + 7 kx] at +0 (98), Huu[j + 7 ky] at +98 (49), Hux[j + 7 kx] at +147 (98)
 constexpr int kBpLgK = 0, kBpLgHuu = 98, kBpLgHux = 147;
 
 // lds: this group's region (kBpLgFloats elements).  Returns nothing: the generic 7x7 inversion never reports failure
 // (utils/cudaUtils.h:291), so err[blk] is always cleared.
+// Global arrays are addressed as (wave-uniform base pointer of the whole batch) + (32-bit element offset of this problem): the
+// per-group part of every address is one VGPR, not a 64-bit pointer pair (a dozen of those overflowed the register file).
+template <typename T>
+struct BpLgArgs {
+    const T* AB; T* Pm; T* pv; const T* Pp; const T* pp; const T* H; const T* g; T* KT; T* du; const T* dcur; T* ApBK; T* Bdu; const T* xb; T* dJexp;
+    unsigned pbN;          // pb * N: knot k of this problem is element block pbN + k of every per-knot array
+    unsigned oxc, oxp2;    // offsets of the current trajectory / the trajectory of the stored boundary cost-to-go inside xb
+    unsigned odJ;          // pb * 2M
+    T rho;
+};
+
 template <typename L, typename T>
-PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a) {
+PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>& a) {
     using V = typename L::V;
     constexpr int NX = 14, NU = 7, NM = 21;
     const typename L::M act = L::all_true();
@@ -38,46 +50,61 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a
     int ks = NBk * (blk + 1) - 1, iterCount;
     V dJ0 = V(T(0)), dJ1 = V(T(0));                       // per-lane partial sums of the expected reduction (computeExpRed)
     if (ks == N - 1) {                                    // last block: cost-to-go at N-1 is the final cost (bpHelpers.cuh:362-367)
-        T* Pprev = a.Pm + NX * NX * (ks - 1); T* pprev = a.pv + NX * (ks - 1);
-        const T* Hf = a.H + NM * NM * ks; const T* gf = a.g + NM * ks;
+        const unsigned oPprev = (a.pbN + ks - 1) * (NX * NX), opprev = (a.pbN + ks - 1) * NX, oHf = (a.pbN + ks) * (NM * NM), ogf = (a.pbN + ks) * NM;
         for (int t = 0; t < 28; t++) {
-            const V v = L::gather(Hf, [t](int l) { const int e = l + 7 * t; return (e % 14) + 21 * (e / 14); });
-            L::scatter(Pl, [t](int l) { return l + 7 * t; }, v, act); L::scatter(Pprev, [t](int l) { return l + 7 * t; }, v, act);
+            const V v = L::gather_at(a.H, oHf, [t](int l) { const int e = l + 7 * t; return (e % 14) + 21 * (e / 14); });
+            L::scatter(Pl, [t](int l) { return l + 7 * t; }, v, act); L::scatter_at(a.Pm, oPprev, [t](int l) { return l + 7 * t; }, v, act);
         }
         for (int t = 0; t < 2; t++) {
-            const V v = L::gather(gf, [t](int l) { return l + 7 * t; });
-            L::scatter(pl, [t](int l) { return l + 7 * t; }, v, act); L::scatter(pprev, [t](int l) { return l + 7 * t; }, v, act);
+            const V v = L::gather_at(a.g, ogf, [t](int l) { return l + 7 * t; });
+            L::scatter(pl, [t](int l) { return l + 7 * t; }, v, act); L::scatter_at(a.pv, opprev, [t](int l) { return l + 7 * t; }, v, act);
         }
         ks--; iterCount = NBk - 2;
         wsync();
     } else {                                              // boundary cost-to-go of the PREVIOUS iteration + linear transform
         iterCount = NBk - 1;
-        const T* bP = a.Pp + NX * NX * ks; const T* bp = a.pp + NX * ks;
-        for (int t = 0; t < 28; t++) L::scatter(Pl, [t](int l) { return l + 7 * t; }, L::gather(bP, [t](int l) { return l + 7 * t; }), act);
+        const unsigned obP = (a.pbN + ks) * (NX * NX), obp = (a.pbN + ks) * NX;
+        for (int t = 0; t < 28; t++) L::scatter(Pl, [t](int l) { return l + 7 * t; }, L::gather_at(a.Pp, obP, [t](int l) { return l + 7 * t; }), act);
         wsync();
         // p = pp + Pp (x - xp2)   (linearXfrmOrLoad): lane l rows l, l+7
         V d0 = V(T(0)), d1 = V(T(0));
         for (int j = 0; j < NX; j++) {
-            const T dxj = a.xcur[NX * (ks + 1) + j] - a.xprev2[NX * (ks + 1) + j];
+            const T dxj = a.xb[a.oxc + NX * (ks + 1) + j] - a.xb[a.oxp2 + NX * (ks + 1) + j];
             d0 = d0 + L::gather(Pl, [j](int l) { return l + NX * j; }) * V(dxj);
             d1 = d1 + L::gather(Pl, [j](int l) { return l + 7 + NX * j; }) * V(dxj);
         }
-        L::scatter(pl, [](int l) { return l; }, d0 + L::gather(bp, [](int l) { return l; }), act);
-        L::scatter(pl, [](int l) { return l + 7; }, d1 + L::gather(bp, [](int l) { return l + 7; }), act);
+        L::scatter(pl, [](int l) { return l; }, d0 + L::gather_at(a.pp, obp, [](int l) { return l; }), act);
+        L::scatter(pl, [](int l) { return l + 7; }, d1 + L::gather_at(a.pp, obp, [](int l) { return l + 7; }), act);
         wsync();
     }
+    // this lane's three columns of AB (z entries l, l+7, l+14), fetched one knot ahead so that the global-memory latency
+    // hides behind the previous knot's arithmetic (a wave of this kernel owns its SIMD alone: 27 KB of LDS per wave)
+    V ABn[3][14];
+#pragma unroll
+    for (int cI = 0; cI < 3; cI++)
+#pragma unroll
+        for (int j = 0; j < NX; j++) ABn[cI][j] = L::gather_at(a.AB, (a.pbN + ks) * (NX * NM), [cI, j](int l) { return (l + 7 * cI) * NX + j; });
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
-        const T* bAB = a.AB + NX * NM * ks; const T* bH = a.H + NM * NM * ks; const T* bg = a.g + NM * ks;
-        const T* bd = a.dcur + NX * ks;
-        // ---- stage AB_k through LDS (coalesced global read), then each lane takes its three columns
-        for (int t = 0; t < 42; t++) L::scatter(ABl, [t](int l) { return l + 7 * t; }, L::gather(bAB, [t](int l) { return l + 7 * t; }), act);
-        wsync();
+        const unsigned knot = a.pbN + ks;                  // element block of this knot in every per-knot array
+        const unsigned obH = knot * (NM * NM), obg = knot * NM, obd = knot * NX;
         V ABc[3][14];
 #pragma unroll
         for (int cI = 0; cI < 3; cI++)
 #pragma unroll
-            for (int j = 0; j < NX; j++) ABc[cI][j] = L::gather(ABl, [cI, j](int l) { return (l + 7 * cI) * NX + j; });
+            for (int j = 0; j < NX; j++) ABc[cI][j] = ABn[cI][j];
+        // cost Hessian / gradient of the lane's columns: the loads are issued here and consumed after the AB2 stage
+        V Hc[3][21], gc[3];
+#pragma unroll
+        for (int cI = 0; cI < 3; cI++) {
+#pragma unroll
+            for (int ky = 0; ky < NM; ky++) Hc[cI][ky] = L::gather_at(a.H, obH, [cI, ky](int l) { return ky * NM + l + 7 * cI; });
+            gc[cI] = L::gather_at(a.g, obg, [cI](int l) { return l + 7 * cI; });
+        }
+        // the B block (columns 14..20) is needed by every lane later: its owners publish it, B(kx, l) at ABl[196 + kx + 14 l]
+#pragma unroll
+        for (int kx = 0; kx < NX; kx++) L::scatter(ABl, [kx](int l) { return 196 + kx + NX * l; }, ABc[2][kx], act);
         // ---- AB2(kx, ky) = sum_j AB(j,kx) (P(j,ky) + rho [kx >= 14, ky == j]) for the lane's three kx, all ky  -> W[ky*21 + kx]
+#pragma nounroll
         for (int ky = 0; ky < NX; ky++) {
             V v0 = V(T(0)), v1 = V(T(0)), v2 = V(T(0));
 #pragma unroll
@@ -87,15 +114,16 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a
                 v1 = v1 + ABc[1][j] * V(pj);
                 v2 = v2 + ABc[2][j] * V(ky == j ? pj + rho : pj);
             }
-            L::scatter(W, [ky](int l) { return ky * NM + l; }, v0, act);
-            L::scatter(W, [ky](int l) { return ky * NM + l + 7; }, v1, act);
-            L::scatter(W, [ky](int l) { return ky * NM + l + 14; }, v2, act);
+            L::scatter(W, [ky](int l) { return l * 16 + ky; }, v0, act);
+            L::scatter(W, [ky](int l) { return (l + 7) * 16 + ky; }, v1, act);
+            L::scatter(W, [ky](int l) { return (l + 14) * 16 + ky; }, v2, act);
         }
         if (M > 1 && dm.on_defect_boundary(iter)) {       // p += P d  (tests the loop counter like the reference, :73)
             V s0 = V(T(0)), s1 = V(T(0));
             for (int j = 0; j < NX; j++) {
-                s0 = s0 + V(bd[j]) * L::gather(Pl, [j](int l) { return l + j * NX; });
-                s1 = s1 + V(bd[j]) * L::gather(Pl, [j](int l) { return l + 7 + j * NX; });
+                const T dj = a.dcur[obd + j];
+                s0 = s0 + V(dj) * L::gather(Pl, [j](int l) { return l + j * NX; });
+                s1 = s1 + V(dj) * L::gather(Pl, [j](int l) { return l + 7 + j * NX; });
             }
             wsync();                                       // every lane has read p's inputs (P) -- p itself is only read below
             L::scatter(pl, [](int l) { return l; }, L::gather(pl, [](int l) { return l; }) + s0, act);
@@ -103,33 +131,48 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a
         }
         wsync();
         // ---- H(ky, kx) = sum_j AB2(ky, j) AB(j, kx) + H_cost for the lane's three kx, all 21 ky; g(kx) = sum_j p_j AB(j,kx) + g_cost
-        V Hc[3][21];
 #pragma unroll
-        for (int cI = 0; cI < 3; cI++)
+        for (int ky = 0; ky < NM; ky++) {                  // one output row at a time: 14 uniform LDS reads feed 42 multiply-adds
+            T w[14];
 #pragma unroll
-            for (int ky = 0; ky < NM; ky++) Hc[cI][ky] = V(T(0));
-        V gc[3] = {V(T(0)), V(T(0)), V(T(0))};
+            for (int j = 0; j < NX; j++) w[j] = W[ky * 16 + j];            // AB2[ky + NM*j]
 #pragma unroll
-        for (int j = 0; j < NX; j++) {
+            for (int cI = 0; cI < 3; cI++) {
+                V dot = V(w[0]) * ABc[cI][0];
 #pragma unroll
-            for (int ky = 0; ky < NM; ky++) {
-                const T w = W[j * NM + ky];                // AB2[ky + NM*j]
-#pragma unroll
-                for (int cI = 0; cI < 3; cI++) Hc[cI][ky] = Hc[cI][ky] + V(w) * ABc[cI][j];
+                for (int j = 1; j < NX; j++) dot = dot + V(w[j]) * ABc[cI][j];
+                Hc[cI][ky] = dot + Hc[cI][ky];
             }
-            const T pj = pl[j];
-#pragma unroll
-            for (int cI = 0; cI < 3; cI++) gc[cI] = gc[cI] + V(pj) * ABc[cI][j];
+            L::sched_fence();
         }
+        {
+            T pv[14];
 #pragma unroll
-        for (int cI = 0; cI < 3; cI++) {
+            for (int j = 0; j < NX; j++) pv[j] = pl[j];
 #pragma unroll
-            for (int ky = 0; ky < NM; ky++) Hc[cI][ky] = Hc[cI][ky] + L::gather(bH, [cI, ky](int l) { return ky * NM + l + 7 * cI; });
-            gc[cI] = gc[cI] + L::gather(bg, [cI](int l) { return l + 7 * cI; });
+            for (int cI = 0; cI < 3; cI++) {
+                V dot = V(pv[0]) * ABc[cI][0];
+#pragma unroll
+                for (int j = 1; j < NX; j++) dot = dot + V(pv[j]) * ABc[cI][j];
+                gc[cI] = dot + gc[cI];
+            }
+        }
+        if (iter > 0) {                                   // prefetch the next knot's columns of AB
+#pragma unroll
+            for (int cI = 0; cI < 3; cI++)
+#pragma unroll
+                for (int j = 0; j < NX; j++) ABn[cI][j] = L::gather_at(a.AB, (knot - 1) * (NX * NM), [cI, j](int l) { return (l + 7 * cI) * NX + j; });
         }
         wsync();                                          // all reads of AB2 (W) done: the region is reused below
         // ---- Huu row of this lane, published Huu / Hux / gu, Gauss-Jordan on [Huu | I]
-        V A[14], Huur[7];
+        V A[14], Huur[7], Hxu[2][7];
+#pragma unroll
+        for (int rI = 0; rI < 2; rI++) {                   // Hxx rows l, l+7 -> LDS (ABl[0..195] is free: AB is not staged), Hxu stays in registers
+#pragma unroll
+            for (int ky = 0; ky < NX; ky++) L::scatter(ABl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, Hc[rI][ky], act);
+#pragma unroll
+            for (int ky = 0; ky < NU; ky++) Hxu[rI][ky] = Hc[rI][14 + ky];
+        }
 #pragma unroll
         for (int ky = 0; ky < NU; ky++) {
             Huur[ky] = Hc[2][14 + ky]; A[ky] = Huur[ky];
@@ -152,60 +195,75 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a
 #undef PDDP_LG_PIV
         wsync();
         // ---- K row of this lane: K(l, kx) = sum_j Hinv(l, j) Hux(j, kx);  du_l = sum_j Hinv(l, j) gu_j
-        T* bKT = a.KT + NX * NU * ks; T* bdu = a.du + NU * ks;
+        const unsigned obKT = knot * (NX * NU), obdu = knot * NU;
         V du;
         {
-#pragma unroll
+#pragma nounroll
             for (int kx = 0; kx < NX; kx++) {
                 V dot = A[7] * V(W[kBpLgHux + 7 * kx]);
 #pragma unroll
                 for (int j = 1; j < NU; j++) dot = dot + A[7 + j] * V(W[kBpLgHux + j + 7 * kx]);
                 L::scatter(W + kBpLgK, [kx](int l) { return l + NU * kx; }, dot, act);
-                L::scatter(bKT, [kx](int l) { return kx + NX * l; }, dot, act);
+                L::scatter_at(a.KT, obKT, [kx](int l) { return kx + NX * l; }, dot, act);
             }
             du = A[7] * V(gul[0]);
 #pragma unroll
             for (int j = 1; j < NU; j++) du = du + A[7 + j] * V(gul[j]);
             L::scatter(dul, [](int l) { return l; }, du, act);
-            L::scatter(bdu, [](int l) { return l; }, du, act);
+            L::scatter_at(a.du, obdu, [](int l) { return l; }, du, act);
         }
         wsync();
         const bool do_ctg = (iter != 0 || blk != 0);      // the cost-to-go in front of knot 0 is never used (:396)
+        // K(j, kx) for the lane's rows / columns kx = l, l+7: used by T1, A - B K and the new cost-to-go
+        V Kr[2][7];
+#pragma unroll
+        for (int rI = 0; rI < 2; rI++)
+#pragma unroll
+            for (int j = 0; j < NU; j++) Kr[rI][j] = L::gather(W + kBpLgK, [rI, j](int l) { return (l + 7 * rI) * NU + j; });
         // ---- T1(kx, ky) = sum_j K(j,kx) Huu(j,ky) - Hxu(kx,ky)  for the lane's rows kx = l, l+7 ("K'Huu - Hxu")
         V T1[2][7];
         if (do_ctg) {
 #pragma unroll
-            for (int rI = 0; rI < 2; rI++)
+            for (int ky = 0; ky < NU; ky++) {
+                T huu[7];
 #pragma unroll
-                for (int ky = 0; ky < NU; ky++) {
-                    V val = L::gather(W + kBpLgK, [rI](int l) { return (l + 7 * rI) * NU; }) * V(W[kBpLgHuu + 7 * ky]);
+                for (int jj = 0; jj < NU; jj++) huu[jj] = W[kBpLgHuu + jj + 7 * ky];
 #pragma unroll
-                    for (int j = 1; j < NU; j++) val = val + L::gather(W + kBpLgK, [rI, j](int l) { return (l + 7 * rI) * NU + j; }) * V(W[kBpLgHuu + j + 7 * ky]);
-                    T1[rI][ky] = val - Hc[rI][14 + ky];
+                for (int rI = 0; rI < 2; rI++) {
+                    V val = Kr[rI][0] * V(huu[0]);
+#pragma unroll
+                    for (int jj = 1; jj < NU; jj++) val = val + Kr[rI][jj] * V(huu[jj]);
+                    T1[rI][ky] = val - Hxu[rI][ky];
                 }
+                L::sched_fence();
+            }
         }
         if (M > 1) {                                      // forward-sweep operands A - B K and B du (computeFSVars)
-            T* bApBK = a.ApBK + NX * NX * ks; T* bBdu = a.Bdu + NX * ks;
-            // column ky = l, l+7 of ApBK (all kx): ApBK(kx,ky) = A(kx,ky) - sum_j B(kx,j) K(j,ky)
+            const unsigned obApBK = knot * (NX * NX), obBdu = knot * NX;
+            // columns ky = l, l+7 of ApBK (all kx): ApBK(kx,ky) = A(kx,ky) - sum_j B(kx,j) K(j,ky)
 #pragma unroll
-            for (int cI = 0; cI < 2; cI++) {
-                V Kc[7];
+            for (int kx = 0; kx < NX; kx++) {
+                T brow[7];
 #pragma unroll
-                for (int j = 0; j < NU; j++) Kc[j] = L::gather(W + kBpLgK, [cI, j](int l) { return (l + 7 * cI) * NU + j; });
+                for (int jj = 0; jj < NU; jj++) brow[jj] = ABl[196 + kx + NX * jj];
 #pragma unroll
-                for (int kx = 0; kx < NX; kx++) {
-                    V val = V(ABl[196 + kx]) * Kc[0];
+                for (int cI = 0; cI < 2; cI++) {
+                    V val = V(brow[0]) * Kr[cI][0];
 #pragma unroll
-                    for (int j = 1; j < NU; j++) val = val + V(ABl[196 + kx + NX * j]) * Kc[j];
-                    L::scatter(bApBK, [cI, kx](int l) { return (l + 7 * cI) * NX + kx; }, ABc[cI][kx] - val, act);
+                    for (int jj = 1; jj < NU; jj++) val = val + V(brow[jj]) * Kr[cI][jj];
+                    L::scatter_at(a.ApBK, obApBK, [cI, kx](int l) { return (l + 7 * cI) * NX + kx; }, ABc[cI][kx] - val, act);
                 }
+                L::sched_fence();
             }
+            T dv[7];
+#pragma unroll
+            for (int jj = 0; jj < NU; jj++) dv[jj] = dul[jj];
 #pragma unroll
             for (int rI = 0; rI < 2; rI++) {               // Bdu rows l, l+7
-                V val = L::gather(ABl, [rI](int l) { return 196 + l + 7 * rI; }) * V(dul[0]);
+                V val = L::gather(ABl, [rI](int l) { return 196 + l + 7 * rI; }) * V(dv[0]);
 #pragma unroll
-                for (int j = 1; j < NU; j++) val = val + L::gather(ABl, [rI, j](int l) { return 196 + l + 7 * rI + NX * j; }) * V(dul[j]);
-                L::scatter(bBdu, [rI](int l) { return l + 7 * rI; }, val, act);
+                for (int jj = 1; jj < NU; jj++) val = val + L::gather(ABl, [rI, jj](int l) { return 196 + l + 7 * rI + NX * jj; }) * V(dv[jj]);
+                L::scatter_at(a.Bdu, obBdu, [rI](int l) { return l + 7 * rI; }, val, act);
             }
         }
         {                                                 // expected reduction, per-lane partial sums (computeExpRed)
@@ -217,27 +275,33 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a
         }
         wsync();
         if (do_ctg) {                                     // new cost-to-go: rows l, l+7 of P, entries l, l+7 of p
-            T* Pprev = a.Pm + NX * NX * (ks - 1); T* pprev = a.pv + NX * (ks - 1);
+            const unsigned oPprev = (knot - 1) * (NX * NX), opprev = (knot - 1) * NX;
+#pragma nounroll
+            for (int ky = 0; ky < NX; ky++) {
+                T kk[7], hx[7];
+#pragma unroll
+                for (int jj = 0; jj < NU; jj++) { kk[jj] = W[kBpLgK + ky * NU + jj]; hx[jj] = W[kBpLgHux + jj + 7 * ky]; }
+#pragma unroll
+                for (int rI = 0; rI < 2; rI++) {
+                    V val = T1[rI][0] * V(kk[0]) - Kr[rI][0] * V(hx[0]);
+#pragma unroll
+                    for (int jj = 1; jj < NU; jj++) val = val + (T1[rI][jj] * V(kk[jj]) - Kr[rI][jj] * V(hx[jj]));
+                    const V v = L::gather(ABl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }) + val;      // Hxx(kx, ky)
+                    L::scatter(Pl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, v, act);
+                    L::scatter_at(a.Pm, oPprev, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, v, act);
+                }
+            }
+            T dv[7], gv[7];
+#pragma unroll
+            for (int jj = 0; jj < NU; jj++) { dv[jj] = dul[jj]; gv[jj] = gul[jj]; }
 #pragma unroll
             for (int rI = 0; rI < 2; rI++) {
-                V Kr[7];                                   // K(j, kx) for this row kx
+                V val = V(dv[0]) * T1[rI][0] - Kr[rI][0] * V(gv[0]);
 #pragma unroll
-                for (int j = 0; j < NU; j++) Kr[j] = L::gather(W + kBpLgK, [rI, j](int l) { return (l + 7 * rI) * NU + j; });
-#pragma unroll
-                for (int ky = 0; ky < NX; ky++) {
-                    V val = T1[rI][0] * V(W[kBpLgK + ky * NU]) - Kr[0] * V(W[kBpLgHux + 7 * ky]);
-#pragma unroll
-                    for (int j = 1; j < NU; j++) val = val + (T1[rI][j] * V(W[kBpLgK + ky * NU + j]) - Kr[j] * V(W[kBpLgHux + j + 7 * ky]));
-                    const V v = Hc[rI][ky] + val;
-                    L::scatter(Pl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, v, act);
-                    L::scatter(Pprev, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, v, act);
-                }
-                V val = V(dul[0]) * T1[rI][0] - Kr[0] * V(gul[0]);
-#pragma unroll
-                for (int j = 1; j < NU; j++) val = val + (V(dul[j]) * T1[rI][j] - Kr[j] * V(gul[j]));
+                for (int jj = 1; jj < NU; jj++) val = val + (V(dv[jj]) * T1[rI][jj] - Kr[rI][jj] * V(gv[jj]));
                 const V v = gc[rI] + val;
                 L::scatter(pl, [rI](int l) { return l + 7 * rI; }, v, act);
-                L::scatter(pprev, [rI](int l) { return l + 7 * rI; }, v, act);
+                L::scatter_at(a.pv, opprev, [rI](int l) { return l + 7 * rI; }, v, act);
             }
         }
         wsync();
@@ -245,8 +309,8 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpArgs<T>& a
     // dJexp[2 blk], dJexp[2 blk + 1]: the 7 partial sums in lane order
     const V a0 = lg_chain_sum<L>(V(T(0)), dJ0), a1 = lg_chain_sum<L>(V(T(0)), dJ1);
     const typename L::M last = L::lane_is(6);
-    L::scatter(a.dJexp, [blk](int) { return 2 * blk; }, a0, last);
-    L::scatter(a.dJexp, [blk](int) { return 2 * blk + 1; }, a1, last);
+    L::scatter_at(a.dJexp, a.odJ, [blk](int) { return 2 * blk; }, a0, last);
+    L::scatter_at(a.dJexp, a.odJ, [blk](int) { return 2 * blk + 1; }, a1, last);
 }
 
 // (problem pb, block blk): pointer set-up of bp_body() (bodies.hpp) around arm_lg_bp_block
@@ -256,21 +320,15 @@ PDDP_HD void arm_lg_bp_body(T* lds, const Buffers<T>& b, const Dims& dm, int blk
     const int N = dm.N;
     const SolverState<T>& st = b.state[pb];
     if (st.done) return;
-    BpArgs<T> a;
-    a.AB = b.AB + (size_t)pb * N * NX * NM;
-    a.Pm = b.P + (size_t)pb * N * NX * NX;   a.pv = b.p + (size_t)pb * N * NX;
-    a.Pp = b.Pp + (size_t)pb * N * NX * NX;  a.pp = b.pp + (size_t)pb * N * NX;
-    a.H = b.H + (size_t)pb * N * NM * NM;    a.g = b.g + (size_t)pb * N * NM;
-    a.KT = b.KT + (size_t)pb * N * NX * NU;  a.du = b.du + (size_t)pb * N * NU;
-    a.dcur = b.dcur + (size_t)pb * N * NX;
-    a.ApBK = b.ApBK + (size_t)pb * N * NX * NX;  a.Bdu = b.Bdu + (size_t)pb * N * NX;
-    a.xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX;
-    a.xprev2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
-    a.dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
-    a.err = b.err + (size_t)pb * dm.M;
+    BpLgArgs<T> a;
+    a.AB = b.AB; a.Pm = b.P; a.pv = b.p; a.Pp = b.Pp; a.pp = b.pp; a.H = b.H; a.g = b.g; a.KT = b.KT; a.du = b.du; a.dcur = b.dcur;
+    a.ApBK = b.ApBK; a.Bdu = b.Bdu; a.xb = b.xb; a.dJexp = b.dJexp;
+    a.pbN = (unsigned)pb * N;
+    a.oxc = ((unsigned)pb * 2 + st.cur) * N * NX; a.oxp2 = ((unsigned)pb * 2 + st.cur2) * N * NX;
+    a.odJ = (unsigned)pb * 2 * dm.M;
     a.rho = st.rho;
     arm_lg_bp_block<L, T>(lds, dm, blk, a);
-    if (write_err) a.err[blk] = 0;                        // the generic 7x7 inversion never reports failure (utils/cudaUtils.h:291)
+    if (write_err) b.err[(size_t)pb * dm.M + blk] = 0;                        // the generic 7x7 inversion never reports failure (utils/cudaUtils.h:291)
 }
 
 }  // namespace pddp

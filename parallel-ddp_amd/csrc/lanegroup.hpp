@@ -65,12 +65,16 @@ struct LgHost {
     template <typename F> static V gather(const T* p, F f) { V r; for (int i = 0; i < kLg; i++) r.l[i] = p[f(i < 7 ? i : 6)]; return r; }
     template <typename F> static void scatter(T* p, F f, const V& v, const M& m) { for (int i = 0; i < 7; i++) if (m.l[i]) p[f(i)] = v.l[i]; }
     template <typename F> static V make(F f) { V r; for (int i = 0; i < kLg; i++) r.l[i] = f(i < 7 ? i : 6); return r; }
+    // element `off + f(lane)` of an array addressed by a wave-uniform base and a 32-bit per-group offset
+    template <typename F> static V gather_at(const T* p, unsigned off, F f) { V r; for (int i = 0; i < kLg; i++) r.l[i] = p[off + (unsigned)f(i < 7 ? i : 6)]; return r; }
+    template <typename F> static void scatter_at(T* p, unsigned off, F f, const V& v, const M& m) { for (int i = 0; i < 7; i++) if (m.l[i]) p[off + (unsigned)f(i)] = v.l[i]; }
     static V vsin(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tsin<T>(v.l[i]); return r; }
     static V vcos(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tcos<T>(v.l[i]); return r; }
     static void vsincos(const V& v, V& sn, V& cs) { sn = vsin(v); cs = vcos(v); }
     static V vabs(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tabs(v.l[i]); return r; }
     static T lane_value(const V& v, int j) { return v.l[j]; }     // host-side extraction (tests)
     static M all_true() { M m; for (int i = 0; i < kLg; i++) m.l[i] = true; return m; }
+    static void sched_fence() {}
 };
 
 // ------------------------------------------------------------------------------------------------ device: gfx950
@@ -134,11 +138,16 @@ struct LgDevice {
     template <typename F> static __device__ __forceinline__ V gather(const T* p, F f) { return p[f(link())]; }
     template <typename F> static __device__ __forceinline__ void scatter(T* p, F f, V v, M m) { if (m && lane() < 7) p[f(lane())] = v; }
     template <typename F> static __device__ __forceinline__ V make(F f) { return f(link()); }
+    // wave-uniform base (SGPR pair) + 32-bit per-lane offset: one VGPR of address instead of a 64-bit pointer pair
+    template <typename F> static __device__ __forceinline__ V gather_at(const T* p, unsigned off, F f) { return p[off + (unsigned)f(link())]; }
+    template <typename F> static __device__ __forceinline__ void scatter_at(T* p, unsigned off, F f, V v, M m) { if (m && lane() < 7) p[off + (unsigned)f(lane())] = v; }
     static __device__ __forceinline__ V vsin(V v) { return tsin<T>(v); }
     static __device__ __forceinline__ V vcos(V v) { return tcos<T>(v); }
     static __device__ __forceinline__ void vsincos(V v, V& sn, V& cs) { double s_, c_; sincos(static_cast<double>(v), &s_, &c_); sn = static_cast<T>(s_); cs = static_cast<T>(c_); }
     static __device__ __forceinline__ V vabs(V v) { return tabs(v); }
     static __device__ __forceinline__ M all_true() { return true; }
+    // keeps the instruction scheduler from hoisting the next block's loads over this point (register pressure)
+    static __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 };
 #endif
 

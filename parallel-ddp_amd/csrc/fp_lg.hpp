@@ -36,40 +36,64 @@ PDDP_HD void lg_bcast14(typename L::V* bc, typename L::V lo, typename L::V hi) {
     bc[11] = L::template bcast<4>(hi); bc[12] = L::template bcast<5>(hi); bc[13] = L::template bcast<6>(hi);
 }
 
-// Linear sweep for one candidate (M > 1).  a.x receives the segment start states.
+// Pointers of the whole batch (wave-uniform) + 32-bit element offsets of this (problem, candidate): one VGPR per address
+// instead of a 64-bit pointer pair per array (lanegroup.hpp gather_at / scatter_at).
+template <typename T>
+struct FpLgArgs {
+    T* xs; T* us; T* ds;                      // candidate trajectories [B][A][N][.]
+    const T* xb; const T* ucur; const T* dcur; const T* KT; const T* du; const T* ApBK; const T* Bdu; const T* xGoal;
+    unsigned slotN;                           // (pb * A + a) * N : knot k of this candidate is block slotN + k of xs / us / ds
+    unsigned pbN;                             // pb * N
+    unsigned oxc;                             // offset of the current trajectory inside xb
+    unsigned oxg;                             // pb * NX
+    T alpha, dt;
+    T* dnorm;                                 // LDS [M] of this candidate
+};
+template <typename T>
+PDDP_HD FpLgArgs<T> fp_lg_args(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T dt, T* dnorm) {
+    FpLgArgs<T> a;
+    a.xs = b.xs; a.us = b.us; a.ds = b.ds; a.xb = b.xb; a.ucur = b.ucur; a.dcur = b.dcur; a.KT = b.KT; a.du = b.du; a.ApBK = b.ApBK; a.Bdu = b.Bdu;
+    a.xGoal = b.xGoal;
+    a.slotN = ((unsigned)pb * dm.A + a_idx) * dm.N; a.pbN = (unsigned)pb * dm.N;
+    a.oxc = ((unsigned)pb * 2 + b.state[pb].cur) * dm.N * 14; a.oxg = (unsigned)pb * 14;
+    a.alpha = b.alpha[a_idx]; a.dt = dt; a.dnorm = dnorm;
+    return a;
+}
+
+// Linear sweep for one candidate (M > 1).  xs receives the segment start states.
 template <typename L, typename T>
-PDDP_HD void arm_lg_forward_sweep(const Dims& dm, const FpArgs<T>& a) {
+PDDP_HD void arm_lg_forward_sweep(const Dims& dm, const FpLgArgs<T>& a) {
     using V = typename L::V;
     constexpr int NX = 14, NP = 7;
     const typename L::M act = L::all_true();
-    V xq = L::gather(a.xcur, [](int l) { return l; }), xv = L::gather(a.xcur, [](int l) { return l + NP; });
+    V xq = L::gather_at(a.xb, a.oxc, [](int l) { return l; }), xv = L::gather_at(a.xb, a.oxc, [](int l) { return l + NP; });
     const int k_last = (dm.M - 1) * dm.NB - 1;             // last defect boundary
     for (int k = 0; k <= k_last; k++) {
-        const T* Ak = a.ApBK + NX * NX * k;
-        const V dq = xq - L::gather(a.xcur, [k](int l) { return NX * k + l; });
-        const V dv = xv - L::gather(a.xcur, [k](int l) { return NX * k + l + NP; });
+        const unsigned oA = (a.pbN + k) * (NX * NX), ob = (a.pbN + k) * NX;
+        const V dq = xq - L::gather_at(a.xb, a.oxc, [k](int l) { return NX * k + l; });
+        const V dv = xv - L::gather_at(a.xb, a.oxc, [k](int l) { return NX * k + l + NP; });
         V bc[14];
         lg_bcast14<L>(bc, dq, dv);
-        V vq = L::gather(Ak, [](int l) { return l; }) * bc[0];
-        V vv = L::gather(Ak, [](int l) { return l + NP; }) * bc[0];
+        V vq = L::gather_at(a.ApBK, oA, [](int l) { return l; }) * bc[0];
+        V vv = L::gather_at(a.ApBK, oA, [](int l) { return l + NP; }) * bc[0];
 #pragma unroll
         for (int i = 1; i < NX; i++) {
-            vq = vq + L::gather(Ak, [i](int l) { return l + NX * i; }) * bc[i];
-            vv = vv + L::gather(Ak, [i](int l) { return l + NP + NX * i; }) * bc[i];
+            vq = vq + L::gather_at(a.ApBK, oA, [i](int l) { return l + NX * i; }) * bc[i];
+            vv = vv + L::gather_at(a.ApBK, oA, [i](int l) { return l + NP + NX * i; }) * bc[i];
         }
         const bool bnd = dm.on_defect_boundary(k);
-        V nq = L::gather(a.xcur, [k](int l) { return NX * (k + 1) + l; });
-        V nv = L::gather(a.xcur, [k](int l) { return NX * (k + 1) + l + NP; });
-        V aq = -V(a.alpha) * L::gather(a.Bdu, [k](int l) { return NX * k + l; }) + vq;
-        V av = -V(a.alpha) * L::gather(a.Bdu, [k](int l) { return NX * k + l + NP; }) + vv;
+        V nq = L::gather_at(a.xb, a.oxc, [k](int l) { return NX * (k + 1) + l; });
+        V nv = L::gather_at(a.xb, a.oxc, [k](int l) { return NX * (k + 1) + l + NP; });
+        V aq = -V(a.alpha) * L::gather_at(a.Bdu, ob, [](int l) { return l; }) + vq;
+        V av = -V(a.alpha) * L::gather_at(a.Bdu, ob, [](int l) { return l + NP; }) + vv;
         if (bnd) {
-            aq = aq + L::gather(a.dcur, [k](int l) { return NX * k + l; });
-            av = av + L::gather(a.dcur, [k](int l) { return NX * k + l + NP; });
+            aq = aq + L::gather_at(a.dcur, ob, [](int l) { return l; });
+            av = av + L::gather_at(a.dcur, ob, [](int l) { return l + NP; });
         }                                                  // the cooperative code adds an exact 0 off the boundaries
         xq = nq + aq; xv = nv + av;
         if (bnd) {
-            L::scatter(a.x, [k](int l) { return NX * (k + 1) + l; }, xq, act);
-            L::scatter(a.x, [k](int l) { return NX * (k + 1) + l + NP; }, xv, act);
+            L::scatter_at(a.xs, (a.slotN + k + 1) * NX, [](int l) { return l; }, xq, act);
+            L::scatter_at(a.xs, (a.slotN + k + 1) * NX, [](int l) { return l + NP; }, xv, act);
         }
     }
 }
@@ -90,34 +114,36 @@ PDDP_HD typename L::V arm_lg_cost(const CostWeights<T>& cw, typename L::V q, typ
 // Rollout of segment bInd of one candidate.  cost_k: [N] per-knot costs of THIS candidate (LDS or host memory).
 // init_rollout: segment starts come from the loaded trajectory (xcur) instead of from the sweep.
 template <typename L, typename T>
-PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, const FpArgs<T>& a, int bInd, const CostWeights<T>& cw,
-                                    const T* xg, T* cost_k, bool init_rollout) {
+PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, const FpLgArgs<T>& a, int bInd, const CostWeights<T>& cw,
+                                    T* cost_k, bool init_rollout) {
     using V = typename L::V;
     constexpr int NX = 14, NU = 7, NP = 7;
     const typename L::M act = L::all_true(), last_lane = L::lane_is(6);
     const int NBk = dm.NB, kStart = bInd * NBk;
     const int iters = (bInd < dm.M - 1) ? NBk : NBk - 1;
-    const V gq = L::gather(xg, [](int l) { return l; }), gv = L::gather(xg, [](int l) { return l + NP; });
-    const T* xstart = (bInd == 0 || init_rollout) ? a.xcur : a.x;
-    V q = L::gather(xstart, [kStart](int l) { return NX * kStart + l; }), qd = L::gather(xstart, [kStart](int l) { return NX * kStart + l + NP; });
-    if (bInd == 0 || init_rollout) {
-        L::scatter(a.x, [kStart](int l) { return NX * kStart + l; }, q, act);
-        L::scatter(a.x, [kStart](int l) { return NX * kStart + l + NP; }, qd, act);
+    const V gq = L::gather_at(a.xGoal, a.oxg, [](int l) { return l; }), gv = L::gather_at(a.xGoal, a.oxg, [](int l) { return l + NP; });
+    const bool from_cur = (bInd == 0 || init_rollout);
+    const T* xstart = from_cur ? a.xb : a.xs;
+    const unsigned ostart = (from_cur ? a.oxc : a.slotN * NX) + NX * kStart;
+    V q = L::gather_at(xstart, ostart, [](int l) { return l; }), qd = L::gather_at(xstart, ostart, [](int l) { return l + NP; });
+    if (from_cur) {
+        L::scatter_at(a.xs, (a.slotN + kStart) * NX, [](int l) { return l; }, q, act);
+        L::scatter_at(a.xs, (a.slotN + kStart) * NX, [](int l) { return l + NP; }, qd, act);
     }
     ArmLgState<L> st;
     for (int k = 0; k < iters; k++) {
         const int kn = kStart + k;
-        const V dq = q - L::gather(a.xcur, [kn](int l) { return NX * kn + l; });
-        const V dv = qd - L::gather(a.xcur, [kn](int l) { return NX * kn + l + NP; });
+        const V dq = q - L::gather_at(a.xb, a.oxc, [kn](int l) { return NX * kn + l; });
+        const V dv = qd - L::gather_at(a.xb, a.oxc, [kn](int l) { return NX * kn + l + NP; });
         V bc[14];
         lg_bcast14<L>(bc, dq, dv);
-        const T* KTk = a.KT + NX * NU * kn;                 // lane r: row r of K = KT[c + r*NX]
-        V Kdx = L::gather(KTk, [](int l) { return l * NX; }) * bc[0];
+        const unsigned oKT = (a.pbN + kn) * (NX * NU), oU = (a.pbN + kn) * NU;      // lane r: row r of K = KT[c + r*NX]
+        V Kdx = L::gather_at(a.KT, oKT, [](int l) { return l * NX; }) * bc[0];
 #pragma unroll
-        for (int cc = 1; cc < NX; cc++) Kdx = Kdx + L::gather(KTk, [cc](int l) { return cc + l * NX; }) * bc[cc];
-        V u = L::gather(a.ucur, [kn](int l) { return NU * kn + l; });
-        u = u - (V(a.alpha) * L::gather(a.du, [kn](int l) { return NU * kn + l; }) + Kdx);
-        L::scatter(a.u, [kn](int l) { return NU * kn + l; }, u, act);
+        for (int cc = 1; cc < NX; cc++) Kdx = Kdx + L::gather_at(a.KT, oKT, [cc](int l) { return cc + l * NX; }) * bc[cc];
+        V u = L::gather_at(a.ucur, oU, [](int l) { return l; });
+        u = u - (V(a.alpha) * L::gather_at(a.du, oU, [](int l) { return l; }) + Kdx);
+        L::scatter_at(a.us, (a.slotN + kn) * NU, [](int l) { return l; }, u, act);
         if (cost_k) {
             const V J = arm_lg_cost<L, T>(cw, q, qd, u, gq, gv, false);
             L::scatter(cost_k, [kn](int) { return kn; }, J, last_lane);
@@ -125,16 +151,17 @@ PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, cons
         const V qdd = arm_lg_dynamics<L>(c, st, q, qd, u);
         const V qn = q + V(a.dt) * qd, qdn = qd + V(a.dt) * qdd;       // Euler (utils/integrators.cuh:24-36)
         if (k < NBk - 1) {
-            L::scatter(a.x, [kn](int l) { return NX * (kn + 1) + l; }, qn, act);
-            L::scatter(a.x, [kn](int l) { return NX * (kn + 1) + l + NP; }, qdn, act);
+            L::scatter_at(a.xs, (a.slotN + kn + 1) * NX, [](int l) { return l; }, qn, act);
+            L::scatter_at(a.xs, (a.slotN + kn + 1) * NX, [](int l) { return l + NP; }, qdn, act);
             q = qn; qd = qdn;
         } else if (bInd < dm.M - 1) {                        // defect against the next segment's start state
             const int ks = (bInd + 1) * NBk;
-            const T* xnext = init_rollout ? a.xcur : a.x;
-            const V eq = qn - L::gather(xnext, [ks](int l) { return NX * ks + l; });
-            const V ev = qdn - L::gather(xnext, [ks](int l) { return NX * ks + l + NP; });
-            L::scatter(a.d, [ks](int l) { return NX * (ks - 1) + l; }, eq, act);
-            L::scatter(a.d, [ks](int l) { return NX * (ks - 1) + l + NP; }, ev, act);
+            const T* xnext = init_rollout ? a.xb : a.xs;
+            const unsigned onext = (init_rollout ? a.oxc : a.slotN * NX) + NX * ks;
+            const V eq = qn - L::gather_at(xnext, onext, [](int l) { return l; });
+            const V ev = qdn - L::gather_at(xnext, onext, [](int l) { return l + NP; });
+            L::scatter_at(a.ds, (a.slotN + ks - 1) * NX, [](int l) { return l; }, eq, act);
+            L::scatter_at(a.ds, (a.slotN + ks - 1) * NX, [](int l) { return l + NP; }, ev, act);
             V sdef = lg_chain_sum<L>(V(T(0)), L::vabs(eq));
             sdef = lg_chain_sum<L>(L::template bcast<6>(sdef), L::vabs(ev));
             L::scatter(a.dnorm, [bInd](int) { return bInd; }, sdef, last_lane);
@@ -142,8 +169,8 @@ PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, cons
     }
     if (bInd == dm.M - 1) {                                 // terminal knot: its (unused) control is carried along
         const int kn = dm.N - 1;
-        const V u = L::gather(a.ucur, [kn](int l) { return NU * kn + l; });
-        L::scatter(a.u, [kn](int l) { return NU * kn + l; }, u, act);
+        const V u = L::gather_at(a.ucur, (a.pbN + kn) * NU, [](int l) { return l; });
+        L::scatter_at(a.us, (a.slotN + kn) * NU, [](int l) { return l; }, u, act);
         if (cost_k) {
             const V J = arm_lg_cost<L, T>(cw, q, qd, u, gq, gv, true);
             L::scatter(cost_k, [kn](int) { return kn; }, J, last_lane);

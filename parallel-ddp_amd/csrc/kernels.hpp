@@ -68,14 +68,14 @@ template <typename T>
 __global__ __launch_bounds__(64) void k_sweep_lg(Buffers<T> b, Dims dm, T dt) {
     const int pb = blockIdx.y, a_idx = blockIdx.x * kLgPerWave + (threadIdx.x >> 3);
     if (!fp_active<T>(b, dm, pb) || a_idx >= dm.A || LgDevice<T>::lane() == 7) return;   // lane 7 of every group stays inactive (lanegroup.hpp)
-    const FpArgs<T> a = fp_args<ArmPlant<T>, T>(b, dm, pb, a_idx, dt, nullptr, nullptr);
+    const FpLgArgs<T> a = fp_lg_args<T>(b, dm, pb, a_idx, dt, nullptr);
     arm_lg_forward_sweep<LgDevice<T>, T>(dm, a);
 }
 // k_fp_lg: grid (B), block 64 * ceil(A*M/8): group i of the block rolls out segment i / A of candidate i % A (the 8 groups
 // of a wave are 8 candidates of one segment: they read the same gains, which the memory pipeline coalesces); per-knot
 // costs meet in LDS and are tree-summed per candidate in the reference's pairing.  Dynamic LDS: A*(N+M) elements.
 template <typename T, int MAXT>
-__global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1)) void k_fp_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
+__global__ __launch_bounds__(MAXT, 1) void k_fp_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int pb = blockIdx.x;
     if (!init_rollout && !fp_active<T>(b, dm, pb)) return;
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1)) void k_fp_lg(Buffers<T
         const int a_idx = inst % A_eff, seg = inst / A_eff;
         ArmLgConst<LgDevice<T>> c;
         arm_lg_load_const<LgDevice<T>, T>(c, &lds_model);
-        const FpArgs<T> a = fp_args<ArmPlant<T>, T>(b, dm, pb, a_idx, dt, nullptr, dnorm + a_idx * dm.M);
-        arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, b.xGoal + (size_t)pb * 14, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
+        const FpLgArgs<T> a = fp_lg_args<T>(b, dm, pb, a_idx, dt, dnorm + a_idx * dm.M);
+        arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
     }
     __syncthreads();
     const Wave w = this_wave();

@@ -397,6 +397,8 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     if (c.plant == 4 && c.A * c.M > 128) return fail(PDDP_EINVAL, "KUKA arm: A * M must not exceed 128 (one workgroup rolls out all candidates of a problem)");
+    if (c.plant == 4 && (double)c.batch * c.N * (c.A * 14 > 441 ? c.A * 14 : 441) >= 4294967296.0)
+        return fail(PDDP_EINVAL, "KUKA arm: batch * N too large for the 32-bit element offsets of the lane-group kernels (split the batch over several handles)");
     SolverBase* s = c.dtype == 0 ? make_plant<float>(c) : c.dtype == 1 ? make_plant<double>(c) : nullptr;
     if (!s) return fail(PDDP_EINVAL, "unsupported plant / integrator / dtype combination (the arm supports Euler only)");
     s->cfg = c;

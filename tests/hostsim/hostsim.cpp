@@ -112,8 +112,9 @@ struct Sim : Base {
                     if constexpr (P::PLANT == 4) {          // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
                         using L = LgHost<T>;
                         ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
-                        if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, fa);
-                        for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, fa, sg, cw, b.xGoal + (size_t)pb * NX, cost_k.data(), false);
+                        const FpLgArgs<T> la = fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data());
+                        if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, la);
+                        for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), false);
                         fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data());
                         continue;
                     }
@@ -163,7 +164,8 @@ struct Sim : Base {
                 if constexpr (P::PLANT == 4) {
                     using L = LgHost<T>;
                     ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
-                    for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, fa, sg, cw, b.xGoal + pb * NX, cost_k.data(), true);
+                    const FpLgArgs<T> la = fp_lg_args<T>(b, dm, (int)pb, 0, dt, dnorm.data());
+                    for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), true);
                 } else {
                     for (int sg = 0; sg < cfg.M; sg++) rollout_seed_segment<P, T>(w, dm, fa, sg);
                     P::load_model(w, sim.plant, &model);

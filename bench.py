@@ -31,7 +31,8 @@ import pyddp  # noqa: E402
 from pyddp import shard  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
-KERNELS = ("k_bp", "k_fp", "k_ls", "k_nis")
+PHASES = ("bp", "fp", "ls", "nis")                      # the four phases of a sweep, in launch order
+PHASE_KERNELS = {"bp": "k_bp_lg", "fp": "k_sweep_lg+k_fp_lg", "ls": "k_ls", "nis": "k_nis_lg"}   # kernels of each phase (KUKA arm, large batch)
 
 
 def example_inputs(N, rng, count):
@@ -47,24 +48,30 @@ def example_inputs(N, rng, count):
     return x, u, g
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=14.0):
     """The oracle's runiLQR_CPU restatement (reference thread-per-phase structure) timed on this host's cores on a
-    bounded sample of the same workload.  The oracle is the CHECKER/baseline only -- never the measured product."""
+    bounded sample of the same workload.  The oracle is the CHECKER/baseline only -- never the measured product.
+    The reference sizes its thread counts from hardware_concurrency (config.cuh:148-161); on a many-core host that
+    over-subscribes 128 knots, so the same code is also timed with CPU_CORES = 8 and the FASTER of the two is reported."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle, default_cfg, example_inputs as ora_inputs
-    cores = os.cpu_count() or 1
-    o = Oracle(default_cfg(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=30, cores=cores, spawn_threads=1),
-               np.float32)
-    rng = np.random.default_rng(99)
-    iters, ms, solves = 0, 0.0, 0
-    t0 = time.time()
-    while time.time() - t0 < budget_s:
-        x0, u0, xg = ora_inputs(4, 128, np.float32, noise=rng.normal(0, 0.001, (128, 14)))
-        r = o.run_ilqr_cpu(x0, u0, xg)
-        iters += r["iters"]; ms += r["t_total_ms"] - r["t_init_ms"]; solves += 1
-    return {"value": round(iters / (ms * 1e-3), 2), "unit": "DDP iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{solves} solves x 30 iterations of the same Kuka N=128 A=8 M=4 problem (runiLQR_CPU semantics, "
-                      f"BP/FSIM threads=min(M,cores), COST/INT threads=cores/2, pthreads created per phase like the reference)"}
+    hw = os.cpu_count() or 1
+    results = {}
+    for cores in sorted({hw, min(hw, 8)}):
+        o = Oracle(default_cfg(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=30, cores=cores, spawn_threads=1), np.float32)
+        rng = np.random.default_rng(99)
+        iters, ms, solves = 0, 0.0, 0
+        t0 = time.time()
+        while time.time() - t0 < budget_s / 2:
+            x0, u0, xg = ora_inputs(4, 128, np.float32, noise=rng.normal(0, 0.001, (128, 14)))
+            r = o.run_ilqr_cpu(x0, u0, xg)
+            iters += r["iters"]; ms += r["t_total_ms"] - r["t_init_ms"]; solves += 1
+        results[cores] = (iters / (ms * 1e-3), solves)
+    best = max(results, key=lambda c: results[c][0])
+    return {"value": round(results[best][0], 2), "unit": "DDP iterations/s", "cores": best, "kind": "port",
+            "sample": "runiLQR_CPU semantics (first-acceptable serial line search, pthreads created per phase like the reference), Kuka N=128 A=8 M=4, "
+                      "30 iterations per solve; " + "; ".join(f"CPU_CORES={c}: {results[c][1]} solves, {results[c][0]:.1f} it/s" for c in sorted(results))
+                      + f"; host has {hw} hardware threads"}
 
 
 def main():
@@ -72,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=2048, help="independent problems per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="independent problems per GPU")
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -114,19 +121,28 @@ def main():
     acc = np.mean([(out["alphaOut"][b][W + 1: W + K + 1] >= 0).mean() for b in range(min(B, 64))])
     J_all = shard.allgather_costs(ctx, s.device_array("Jout"), B, cfg.max_iter + 2, int(iters.min()) - 1)   # RCCL exchange
 
-    # ---- per-kernel durations with HIP events on the solver's own stream (second pass, same state machine)
-    ms_tot, ms_phase = s.time_sweeps(min(K, 20), phases=True)
-    nsw = min(K, 20)
-    per_launch_ms = [v / nsw for v in ms_phase]
+    # ---- per-phase kernel durations with HIP events on the solver's own stream: the SAME sweeps again (reload, same warm-up),
+    # launched kernel by kernel with an event after every launch
+    s.load(x0, u0, xg)
+    s.iterate(W); s.sync()
+    ms_tot, ms_phase = s.time_sweeps(K, phases=True)
+    per_launch_ms = [v / K for v in ms_phase]
     dom = int(np.argmax(per_launch_ms))
     alg = pyddp.algorithmic_bytes(n, m, N, A, M, 4)
-    bytes_launch = alg[KERNELS[dom]] * B
+    alg_phase = {"bp": alg["k_bp"], "fp": alg["k_fp"], "ls": alg["k_ls"], "nis": alg["k_nis"]}
+    bytes_launch = alg_phase[PHASES[dom]] * B
     achieved = bytes_launch / (per_launch_ms[dom] * 1e-3) / 1e9
     sweep_bytes = sum(alg.values()) * B
-    roof = {"bound": "hbm", "kernel": KERNELS[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": args.traffic_bytes,
+    traffic = args.traffic_bytes
+    tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # HBM bytes per launch from the separate --pmc passes
+    if traffic is None and os.path.exists(tfile):
+        tj = json.load(open(tfile))
+        if tj.get("batch") == B:
+            traffic = tj.get("phase_bytes", {}).get(PHASES[dom])
+    roof = {"bound": "hbm", "kernel": PHASE_KERNELS[PHASES[dom]], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": round(per_launch_ms[dom], 5),
-            "per_kernel_ms": {k: round(v, 5) for k, v in zip(KERNELS, per_launch_ms)},
+            "per_phase_ms": {PHASE_KERNELS[k]: round(v, 5) for k, v in zip(PHASES, per_launch_ms)},
             "whole_sweep_GBs": round(sweep_bytes / (t_local / K) / 1e9, 2)}
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),

@@ -107,8 +107,10 @@ int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGo
 int pddp_stream(pddp_handle h, void** hip_stream);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
-/* Runs `sweeps` sweeps bracketed by HIP events on the solver's stream; ms_total = elapsed, ms_phase[4] = summed
- * durations of the four kernels (bp, fp, ls, nis) measured with per-launch events in a second pass. */
+/* Runs `sweeps` sweeps timed with HIP events on the solver's stream.  ms_phase == NULL: one event pair around the sweeps as
+ * pddp_iterate enqueues them, ms_total = elapsed.  Otherwise the sweeps are launched kernel by kernel with an event after
+ * every launch: ms_phase[4] = summed durations of the four phases (backward pass, forward pass, line search, next-
+ * iteration setup), ms_total = their sum. */
 int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase);
 /* Freeze / unfreeze the exit tests so a benchmark can time a fixed number of full-work sweeps. */
 int pddp_set_benchmark_mode(pddp_handle h, int on);

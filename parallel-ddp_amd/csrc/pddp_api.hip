@@ -285,31 +285,27 @@ struct Solver : SolverBase {
         return 0;
     }
     int time_sweeps(int sweeps, float* ms_total, float* ms_phase) override {
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipStreamSynchronize(stream));
-        HIPCHK(hipEventRecord(e0, stream));
-        int rc = iterate(sweeps);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(e1, stream));
-        HIPCHK(hipEventSynchronize(e1));
-        if (ms_total) HIPCHK(hipEventElapsedTime(ms_total, e0, e1));
-        if (ms_phase) {   // second pass: an event pair around every launch of each of the four kernels
-            std::vector<hipEvent_t> ev(5 * (size_t)sweeps);
-            for (auto& e : ev) HIPCHK(hipEventCreate(&e));
-            for (int i = 0; i < sweeps; i++)
-                for (int ph = 0; ph < 4; ph++) {
-                    if (ph == 0) HIPCHK(hipEventRecord(ev[5 * i], stream));
-                    launch_sweep(stream, ph);
-                    HIPCHK(hipEventRecord(ev[5 * i + ph + 1], stream));
-                }
-            HIPCHK(hipStreamSynchronize(stream));
-            for (int ph = 0; ph < 4; ph++) ms_phase[ph] = 0;
-            for (int i = 0; i < sweeps; i++)
-                for (int ph = 0; ph < 4; ph++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[5 * i + ph], ev[5 * i + ph + 1])); ms_phase[ph] += ms; }
-            for (auto& e : ev) hipEventDestroy(e);
+        if (!ms_phase) {                       // total only: the sweeps exactly as pddp_iterate enqueues them (graph replay if configured)
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            HIPCHK(hipEventRecord(e0, stream));
+            int rc = iterate(sweeps);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e1, stream));
+            HIPCHK(hipEventSynchronize(e1));
+            if (ms_total) HIPCHK(hipEventElapsedTime(ms_total, e0, e1));
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            return 0;
         }
-        hipEventDestroy(e0); hipEventDestroy(e1);
+        // per phase: ONE pass, kernel by kernel, an event after every launch (the sweeps are not replayed a second time:
+        // the state machine moves on, and later sweeps do different amounts of work)
+        std::vector<double> ph(4 * (size_t)sweeps, 0.0);
+        int rc = iterate_traced(sweeps, ph.data(), 0, sweeps);
+        if (rc) return rc;
+        double tot = 0;
+        for (int k = 0; k < 4; k++) { double sum = 0; for (int i = 0; i < sweeps; i++) sum += ph[(size_t)k * sweeps + i]; ms_phase[k] = (float)sum; tot += sum; }
+        if (ms_total) *ms_total = (float)tot;
         return 0;
     }
     int array(const char* name, void** ptr, size_t* bytes) override {

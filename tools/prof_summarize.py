@@ -69,6 +69,12 @@ def main(src, dst):
                 "|---|" + "---|" * len({c for (_, c) in sq})]
         for k in sorted({k for (k, _) in sq if k.startswith("k_")}):
             out.append(f"| {k} | " + " | ".join(f"{statistics.mean(sq[(k, c)]):.3g}" if (k, c) in sq else "-" for c in sorted({c for (_, c) in sq})) + " |")
+    # HBM bytes per launch of each sweep phase, for bench.py's roofline.traffic (only valid for the profiled batch size)
+    if line:
+        tr = lambda ks: sum((summary.get(k, {}).get("traffic_bytes") or 0) for k in ks) or None
+        phase_bytes = {"bp": tr(["k_bp_lg", "k_bp"]), "fp": tr(["k_sweep_lg", "k_fp_lg", "k_fp"]), "ls": tr(["k_ls"]), "nis": tr(["k_nis_lg", "k_nis"])}
+        json.dump({"batch": line["config"]["problems_per_gpu"], "source": os.path.basename(dst), "phase_bytes": phase_bytes},
+                  open(os.path.join(os.path.dirname(os.path.abspath(dst)), "roofline_traffic.json"), "w"), indent=1)
     open(os.path.join(dst, "summary.md"), "w").write("\n".join(out) + "\n")
     json.dump(summary, open(os.path.join(dst, "summary.json"), "w"), indent=1)
     print("\n".join(out))

@@ -120,7 +120,7 @@ struct LgDevice {
     //   3. J >= 4 only: lane 3 would have to read the disabled lane 7 in step 2 (it keeps its old value): it takes lane 2's.
     template <int J> static __device__ __forceinline__ int bc32(int v) {
         constexpr int q = J & 3;
-        const int t = __builtin_amdgcn_update_dpp(0, v, q * 0x55, 0xF, 0xF, false);                   // quad_perm:[q,q,q,q]
+        const int t = __builtin_amdgcn_mov_dpp(v, q * 0x55, 0xF, 0xF, true);                          // quad_perm:[q,q,q,q]; no "old" to initialise
         if constexpr (J < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false);        // banks 1,3 <- lane-4
         else {
             const int r = __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false);                  // banks 0,2 <- lane+4

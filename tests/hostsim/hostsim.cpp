@@ -37,7 +37,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
 }
 
 struct Base {
-    pddp_config cfg; int bench = 0; int bp_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
+    pddp_config cfg; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
     virtual ~Base() {}
     virtual int load(const void*, const void*, const void*, const void*, const void*, const void*, const void*, int, int, int) = 0;
     virtual int iterate(int) = 0;
@@ -94,7 +94,7 @@ struct Sim : Base {
         const int B = cfg.batch; const Wave w = this_wave();
         if (ph == PDDP_PHASE_BP) {
             if constexpr (P::PLANT == 4) {                    // the arm's backward pass runs on lane groups (bp_lg.hpp)
-                if (!bp_coop) {
+                if (!bp_coop && !bp_default_coop) {
                     static T lds[kBpLgFloats];
                     for (int pb = 0; pb < B; pb++) for (int blk = 0; blk < cfg.M; blk++) arm_lg_bp_body<LgHost<T>, T>(lds, b, dm, blk, pb, true);
                     return;
@@ -274,6 +274,7 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     Base* s = c.dtype == 0 ? mk<float>(c) : c.dtype == 1 ? mk<double>(c) : nullptr;
     if (!s) return fail(PDDP_EINVAL, "unsupported plant / integrator / dtype combination");
+    if (const char* v = std::getenv("PDDP_BP")) s->bp_default_coop = (std::string(v) == "coop");     // same override as the library
     *out = new pddp_solver{s};
     return 0;
 }

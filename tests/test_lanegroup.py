@@ -39,10 +39,15 @@ def test_lane_group_gradient_bit_identical_to_cooperative(backend, dtype):
 def test_lane_group_backward_pass_bit_identical_to_cooperative(backend, dtype, N, M):
     """k_bp_lg (PHASE_BP for the arm) against the wave-cooperative k_bp (PHASE_BP_COOP) from identical inputs: boundary
     cost-to-go, defects, shifted trajectory, regulariser, arbitrary (non-diagonal) cost Hessians."""
+    import os
     import pyddp
     from oracle_binding import example_inputs
     n, m, nm = 14, 7, 21
-    s = make_solver(backend, 4, dtype=0 if dtype == np.float32 else 1, N=N, M=M, A=2, wafr_urdf=1, total_time=0.5, batch=3)
+    os.environ["PDDP_BP"] = "lg"          # small batches default to the cooperative kernel: force the lane-group one for PHASE_BP
+    try:
+        s = make_solver(backend, 4, dtype=0 if dtype == np.float32 else 1, N=N, M=M, A=2, wafr_urdf=1, total_time=0.5, batch=3)
+    finally:
+        del os.environ["PDDP_BP"]
     rng = np.random.default_rng(5)
     xs, us, gs = [], [], []
     for b in range(3):
@@ -74,3 +79,26 @@ def test_lane_group_backward_pass_bit_identical_to_cooperative(backend, dtype, N
     assert np.abs(ref["KT"]).max() > 0 and np.isfinite(ref["P"]).all()
     for name in ref:
         assert np.array_equal(ref[name], lg[name]), name
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_whole_solve_identical_with_either_backward_pass(backend):
+    """The same solves with the lane-group and with the cooperative backward pass: identical cost traces, bit for bit."""
+    import os
+    from oracle_binding import example_inputs
+    kw = dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=10, batch=4)
+    xs, us, gs = [], [], []
+    for b in range(4):
+        x, u, xg = example_inputs(4, 64, np.float32, noise=RNG.normal(0, 0.002 * (b + 1), (64, 14)))
+        xs.append(x); us.append(u); gs.append(xg)
+    outs = {}
+    for mode in ("lg", "coop"):
+        os.environ["PDDP_BP"] = mode
+        try:
+            s = make_solver(backend, 4, **kw)
+        finally:
+            del os.environ["PDDP_BP"]
+        outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    assert np.array_equal(outs["lg"]["Jout"], outs["coop"]["Jout"]) and np.array_equal(outs["lg"]["alphaOut"], outs["coop"]["alphaOut"])
+    assert np.array_equal(outs["lg"]["x"], outs["coop"]["x"]) and np.array_equal(outs["lg"]["KT"], outs["coop"]["KT"])
+    assert outs["lg"]["Jout"][0][10] < outs["lg"]["Jout"][0][0]

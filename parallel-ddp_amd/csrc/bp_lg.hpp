@@ -21,8 +21,11 @@
 
 namespace pddp {
 
-constexpr int kBpLgAB = 0, kBpLgP = 296, kBpLgp = 492, kBpLgW = 508, kBpLgGu = 844, kBpLgDu = 852, kBpLgFloats = 860;
-// W region (336): AB2 row-contiguous, AB2(kx,ky) at [kx*16 + ky] (21 rows of 14, padded to 16) while H is formed;
+// LDS map of one group (floats): B block of AB (98), P (196; between the H stage and the end of the knot it holds Hxx, which the new
+// cost-to-go overwrites element by element), p (14), W (294), gu (7), du (7) = 2480 bytes -> 8 groups = 19.4 KB per wave, 8 waves per CU.
+constexpr int kBpLgB = 0, kBpLgP = 98, kBpLgp = 294, kBpLgW = 308, kBpLgGu = 602, kBpLgDu = 609, kBpLgFloats = 620;
+constexpr int kBpLgWs = 14;    // row stride of AB2 in W
+// W region (294): AB2 row-contiguous, AB2(kx,ky) at [kx*14 + ky] while H is formed;
 // then K[ky + 7 kx] at +0 (98), Huu[j + 7 ky] at +98 (49), Hux[j + 7 kx] at +147 (98)
 constexpr int kBpLgK = 0, kBpLgHuu = 98, kBpLgHux = 147;
 
@@ -44,7 +47,7 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
     using V = typename L::V;
     constexpr int NX = 14, NU = 7, NM = 21;
     const typename L::M act = L::all_true();
-    T* ABl = lds + kBpLgAB; T* Pl = lds + kBpLgP; T* pl = lds + kBpLgp; T* W = lds + kBpLgW; T* gul = lds + kBpLgGu; T* dul = lds + kBpLgDu;
+    T* Bl = lds + kBpLgB; T* Pl = lds + kBpLgP; T* pl = lds + kBpLgp; T* W = lds + kBpLgW; T* gul = lds + kBpLgGu; T* dul = lds + kBpLgDu;
     const int N = dm.N, M = dm.M, NBk = dm.NB;
     const T rho = a.rho;
     int ks = NBk * (blk + 1) - 1, iterCount;
@@ -77,8 +80,8 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
         L::scatter(pl, [](int l) { return l + 7; }, d1 + L::gather_at(a.pp, obp, [](int l) { return l + 7; }), act);
         wsync();
     }
-    // this lane's three columns of AB (z entries l, l+7, l+14), fetched one knot ahead so that the global-memory latency
-    // hides behind the previous knot's arithmetic (a wave of this kernel owns its SIMD alone: 27 KB of LDS per wave)
+    // this lane's three columns of AB (z entries l, l+7, l+14), fetched one knot ahead: the global-memory latency hides behind the
+    // previous knot's arithmetic
     V ABn[3][14];
 #pragma unroll
     for (int cI = 0; cI < 3; cI++)
@@ -100,9 +103,9 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
             for (int ky = 0; ky < NM; ky++) Hc[cI][ky] = L::gather_at(a.H, obH, [cI, ky](int l) { return ky * NM + l + 7 * cI; });
             gc[cI] = L::gather_at(a.g, obg, [cI](int l) { return l + 7 * cI; });
         }
-        // the B block (columns 14..20) is needed by every lane later: its owners publish it, B(kx, l) at ABl[196 + kx + 14 l]
+        // the B block (columns 14..20) is needed by every lane later: its owners publish it, B(kx, l) at Bl[kx + 14 l]
 #pragma unroll
-        for (int kx = 0; kx < NX; kx++) L::scatter(ABl, [kx](int l) { return 196 + kx + NX * l; }, ABc[2][kx], act);
+        for (int kx = 0; kx < NX; kx++) L::scatter(Bl, [kx](int l) { return kx + NX * l; }, ABc[2][kx], act);
         // ---- AB2(kx, ky) = sum_j AB(j,kx) (P(j,ky) + rho [kx >= 14, ky == j]) for the lane's three kx, all ky  -> W[ky*21 + kx]
 #pragma nounroll
         for (int ky = 0; ky < NX; ky++) {
@@ -114,9 +117,9 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
                 v1 = v1 + ABc[1][j] * V(pj);
                 v2 = v2 + ABc[2][j] * V(ky == j ? pj + rho : pj);
             }
-            L::scatter(W, [ky](int l) { return l * 16 + ky; }, v0, act);
-            L::scatter(W, [ky](int l) { return (l + 7) * 16 + ky; }, v1, act);
-            L::scatter(W, [ky](int l) { return (l + 14) * 16 + ky; }, v2, act);
+            L::scatter(W, [ky](int l) { return l * kBpLgWs + ky; }, v0, act);
+            L::scatter(W, [ky](int l) { return (l + 7) * kBpLgWs + ky; }, v1, act);
+            L::scatter(W, [ky](int l) { return (l + 14) * kBpLgWs + ky; }, v2, act);
         }
         if (M > 1 && dm.on_defect_boundary(iter)) {       // p += P d  (tests the loop counter like the reference, :73)
             V s0 = V(T(0)), s1 = V(T(0));
@@ -135,13 +138,14 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
         for (int ky = 0; ky < NM; ky++) {                  // one output row at a time: 14 uniform LDS reads feed 42 multiply-adds
             T w[14];
 #pragma unroll
-            for (int j = 0; j < NX; j++) w[j] = W[ky * 16 + j];            // AB2[ky + NM*j]
+            for (int j = 0; j < NX; j++) w[j] = W[ky * kBpLgWs + j];            // AB2[ky + NM*j]
 #pragma unroll
             for (int cI = 0; cI < 3; cI++) {
                 V dot = V(w[0]) * ABc[cI][0];
 #pragma unroll
                 for (int j = 1; j < NX; j++) dot = dot + V(w[j]) * ABc[cI][j];
                 Hc[cI][ky] = dot + Hc[cI][ky];
+                L::pin(Hc[cI][ky]);
             }
             L::sched_fence();
         }
@@ -167,9 +171,9 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
         // ---- Huu row of this lane, published Huu / Hux / gu, Gauss-Jordan on [Huu | I]
         V A[14], Huur[7], Hxu[2][7];
 #pragma unroll
-        for (int rI = 0; rI < 2; rI++) {                   // Hxx rows l, l+7 -> LDS (ABl[0..195] is free: AB is not staged), Hxu stays in registers
+        for (int rI = 0; rI < 2; rI++) {                   // Hxx rows l, l+7 -> over P in LDS (P's last reader was the AB2 stage), Hxu stays in registers
 #pragma unroll
-            for (int ky = 0; ky < NX; ky++) L::scatter(ABl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, Hc[rI][ky], act);
+            for (int ky = 0; ky < NX; ky++) L::scatter(Pl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, Hc[rI][ky], act);
 #pragma unroll
             for (int ky = 0; ky < NU; ky++) Hxu[rI][ky] = Hc[rI][14 + ky];
         }
@@ -245,7 +249,7 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
             for (int kx = 0; kx < NX; kx++) {
                 T brow[7];
 #pragma unroll
-                for (int jj = 0; jj < NU; jj++) brow[jj] = ABl[196 + kx + NX * jj];
+                for (int jj = 0; jj < NU; jj++) brow[jj] = Bl[kx + NX * jj];
 #pragma unroll
                 for (int cI = 0; cI < 2; cI++) {
                     V val = V(brow[0]) * Kr[cI][0];
@@ -260,9 +264,9 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
             for (int jj = 0; jj < NU; jj++) dv[jj] = dul[jj];
 #pragma unroll
             for (int rI = 0; rI < 2; rI++) {               // Bdu rows l, l+7
-                V val = L::gather(ABl, [rI](int l) { return 196 + l + 7 * rI; }) * V(dv[0]);
+                V val = L::gather(Bl, [rI](int l) { return l + 7 * rI; }) * V(dv[0]);
 #pragma unroll
-                for (int jj = 1; jj < NU; jj++) val = val + L::gather(ABl, [rI, jj](int l) { return 196 + l + 7 * rI + NX * jj; }) * V(dv[jj]);
+                for (int jj = 1; jj < NU; jj++) val = val + L::gather(Bl, [rI, jj](int l) { return l + 7 * rI + NX * jj; }) * V(dv[jj]);
                 L::scatter_at(a.Bdu, obBdu, [rI](int l) { return l + 7 * rI; }, val, act);
             }
         }
@@ -286,7 +290,7 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
                     V val = T1[rI][0] * V(kk[0]) - Kr[rI][0] * V(hx[0]);
 #pragma unroll
                     for (int jj = 1; jj < NU; jj++) val = val + (T1[rI][jj] * V(kk[jj]) - Kr[rI][jj] * V(hx[jj]));
-                    const V v = L::gather(ABl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }) + val;      // Hxx(kx, ky)
+                    const V v = L::gather(Pl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }) + val;       // Hxx(kx, ky), overwritten in place
                     L::scatter(Pl, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, v, act);
                     L::scatter_at(a.Pm, oPprev, [rI, ky](int l) { return ky * NX + l + 7 * rI; }, v, act);
                 }

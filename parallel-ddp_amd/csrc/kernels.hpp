@@ -101,7 +101,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_fp_lg(Buffers<T> b, Dims dm, CostWe
     const int wave_id = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
     for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M);
 }
-// k_bp_lg: grid (ceil(B*M/8)), block 64 -- one 8-lane group per (problem, block of knots) (bp_lg.hpp); 8 x 3.2 KB of LDS.
+// k_bp_lg: grid (ceil(B*M/8)), block 64 -- one 8-lane group per (problem, block of knots) (bp_lg.hpp); 8 x 2.4 KB of LDS.
 template <typename T>
 __global__ __launch_bounds__(64) void k_bp_lg(Buffers<T> b, Dims dm, int batch) {
     __shared__ __attribute__((aligned(16))) T lds[kLgPerWave * kBpLgFloats];

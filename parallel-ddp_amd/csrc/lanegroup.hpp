@@ -75,6 +75,7 @@ struct LgHost {
     static T lane_value(const V& v, int j) { return v.l[j]; }     // host-side extraction (tests)
     static M all_true() { M m; for (int i = 0; i < kLg; i++) m.l[i] = true; return m; }
     static void sched_fence() {}
+    static void pin(V&) {}
 };
 
 // ------------------------------------------------------------------------------------------------ device: gfx950
@@ -147,7 +148,10 @@ struct LgDevice {
     static __device__ __forceinline__ V vabs(V v) { return tabs(v); }
     static __device__ __forceinline__ M all_true() { return true; }
     // keeps the instruction scheduler from hoisting the next block's loads over this point (register pressure)
-    static __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+    static __device__ __forceinline__ void sched_fence() { __asm__ volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    // forces a value to be materialised HERE: stops the vectoriser from collecting the arithmetic of many unrolled iterations
+    // into one late block (which would keep every iteration's loaded operands alive and spill them)
+    static __device__ __forceinline__ void pin(V& v) { __asm__ volatile("" : "+v"(v)); }
 };
 #endif
 

@@ -174,3 +174,53 @@ def test_warm_start_arrays(backend):
     assert np.array_equal(kept["Jout"][0], given["Jout"][0]) and np.array_equal(kept["alphaOut"][0], given["alphaOut"][0])
     assert np.array_equal(kept["x"][0], given["x"][0])
     assert not np.array_equal(kept["Jout"][0][1:], cold["Jout"][0][1:])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_baseline_config4a_mpc_rollout_batch(backend):
+    """BASELINE configs[3], stage 4a: the WAFR_MPC_examples problem shape -- Kuka, N=64, T=0.5 s, M=4, A=8,
+    MPC_MODE gravity 0, TOL_COST 1e-5 -- as a batch of independent rollouts with different goals and start states, joint-space
+    cost.  Every rollout must follow the oracle's GPU-semantics driver (float64: identical alpha sequence, J to 1e-8)."""
+    kw = dict(N=64, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=8, ignore_max_rho_exit=0)
+    B = 5
+    s = make_solver(backend, 4, dtype=1, batch=B, **kw)
+    o = Oracle(default_cfg(4, cores=8, spawn_threads=0, **kw), np.float64)
+    xs, us, gs, refs = [], [], [], []
+    for r in range(B):
+        x0, u0, xg = example_inputs(4, 64, np.float64, noise=RNG.normal(0, 0.01, (64, 14)))
+        x0 = x0.reshape(64, 14); x0[:, :7] += 0.05 * r; x0 = x0.ravel()          # rollout r starts elsewhere ...
+        u0 = np.full(64 * 7, 0.01)                                                 # ... with the MPC example's u = 0.01 (no gravity to hold)
+        xg = xg.copy(); xg[:7] += 0.1 * np.sin(2 * np.pi * r / B)                  # ... and tracks another point of the goal curve
+        xs.append(x0); us.append(u0); gs.append(xg)
+        refs.append(o.run_ilqr_gpusem(x0, u0, xg))
+    out = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    for r in range(B):
+        it = refs[r]["iters"]
+        assert out["iters"][r] == it
+        assert list(out["alphaOut"][r][: it + 1]) == list(refs[r]["alphaOut"][: it + 1])
+        np.testing.assert_allclose(out["Jout"][r][: it + 1], refs[r]["Jout"][: it + 1], rtol=1e-8)
+        np.testing.assert_allclose(out["x"][r].ravel(), refs[r]["x"], rtol=0, atol=1e-8 * max(np.abs(refs[r]["x"]).max(), 1))
+
+
+@pytest.mark.gpu
+def test_baseline_config5_quadrotor_full_size_fp32_vs_fp64():
+    """BASELINE configs[4]: quadrotor, N=256, RK3, 16 alphas, M=4, T=4 s.  float64 follows the oracle; float32 and float64 from the
+    same stored inputs: report where they part, require the leading iterations to agree."""
+    kw = dict(N=256, M=4, A=16, integrator=3, total_time=4.0, max_iter=6, tol_cost=0.0)
+    noise = np.random.default_rng(11).normal(0, 0.001, (256, 12))
+    res = {}
+    for dt in (np.float32, np.float64):
+        s = make_solver("hip", 3, dtype=0 if dt == np.float32 else 1, **kw)
+        x0, u0, xg = example_inputs(3, 256, dt, noise=noise)
+        res[dt] = s.solve(x0, u0, xg)
+    o = Oracle(default_cfg(3, cores=8, spawn_threads=0, **kw), np.float64)
+    r = o.run_ilqr_gpusem(*example_inputs(3, 256, np.float64, noise=noise))
+    it = r["iters"]
+    assert list(res[np.float64]["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(res[np.float64]["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-7)
+    a32, a64 = res[np.float32]["alphaOut"][0], res[np.float64]["alphaOut"][0]
+    first_diff = next((i for i in range(7) if a32[i] != a64[i]), 7)
+    print("quadrotor N=256 RK3 A=16: float32 and float64 alpha sequences agree for", first_diff, "iterations;",
+          "J rel dev", np.abs(res[np.float32]["Jout"][0][:first_diff] / res[np.float64]["Jout"][0][:first_diff] - 1).max())
+    assert first_diff >= 2
+    np.testing.assert_allclose(res[np.float32]["Jout"][0][:first_diff], res[np.float64]["Jout"][0][:first_diff], rtol=5e-3)

@@ -131,18 +131,30 @@ PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, cons
         L::scatter_at(a.xs, (a.slotN + kStart) * NX, [](int l) { return l + NP; }, qd, act);
     }
     ArmLgState<L> st;
+    // operands of one step that do not depend on the state (reference point, gain row, feed-forward): fetched one step ahead so that
+    // their global-memory latency hides behind the previous step's dynamics (a wave of this kernel has its SIMD to itself)
+    V nxq, nxv, nK[NX], nuc, ndu;
+    auto fetch = [&](int kn) {
+        const unsigned oKT = (a.pbN + kn) * (NX * NU), oU = (a.pbN + kn) * NU;       // lane r: row r of K = KT[c + r*NX]
+        nxq = L::gather_at(a.xb, a.oxc, [kn](int l) { return 14 * kn + l; });
+        nxv = L::gather_at(a.xb, a.oxc, [kn](int l) { return 14 * kn + l + 7; });
+#pragma unroll
+        for (int cc = 0; cc < NX; cc++) nK[cc] = L::gather_at(a.KT, oKT, [cc](int l) { return cc + l * 14; });
+        nuc = L::gather_at(a.ucur, oU, [](int l) { return l; });
+        ndu = L::gather_at(a.du, oU, [](int l) { return l; });
+    };
+    fetch(kStart);
     for (int k = 0; k < iters; k++) {
         const int kn = kStart + k;
-        const V dq = q - L::gather_at(a.xb, a.oxc, [kn](int l) { return NX * kn + l; });
-        const V dv = qd - L::gather_at(a.xb, a.oxc, [kn](int l) { return NX * kn + l + NP; });
+        const V dq = q - nxq, dv = qd - nxv;
         V bc[14];
         lg_bcast14<L>(bc, dq, dv);
-        const unsigned oKT = (a.pbN + kn) * (NX * NU), oU = (a.pbN + kn) * NU;      // lane r: row r of K = KT[c + r*NX]
-        V Kdx = L::gather_at(a.KT, oKT, [](int l) { return l * NX; }) * bc[0];
+        V Kdx = nK[0] * bc[0];
 #pragma unroll
-        for (int cc = 1; cc < NX; cc++) Kdx = Kdx + L::gather_at(a.KT, oKT, [cc](int l) { return cc + l * NX; }) * bc[cc];
-        V u = L::gather_at(a.ucur, oU, [](int l) { return l; });
-        u = u - (V(a.alpha) * L::gather_at(a.du, oU, [](int l) { return l; }) + Kdx);
+        for (int cc = 1; cc < NX; cc++) Kdx = Kdx + nK[cc] * bc[cc];
+        V u = nuc;
+        u = u - (V(a.alpha) * ndu + Kdx);
+        fetch(kn + 1);                                       // kn + 1 <= N - 1: always inside the arrays
         L::scatter_at(a.us, (a.slotN + kn) * NU, [](int l) { return l; }, u, act);
         if (cost_k) {
             const V J = arm_lg_cost<L, T>(cw, q, qd, u, gq, gv, false);

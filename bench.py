@@ -167,6 +167,21 @@ def main():
     shard.finalize(ctx)
 
 
+def convergence_iteration(J, alpha, iters):
+    """Reference-style convergence point of one cost trace (examples/WAFR_iLQR_examples.cu:150-187)."""
+    rej = 0
+    for i in range(1, iters + 1):
+        if alpha[i] < 0:
+            rej += 1
+            if rej == 3:
+                return i - 2
+        else:
+            rej = 0
+            if J[i - 1] > 0 and (J[i - 1] - J[i]) / J[i - 1] < 1e-4:
+                return i
+    return iters
+
+
 def latency_single_problem(device):
     """The reference's own figures of merit for ONE problem (examples/WAFR_iLQR_examples.cu:141-187): iterations/s of a
     solve = iter / (tTime - initTime), and ms to convergence with the default TOL_COST 1e-4 (config.cuh:85-87)."""
@@ -176,16 +191,20 @@ def latency_single_problem(device):
         cfg = pyddp.default_config(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=tol, total_time=0.5, batch=1, max_iter=max_iter,
                                    device=device, use_graph=1)
         s = pyddp.Solver(cfg)
-        its, mss, Js = [], [], []
+        its, mss, Js, convs = [], [], [], []
         for rep in range(21):
             x0, u0, xg = example_inputs(128, rng, 1)
             r = s.solve_timed(x0, u0, xg)
             if rep == 0:
                 continue                           # first solve instantiates the graph
             its.append(r["iters"]); mss.append(r["ms_loop"]); Js.append(r["J_final"])
+            convs.append(convergence_iteration(r["Jout"][0], r["alphaOut"][0], r["iters"]))
         res[name] = {"median_iterations": float(np.median(its)), "median_ms": round(float(np.median(mss)), 3),
                      "iterations_per_s": round(float(np.median(np.asarray(its) / (np.asarray(mss) * 1e-3))), 1),
-                     "median_J_final": round(float(np.median(Js)), 3), "solves": len(its)}
+                     "median_J_final": round(float(np.median(Js)), 3), "solves": len(its),
+                     # first iteration with relative decrease < 1e-4, or the first of 3 consecutive rejections
+                     "median_iterations_to_convergence": float(np.median(convs)),
+                     "median_ms_to_convergence": round(float(np.median(np.asarray(convs) * np.asarray(mss) / np.asarray(its))), 3)}
         s.close()
     return res
 

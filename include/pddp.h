@@ -152,6 +152,7 @@ int pddp_run_phase(pddp_handle h, int phase);
  *        2 _integrator -> xnext[count][n]               (utils/integrators.cuh)
  *        3 _integratorGradient -> AB[count][n*(n+m)]
  *        4 dynamics on lane groups (KUKA arm only; the forward pass's code path) -> qdd[count][npos]
+ *        6 the same with packed 6x6 products (the variant the forward pass runs) -> qdd[count][npos]
  *        5 dynamicsGradient on lane groups (KUKA arm only; next-iteration setup's code path) -> dqdd[count][npos*(n+m)] */
 int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);
 

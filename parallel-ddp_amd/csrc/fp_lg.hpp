@@ -160,7 +160,7 @@ PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, cons
             const V J = arm_lg_cost<L, T>(cw, q, qd, u, gq, gv, false);
             L::scatter(cost_k, [kn](int) { return kn; }, J, last_lane);
         }
-        const V qdd = arm_lg_dynamics<L>(c, st, q, qd, u);
+        const V qdd = arm_lg_dynamics<L, true>(c, st, q, qd, u);
         const V qn = q + V(a.dt) * qd, qdn = qd + V(a.dt) * qdd;       // Euler (utils/integrators.cuh:24-36)
         if (k < NBk - 1) {
             L::scatter_at(a.xs, (a.slotN + kn + 1) * NX, [](int l) { return l; }, qn, act);

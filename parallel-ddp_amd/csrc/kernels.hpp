@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64) void k_plant_eval_lg(const void* model, int cou
     if (L::lane() == 7) return;                              // lane 7 of every group stays inactive (lanegroup.hpp)
     for (int i = blockIdx.x * kLgPerWave + (threadIdx.x >> 3); i < count; i += gridDim.x * kLgPerWave) {
         const T q = x[(size_t)i * 14 + L::lane()], qd = x[(size_t)i * 14 + 7 + L::lane()], uu = u[(size_t)i * 7 + L::lane()];
+        if (grad == 2) { out[(size_t)i * 7 + L::lane()] = arm_lg_dynamics<L, true>(c, st, q, qd, uu); continue; }   // packed variant (forward pass)
         const T qdd = arm_lg_dynamics<L>(c, st, q, qd, uu);
         if (!grad) out[(size_t)i * 7 + L::lane()] = qdd;
         else { T* o = out + (size_t)i * 147 + L::lane(); arm_lg_gradient<L>(c, st, qd, qdd, [o](int jj, T val) { o[7 * jj] = val; }); }

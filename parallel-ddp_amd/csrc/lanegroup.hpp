@@ -48,9 +48,20 @@ template <typename T> inline Vec8<T>& operator+=(Vec8<T>& a, const Vec8<T>& b) {
 template <typename T> inline Vec8<T>& operator-=(Vec8<T>& a, const Vec8<T>& b) { for (int i = 0; i < kLg; i++) a.l[i] = a.l[i] - b.l[i]; return a; }
 template <typename T> inline Vec8<T>& operator*=(Vec8<T>& a, const Vec8<T>& b) { for (int i = 0; i < kLg; i++) a.l[i] = a.l[i] * b.l[i]; return a; }
 
+// a pair of per-lane values that the device executes with ONE packed instruction (v_pk_mul_f32 / v_pk_add_f32)
+template <typename V>
+struct LgPair { V x, y; };
+template <typename V> inline LgPair<V> operator*(const LgPair<V>& a, const LgPair<V>& b) { return LgPair<V>{a.x * b.x, a.y * b.y}; }
+template <typename V> inline LgPair<V> operator+(const LgPair<V>& a, const LgPair<V>& b) { return LgPair<V>{a.x + b.x, a.y + b.y}; }
+template <typename V> inline LgPair<V> operator-(const LgPair<V>& a, const LgPair<V>& b) { return LgPair<V>{a.x - b.x, a.y - b.y}; }
+
 template <typename T>
 struct LgHost {
     using V = Vec8<T>;
+    using V2 = LgPair<Vec8<T>>;
+    static V2 pair(const V& a, const V& b) { return V2{a, b}; }
+    static V2 splat(const V& a) { return V2{a, a}; }
+    template <typename F> static V2 gather2(const T* p, F f) { V2 r; for (int i = 0; i < kLg; i++) { const int o = f(i < 7 ? i : 6); r.x.l[i] = p[o]; r.y.l[i] = p[o + 1]; } return r; }
     using M = Mask8;
     using Scalar = T;
     static constexpr bool kDevice = false;
@@ -83,6 +94,11 @@ struct LgHost {
 template <typename T>
 struct LgDevice {
     using V = T;
+    typedef T V2 __attribute__((ext_vector_type(2)));      // float: one v_pk_* instruction per operation on both halves
+    static __device__ __forceinline__ V2 pair(V a, V b) { V2 r; r.x = a; r.y = b; return r; }
+    static __device__ __forceinline__ V2 splat(V a) { V2 r; r.x = a; r.y = a; return r; }
+    // p[f(lane)], p[f(lane) + 1] as one 8-byte access (f(lane) must be even and p 8-byte aligned)
+    template <typename F> static __device__ __forceinline__ V2 gather2(const T* p, F f) { return *reinterpret_cast<const V2*>(p + f(link())); }
     using M = bool;
     using Scalar = T;
     static constexpr bool kDevice = true;

@@ -346,8 +346,8 @@ struct Solver : SolverBase {
         return 0;
     }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
-        if (what < 0 || what > 5 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
-        const size_t osz = (what == 0 || what == 4 ? NP : (what == 1 || what == 5) ? NP * NM : what == 2 ? NX : NX * NM);
+        if (what < 0 || what > 6 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
+        const size_t osz = (what == 0 || what == 4 || what == 6 ? NP : (what == 1 || what == 5) ? NP * NM : what == 2 ? NX : NX * NM);
         T *dx, *du_, *dout;
         HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&du_, (size_t)count * NU * sizeof(T)));
         HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
@@ -355,7 +355,7 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
         int grid = count < 4096 ? count : 4096;
         if (const char* g = std::getenv("PDDP_EVAL_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;   // micro-benchmarks (tools/)
-        if (what >= 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout, what == 5); }
+        if (what >= 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout, what == 5 ? 1 : (what == 6 ? 2 : 0)); }
         else hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));

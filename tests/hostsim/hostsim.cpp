@@ -236,6 +236,11 @@ struct Sim : Base {
                     using L = LgHost<T>;
                     ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model); ArmLgState<L> st;
                     const auto qdv = L::gather(xi, [](int l) { return l + 7; });
+                    if (what == 6) {
+                        const auto rp = arm_lg_dynamics<L, true>(c, st, L::gather(xi, [](int l) { return l; }), qdv, L::gather(ui, [](int l) { return l; }));
+                        for (int e = 0; e < 7; e++) out[(size_t)i * NP + e] = rp.l[e];
+                        continue;
+                    }
                     const auto r = arm_lg_dynamics<L>(c, st, L::gather(xi, [](int l) { return l; }), qdv, L::gather(ui, [](int l) { return l; }));
                     if (what == 4) for (int e = 0; e < 7; e++) out[(size_t)i * NP + e] = r.l[e];
                     else { T* o = out + (size_t)i * NP * NM; arm_lg_gradient<L>(c, st, qdv, r, [o](int jj, const Vec8<T>& val) { for (int e = 0; e < 7; e++) o[7 * jj + e] = val.l[e]; }); }

@@ -16,9 +16,10 @@ def test_lane_group_dynamics_bit_identical_to_cooperative(backend, dtype):
     count = 203                                   # not a multiple of 8: the last wave has idle groups
     x = np.concatenate([RNG.normal(0, 2, (count, 7)), RNG.normal(0, 5, (count, 7))], axis=1).astype(dtype)
     u = RNG.normal(0, 50, (count, 7)).astype(dtype)
-    coop, lg = s.plant_eval(0, x, u), s.plant_eval(4, x, u)
+    coop, lg, lg_packed = s.plant_eval(0, x, u), s.plant_eval(4, x, u), s.plant_eval(6, x, u)
     assert np.isfinite(coop).all()
     assert np.array_equal(coop, lg)
+    assert np.array_equal(coop, lg_packed)          # the forward pass's variant: 6x6 products two rows per packed instruction
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

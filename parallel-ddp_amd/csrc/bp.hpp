@@ -61,17 +61,17 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
         PDDP_FOR(e, NX * NX) s.Pm[e] = bP[e];
         PDDP_FOR(e, NX) s.dx[e] = a.xcur[NX * (ks + 1) + e] - a.xprev2[NX * (ks + 1) + e];
     }
-    wsync();
+    wsync(w);
     if (lin) {                                // p = pp + Pp (x - xp2)   (linearXfrmOrLoad)
         const T* bp = a.pp + NX * ks;
         PDDP_FOR(r, NX) { T dot = 0; for (int j = 0; j < NX; j++) dot += s.Pm[r + NX * j] * s.dx[j]; s.pv[r] = dot + bp[r]; }
-        wsync();
+        wsync(w);
     }
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
         const T* bAB = a.AB + NX * NM * ks; const T* bH = a.H + NM * NM * ks; const T* bg = a.g + NM * ks;
         const T* bd = a.dcur + NX * ks;
         PDDP_FOR(e, NX * NM) s.AB[e] = bAB[e];
-        wsync();
+        wsync(w);
         PDDP_FOR(e, NX * NM) {                // AB2 = AB' (P + rho I on the B rows)
             const int ky = e / NM, kx = e % NM;
             T val = 0;
@@ -81,7 +81,7 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
         if (M > 1 && dm.on_defect_boundary(iter)) {   // p += P d  (tests the loop counter like the reference, :73)
             PDDP_FOR(r, NX) { T val = 0; for (int j = 0; j < NX; j++) val += bd[j] * s.Pm[r + j * NX]; s.pv[r] += val; }
         }
-        wsync();
+        wsync(w);
         PDDP_FOR(e, NM * NM) {                // H = (AB2 AB)' + H_cost
             const int ky = e / NM, kx = e % NM;
             T dot = 0;
@@ -93,20 +93,20 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
             for (int j = 0; j < NX; j++) dot += s.pv[j] * s.AB[kx * NX + j];
             s.g[kx] = dot + bg[kx];
         }
-        wsync();
+        wsync(w);
         T* bKT = a.KT + NX * NU * ks; T* bdu = a.du + NU * ks;
         if (NU == 1) {                        // scalar Huu (computeKTdu_dim1)
             if (s.H[oHUU] <= T(0)) return 1;
             const T val = T(1) / s.H[oHUU];
             PDDP_FOR(ky, NX) { const T k = s.H[oHUX + ky * NM] * val; s.K[ky] = k; bKT[ky] = k; }
             if (w.lane == 0) { const T v = s.g[oHUX] * val; s.du[0] = v; bdu[0] = v; }
-            wsync();
+            wsync(w);
         } else {
             T* Hinv;
             if (NU == 4) {                    // adjugate inverse with a det > 0 test (invHuu_dim4)
                 T* A2 = &s.Huu[16]; T* adj = &s.Huu[0];
                 PDDP_FOR(e, 16) A2[e] = s.H[oHUU + (e % 4) + NM * (e / 4)];
-                wsync();
+                wsync(w);
                 PDDP_FOR(e, 16) {
                     const int ky = e / 4, kx = e % 4;
                     const int r0 = (kx + 1) % 4, c0 = (ky + 1) % 4, r1 = (r0 + 1) % 4, c1 = (c0 + 1) % 4, r2 = (r1 + 1) % 4, c2 = (c1 + 1) % 4;
@@ -116,28 +116,28 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
                     const T cdet = f0 * f4 * f8 + f3 * f7 * f2 + f6 * f1 * f5 - f2 * f4 * f6 - f5 * f7 * f0 - f8 * f1 * f3;
                     adj[ky * 4 + kx] = ((kx + ky) % 2 ? T(-1) : T(1)) * cdet;
                 }
-                wsync();
+                wsync(w);
                 const T val = T(1) / (adj[0] * A2[0] + adj[1] * A2[1] + adj[2] * A2[2] + adj[3] * A2[3]);
                 if (val <= T(0)) return 1;
-                wsync();                      // every lane has read A2[0..3] before it is overwritten
+                wsync(w);                      // every lane has read A2[0..3] before it is overwritten
                 PDDP_FOR(e, 16) { const int ky = e / 4, kx = e % 4; A2[kx * 4 + ky] = val * adj[ky * 4 + kx]; }
-                wsync();
+                wsync(w);
                 Hinv = A2;
             } else {                          // [Huu | I] unpivoted Gauss-Jordan, never reports failure (invHuu)
                 T* A = &s.Huu[0]; T* gjC = &s.Huu[2 * NU * NU]; T* gjR = gjC + NU;
                 PDDP_FOR(e, NU * NU) { const int ky = e / NU, kx = e % NU; A[e] = s.H[oHUU + kx + NM * ky]; A[NU * NU + e] = T(kx == ky ? 1 : 0); }
-                wsync();
+                wsync(w);
                 for (int piv = 0; piv < NU; piv++) {
                     PDDP_FOR(kr, NU) gjC[kr] = A[kr + piv * NU];
                     PDDP_FOR(kc, NU + 1) gjR[kc] = A[piv + (piv + kc) * NU];
-                    wsync();
+                    wsync(w);
                     PDDP_FOR(e, NU * (NU + 1)) {
                         const int kr = e % NU, kc = e / NU;
                         const T inv = T(1) / gjR[0];
                         T& v = A[kr + (kc + piv) * NU];
                         if (kr == piv) v *= inv; else v -= gjC[kr] * inv * gjR[kc];
                     }
-                    wsync();
+                    wsync(w);
                 }
                 Hinv = &A[NU * NU];
             }
@@ -153,7 +153,7 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
                 for (int j = 0; j < NU; j++) dot += Hinv[r + NU * j] * s.g[oHUX + j];
                 s.du[r] = dot; bdu[r] = dot;
             }
-            wsync();
+            wsync(w);
         }
         const bool do_ctg = (iter != 0 || blk != 0);   // the cost-to-go in front of knot 0 is never used (:396)
         if (do_ctg) {
@@ -180,7 +180,7 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
             s.dJ[ind] += s.du[ind] * s.g[oHUX + ind];
             s.dJ[NU + ind] += s.du[ind] * dot;
         }
-        wsync();
+        wsync(w);
         if (do_ctg) {
             T* Pprev = a.Pm + NX * NX * (ks - 1); T* pprev = a.pv + NX * (ks - 1);
             PDDP_FOR(e, NX * NX) {
@@ -197,7 +197,7 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
                 s.pv[kx] = v; pprev[kx] = v;
             }
         }
-        wsync();
+        wsync(w);
     }
     if (w.lane == 0) {
         T a0 = s.dJ[0], a1 = s.dJ[NU];

@@ -19,6 +19,14 @@ __global__ __launch_bounds__(64) void k_bp(Buffers<T> b, Dims dm) {
     bp_body<P, T>(this_wave(), s, b, dm, blockIdx.x, blockIdx.y);
 }
 
+// the same with a whole 256-thread workgroup per block of knots: every stage has 98..441 independent outputs, so when only a few
+// problems are in flight (one MPC solve: the latency case) four waves per block cut the per-knot time
+template <typename P, typename T>
+__global__ __launch_bounds__(256) void k_bp_wide(Buffers<T> b, Dims dm) {
+    __shared__ BpScratch<P, T> s;
+    bp_body<P, T>(this_block(), s, b, dm, blockIdx.x, blockIdx.y);
+}
+
 // forward pass: grid (A, B), block M*64, dynamic LDS.  One workgroup per (candidate alpha, problem): wave 0 runs the
 // linear sweep, then wave b rolls out segment b, then wave 0 reduces cost and defect.  Replaces forwardSweepKern<<<A,14>>>,
 // forwardSimKern<<<(M,A),(8,7)>>>, costKern<<<A,N>>> and defectKern<<<A,N>>> (DDPWrappers.cuh:73, fpHelpers.cuh:366,383,388).

@@ -90,6 +90,7 @@ struct Solver : SolverBase {
     // backward pass of the arm: the lane-group kernel carries 8 (problem, block) pairs per wave and wins once the GPU is
     // full; the wave-cooperative kernel has the shorter critical path for a handful of problems.  PDDP_BP=lg|coop overrides.
     bool bp_lane_groups = false;
+    bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
     size_t fp_lds = 0;
@@ -120,7 +121,8 @@ struct Solver : SolverBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
         bp_lane_groups = (size_t)c.batch * c.M >= 2048;
-        if (const char* v = std::getenv("PDDP_BP")) bp_lane_groups = (std::string(v) == "lg");
+        bp_wide = (size_t)c.batch * c.M <= 256 && P::NX >= 12;
+        if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); }
         sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
@@ -217,7 +219,10 @@ struct Solver : SolverBase {
             bool lane_groups = false;
             if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups;
             if constexpr (P::PLANT == 4) { if (lane_groups) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
-            if (!lane_groups) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
+            if (!lane_groups) {
+                if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
+                else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
+            }
         }
         if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);

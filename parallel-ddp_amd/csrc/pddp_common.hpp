@@ -29,14 +29,24 @@ constexpr int kWave = 64;  // CDNA wavefront width
 
 struct Wave {
     int lane;    // first index this lane handles
-    int nlanes;  // stride between indices (64 on the GPU, 1 in host emulation)
+    int nlanes;  // stride between indices (64 on the GPU, 1 in host emulation; 256 for a whole-workgroup "wave")
+    int block;   // 1: the cooperating lanes are a whole workgroup, stage boundaries are s_barrier
 };
 
 PDDP_HD Wave this_wave() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return Wave{static_cast<int>(threadIdx.x) & (kWave - 1), kWave};
+    return Wave{static_cast<int>(threadIdx.x) & (kWave - 1), kWave, 0};
 #else
-    return Wave{0, 1};
+    return Wave{0, 1, 0};
+#endif
+}
+// every thread of the workgroup as one cooperating set (used where a unit of work has more independent outputs per stage than a
+// wave has lanes and the latency of ONE unit matters: the backward pass of a single problem)
+PDDP_HD Wave this_block() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return Wave{static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x), 1};
+#else
+    return Wave{0, 1, 0};
 #endif
 }
 // Wave-local stage boundary: LDS operations of one wave are issued and retired in order, so only the
@@ -46,6 +56,15 @@ PDDP_HD void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// stage boundary of the cooperating set `w`
+PDDP_HD void wsync(const Wave& w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (w.block) __syncthreads(); else wsync();
+#else
+    (void)w;
 #endif
 }
 

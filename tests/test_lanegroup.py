@@ -93,7 +93,7 @@ def test_whole_solve_identical_with_either_backward_pass(backend):
         x, u, xg = example_inputs(4, 64, np.float32, noise=RNG.normal(0, 0.002 * (b + 1), (64, 14)))
         xs.append(x); us.append(u); gs.append(xg)
     outs = {}
-    for mode in ("lg", "coop"):
+    for mode in ("lg", "coop", "wide"):
         os.environ["PDDP_BP"] = mode
         try:
             s = make_solver(backend, 4, **kw)
@@ -102,4 +102,5 @@ def test_whole_solve_identical_with_either_backward_pass(backend):
         outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
     assert np.array_equal(outs["lg"]["Jout"], outs["coop"]["Jout"]) and np.array_equal(outs["lg"]["alphaOut"], outs["coop"]["alphaOut"])
     assert np.array_equal(outs["lg"]["x"], outs["coop"]["x"]) and np.array_equal(outs["lg"]["KT"], outs["coop"]["KT"])
+    assert np.array_equal(outs["wide"]["Jout"], outs["coop"]["Jout"]) and np.array_equal(outs["wide"]["KT"], outs["coop"]["KT"])
     assert outs["lg"]["Jout"][0][10] < outs["lg"]["Jout"][0][0]

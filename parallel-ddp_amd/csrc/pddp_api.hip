@@ -120,8 +120,8 @@ struct Solver : SolverBase {
         HIPCHK(hipSetDevice(c.device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
-        bp_lane_groups = (size_t)c.batch * c.M >= 2048;
-        bp_wide = (size_t)c.batch * c.M <= 256 && P::NX >= 12;
+        bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
+        bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); }
         sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;

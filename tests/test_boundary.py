@@ -69,3 +69,41 @@ def test_reference_example_shape_through_the_facade():
     assert J[1] < J[0] and min(J) < 0.15 * J[0]
     phases = re.search(r"BP ([0-9.]+) FP ([0-9.]+) NIS ([0-9.]+) ms", r.stdout)
     assert phases and all(float(v) > 0 for v in phases.groups())
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(N=100), "power of two"),
+    (dict(N=128, M=3), "M must divide N"),
+    (dict(N=128, M=128), "N/M >= 2"),
+    (dict(A=0), "A in"),
+    (dict(A=65), "A in"),
+    (dict(batch=0), "batch"),
+    (dict(integrator=3), "Euler"),                       # the arm is Euler-only, like config.cuh:58
+    (dict(dtype=2), "unsupported"),
+    (dict(N=128, M=16, A=16), "A * M"),                  # lane-group forward pass: one workgroup per problem
+])
+def test_create_rejects_bad_configurations_with_a_code_and_a_message(kw, msg):
+    """Errors are codes + pddp_last_error(), never exit() (the reference's gpuAssert exits, utils/cudaUtils.cu:31-37).
+    Validation comes before the device check, so this runs without a GPU on the product library."""
+    lib = ctypes.CDLL(pyddp.library_path())
+    lib.pddp_last_error.restype = ctypes.c_char_p
+    cfg = pyddp.default_config(4, **{**dict(N=64, M=4, A=8), **kw})
+    h = ctypes.c_void_p()
+    rc = lib.pddp_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == -1, rc                                  # PDDP_EINVAL
+    assert msg in lib.pddp_last_error().decode(), lib.pddp_last_error().decode()
+    assert not h.value
+
+
+def test_default_config_matches_config_cuh():
+    """pddp_default_config = the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them."""
+    exp = {1: dict(N=128, A=32, integrator=3, alpha_base=0.75, rho_init=10.0, max_defect=1.0, total_time=4.0),
+           2: dict(N=128, A=32, integrator=3, alpha_base=0.75, rho_init=10.0, max_defect=0.75, total_time=4.0),
+           3: dict(N=128, A=16, integrator=3, alpha_base=0.5, rho_init=1.0, max_defect=1.0, total_time=4.0),
+           4: dict(N=64, A=16, integrator=1, alpha_base=0.5, rho_init=12.5, max_defect=1.0, total_time=0.5)}
+    for plant, e in exp.items():
+        c = pyddp.default_config(plant)
+        for k, v in e.items():
+            assert getattr(c, k) == v, (plant, k)
+        assert c.M == 4 and c.max_iter == 100 and c.tol_cost == 0.0001 and c.exp_red_min == 0.05 and c.exp_red_max == 1.25
+        assert (c.Q1, c.Q2, c.R, c.QF1, c.QF2) == (0.1, 0.001, 0.0001, 1000.0, 1000.0)

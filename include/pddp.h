@@ -103,6 +103,16 @@ int pddp_solve(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal,
 int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal, const void* KT0, const void* P0, const void* p0,
                   const void* d0, void* Jout, int* alphaOut, int forward_rollout, int clear_vars, int ignore_first_defect,
                   int poll_every, double* times_ms, double* phase_ms, int* sweeps_out);
+/* runiLQR_MPC_GPU (DDPHelpers/MPCHelpers.cuh:864-1045) for the batch, joint-space cost.  The handle holds the previous solution (seed it
+ * with pddp_solve).  Per problem: loadVarsGPU_MPC (:602-655) shifts it by shift[b] knots (x, d, P, p hold their last knot; u, KT are
+ * zero-filled), or clears u, KT, P, p when clear_vars, and rolls the trajectory out open loop from the measured state xActual
+ * (full_rollout = FULL_ROLLOUT, :37-39: the whole horizon; otherwise the first shooting segment plus the last shift[b] knots with
+ * feedback); then the iLQR loop with this call's max_iter (<= config.max_iter) and, when > 0, a time budget in ms checked every
+ * poll_every sweeps; then storeVarsGPU_MPC (:755-774): success[b] = an accepted iteration used a step-size index > 0 (sic, :986-991),
+ * otherwise the solution falls back to the shifted previous one.  x [batch][N][n], u, KT, Jout, alphaOut as pddp_store. */
+int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout,
+                   int ignore_first_defect, int max_iter, double time_budget_ms, int poll_every, void* x, void* u, void* KT, void* Jout,
+                   int* alphaOut, int* success, int* iters);
 /* The HIP stream every kernel of this handle is enqueued on (a hipStream_t). */
 int pddp_stream(pddp_handle h, void** hip_stream);
 
@@ -132,6 +142,7 @@ int pddp_array_ptr(pddp_handle h, const char* name, void** device_ptr, size_t* b
 typedef struct pddp_state {      /* per problem, all scalars as double regardless of dtype */
     double rho, drho, prevJ, dJ, z;
     int iter, alphaIndex, ignore_defect, accepted, done, cur, cur2, bp_retries;
+    int pw;   /* the backward pass writes array "P" (0) or "Pp" (1) and reads the boundary cost-to-go from the other one */
 } pddp_state;
 int pddp_get_state(pddp_handle h, pddp_state* out /* [batch] */);
 int pddp_set_state(pddp_handle h, const pddp_state* in /* [batch] */);

@@ -87,7 +87,17 @@ typedef struct ora_result {
                                ora_result *res);                                                              \
     int ora_run_ilqr_gpusem_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,        \
                                   int *alphaOut, int rollout, int ignoreFirstDefect, REAL *KT_out,            \
-                                  ora_result *res);
+                                  ora_result *res);                                                           \
+    /* MPC wrapper, GPU semantics (DDPHelpers/MPCHelpers.cuh:602-655 load, :864-1016 loop, :755-774 store): a    */ \
+    /* persistent state is seeded with a trajectory, then every solve shifts it by `shift` knots, rolls it out  */ \
+    /* from the measured state and iterates; returns `iter`, *success = an accepted step with alpha index > 0   */ \
+    void *ora_gs_create_##SUF(const ora_cfg *c);                                                              \
+    void ora_gs_destroy_##SUF(void *h);                                                                       \
+    void ora_gs_set_traj_##SUF(void *h, const REAL *x, const REAL *u);                                        \
+    void ora_gs_get_traj_##SUF(void *h, REAL *x, REAL *u, REAL *KT, REAL *d);                                 \
+    int ora_gs_mpc_solve_##SUF(void *h, const REAL *xActual, const REAL *xGoal, int shift, int clear_vars,    \
+                               int full_rollout, int ignoreFirstDefect, int max_iter, REAL *Jout,            \
+                               int *alphaOut, int *success);
 
 ORA_DECL(f32, float)
 ORA_DECL(f64, double)

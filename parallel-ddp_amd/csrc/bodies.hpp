@@ -17,8 +17,8 @@ PDDP_HD void bp_body(const Wave& w, BpScratch<P, T>& s, const Buffers<T>& b, con
     if (st.done) return;
     BpArgs<T> a;
     a.AB = b.AB + (size_t)pb * N * NX * NM;
-    a.Pm = b.P + (size_t)pb * N * NX * NX;   a.pv = b.p + (size_t)pb * N * NX;
-    a.Pp = b.Pp + (size_t)pb * N * NX * NX;  a.pp = b.pp + (size_t)pb * N * NX;
+    a.Pm = (st.pw ? b.Pp : b.P) + (size_t)pb * N * NX * NX;   a.pv = (st.pw ? b.pp : b.p) + (size_t)pb * N * NX;     // written
+    a.Pp = (st.pw ? b.P : b.Pp) + (size_t)pb * N * NX * NX;   a.pp = (st.pw ? b.p : b.pp) + (size_t)pb * N * NX;     // previous iteration's
     a.H = b.H + (size_t)pb * N * NM * NM;    a.g = b.g + (size_t)pb * N * NM;
     a.KT = b.KT + (size_t)pb * N * NX * NU;  a.du = b.du + (size_t)pb * N * NU;
     a.dcur = b.dcur + (size_t)pb * N * NX;
@@ -90,7 +90,7 @@ PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp
 // knot k of problem pb.
 //   accepted: winner candidate -> current trajectory (x into the other half of xb, u, d), then AB_k, H_k, g_k there;
 //   rejected: trajectory and derivatives are unchanged (the reference recomputes identical values);
-//   always (unless the backward pass failed): boundary cost-to-go P,p -> Pp,pp (only block-boundary slots are ever read).
+//   (the reference's P -> Pp, p -> pp copies are a flip of state.pw in the line-search kernel)
 // mode 1 = initAlgGPU derivatives (no copies).
 template <typename P, int INTEG, typename T>
 PDDP_HD void nis_body(const Wave& w, NisScratch<P, INTEG, T>& s, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt,
@@ -102,11 +102,6 @@ PDDP_HD void nis_body(const Wave& w, NisScratch<P, INTEG, T>& s, const Buffers<T
     T* uc = b.ucur + ((size_t)pb * N + k) * NU;
     if (mode == 0) {
         if (st.accepted < 0) return;                           // backward pass failed: nothing moved
-        if (dm.M > 1 && dm.on_defect_boundary(k)) {            // Pp <- P, pp <- p at the slots the next backward pass reads
-            const size_t o = ((size_t)pb * N + k);
-            PDDP_FOR(e, NX * NX) b.Pp[o * NX * NX + e] = b.P[o * NX * NX + e];
-            PDDP_FOR(e, NX) b.pp[o * NX + e] = b.p[o * NX + e];
-        }
         if (st.accepted != 1) return;
         const size_t slot = (size_t)pb * dm.A + st.alphaIndex;
         const T* xw = b.xs + (slot * N + k) * NX; const T* uw = b.us + (slot * N + k) * NU;
@@ -141,7 +136,8 @@ PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const
         st.rho = T(sp.rho_init); st.drho = T(1.0); st.dJ = 0; st.z = 0;
         st.prevJ = J + T(2 * sp.tol_cost);
         st.iter = 1; st.alphaIndex = 0; st.ignore_defect = ignore_first_defect; st.accepted = 1; st.done = 0;
-        st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.pad = 0;
+        st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.took_step = 0;
+        st.pw = b.state[pb].pw;        // a warm start must read the cost-to-go of the iteration before the previous exit: keep the buffer roles
         b.state[pb] = st;
         const size_t ho = (size_t)pb * (sp.max_iter + 2);
         b.Jout[ho] = st.prevJ - T(2 * sp.tol_cost);

@@ -37,6 +37,7 @@ template <typename T>
 struct BpLgArgs {
     const T* AB; T* Pm; T* pv; const T* Pp; const T* pp; const T* H; const T* g; T* KT; T* du; const T* dcur; T* ApBK; T* Bdu; const T* xb; T* dJexp;
     unsigned pbN;          // pb * N: knot k of this problem is element block pbN + k of every per-knot array
+    unsigned oPw, opw, oPr, opr;   // element offsets of the written / read half of the cost-to-go double buffer (Pm, pv are its base: P, p)
     unsigned oxc, oxp2;    // offsets of the current trajectory / the trajectory of the stored boundary cost-to-go inside xb
     unsigned odJ;          // pb * 2M
     T rho;
@@ -53,7 +54,7 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
     int ks = NBk * (blk + 1) - 1, iterCount;
     V dJ0 = V(T(0)), dJ1 = V(T(0));                       // per-lane partial sums of the expected reduction (computeExpRed)
     if (ks == N - 1) {                                    // last block: cost-to-go at N-1 is the final cost (bpHelpers.cuh:362-367)
-        const unsigned oPprev = (a.pbN + ks - 1) * (NX * NX), opprev = (a.pbN + ks - 1) * NX, oHf = (a.pbN + ks) * (NM * NM), ogf = (a.pbN + ks) * NM;
+        const unsigned oPprev = a.oPw + (a.pbN + ks - 1) * (NX * NX), opprev = a.opw + (a.pbN + ks - 1) * NX, oHf = (a.pbN + ks) * (NM * NM), ogf = (a.pbN + ks) * NM;
         for (int t = 0; t < 28; t++) {
             const V v = L::gather_at(a.H, oHf, [t](int l) { const int e = l + 7 * t; return (e % 14) + 21 * (e / 14); });
             L::scatter(Pl, [t](int l) { return l + 7 * t; }, v, act); L::scatter_at(a.Pm, oPprev, [t](int l) { return l + 7 * t; }, v, act);
@@ -66,8 +67,8 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
         wsync();
     } else {                                              // boundary cost-to-go of the PREVIOUS iteration + linear transform
         iterCount = NBk - 1;
-        const unsigned obP = (a.pbN + ks) * (NX * NX), obp = (a.pbN + ks) * NX;
-        for (int t = 0; t < 28; t++) L::scatter(Pl, [t](int l) { return l + 7 * t; }, L::gather_at(a.Pp, obP, [t](int l) { return l + 7 * t; }), act);
+        const unsigned obP = a.oPr + (a.pbN + ks) * (NX * NX), obp = a.opr + (a.pbN + ks) * NX;
+        for (int t = 0; t < 28; t++) L::scatter(Pl, [t](int l) { return l + 7 * t; }, L::gather_at(a.Pm, obP, [t](int l) { return l + 7 * t; }), act);
         wsync();
         // p = pp + Pp (x - xp2)   (linearXfrmOrLoad): lane l rows l, l+7
         V d0 = V(T(0)), d1 = V(T(0));
@@ -76,8 +77,8 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
             d0 = d0 + L::gather(Pl, [j](int l) { return l + NX * j; }) * V(dxj);
             d1 = d1 + L::gather(Pl, [j](int l) { return l + 7 + NX * j; }) * V(dxj);
         }
-        L::scatter(pl, [](int l) { return l; }, d0 + L::gather_at(a.pp, obp, [](int l) { return l; }), act);
-        L::scatter(pl, [](int l) { return l + 7; }, d1 + L::gather_at(a.pp, obp, [](int l) { return l + 7; }), act);
+        L::scatter(pl, [](int l) { return l; }, d0 + L::gather_at(a.pv, obp, [](int l) { return l; }), act);
+        L::scatter(pl, [](int l) { return l + 7; }, d1 + L::gather_at(a.pv, obp, [](int l) { return l + 7; }), act);
         wsync();
     }
     // this lane's three columns of AB (z entries l, l+7, l+14), fetched one knot ahead: the global-memory latency hides behind the
@@ -279,7 +280,7 @@ PDDP_HD void arm_lg_bp_block(T* lds, const Dims& dm, int blk, const BpLgArgs<T>&
         }
         wsync();
         if (do_ctg) {                                     // new cost-to-go: rows l, l+7 of P, entries l, l+7 of p
-            const unsigned oPprev = (knot - 1) * (NX * NX), opprev = (knot - 1) * NX;
+            const unsigned oPprev = a.oPw + (knot - 1) * (NX * NX), opprev = a.opw + (knot - 1) * NX;
 #pragma nounroll
             for (int ky = 0; ky < NX; ky++) {
                 T kk[7], hx[7];
@@ -328,6 +329,10 @@ PDDP_HD void arm_lg_bp_body(T* lds, const Buffers<T>& b, const Dims& dm, int blk
     a.AB = b.AB; a.Pm = b.P; a.pv = b.p; a.Pp = b.Pp; a.pp = b.pp; a.H = b.H; a.g = b.g; a.KT = b.KT; a.du = b.du; a.dcur = b.dcur;
     a.ApBK = b.ApBK; a.Bdu = b.Bdu; a.xb = b.xb; a.dJexp = b.dJexp;
     a.pbN = (unsigned)pb * N;
+    {   // P and Pp (p and pp) are the two halves of one allocation: Pp = P + half
+        const unsigned halfP = (unsigned)(b.Pp - b.P), halfp = (unsigned)(b.pp - b.p);
+        a.oPw = st.pw ? halfP : 0u; a.opw = st.pw ? halfp : 0u; a.oPr = st.pw ? 0u : halfP; a.opr = st.pw ? 0u : halfp;
+    }
     a.oxc = ((unsigned)pb * 2 + st.cur) * N * NX; a.oxp2 = ((unsigned)pb * 2 + st.cur2) * N * NX;
     a.odJ = (unsigned)pb * 2 * dm.M;
     a.rho = st.rho;

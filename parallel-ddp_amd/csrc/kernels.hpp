@@ -9,6 +9,7 @@
 #include "fp_lg.hpp"
 #include "nis_lg.hpp"
 #include "bp_lg.hpp"
+#include "mpc.hpp"
 
 namespace pddp {
 
@@ -177,6 +178,17 @@ __global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
     PDDP_FOR(i, NX) b.xb[((size_t)pb * 2 * N + k) * NX + i] = b.xs[(slot * N + k) * NX + i];
     PDDP_FOR(i, NU) b.ucur[((size_t)pb * N + k) * NU + i] = b.us[(slot * N + k) * NU + i];
     PDDP_FOR(i, NX) b.dcur[((size_t)pb * N + k) * NX + i] = b.ds[(slot * N + k) * NX + i];
+}
+
+// MPC warm start / fall-back (mpc.hpp): grid (B), block 64.
+template <typename P, int INTEG, typename T>
+__global__ __launch_bounds__(64) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout) {
+    __shared__ MpcScratch<P, T> s;
+    mpc_load_body<P, INTEG, T>(this_wave(), s, b, mb, dm, dt, blockIdx.x, xActual + (size_t)blockIdx.x * P::NX, shift[blockIdx.x], clear_vars, full_rollout);
+}
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm) {
+    mpc_store_body<P, T>(this_wave(), b, mb, dm, blockIdx.x);
 }
 
 // initial cost + solver state: grid (B), block 64, dynamic LDS N*sizeof(T).

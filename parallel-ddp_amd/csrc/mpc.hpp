@@ -1,0 +1,139 @@
+// MPC warm start: what loadVarsGPU_MPC and storeVarsGPU_MPC do around the iLQR loop (DDPHelpers/MPCHelpers.cuh:602-655, 755-774;
+// joint-space cost).  One wavefront per problem.
+//
+//   load   shift the previous solution by `shift` knots -- x, d, P, p, Pp, pp hold their last knot, u and KT are zero-filled
+//          (shiftAndCopy :427-465, FLAG) and their knots N-2, N-1 are not touched, exactly like the reference --, or clear
+//          u, KT, P, p, Pp, pp; zero du, dmax, err and AB at knot N-2; then roll the trajectory out open loop from the MEASURED state
+//          with the shifted controls (rolloutMPC :525-560; FULL_ROLLOUT = the whole horizon, otherwise the first shooting segment,
+//          plus rolloutMPC2 :570-598 for the last `shift` knots with feedback around the shifted previous trajectory).
+//          The shifted previous solution is kept (x_old, u_old, KT_old) as the fall-back.
+//   store  a solve counts as successful when an accepted iteration used a step-size index > 0 (sic, :986-991); otherwise the
+//          current trajectory, controls and gains fall back to the shifted previous solution.
+// Data-movement difference: the reference shifts the winner's candidate slot and copies into d_xp; here the current trajectory is
+// one half of xb, and the load leaves the rolled-out trajectory in half 0 and the shifted previous one in half 1.
+#pragma once
+
+#include "fp.hpp"
+#include "solver_state.hpp"
+
+namespace pddp {
+
+template <typename T>
+struct MpcBuffers {      // extra arrays of a handle that has been used for MPC: [B][N][.]
+    T *x_old, *u_old, *KT_old;
+};
+
+// dst[k] = src[min(k + shift, DIM_N - 1)] (or 0 beyond the data when zero_fill) for k < DIM_N - 1; one lane per element, knots in
+// ascending order so that shifting in place is safe.  dst2 (optional) receives the same values.  When copy_last, knot DIM_N - 1 of
+// src is also copied to dst/dst2 (needed when dst is not src).
+template <typename T>
+PDDP_HD void mpc_shift(const Wave& w, T* dst, T* dst2, const T* src, int per_knot, int DIM_N, int shift, bool zero_fill, bool copy_last) {
+    PDDP_FOR(i, per_knot) {
+        int ksrc = shift;
+        for (int k = 0; k < DIM_N - 1; k++) {
+            const T val = (zero_fill && ksrc >= DIM_N - 1) ? T(0) : src[(size_t)per_knot * ksrc + i];
+            dst[(size_t)per_knot * k + i] = val;
+            if (dst2) dst2[(size_t)per_knot * k + i] = val;
+            if (ksrc < DIM_N - 1) ksrc++;
+        }
+        if (copy_last) {
+            const T val = src[(size_t)per_knot * (DIM_N - 1) + i];
+            dst[(size_t)per_knot * (DIM_N - 1) + i] = val;
+            if (dst2) dst2[(size_t)per_knot * (DIM_N - 1) + i] = val;
+        }
+    }
+}
+
+template <typename P, typename T>
+struct MpcScratch {
+    typename P::Scratch plant;
+    IntegScratch<P, T> integ;
+    T x[P::NX], xn[P::NX], u[P::NU], dx[P::NX];
+};
+
+template <typename P, int INTEG, typename T>
+PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>& b, const MpcBuffers<T>& mb, const Dims& dm, T dt, int pb,
+                           const T* xActual, int shift, int clear_vars, int full_rollout) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    const int N = dm.N;
+    const int cur = b.state[pb].cur;
+    T* x0 = b.xb + ((size_t)pb * 2 + 0) * N * NX;          // after the load: the rolled-out trajectory
+    T* x1 = b.xb + ((size_t)pb * 2 + 1) * N * NX;          // after the load: the shifted previous trajectory (the reference's d_xp)
+    T* xsrc = cur == 0 ? x0 : x1;
+    T* u = b.ucur + (size_t)pb * N * NU; T* d = b.dcur + (size_t)pb * N * NX;
+    T* KT = b.KT + (size_t)pb * N * NX * NU;
+    T* Pm = b.P + (size_t)pb * N * NX * NX; T* Pp = b.Pp + (size_t)pb * N * NX * NX; T* pv = b.p + (size_t)pb * N * NX; T* pp = b.pp + (size_t)pb * N * NX;
+    T* x_old = mb.x_old + (size_t)pb * N * NX; T* u_old = mb.u_old + (size_t)pb * N * NU; T* KT_old = mb.KT_old + (size_t)pb * N * NX * NU;
+    // ---- shift (shift == 0 degenerates to plain copies of the current values, which is what the reference's buffers hold then)
+    mpc_shift<T>(w, cur == 0 ? x0 : x1, cur == 0 ? x1 : x0, xsrc, NX, N, shift, false, true);
+    if (shift > 0) mpc_shift<T>(w, d, nullptr, d, NX, N, shift, false, false);
+    if (clear_vars) {
+        PDDP_FOR(e, N * NU) u[e] = 0;
+        PDDP_FOR(e, N * NX * NU) KT[e] = 0;
+        PDDP_FOR(e, N * NX * NX) { Pm[e] = 0; Pp[e] = 0; }
+        PDDP_FOR(e, N * NX) { pv[e] = 0; pp[e] = 0; }
+    } else if (shift > 0) {
+        mpc_shift<T>(w, u, nullptr, u, NU, N - 1, shift, true, false);
+        mpc_shift<T>(w, KT, nullptr, KT, NX * NU, N - 1, shift, true, false);
+        mpc_shift<T>(w, Pm, nullptr, Pm, NX * NX, N, shift, false, false); mpc_shift<T>(w, pv, nullptr, pv, NX, N, shift, false, false);
+        mpc_shift<T>(w, Pp, nullptr, Pp, NX * NX, N, shift, false, false); mpc_shift<T>(w, pp, nullptr, pp, NX, N, shift, false, false);
+    }
+    PDDP_FOR(e, N * NU) b.du[(size_t)pb * N * NU + e] = 0;
+    PDDP_FOR(e, dm.A) b.dmax[(size_t)pb * dm.A + e] = 0;
+    PDDP_FOR(e, dm.M) b.err[(size_t)pb * dm.M + e] = 0;
+    PDDP_FOR(e, NX * NM) b.AB[((size_t)pb * N + N - 2) * NX * NM + e] = 0;
+    wsync();
+    // the fall-back: shifted previous trajectory / controls / gains (u_old is the reference's d_up: knots N-2, N-1 keep whatever they held)
+    PDDP_FOR(e, N * NX) x_old[e] = x1[e];
+    PDDP_FOR(e, N * NU) u_old[e] = u[e];
+    PDDP_FOR(e, N * NX * NU) KT_old[e] = KT[e];
+    // ---- open-loop rollout from the measured state (rolloutMPC)
+    P::load_model(w, s.plant, reinterpret_cast<const typename P::Model*>(b.model));
+    PDDP_FOR(i, NX) { const T v = xActual[i]; s.x[i] = v; x0[i] = v; }
+    wsync();
+    const int n_roll = full_rollout ? N : dm.NB;
+    for (int k = 0; k < n_roll - 1; k++) {
+        PDDP_FOR(i, NU) s.u[i] = u[NU * k + i];
+        wsync();
+        integrator_step<P, INTEG>(w, s.plant, s.integ, s.xn, s.x, s.u, dt);
+        PDDP_FOR(i, NX) { const T v = s.xn[i]; x0[NX * (k + 1) + i] = v; s.x[i] = v; }
+        wsync();
+    }
+    // ---- the last `shift` knots with feedback around the shifted previous trajectory (rolloutMPC2; only without FULL_ROLLOUT)
+    if (!full_rollout && dm.M > 1 && shift > 0) {
+        const int ks = N - 1 - shift;
+        PDDP_FOR(i, NX) s.x[i] = x0[NX * ks + i];
+        wsync();
+        for (int k = 0; k < shift; k++) {
+            const int kn = ks + k;
+            PDDP_FOR(i, NX) s.dx[i] = s.x[i] - x1[NX * kn + i];
+            wsync();
+            PDDP_FOR(r, NU) {
+                const T* KTk = KT + NX * NU * kn;
+                T Kdx = 0;
+                for (int c = 0; c < NX; c++) Kdx += KTk[c + r * NX] * s.dx[c];
+                const T uv = u[NU * kn + r] - Kdx;
+                s.u[r] = uv; u[NU * kn + r] = uv;
+            }
+            wsync();
+            integrator_step<P, INTEG>(w, s.plant, s.integ, s.xn, s.x, s.u, dt);
+            PDDP_FOR(i, NX) { const T v = s.xn[i]; x0[NX * (kn + 1) + i] = v; s.x[i] = v; }
+            wsync();
+        }
+    }
+}
+
+// after the loop: fall back to the shifted previous solution when the solve did not take a step
+template <typename P, typename T>
+PDDP_HD void mpc_store_body(const Wave& w, const Buffers<T>& b, const MpcBuffers<T>& mb, const Dims& dm, int pb) {
+    constexpr int NX = P::NX, NU = P::NU;
+    const int N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    if (st.took_step) return;
+    T* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX;
+    PDDP_FOR(e, N * NX) xc[e] = mb.x_old[(size_t)pb * N * NX + e];
+    PDDP_FOR(e, N * NU) b.ucur[(size_t)pb * N * NU + e] = mb.u_old[(size_t)pb * N * NU + e];
+    PDDP_FOR(e, N * NX * NU) b.KT[(size_t)pb * N * NX * NU + e] = mb.KT_old[(size_t)pb * N * NX * NU + e];
+}
+
+}  // namespace pddp

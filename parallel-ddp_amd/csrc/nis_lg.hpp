@@ -29,12 +29,6 @@ PDDP_HD void arm_lg_nis_body(const ArmLgConst<L>& c, const Buffers<T>& b, const 
     if (mode == 0) {
         if (st.accepted < 0) return;                           // backward pass failed: nothing moved
         const bool bnd = dm.M > 1 && dm.on_defect_boundary(k);
-        if (bnd) {                                             // Pp <- P, pp <- p at the slots the next backward pass reads
-            for (int t = 0; t < NX * NX / 7; t++)
-                L::scatter_at(b.Pp, knot * (NX * NX), [t](int l) { return l + 7 * t; }, L::gather_at(b.P, knot * (NX * NX), [t](int l) { return l + 7 * t; }), act);
-            for (int t = 0; t < 2; t++)
-                L::scatter_at(b.pp, knot * NX, [t](int l) { return l + 7 * t; }, L::gather_at(b.p, knot * NX, [t](int l) { return l + 7 * t; }), act);
-        }
         if (st.accepted != 1) return;                          // rejected: trajectory and derivatives are unchanged
         const unsigned wknot = ((unsigned)pb * dm.A + st.alphaIndex) * N + k;  // this knot in the winner's candidate slot
         q = L::gather_at(b.xs, wknot * NX, [](int l) { return l; }); qd = L::gather_at(b.xs, wknot * NX, [](int l) { return l + NP; });

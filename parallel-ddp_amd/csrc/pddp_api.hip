@@ -62,6 +62,8 @@ struct SolverBase {
     virtual int run_phase(int phase) = 0;
     virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
     virtual int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) = 0;
+    virtual int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
+                          int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) = 0;
     int bench_mode = 0;
     hipStream_t stream = nullptr;
 };
@@ -81,6 +83,8 @@ template <typename P, int INTEG, typename T>
 struct Solver : SolverBase {
     static constexpr int NX = P::NX, NU = P::NU, NM = NX + NU, NP = P::NPOS;
     Buffers<T> b{};
+    MpcBuffers<T> mb{};
+    T* d_xActual = nullptr; int* d_shift = nullptr;
     Dims dm{};
     SolverParams sp{};
     CostWeights<T> cw{};
@@ -132,12 +136,17 @@ struct Solver : SolverBase {
 #define AL(name, count) if ((rc = alloc(#name, &b.name, (count)))) return rc
         AL(xs, B * A * N * NX); AL(us, B * A * N * NU); AL(ds, B * A * N * NX);
         AL(xb, B * 2 * N * NX); AL(ucur, B * N * NU); AL(dcur, B * N * NX);
-        AL(P, B * N * NX * NX); AL(p, B * N * NX); AL(Pp, B * N * NX * NX); AL(pp, B * N * NX);
+        AL(P, 2 * B * N * NX * NX); AL(p, 2 * B * N * NX);     // double buffers: the second half is Pp / pp
         AL(AB, B * N * NX * NM); AL(H, B * N * NM * NM); AL(g, B * N * NM);
         AL(KT, B * N * NX * NU); AL(du, B * N * NU); AL(ApBK, B * N * NX * NX); AL(Bdu, B * N * NX);
         AL(J, B * A); AL(dmax, B * A); AL(dJexp, B * 2 * M); AL(alpha, A); AL(xGoal, B * NX);
         AL(Jout, B * (c.max_iter + 2)); AL(err, B * M); AL(alphaOut, B * (c.max_iter + 2)); AL(state, B);
 #undef AL
+        b.Pp = b.P + B * N * NX * NX; b.pp = b.p + B * N * NX;
+        arrays["P"].second /= 2; arrays["p"].second /= 2;
+        arrays["Pp"] = {b.Pp, arrays["P"].second}; arrays["pp"] = {b.pp, arrays["p"].second};
+        if ((rc = alloc("x_old", &mb.x_old, B * N * NX)) || (rc = alloc("u_old", &mb.u_old, B * N * NU)) || (rc = alloc("KT_old", &mb.KT_old, B * N * NX * NU))) return rc;
+        if ((rc = alloc("xActual", &d_xActual, B * NX)) || (rc = alloc("shift", &d_shift, B))) return rc;
         std::vector<T> al(A);
         for (size_t i = 0; i < A; i++) al[i] = (T)std::pow(c.alpha_base, (double)i);   // nisInitHelpers.cuh:829
         HIPCHK(hipMemcpy(b.alpha, al.data(), A * sizeof(T), hipMemcpyHostToDevice));
@@ -230,7 +239,7 @@ struct Solver : SolverBase {
     }
     int iterate(int sweeps) override {
         if (cfg.use_graph) {
-            if (!graph || graph_mode != bench_mode) {
+            if (!graph || graph_mode != bench_mode + 2 * sp.max_iter) {
                 if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
                 hipGraph_t gr;
                 HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -238,7 +247,7 @@ struct Solver : SolverBase {
                 HIPCHK(hipStreamEndCapture(stream, &gr));
                 HIPCHK(hipGraphInstantiate(&graph, gr, nullptr, nullptr, 0));
                 HIPCHK(hipGraphDestroy(gr));
-                graph_mode = bench_mode;
+                graph_mode = bench_mode + 2 * sp.max_iter;
             }
             for (int i = 0; i < sweeps; i++) HIPCHK(hipGraphLaunch(graph, stream));
         } else {
@@ -266,6 +275,43 @@ struct Solver : SolverBase {
         return 0;
     }
     int sync() override { HIPCHK(hipStreamSynchronize(stream)); return 0; }
+    // runiLQR_MPC_GPU (MPCHelpers.cuh:864-1045) for the batch
+    int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
+                  int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) override {
+        const size_t B = cfg.batch, N = cfg.N;
+        if (max_iter < 1 || max_iter > cfg.max_iter) return fail(PDDP_EINVAL, "mpc_solve: max_iter must be in [1, config.max_iter]");
+        for (size_t i = 0; i < B; i++) if (shift[i] < 0 || shift[i] >= (int)N - 1) return fail(PDDP_EINVAL, "mpc_solve: shift must be in [0, N-2]");
+        const double t0 = now_ms();
+        HIPCHK(hipMemcpyAsync(d_xActual, xActual, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(b.xGoal, xGoal, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(d_shift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+        const int saved_max_iter = sp.max_iter;
+        sp.max_iter = max_iter;                                  // acceptRejectTrajGPU(..., max_iter)
+        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ifd, 0);
+        launch_nis(stream, 1);
+        HIPCHK(hipGetLastError());
+        std::vector<int> done(B);
+        int rc = 0;
+        const int chunk = poll_every > 0 ? poll_every : 4;
+        for (int guard = 0; guard < 100000; guard++) {
+            if (budget_ms > 0 && now_ms() - t0 > budget_ms) break;   // time_budget (MPCHelpers.cuh:919,941,1001): checked between chunks of sweeps
+            if ((rc = iterate(chunk))) break;
+            if ((rc = status(done.data(), nullptr))) break;
+            bool all = true;
+            for (int v : done) all &= (v != 0);
+            if (all) break;
+        }
+        sp.max_iter = saved_max_iter;
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm);
+        HIPCHK(hipGetLastError());
+        if ((rc = store(x, u, KT, Jout, alphaOut, nullptr))) return rc;
+        std::vector<SolverState<T>> st(B);
+        HIPCHK(hipMemcpy(st.data(), b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < B; i++) { if (success) success[i] = st[i].took_step; if (iters) iters[i] = st[i].iter; }
+        return 0;
+    }
     int status(int* done, int* iters) override {
         std::vector<SolverState<T>> st(cfg.batch);
         HIPCHK(hipMemcpyAsync(st.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
@@ -325,7 +371,7 @@ struct Solver : SolverBase {
         for (int i = 0; i < cfg.batch; i++) {
             const auto& s = st[i]; pddp_state& o = out[i];
             o.rho = s.rho; o.drho = s.drho; o.prevJ = s.prevJ; o.dJ = s.dJ; o.z = s.z; o.iter = s.iter; o.alphaIndex = s.alphaIndex;
-            o.ignore_defect = s.ignore_defect; o.accepted = s.accepted; o.done = s.done; o.cur = s.cur; o.cur2 = s.cur2; o.bp_retries = s.bp_retries;
+            o.ignore_defect = s.ignore_defect; o.accepted = s.accepted; o.done = s.done; o.cur = s.cur; o.cur2 = s.cur2; o.bp_retries = s.bp_retries; o.pw = s.pw;
         }
         return 0;
     }
@@ -334,7 +380,7 @@ struct Solver : SolverBase {
         for (int i = 0; i < cfg.batch; i++) {
             auto& s = st[i]; const pddp_state& o = in[i];
             s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
-            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.pad = 0;
+            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw;
         }
         HIPCHK(hipMemcpy(b.state, st.data(), cfg.batch * sizeof(SolverState<T>), hipMemcpyHostToDevice));
         return 0;
@@ -453,6 +499,12 @@ extern "C" int pddp_hbm_calibration(int device, size_t bytes, int reps) {
     return 0;
 }
 
+extern "C" int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd,
+                              int max_iter, double time_budget_ms, int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) {
+    IMPL(h);
+    if (!xActual || !xGoal || !shift) return fail(PDDP_EINVAL, "pddp_mpc_solve: null argument");
+    return s->mpc_solve(xActual, xGoal, shift, clear_vars, full_rollout, ifd, max_iter, time_budget_ms, poll_every, x, u, KT, Jout, alphaOut, success, iters);
+}
 extern "C" int pddp_stream(pddp_handle h, void** hip_stream) { IMPL(h); if (!hip_stream) return fail(PDDP_EINVAL, "null argument"); *hip_stream = (void*)s->stream; return 0; }
 
 // runiLQR_GPU (DDPWrappers.cuh:10-138) for the batch.

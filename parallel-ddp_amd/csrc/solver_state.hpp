@@ -11,8 +11,9 @@
 //   xb[B][2][N][n]                                  current trajectory and the one the boundary cost-to-go was
 //                                                   computed at (reference d_xp / d_xp2), selected by state.cur/cur2
 //   ucur[B][N][m] dcur[B][N][n]                     current controls / defects (reference d_up / d_dp)
-//   P[B][N][n*n] p[B][N][n] Pp, pp                  cost-to-go (slot j = knot j+1) and its previous-iteration copy;
-//                                                   only the M-1 block-boundary slots of Pp/pp are ever read
+//   P[B][N][n*n] p[B][N][n] Pp, pp                  cost-to-go (slot j = knot j+1), double-buffered: the backward pass writes the half
+//                                                   state.pw and reads the block-boundary slots of the other one (the previous
+//                                                   iteration's, the reference's d_Pp / d_pp); "Pp <- P" is a flip of state.pw
 //   AB[B][N][n*(n+m)] H[B][N][(n+m)^2] g[B][N][n+m] derivatives;  KT[B][N][n*m] du[B][N][m]  gains
 //   ApBK[B][N][n*n] Bdu[B][N][n]                    sweep operands (M > 1)
 //   J[B][A] dmax[B][A] dJexp[B][2M] err[B][M]       line-search inputs
@@ -33,7 +34,8 @@ struct SolverState {
     int done;            // 0 running, 1 cost tolerance, 2 max_iter, 3 max rho
     int cur, cur2;       // which half of xb holds the current trajectory / the trajectory of the stored Pp,pp
     int bp_retries;
-    int pad;
+    int pw;              // which half of the cost-to-go double buffer (P = 0, Pp = 1) the next backward pass WRITES; it reads the other one
+    int took_step;       // MPC: an accepted iteration of this solve used a step-size index > 0 (MPCHelpers.cuh:986-991)
 };
 
 struct SolverParams {    // read-only per launch (reference macros, config.cuh)
@@ -106,11 +108,12 @@ PDDP_HD void line_search_accept(SolverState<T>& st, const SolverParams& sp, cons
         rho_decrease(st);
         dJ = dJ / st.prevJ; st.prevJ = J[aidx];
         st.alphaIndex = aidx; alphaOut[st.iter] = aidx; Jout[st.iter] = J[aidx];
+        if (aidx > 0) st.took_step = 1;
         st.accepted = 1; st.dJ = dJ;
         st.cur = 1 - st.cur;                            // the winner is copied into the other half of xb by the NIS launch
         if (dJ < T(sp.tol_cost)) { st.done = 1; return; }
     }
-    if (st.iter == sp.max_iter) st.done = 2; else st.iter += 1;
+    if (st.iter == sp.max_iter) st.done = 2; else { st.iter += 1; st.pw ^= 1; }   // Pp <- P, pp <- p of nextIterationSetupGPU (:266-267), by index
 }
 
 }  // namespace pddp

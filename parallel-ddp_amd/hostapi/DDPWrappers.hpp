@@ -14,6 +14,8 @@
 // or an MPC shift): d_P d_p d_Pp d_pp d_AB d_H d_g d_KT d_du d_ApBK d_Bdu d_JT d_dJexp d_err d_alpha d_xGoal d_up d_dp
 // and the per-alpha tables d_x/h_d_x, d_u/h_d_u, d_d/h_d_d.  Differences, all consequences of copies the reference makes
 // and this design does not:
+//   * d_P / d_Pp (d_p / d_pp) are the two halves of the cost-to-go double buffer: "Pp <- P" is a flip of an index
+//     (pddp_state.pw), so after a solve the last cost-to-go is in d_P or in d_Pp (pddp_get_state tells which);
 //   * d_xp / d_xp2 are the two halves of one double buffer whose roles (current trajectory / trajectory the stored
 //     boundary cost-to-go belongs to) alternate with every accepted iteration instead of being copied;
 //   * the per-alpha slots are pure outputs of the forward pass: after a solve h_d_x[*alphaIndex] holds the winner, the

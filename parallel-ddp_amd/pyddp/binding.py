@@ -27,7 +27,7 @@ class PddpConfig(C.Structure):
 class PddpState(C.Structure):
     _fields_ = [("rho", C.c_double), ("drho", C.c_double), ("prevJ", C.c_double), ("dJ", C.c_double), ("z", C.c_double),
                 ("iter", C.c_int), ("alphaIndex", C.c_int), ("ignore_defect", C.c_int), ("accepted", C.c_int),
-                ("done", C.c_int), ("cur", C.c_int), ("cur2", C.c_int), ("bp_retries", C.c_int)]
+                ("done", C.c_int), ("cur", C.c_int), ("cur2", C.c_int), ("bp_retries", C.c_int), ("pw", C.c_int)]
 
 
 class DeviceArray:
@@ -161,6 +161,21 @@ class Solver:
         out["done"], out["iters"], out["sweeps"] = done, iters, sweeps
         return out
 
+    def mpc_solve(self, xActual, xGoal, shift, clear_vars=0, full_rollout=1, ignore_first_defect=1, max_iter=None, time_budget_ms=0.0, poll_every=4):
+        """runiLQR_MPC_GPU (pddp_mpc_solve): warm start from the handle's previous solution shifted by `shift` knots and rolled out
+        from the measured state, iterate, fall back to the shifted previous solution when no step was taken."""
+        B, N, n, m, mi = self.cfg.batch, self.cfg.N, self.n, self.m, self.cfg.max_iter
+        xActual, xGoal = self.arr(xActual), self.arr(xGoal)
+        shift = np.ascontiguousarray(np.broadcast_to(np.asarray(shift, np.int32), (B,)))
+        out = dict(x=np.zeros((B, N, n), self.dtype), u=np.zeros((B, N, m), self.dtype), KT=np.zeros((B, N, m, n), self.dtype),
+                   Jout=np.zeros((B, mi + 2), self.dtype), alphaOut=np.zeros((B, mi + 2), np.int32), success=np.zeros(B, np.int32), iters=np.zeros(B, np.int32))
+        self.lib.pddp_mpc_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.pddp_mpc_solve(self.h, _p(xActual), _p(xGoal), _p(shift), int(clear_vars), int(full_rollout), int(ignore_first_defect),
+                                          int(max_iter if max_iter is not None else mi), float(time_budget_ms), int(poll_every),
+                                          _p(out["x"]), _p(out["u"]), _p(out["KT"]), _p(out["Jout"]), _p(out["alphaOut"]), _p(out["success"]), _p(out["iters"])))
+        return out
+
     def solve_timed(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1):
         """pddp_solve: the whole runiLQR_GPU call in C (load, init, sweeps until every problem exits, store), with the
         reference's two timers: ms_total (*tTime) and ms_init (*initTime); ms_loop = their difference."""
@@ -209,6 +224,14 @@ class Solver:
         ptr, nb = C.c_void_p(), C.c_size_t(0)
         self._chk(self.lib.pddp_array_ptr(self.h, name.encode(), C.byref(ptr), C.byref(nb)))
         return DeviceArray(ptr.value, nb.value // np.dtype(self._adtype(name)).itemsize, np.dtype(self._adtype(name)))
+
+    def get_cost_to_go(self):
+        """(P, p) the last backward pass wrote and (Pp, pp) the one before: the double buffer's halves in their current roles."""
+        pw = [st.pw for st in self.get_state()]
+        B = self.cfg.batch
+        P, Pp, p, pp = (self.get(k).reshape(B, -1) for k in ("P", "Pp", "p", "pp"))
+        w = np.asarray(pw)[:, None].astype(bool)
+        return np.where(w, Pp, P), np.where(w, pp, p), np.where(w, P, Pp), np.where(w, p, pp)
 
     def get_state(self):
         st = (PddpState * self.cfg.batch)()

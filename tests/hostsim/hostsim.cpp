@@ -16,6 +16,7 @@
 #include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/nis_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/bp_lg.hpp"
+#include "../../parallel-ddp_amd/csrc/mpc.hpp"
 #include "../../parallel-ddp_amd/csrc/iiwa14_model_data.h"
 
 using namespace pddp;
@@ -48,6 +49,7 @@ struct Base {
     virtual int set_state(const pddp_state*) = 0;
     virtual int run_phase(int) = 0;
     virtual int plant_eval(int, int, const void*, const void*, void*) = 0;
+    virtual int mpc_solve(const void*, const void*, const int*, int, int, int, int, void*, void*, void*, void*, int*, int*, int*) = 0;
 };
 struct pddp_solver { Base* impl; };
 
@@ -62,7 +64,7 @@ static void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
 template <typename P, int INTEG, typename T>
 struct Sim : Base {
     static constexpr int NX = P::NX, NU = P::NU, NM = NX + NU, NP = P::NPOS;
-    Buffers<T> b{}; Dims dm{}; SolverParams sp{}; CostWeights<T> cw{}; T dt{};
+    Buffers<T> b{}; MpcBuffers<T> mb{}; Dims dm{}; SolverParams sp{}; CostWeights<T> cw{}; T dt{};
     typename P::Model model;
     std::map<std::string, std::pair<void*, size_t>> arrays;
     std::vector<void*> allocs;
@@ -81,12 +83,16 @@ struct Sim : Base {
 #define AL(name, count) al(#name, &b.name, (count))
         AL(xs, B * A * N * NX); AL(us, B * A * N * NU); AL(ds, B * A * N * NX);
         AL(xb, B * 2 * N * NX); AL(ucur, B * N * NU); AL(dcur, B * N * NX);
-        AL(P, B * N * NX * NX); AL(p, B * N * NX); AL(Pp, B * N * NX * NX); AL(pp, B * N * NX);
+        AL(P, 2 * B * N * NX * NX); AL(p, 2 * B * N * NX);
         AL(AB, B * N * NX * NM); AL(H, B * N * NM * NM); AL(g, B * N * NM);
         AL(KT, B * N * NX * NU); AL(du, B * N * NU); AL(ApBK, B * N * NX * NX); AL(Bdu, B * N * NX);
         AL(J, B * A); AL(dmax, B * A); AL(dJexp, B * 2 * M); AL(alpha, A); AL(xGoal, B * NX);
         AL(Jout, B * (c.max_iter + 2)); AL(err, B * M); AL(alphaOut, B * (c.max_iter + 2)); AL(state, B);
 #undef AL
+        b.Pp = b.P + B * N * NX * NX; b.pp = b.p + B * N * NX;
+        arrays["P"].second /= 2; arrays["p"].second /= 2;
+        arrays["Pp"] = {b.Pp, arrays["P"].second}; arrays["pp"] = {b.pp, arrays["p"].second};
+        al("x_old", &mb.x_old, B * N * NX); al("u_old", &mb.u_old, B * N * NU); al("KT_old", &mb.KT_old, B * N * NX * NU);
         for (size_t i = 0; i < A; i++) b.alpha[i] = (T)std::pow(c.alpha_base, (double)i);
         fill_model(model, c); b.model = &model;
     }
@@ -182,6 +188,29 @@ struct Sim : Base {
         phase(PDDP_PHASE_INIT_NIS);
         return 0;
     }
+    int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter,
+                  void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) override {
+        const size_t B = cfg.batch; const Wave w = this_wave();
+        if (max_iter < 1 || max_iter > cfg.max_iter) return fail(PDDP_EINVAL, "mpc_solve: max_iter must be in [1, config.max_iter]");
+        std::memcpy(b.xGoal, xGoal, B * NX * sizeof(T));
+        static MpcScratch<P, T> ms; std::vector<T> cost_k(cfg.N);
+        const int saved = sp.max_iter; sp.max_iter = max_iter;
+        for (size_t pb = 0; pb < B; pb++) {
+            mpc_load_body<P, INTEG, T>(w, ms, b, mb, dm, dt, (int)pb, (const T*)xActual + pb * NX, shift[pb], clear_vars, full_rollout);
+            init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 0, (int)pb);
+        }
+        phase(PDDP_PHASE_INIT_NIS);
+        for (int guard = 0; guard < 100000; guard++) {
+            iterate(1);
+            bool all = true; for (size_t pb = 0; pb < B; pb++) all &= (b.state[pb].done != 0);
+            if (all) break;
+        }
+        sp.max_iter = saved;
+        for (size_t pb = 0; pb < B; pb++) mpc_store_body<P, T>(w, b, mb, dm, (int)pb);
+        store(x, u, KT, Jout, alphaOut, nullptr);
+        for (size_t pb = 0; pb < B; pb++) { if (success) success[pb] = b.state[pb].took_step; if (iters) iters[pb] = b.state[pb].iter; }
+        return 0;
+    }
     int iterate(int sweeps) override { for (int i = 0; i < sweeps; i++) for (int ph = 0; ph < 4; ph++) phase(ph); return 0; }
     int status(int* done, int* iters) override {
         for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = b.state[i].done; if (iters) iters[i] = b.state[i].iter; }
@@ -208,7 +237,7 @@ struct Sim : Base {
         for (int i = 0; i < cfg.batch; i++) {
             const auto& s = b.state[i]; pddp_state& o = out[i];
             o.rho = s.rho; o.drho = s.drho; o.prevJ = s.prevJ; o.dJ = s.dJ; o.z = s.z; o.iter = s.iter; o.alphaIndex = s.alphaIndex;
-            o.ignore_defect = s.ignore_defect; o.accepted = s.accepted; o.done = s.done; o.cur = s.cur; o.cur2 = s.cur2; o.bp_retries = s.bp_retries;
+            o.ignore_defect = s.ignore_defect; o.accepted = s.accepted; o.done = s.done; o.cur = s.cur; o.cur2 = s.cur2; o.bp_retries = s.bp_retries; o.pw = s.pw;
         }
         return 0;
     }
@@ -216,7 +245,7 @@ struct Sim : Base {
         for (int i = 0; i < cfg.batch; i++) {
             auto& s = b.state[i]; const pddp_state& o = in[i];
             s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
-            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.pad = 0;
+            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw;
         }
         return 0;
     }
@@ -327,5 +356,9 @@ extern "C" int pddp_solve_ex(pddp_handle h, void* x0, void* u0, const void* xGoa
 }
 extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
     return pddp_solve_ex(h, x0, u0, xGoal, nullptr, nullptr, nullptr, nullptr, Jout, alphaOut, 0, clear, ifd, 1, times_ms, nullptr, nullptr);
+}
+extern "C" int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd,
+                              int max_iter, double, int, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) {
+    return h->impl->mpc_solve(xActual, xGoal, shift, clear_vars, full_rollout, ifd, max_iter, x, u, KT, Jout, alphaOut, success, iters);
 }
 extern "C" int pddp_stream(pddp_handle, void** st) { if (st) *st = nullptr; return 0; }

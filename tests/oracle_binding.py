@@ -187,6 +187,44 @@ class Oracle:
         return self._run("run_ilqr_gpusem", x0, u0, xGoal, **kw)
 
 
+class OracleMpc:
+    """Persistent GPU-semantics solver state of the oracle for the MPC wrapper (ora_gs_*)."""
+
+    def __init__(self, cfg, dtype=np.float64):
+        self.c, self.dtype, self.suf = cfg, np.dtype(dtype), _suf(dtype)
+        self.npos, self.n, self.m = PLANT_DIMS[cfg.plant]
+        f = getattr(lib(), f"ora_gs_create_{self.suf}"); f.restype = C.c_void_p
+        self.h = C.c_void_p(f(C.byref(cfg)))
+
+    def _f(self, name):
+        return getattr(lib(), f"ora_gs_{name}_{self.suf}")
+
+    def set_traj(self, x, u):
+        x, u = np.ascontiguousarray(x, self.dtype), np.ascontiguousarray(u, self.dtype)
+        self._f("set_traj")(self.h, _p(x), _p(u))
+
+    def get_traj(self):
+        N = self.c.N
+        x, u, KT, d = (np.zeros(N * self.n, self.dtype), np.zeros(N * self.m, self.dtype), np.zeros(N * self.n * self.m, self.dtype), np.zeros(N * self.n, self.dtype))
+        self._f("get_traj")(self.h, _p(x), _p(u), _p(KT), _p(d))
+        return x, u, KT, d
+
+    def mpc_solve(self, xActual, xGoal, shift, clear_vars=0, full_rollout=1, ignore_first_defect=1, max_iter=None):
+        xActual, xGoal = np.ascontiguousarray(xActual, self.dtype), np.ascontiguousarray(xGoal, self.dtype)
+        mi = self.c.max_iter
+        Jout, aout, succ = np.zeros(mi + 2, self.dtype), np.full(mi + 2, -99, np.int32), C.c_int(0)
+        it = self._f("mpc_solve")(self.h, _p(xActual), _p(xGoal), int(shift), int(clear_vars), int(full_rollout), int(ignore_first_defect),
+                                  int(max_iter if max_iter is not None else mi), _p(Jout), _p(aout), C.byref(succ))
+        x, u, KT, d = self.get_traj()
+        return dict(iters=it, Jout=Jout, alphaOut=aout, success=succ.value, x=x, u=u, KT=KT, d=d)
+
+    def __del__(self):
+        try:
+            self._f("destroy")(self.h)
+        except Exception:
+            pass
+
+
 # ---- the reference example's inputs (examples/WAFR_iLQR_examples.cu:69-121), noise supplied by the caller
 def example_inputs(plant, N, dtype=np.float32, noise=None, wafr_urdf=1):
     npos, n, m = PLANT_DIMS[plant]

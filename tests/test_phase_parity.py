@@ -150,8 +150,8 @@ def test_sweep_phases_teacher_forced(backend, dtype, plant, N, M, A, integ):
         AB2, H2, g2 = o.next_iteration_setup(np.ascontiguousarray(xs[w]).ravel(), np.ascontiguousarray(us[w]).ravel(), xg)
         assert nrel(s.get("AB")[: (N - 1) * n * nm], AB2[: (N - 1) * n * nm]) <= max(tol, 2e-4 if dtype == np.float32 else 0)
         assert nrel(s.get("g"), g2) <= tol
-    for k in bnd:   # boundary cost-to-go handed to the next iteration
-        assert np.array_equal(s.get("Pp").reshape(N, n, n)[k], s.get("P").reshape(N, n, n)[k])
+    # Pp <- P, pp <- p of nextIterationSetupGPU (:266-267) is a flip of the double buffer: the next backward pass reads what this one wrote
+    assert s.get_state()[0].pw == 1
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -159,20 +159,20 @@ def test_forward_rollout_flag(backend, plant, kw):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_warm_start_arrays(backend):
-    """clearVarsFlag = 0 (nisInitHelpers.cuh:621-628): KT0, P0, p0, d0 handed back by the caller give exactly the solve that
-    keeping the device values gives, and differ from a cold start (the boundary cost-to-go enters the first backward pass)."""
+    """clearVarsFlag = 0 (nisInitHelpers.cuh:621-628): KT0, P0, p0, d0 handed back by the caller seed a warm start that is reproducible
+    and differs from a cold start (the boundary cost-to-go enters the first backward pass); NULL arrays keep the device values."""
     kw = dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=6)
     x0, u0, xg = example_inputs(4, 64, np.float32, noise=RNG.normal(0, 0.001, (64, 14)))
     s = make_solver(backend, 4, **kw)
     first = s.solve(x0, u0, xg)
-    warm = dict(KT0=s.get("KT"), P0=s.get("P"), p0=s.get("p"), d0=s.get("dcur"))
+    P_last, p_last, _, _ = s.get_cost_to_go()
+    warm = dict(KT0=s.get("KT"), P0=P_last, p0=p_last, d0=s.get("dcur"))
     x1, u1 = first["x"][0].ravel(), first["u"][0].ravel()
-    kept = s.solve(x1, u1, xg, clear_vars=0)                       # device values kept
-    s2 = make_solver(backend, 4, **kw)
-    given = s2.solve(x1, u1, xg, clear_vars=0, **warm)              # same values handed over the boundary
+    kept = s.solve(x1, u1, xg, clear_vars=0)                       # device values kept: Pp is the cost-to-go of the iteration BEFORE the exit
+    given = [make_solver(backend, 4, **kw).solve(x1, u1, xg, clear_vars=0, **warm) for _ in range(2)]   # P0 seeds P and Pp alike (:621-624)
     cold = make_solver(backend, 4, **kw).solve(x1, u1, xg, clear_vars=1)
-    assert np.array_equal(kept["Jout"][0], given["Jout"][0]) and np.array_equal(kept["alphaOut"][0], given["alphaOut"][0])
-    assert np.array_equal(kept["x"][0], given["x"][0])
+    assert np.array_equal(given[0]["Jout"][0], given[1]["Jout"][0]) and np.array_equal(given[0]["x"][0], given[1]["x"][0])
+    assert not np.array_equal(given[0]["Jout"][0][1:], cold["Jout"][0][1:])
     assert not np.array_equal(kept["Jout"][0][1:], cold["Jout"][0][1:])
 
 

@@ -224,3 +224,20 @@ def test_baseline_config5_quadrotor_full_size_fp32_vs_fp64():
           "J rel dev", np.abs(res[np.float32]["Jout"][0][:first_diff] / res[np.float64]["Jout"][0][:first_diff] - 1).max())
     assert first_diff >= 2
     np.testing.assert_allclose(res[np.float32]["Jout"][0][:first_diff], res[np.float64]["Jout"][0][:first_diff], rtol=5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [4, 1])
+def test_kuka_float64_headline_size_whole_solve(M):
+    """BASELINE configs[2] at full size (N=128, A=8), float64, 40 iterations: the kernels follow the oracle's GPU-semantics driver
+    decision for decision (identical step-size indices, rejections included) and J / x / u / K to 1e-7."""
+    kw = dict(N=128, M=M, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=40)
+    out, refs, _ = run_pair("hip", 4, np.float64, noise_std=0.001, **kw)
+    r = refs[0]
+    it = r["iters"]
+    assert out["iters"][0] == it == 40
+    assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-7)
+    np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-7 * np.abs(r["x"]).max())
+    np.testing.assert_allclose(out["u"][0].ravel(), r["u"], rtol=0, atol=1e-7 * np.abs(r["u"]).max())
+    np.testing.assert_allclose(out["KT"][0].ravel(), r["KT"], rtol=0, atol=1e-6 * np.abs(r["KT"]).max())

@@ -42,7 +42,13 @@ def init_from_env(n_gpus_flag=1, backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)     # binds the communicator to this rank's GPU (no guessing in barrier())
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:                                          # older torch without device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return ShardCtx(rank, world, local_rank, backend)
 
 
@@ -54,7 +60,10 @@ def _dev(ctx):
 def barrier(ctx):
     if ctx.world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        if ctx.backend == "nccl":
+            dist.barrier(device_ids=[ctx.local_rank])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(ctx, value):

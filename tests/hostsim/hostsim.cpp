@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/pddp.h"
+#include "lanegroup_host.hpp"
 #include "../../parallel-ddp_amd/csrc/bodies.hpp"
 #include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/nis_lg.hpp"

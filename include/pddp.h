@@ -113,6 +113,11 @@ int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGo
 int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout,
                    int ignore_first_defect, int max_iter, double time_budget_ms, int poll_every, void* x, void* u, void* KT, void* Jout,
                    int* alphaOut, int* success, int* iters);
+/* New joint-space cost weights for the following loads / solves (the reference passes Q1, Q2, R, QF1, QF2 on every call,
+ * DDPWrappers.cuh:17-21, MPCHelpers.cuh:862-866 through costParams).  Takes effect at the next pddp_load / pddp_solve / pddp_mpc_solve:
+ * the cost gradient and Hessian of the current trajectory are rebuilt there.  Arm plant only (the other plants' weights are
+ * constants of plants/cost_{pend,cart,quad}.cuh). */
+int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2);
 /* The HIP stream every kernel of this handle is enqueued on (a hipStream_t). */
 int pddp_stream(pddp_handle h, void** hip_stream);
 

@@ -62,6 +62,7 @@ struct SolverBase {
     virtual int run_phase(int phase) = 0;
     virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
     virtual int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) = 0;
+    virtual int set_cost(double Q1, double Q2, double R, double QF1, double QF2) = 0;
     virtual int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
                           int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) = 0;
     int bench_mode = 0;
@@ -276,6 +277,13 @@ struct Solver : SolverBase {
     }
     int sync() override { HIPCHK(hipStreamSynchronize(stream)); return 0; }
     // runiLQR_MPC_GPU (MPCHelpers.cuh:864-1045) for the batch
+    int set_cost(double Q1, double Q2, double R, double QF1, double QF2) override {
+        HIPCHK(hipStreamSynchronize(stream));
+        cfg.Q1 = Q1; cfg.Q2 = Q2; cfg.R = R; cfg.QF1 = QF1; cfg.QF2 = QF2;
+        cw.Q1 = (T)Q1; cw.Q2 = (T)Q2; cw.R = (T)R; cw.QF1 = (T)QF1; cw.QF2 = (T)QF2;
+        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; }   // the weights are kernel arguments baked into the captured sweep
+        return 0;
+    }
     int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
                   int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) override {
         const size_t B = cfg.batch, N = cfg.N;
@@ -468,6 +476,7 @@ extern "C" int pddp_sync(pddp_handle h) { IMPL(h); return s->sync(); }
 extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); return s->status(done, iters); }
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { IMPL(h); return s->store(x, u, KT, Jout, alphaOut, dmax); }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
+extern "C" int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2) { IMPL(h); return s->set_cost(Q1, Q2, R, QF1, QF2); }
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { IMPL(h); s->bench_mode = on ? 1 : 0; return 0; }
 extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { IMPL(h); void* p; return s->array(name, &p, bytes); }
 extern "C" int pddp_array_ptr(pddp_handle h, const char* name, void** ptr, size_t* bytes) { IMPL(h); if (!ptr || !bytes) return fail(PDDP_EINVAL, "null argument"); return s->array(name, ptr, bytes); }

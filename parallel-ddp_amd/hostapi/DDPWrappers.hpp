@@ -86,7 +86,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     c.dtype = std::is_same<T, double>::value ? 1 : 0;
     c.N = NUM_TIME_STEPS; c.M = M_BLOCKS; c.A = NUM_ALPHA; c.integrator = INTEGRATOR; c.batch = 1; c.max_iter = MAX_ITER;
     c.wafr_urdf = USE_WAFR_URDF; c.mpc_mode = MPC_MODE; c.ignore_max_rho_exit = IGNORE_MAX_ROX_EXIT; c.device = PDDP_DEVICE;
-    c.use_graph = PDDP_PHASE_TIMERS ? 0 : 1;
+    c.use_graph = 1;   // sweeps replay from a hipGraph; with PDDP_PHASE_TIMERS runiLQR_GPU asks pddp_solve_ex for per-phase times, which launches kernel by kernel
     c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
     c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX;
     c.Q1 = _Q1; c.Q2 = _Q2; c.R = _R; c.QF1 = _QF1; c.QF2 = _QF2;

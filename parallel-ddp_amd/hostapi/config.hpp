@@ -201,5 +201,8 @@ typedef float algType;                //                                        
 typedef struct ihipStream_t* pddpStream_t;
 
 #include "DDPWrappers.hpp"
+#if MPC_MODE
+#include "MPCHelpers.hpp"             // config.cuh:264-270 includes MPCHelpers.cuh instead of DDPWrappers.cuh in MPC_MODE; here it adds to it
+#endif
 
 #endif

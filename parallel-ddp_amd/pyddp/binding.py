@@ -189,6 +189,11 @@ class Solver:
                     iters=int(iters[0]) if B == 1 else iters, ms_total=times[0], ms_init=times[1], ms_loop=times[0] - times[1],
                     J_final=float(Jout[0][iters[0]]))
 
+    def set_cost(self, Q1, Q2, R, QF1, QF2):
+        """pddp_set_cost: joint-space cost weights for the following loads / solves."""
+        self.lib.pddp_set_cost.argtypes = [C.c_void_p] + [C.c_double] * 5
+        self._chk(self.lib.pddp_set_cost(self.h, Q1, Q2, R, QF1, QF2))
+
     # ---- measurement
     def set_benchmark_mode(self, on):
         self._chk(self.lib.pddp_set_benchmark_mode(self.h, int(on)))

@@ -71,6 +71,53 @@ def test_reference_example_shape_through_the_facade():
     assert phases and all(float(v) > 0 for v in phases.groups())
 
 
+def test_mpc_facade_compiles_with_plain_gxx_and_fails_loudly_without_gpu():
+    build_examples()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    r = subprocess.run([os.path.join(PKG, "examples", "MPC_examples"), "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_mpc_lockstep_loop_through_the_struct_facade():
+    """testMPC_lockstep's shape (examples/WAFR_MPC_examples.cu:160-238) against hostapi/MPCHelpers.hpp: warm start, then
+    receding-horizon cycles of one knot with a 10-iteration cap; the bookkeeping of storeVarsGPU_MPC (MPCHelpers.cuh:755-774)
+    shows in last_successful_solve (1 after a successful solve, counting up otherwise)."""
+    build_examples()
+    r = subprocess.run([os.path.join(PKG, "examples", "MPC_examples"), "12", "10", "1000", "1.0", "0.001"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    warm = re.search(r"warm start: (\d+) iterations, J ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert warm and int(warm.group(1)) >= 5 and float(warm.group(3)) < 0.2 * float(warm.group(2))
+    cyc = [(int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(5)))
+           for m in re.finditer(r"cycle\s+\d+\s+shift (\d+)\s+iterations\s+(\d+)\s+J ([0-9.]+) -> ([0-9.]+)\s+last_successful_solve (\d+)", r.stdout)]
+    assert len(cyc) == 12
+    assert all(c[0] == 1 and 1 <= c[1] <= 10 and c[3] <= c[2] * (1 + 1e-6) for c in cyc)
+    assert sum(c[4] == 1 for c in cyc) >= 6                 # most cycles take a step
+    streak = 0
+    for c in cyc:                                           # the failure counter counts up by one per unsuccessful solve
+        streak = 1 if c[4] == 1 else streak + 1
+        assert c[4] == streak or c[4] == 1
+    # every cycle re-converges from the open-loop rollout of the shifted controls to the neighbourhood of the warm-start optimum
+    assert all(c[3] < 1.5 * float(warm.group(3)) for c in cyc)
+
+
+@pytest.mark.gpu
+def test_set_cost_equals_creating_with_those_weights():
+    x0, u0, xg = example_inputs(4, 32, np.float32)
+    kw = dict(N=32, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=15)
+    a = pyddp.Solver(pyddp.default_config(4, Q1=0.3, Q2=0.002, R=0.0005, QF1=500.0, QF2=200.0, **kw))
+    ra = a.solve(x0, u0, xg)
+    b = pyddp.Solver(pyddp.default_config(4, **kw))
+    rb0 = b.solve(x0, u0, xg)
+    b.set_cost(0.3, 0.002, 0.0005, 500.0, 200.0)
+    rb = b.solve(x0, u0, xg)
+    assert not np.array_equal(rb0["Jout"], rb["Jout"])
+    for k in ("Jout", "alphaOut", "x", "u"):
+        assert np.array_equal(ra[k], rb[k]), k
+
+
 @pytest.mark.parametrize("kw,msg", [
     (dict(N=100), "power of two"),
     (dict(N=128, M=3), "M must divide N"),

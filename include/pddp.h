@@ -51,6 +51,13 @@ typedef struct pddp_config {
     double tol_cost;      /* TOL_COST                                                        config.cuh:85-87   */
     double exp_red_min, exp_red_max;   /* EXP_RED_MIN / EXP_RED_MAX                          config.cuh:117-122 */
     double Q1, Q2, R, QF1, QF2;        /* _Q1 _Q2 _R _QF1 _QF2 (arm joint cost)   plants/cost_arm.cuh:97-103   */
+    /* End-effector cost family of the arm (plant 4; plants/cost_arm.cuh:104-115, 206-389), in the configuration of
+     * examples/WAFR_MPC_examples.cu:4-37 (USE_EE_VEL_COST 0, USE_SMOOTH_ABS 0, USE_LIMITS_FLAG 0). */
+    int ee_cost;          /* EE_COST: xGoal[b][0..5] = tool-point goal (x, y, z, roll, pitch, yaw)   config.cuh:165-167 */
+    int ee_cost_shift;    /* use_cost_shift of runiLQR_MPC_GPU: final EE weights from knot N-1-shift[b] on  MPCHelpers.cuh:866,876 */
+    double Q_EE1, Q_EE2, QF_EE1, QF_EE2;   /* _Q_EE1 (xyz) _Q_EE2 (rpy) and the final ones                                   */
+    double R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE;   /* control weight; nominal-state weights on q and qd (target: array "xTarget") */
+    double ee_on_link_z;  /* EE_ON_LINK_Z: tool point on the last link's z axis (0.0635 = EE_TYPE 1, flange)   dynamics_arm.cuh:48-65 */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */
@@ -113,6 +120,10 @@ int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGo
 int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout,
                    int ignore_first_defect, int max_iter, double time_budget_ms, int poll_every, void* x, void* u, void* KT, void* Jout,
                    int* alphaOut, int* success, int* iters);
+/* End-effector cost weights for the following loads / solves (costParams of runiLQR_MPC_GPU, MPCHelpers.cuh:118-135); requires a
+ * handle created with ee_cost = 1. */
+int pddp_set_cost_ee(pddp_handle h, double Q_EE1, double Q_EE2, double QF_EE1, double QF_EE2, double R_EE, double Q_xEE, double QF_xEE,
+                     double Q_xdEE, double QF_xdEE);
 /* New joint-space cost weights for the following loads / solves (the reference passes Q1, Q2, R, QF1, QF2 on every call,
  * DDPWrappers.cuh:17-21, MPCHelpers.cuh:862-866 through costParams).  Takes effect at the next pddp_load / pddp_solve / pddp_mpc_solve:
  * the cost gradient and Hessian of the current trajectory are rebuilt there.  Arm plant only (the other plants' weights are
@@ -135,8 +146,8 @@ int pddp_set_benchmark_mode(pddp_handle h, int on);
 int pddp_hbm_calibration(int device, size_t bytes, int reps);
 
 /* ---- teacher-forced phase hooks (tests) ------------------------------------------------------------- */
-/* Named device arrays: xs us ds xb ucur dcur P p Pp pp AB H g KT du ApBK Bdu J dmax dJexp alpha xGoal Jout
- * (element type = dtype), err alphaOut (int), state (see pddp_state below). */
+/* Named device arrays: xs us ds xb ucur dcur P p Pp pp AB H g KT du ApBK Bdu J dmax dJexp alpha xGoal xTarget costk Jout
+ * (element type = dtype), err alphaOut tshift (int), state (see pddp_state below). */
 int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes);
 int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes);
 int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes);

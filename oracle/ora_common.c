@@ -24,4 +24,7 @@ void ora_default_cfg(ora_cfg *c, int plant) {
     c->tol_cost = 0.0001;
     c->exp_red_min = 0.05; c->exp_red_max = 1.25;
     c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
+    /* plants/cost_arm.cuh:104-115; EE_TYPE 1 (dynamics_arm.cuh:57-58) */
+    c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
+    c->ee_on_link_z = 0.0635;
 }

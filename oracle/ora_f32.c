@@ -4,4 +4,6 @@ typedef float real;
 #define RSIN sinf
 #define RCOS cosf
 #define RABS fabsf
+#define RATAN2 atan2f
+#define RSQRT sqrtf
 #include "ora_impl.h"

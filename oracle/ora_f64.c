@@ -4,4 +4,6 @@ typedef double real;
 #define RSIN sin
 #define RCOS cos
 #define RABS fabs
+#define RATAN2 atan2
+#define RSQRT sqrt
 #include "ora_impl.h"

@@ -45,6 +45,14 @@ typedef struct ora_cfg {
     double tol_cost;    /* TOL_COST                                                  config.cuh:85-87   */
     double exp_red_min, exp_red_max;    /*                                           config.cuh:117-122 */
     double Q1, Q2, R, QF1, QF2;         /* arm joint-space cost weights  plants/cost_arm.cuh:97-103     */
+    /* end-effector cost family (EE_COST 1 with USE_EE_VEL_COST 0, USE_SMOOTH_ABS 0, USE_LIMITS_FLAG 0; plants/cost_arm.cuh:104-115,206-389).
+     * PARITY UNPINNED: the survey recorded no reference outputs for this family and the reference cannot be built here; the restatement
+     * follows the reference's index expressions and is cross-checked analytically (tests/test_ee_cost.py), nothing more. */
+    int ee_cost;        /* EE_COST: xGoal = (x, y, z, roll, pitch, yaw) of the tool point          config.cuh:165-167 */
+    int ee_cost_shift;  /* use_cost_shift of runiLQR_MPC_GPU (finalCostShift = shift)              MPCHelpers.cuh:866,876 */
+    double Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE;
+    double ee_on_link_z;                /* EE_ON_LINK_Z (EE_TYPE 1: 0.0635)                         dynamics_arm.cuh:48-65 */
+    double xTarget[14];                 /* nominal-state target (d_xTarget); zeros = the reference's xTarget == nullptr case */
 } ora_cfg;
 
 /* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */
@@ -88,6 +96,10 @@ typedef struct ora_result {
     int ora_run_ilqr_gpusem_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,        \
                                   int *alphaOut, int rollout, int ignoreFirstDefect, REAL *KT_out,            \
                                   ora_result *res);                                                           \
+    /* end-effector kinematics and cost (arm, ee_cost = 1): eePos[6], deePos[7][6] (NULL to skip); cost of one knot; H_k, g_k */        \
+    void ora_ee_pos_##SUF(const ora_cfg *c, const REAL *x, REAL *eePos, REAL *deePos);                        \
+    REAL ora_ee_cost_##SUF(const ora_cfg *c, const REAL *xk, const REAL *uk, const REAL *goal, int k, int tshift); \
+    void ora_ee_cost_grad_##SUF(const ora_cfg *c, REAL *Hk, REAL *gk, const REAL *xk, const REAL *uk, const REAL *goal, int k, int tshift); \
     /* MPC wrapper, GPU semantics (DDPHelpers/MPCHelpers.cuh:602-655 load, :864-1016 loop, :755-774 store): a    */ \
     /* persistent state is seeded with a trajectory, then every solve shifts it by `shift` knots, rolls it out  */ \
     /* from the measured state and iterates; returns `iter`, *success = an accepted step with alpha index > 0   */ \

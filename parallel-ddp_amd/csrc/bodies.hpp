@@ -40,7 +40,7 @@ PDDP_HD bool fp_active(const Buffers<T>& b, const Dims& dm, int pb) {
     return true;
 }
 template <typename P, typename T>
-PDDP_HD FpArgs<T> fp_args(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T dt, T* segx, T* dnorm) {
+PDDP_HD FpArgs<T> fp_args(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T dt, T* segx, T* dnorm, T* segJ = nullptr) {
     constexpr int NX = P::NX, NU = P::NU;
     const int N = dm.N;
     const SolverState<T>& st = b.state[pb];
@@ -52,12 +52,15 @@ PDDP_HD FpArgs<T> fp_args(const Buffers<T>& b, const Dims& dm, int pb, int a_idx
     a.KT = b.KT + (size_t)pb * N * NX * NU; a.du = b.du + (size_t)pb * N * NU;
     a.ApBK = b.ApBK + (size_t)pb * N * NX * NX; a.Bdu = b.Bdu + (size_t)pb * N * NX;
     a.alpha = b.alpha[a_idx]; a.dt = dt; a.segx = segx; a.dnorm = dnorm;
+    a.xt = b.xTarget + (size_t)pb * NX; a.segJ = segJ; a.tshift = b.tshift[pb];
     return a;
 }
 // cost tree-sum and defect max of one candidate, by one wave
 template <typename T>
-PDDP_HD void fp_reduce(const Wave& w, const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T* cost_k, const T* dnorm) {
-    const T J = tree_sum<T>(w, cost_k, dm.N);
+PDDP_HD void fp_reduce(const Wave& w, const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T* cost_k, const T* dnorm, const T* segJ = nullptr) {
+    T J;
+    if (segJ) { J = 0; for (int i = 0; i < dm.M; i++) J += segJ[i]; }     // end-effector cost: costKern<T,0>, fpHelpers.cuh:169-178
+    else J = tree_sum<T>(w, cost_k, dm.N);
     if (w.lane == 0) {
         T mx = 0;
         for (int i = 0; i < dm.M; i++) mx = tmax(mx, dnorm[i]);
@@ -116,26 +119,53 @@ PDDP_HD void nis_body(const Wave& w, NisScratch<P, INTEG, T>& s, const Buffers<T
     }
     P::load_model(w, s.plant, reinterpret_cast<const typename P::Model*>(b.model));
     nis_knot<P, INTEG, T>(w, s, dm, k, xc, uc, b.xGoal + (size_t)pb * NX, cw, dt,
-                          b.AB + ((size_t)pb * N + k) * NX * NM, b.H + ((size_t)pb * N + k) * NM * NM, b.g + ((size_t)pb * N + k) * NM);
+                          b.AB + ((size_t)pb * N + k) * NX * NM, b.H + ((size_t)pb * N + k) * NM * NM, b.g + ((size_t)pb * N + k) * NM,
+                          b.xTarget + (size_t)pb * NX, b.tshift[pb], mode == 1 ? b.costk + (size_t)pb * N + k : nullptr);
 }
 
 // cost of the loaded trajectory, prevJ = J + 2 TOL_COST, Jout[0], alphaOut[0], fresh solver state
 // (initAlgGPU, nisInitHelpers.cuh:363,385-395, and the locals of runiLQR_GPU, DDPWrappers.cuh:24).
+// End-effector cost (stage: 0 joint-space cost, everything in one call; 1 fresh state only, the cost follows; 2 the cost: per-knot
+// values the setup kernel left in b.costk (costGrad's d_JT[k], nisInitHelpers.cuh:368) tree-summed (costKern<T,1>, fpHelpers.cuh:179-190),
+// or, after an initial rollout, the rollout's own sum (costKern<T,0><<<1,1>>>, nisInitHelpers.cuh:387).  prev_alpha: the winner index
+// the previous solve on these buffers ended with.  The reference reads the initial cost from d_JT[*alphaIndex] (:392) although
+// costKern<T,1> leaves the sum in d_JT[0] and the cost of KNOT a in d_JT[a]: an MPC solve (which keeps *alphaIndex, MPCHelpers.cuh)
+// that follows a solve ending with alphaIndex = a > 0 therefore starts from prevJ = cost of knot a.  Kept, sic.
 template <typename P, typename T>
 PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw,
-                            const SolverParams& sp, int ignore_first_defect, int rollout, int pb) {
+                            const SolverParams& sp, int ignore_first_defect, int rollout, int pb, int stage = 0, int keep_alpha = 0) {
     constexpr int NX = P::NX, NU = P::NU;
     const int N = dm.N;
     const T* x = b.xb + ((size_t)pb * 2 + 0) * N * NX; const T* u = b.ucur + (size_t)pb * N * NU;
     const T* xg = b.xGoal + (size_t)pb * NX;
-    PDDP_FOR(k, N) cost_k[k] = P::cost(cw, x + (size_t)k * NX, u + (size_t)k * NU, xg, k, N);
-    wsync();
-    const T J = tree_sum<T>(w, cost_k, N);
+    T J = 0;
+    if (stage == 0) {
+        PDDP_FOR(k, N) cost_k[k] = P::cost(cw, x + (size_t)k * NX, u + (size_t)k * NU, xg, k, N);
+        wsync();
+        J = tree_sum<T>(w, cost_k, N);
+    } else if (stage == 2) {
+        const size_t ho = (size_t)pb * (sp.max_iter + 2);
+        if (rollout) J = b.J[(size_t)pb * dm.A];
+        else {
+            const int a0 = b.state[pb].alphaIndex;
+            PDDP_FOR(k, N) cost_k[k] = b.costk[(size_t)pb * N + k];
+            wsync();
+            const T Jk = (a0 > 0 && a0 < N) ? cost_k[a0] : T(0);
+            wsync();
+            J = tree_sum<T>(w, cost_k, N);
+            if (a0 > 0 && a0 < N) J = Jk;
+        }
+        if (w.lane == 0) {
+            b.state[pb].prevJ = J + T(2 * sp.tol_cost);
+            b.Jout[ho] = b.state[pb].prevJ - T(2 * sp.tol_cost);
+        }
+        return;
+    }
     if (w.lane == 0) {
         SolverState<T> st;
         st.rho = T(sp.rho_init); st.drho = T(1.0); st.dJ = 0; st.z = 0;
         st.prevJ = J + T(2 * sp.tol_cost);
-        st.iter = 1; st.alphaIndex = 0; st.ignore_defect = ignore_first_defect; st.accepted = 1; st.done = 0;
+        st.iter = 1; st.alphaIndex = keep_alpha ? b.state[pb].alphaIndex : 0; st.ignore_defect = ignore_first_defect; st.accepted = 1; st.done = 0;
         st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.took_step = 0;
         st.pw = b.state[pb].pw;        // a warm start must read the cost-to-go of the iteration before the previous exit: keep the buffer roles
         b.state[pb] = st;

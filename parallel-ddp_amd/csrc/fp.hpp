@@ -13,6 +13,7 @@
 //  * the rollout keeps x_k,u_k in LDS, so cost and defect are reduced from LDS in the same launch.
 #pragma once
 
+#include "ee_cost.hpp"
 #include "integrators.hpp"
 
 namespace pddp {
@@ -28,6 +29,7 @@ struct SimScratch {
     typename P::Scratch plant;
     IntegScratch<P, T> integ;
     T x[P::NX], xn[P::NX], u[P::NU], dx[P::NX];
+    EeScratch<T> ee;
 };
 
 template <typename T>
@@ -38,6 +40,8 @@ struct FpArgs {
     T alpha; T dt;
     T* segx;                                  // LDS [M][NX]: segment start states handed from the sweep to the rollouts
     T* dnorm;                                 // LDS [M]: 1-norm of each segment's boundary defect (0 for the last segment)
+    // end-effector cost only: goal is the 6-vector, xt the nominal-state target, segJ (LDS [M]) the segment's accumulated cost
+    const T* xt; T* segJ; int tshift;
 };
 
 // Linear sweep (M > 1): x_{k+1} = xcur_{k+1} + (A-BK)_k (x_k - xcur_k) - alpha (B du)_k + [boundary] d_k, serial in k.
@@ -80,7 +84,12 @@ PDDP_HD void forward_sim_segment(const Wave& w, SimScratch<P, T>& s, const Dims&
                                  const CostWeights<T>& cw, const T* xg, T* cost_k) {
     constexpr int NX = P::NX, NU = P::NU;
     const int NBk = dm.NB, kStart = bInd * NBk;
-    const int iters = (bInd < dm.M - 1) ? NBk : NBk - 1;
+    bool ee = false;
+    if constexpr (P::PLANT == 4) ee = cw.ee != 0;
+    // with the end-effector cost the last segment also runs the control law and the dynamics at knot N-1: the tool point of the
+    // final state comes out of the dynamics (forwardSimInner, fpHelpers.cuh:236: iters = N_BLOCKS_F)
+    const int iters = (bInd < dm.M - 1 || ee) ? NBk : NBk - 1;
+    if constexpr (P::PLANT == 4) { if (ee) { PDDP_FOR(i, 7) s.ee.acc[i] = 0; } }
     if (bInd == 0) { PDDP_FOR(i, NX) { const T v = a.xcur[i]; s.x[i] = v; a.x[i] = v; } }
     else { PDDP_FOR(i, NX) s.x[i] = a.segx[NX * bInd + i]; }
     wsync();
@@ -97,8 +106,16 @@ PDDP_HD void forward_sim_segment(const Wave& w, SimScratch<P, T>& s, const Dims&
             s.u[r] = uv; a.u[NU * kn + r] = uv;
         }
         wsync();
-        if (cost_k && w.lane == 0) cost_k[kn] = P::cost(cw, s.x, s.u, xg, kn, dm.N);
+        if (!ee && cost_k && w.lane == 0) cost_k[kn] = P::cost(cw, s.x, s.u, xg, kn, dm.N);
         integrator_step<P, INTEG>(w, s.plant, s.integ, s.xn, s.x, s.u, a.dt);
+        if constexpr (P::PLANT == 4) {
+            if (ee && (k < NBk - 1 || bInd == dm.M - 1)) {    // not on the "final" state of a non-final segment (:259-265)
+                ee_position<T>(w, s.plant, cw, s.ee);
+                ee_cost_accumulate<T>(w, s.ee, cw, xg, a.xt, s.x, s.u, kn, dm.N, a.tshift);
+                wsync(w);
+            }
+        }
+        if (ee && kn == dm.N - 1) break;                     // the step out of the last knot is not stored anywhere
         if (k < NBk - 1) {
             PDDP_FOR(i, NX) { const T v = s.xn[i]; a.x[NX * (kn + 1) + i] = v; s.x[i] = v; }
         } else if (bInd < dm.M - 1) {         // last step of a non-final segment: defect against the next start state
@@ -107,6 +124,16 @@ PDDP_HD void forward_sim_segment(const Wave& w, SimScratch<P, T>& s, const Dims&
             if (w.lane == 0) { T sdef = 0; for (int c = 0; c < NX; c++) sdef += tabs(s.dx[c]); a.dnorm[bInd] = sdef; }   // defectKern
         }
         wsync();
+    }
+    if constexpr (P::PLANT == 4) {
+        if (ee) {                                 // forwardSimKern, fpHelpers.cuh:298-300
+            if (w.lane == 0) {
+                a.segJ[bInd] = s.ee.acc[0] + s.ee.acc[1] + s.ee.acc[2] + s.ee.acc[3] + s.ee.acc[4] + s.ee.acc[5] + s.ee.acc[6];
+                if (bInd == dm.M - 1) a.dnorm[bInd] = 0;
+            }
+            wsync(w);
+            return;
+        }
     }
     if (bInd == dm.M - 1) {                   // final knot: terminal cost, and its (unused) control is carried along
         const int kn = dm.N - 1;

@@ -36,7 +36,7 @@ struct FpLds {
     static PDDP_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
     static size_t bytes(int M, int N) {
         return align16(sizeof(SweepScratch<P, T>)) + (size_t)M * align16(sizeof(SimScratch<P, T>)) +
-               align16(sizeof(T) * (size_t)N) + align16(sizeof(T) * (size_t)M * P::NX) + align16(sizeof(T) * (size_t)M);
+               align16(sizeof(T) * (size_t)N) + align16(sizeof(T) * (size_t)M * P::NX) + 2 * align16(sizeof(T) * (size_t)M);
     }
 };
 
@@ -55,9 +55,10 @@ __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_ro
     ptr += (size_t)M * L::align16(sizeof(SimScratch<P, T>));
     T* cost_k = reinterpret_cast<T*>(ptr); ptr += L::align16(sizeof(T) * (size_t)dm.N);
     T* segx = reinterpret_cast<T*>(ptr); ptr += L::align16(sizeof(T) * (size_t)M * P::NX);
-    T* dnorm = reinterpret_cast<T*>(ptr);
+    T* dnorm = reinterpret_cast<T*>(ptr); ptr += L::align16(sizeof(T) * (size_t)M);
+    T* segJ = reinterpret_cast<T*>(ptr);
     const Wave w = this_wave();
-    const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm);
+    const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm, segJ);
     if (init_rollout) {
         rollout_seed_segment<P, T>(w, dm, a, wave_id);
         __syncthreads();
@@ -68,7 +69,9 @@ __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_ro
     P::load_model(w, sim.plant, reinterpret_cast<const typename P::Model*>(b.model));
     forward_sim_segment<P, INTEG, T>(w, sim, dm, a, wave_id, cw, b.xGoal + (size_t)pb * P::NX, cost_k);
     __syncthreads();
-    if (wave_id == 0) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm);
+    bool ee = false;
+    if constexpr (P::PLANT == 4) ee = cw.ee != 0;
+    if (wave_id == 0) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm, ee ? segJ : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- KUKA arm: lane-group forward pass
@@ -193,9 +196,10 @@ __global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb
 
 // initial cost + solver state: grid (B), block 64, dynamic LDS N*sizeof(T).
 template <typename P, typename T>
-__global__ __launch_bounds__(64) void k_init_cost(Buffers<T> b, Dims dm, CostWeights<T> cw, SolverParams sp, int ignore_first_defect, int rollout) {
+__global__ __launch_bounds__(64) void k_init_cost(Buffers<T> b, Dims dm, CostWeights<T> cw, SolverParams sp, int ignore_first_defect, int rollout,
+                                                  int stage, int keep_alpha) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    init_cost_body<P, T>(this_wave(), reinterpret_cast<T*>(lds_raw), b, dm, cw, sp, ignore_first_defect, rollout, blockIdx.x);
+    init_cost_body<P, T>(this_wave(), reinterpret_cast<T*>(lds_raw), b, dm, cw, sp, ignore_first_defect, rollout, blockIdx.x, stage, keep_alpha);
 }
 // ---------------------------------------------------------------------------------------------- HBM counter calibration (profiling tool)
 // Streams `count` floats from src to dst with the access shape the sweep kernels use (one dword per lane, consecutive

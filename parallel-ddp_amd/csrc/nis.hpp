@@ -6,6 +6,7 @@
 // winner -> xp/up/dp, :266-276) are folded into the same launch: see kernels.hip.
 #pragma once
 
+#include "ee_cost.hpp"
 #include "integrators.hpp"
 
 namespace pddp {
@@ -16,16 +17,30 @@ struct NisScratch {
     typename P::GradScratch pgrad;
     IntegGradScratch<P, INTEG, T> integ;
     T x[P::NX], u[P::NU];
+    EeScratch<T> ee;
+    T qdd[P::NPOS];
 };
 
 // xk/uk: the knot's state and control (global).  Writes ABk (k < N-1), Hk, gk (global).
 template <typename P, int INTEG, typename T>
 PDDP_HD void nis_knot(const Wave& w, NisScratch<P, INTEG, T>& s, const Dims& dm, int k, const T* xk, const T* uk, const T* xg,
-                      const CostWeights<T>& cw, T dt, T* ABk, T* Hk, T* gk) {
+                      const CostWeights<T>& cw, T dt, T* ABk, T* Hk, T* gk, const T* xt = nullptr, int tshift = 0, T* cost_out = nullptr) {
     constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
     PDDP_FOR(i, NX) s.x[i] = xk[i];
     PDDP_FOR(i, NU) s.u[i] = uk[i];
     wsync();
+    if constexpr (P::PLANT == 4) {
+        if (cw.ee) {   // costGradientHessianKern, end-effector branch (nisInitHelpers.cuh:52-84): the kinematics come with the dynamics gradient
+            if (k < dm.N - 1) integrator_gradient<P, INTEG>(w, s.plant, s.pgrad, s.integ, ABk, s.x, s.u, dt);
+            else P::dynamics(w, s.plant, s.qdd, s.x, s.u);
+            wsync(w);
+            ee_position<T>(w, s.plant, cw, s.ee);
+            ee_jacobian<T>(w, s.plant, cw, s.ee);
+            ee_cost_grad<T>(w, s.ee, cw, xg, xt, s.x, s.u, k, dm.N, tshift, Hk, gk);
+            if (cost_out && w.lane == 0) *cost_out = ee_cost_knot<T>(s.ee, cw, xg, xt, s.x, s.u, k, dm.N, tshift);
+            return;
+        }
+    }
     PDDP_FOR(e, NM * NM) { const int i = e / NM, j = e % NM; Hk[e] = (i == j) ? P::weight(cw, i, k, dm.N) : T(0); }
     PDDP_FOR(i, NM) gk[i] = P::weight(cw, i, k, dm.N) * (i < NX ? (s.x[i] - xg[i]) : s.u[i - NX]);
     if (k < dm.N - 1) integrator_gradient<P, INTEG>(w, s.plant, s.pgrad, s.integ, ABk, s.x, s.u, dt);

@@ -41,6 +41,8 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->max_defect = plant == 2 ? 0.75 : 1.0;
     c->tol_cost = 0.0001; c->exp_red_min = 0.05; c->exp_red_max = 1.25;
     c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
+    c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
+    c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
     return 0;
 }
 
@@ -63,6 +65,7 @@ struct SolverBase {
     virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
     virtual int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) = 0;
     virtual int set_cost(double Q1, double Q2, double R, double QF1, double QF2) = 0;
+    virtual int set_cost_ee(const double* v) = 0;
     virtual int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
                           int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) = 0;
     int bench_mode = 0;
@@ -131,6 +134,8 @@ struct Solver : SolverBase {
         sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
+        cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
+        cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
         dt = (T)(c.total_time / (c.N - 1));                       // TIME_STEP, config.cuh:136
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
         int rc = 0;
@@ -148,6 +153,7 @@ struct Solver : SolverBase {
         arrays["Pp"] = {b.Pp, arrays["P"].second}; arrays["pp"] = {b.pp, arrays["p"].second};
         if ((rc = alloc("x_old", &mb.x_old, B * N * NX)) || (rc = alloc("u_old", &mb.u_old, B * N * NU)) || (rc = alloc("KT_old", &mb.KT_old, B * N * NX * NU))) return rc;
         if ((rc = alloc("xActual", &d_xActual, B * NX)) || (rc = alloc("shift", &d_shift, B))) return rc;
+        if ((rc = alloc("xTarget", &b.xTarget, B * NX)) || (rc = alloc("costk", &b.costk, B * N)) || (rc = alloc("tshift", &b.tshift, B))) return rc;
         std::vector<T> al(A);
         for (size_t i = 0; i < A; i++) al[i] = (T)std::pow(c.alpha_base, (double)i);   // nisInitHelpers.cuh:829
         HIPCHK(hipMemcpy(b.alpha, al.data(), A * sizeof(T), hipMemcpyHostToDevice));
@@ -192,13 +198,16 @@ struct Solver : SolverBase {
         HIPCHK(hipMemsetAsync(b.du, 0, B * N * NU * sizeof(T), stream));   // always (:630-632)
         HIPCHK(hipMemsetAsync(b.err, 0, B * cfg.M * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(b.dmax, 0, B * cfg.A * sizeof(T), stream));
+        const int ee = cfg.ee_cost ? 1 : 0;                          // end-effector cost: the initial cost comes out of the setup kernel (stage 2)
+        HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
         if (rollout) {                                               // forwardRolloutFlag (:642-648)
-            hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, 1);   // state.cur = 0
+            hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, 1, ee, 0);   // state.cur = 0
             launch_fp(stream, 1);
             hipLaunchKernelGGL((k_adopt_slot0<P, T>), dim3(N, B), dim3(64), 0, stream, b, dm);
         }
-        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, rollout);
+        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, rollout, ee, 0);
         launch_nis(stream, 1);
+        if (ee) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ignore_first_defect, rollout, 2, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
@@ -206,6 +215,12 @@ struct Solver : SolverBase {
     // forward pass: the arm runs on lane groups (fp_lg.hpp), the closed-form plants on the wave-cooperative kernel
     void launch_fp(hipStream_t s, int init_rollout) {
         const unsigned B = cfg.batch;
+        bool lane_groups = false;
+        if constexpr (P::PLANT == 4) lane_groups = !cfg.ee_cost;   // the end-effector cost runs on the wave-cooperative kernels
+        if (!lane_groups) {
+            hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
+            return;
+        }
         if constexpr (P::PLANT == 4) {
             const int A_eff = init_rollout ? 1 : cfg.A;
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
@@ -214,14 +229,14 @@ struct Solver : SolverBase {
             if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
             else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
             else hipLaunchKernelGGL((k_fp_lg<T, 1024>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
-        } else {
-            hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
         }
     }
     void launch_nis(hipStream_t s, int mode) {
         const unsigned B = cfg.batch;
-        if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
-        else hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
+        if constexpr (P::PLANT == 4) {
+            if (!cfg.ee_cost) { hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode); return; }
+        }
+        hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
     void launch_sweep(hipStream_t s, int only = -1) {
         const unsigned B = cfg.batch;
@@ -284,6 +299,15 @@ struct Solver : SolverBase {
         if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; }   // the weights are kernel arguments baked into the captured sweep
         return 0;
     }
+    int set_cost_ee(const double* v) override {
+        if (!cfg.ee_cost) return fail(PDDP_EINVAL, "pddp_set_cost_ee: the handle was not created with ee_cost = 1");
+        HIPCHK(hipStreamSynchronize(stream));
+        cfg.Q_EE1 = v[0]; cfg.Q_EE2 = v[1]; cfg.QF_EE1 = v[2]; cfg.QF_EE2 = v[3]; cfg.R_EE = v[4]; cfg.Q_xEE = v[5]; cfg.QF_xEE = v[6]; cfg.Q_xdEE = v[7]; cfg.QF_xdEE = v[8];
+        cw.Q_EE1 = (T)v[0]; cw.Q_EE2 = (T)v[1]; cw.QF_EE1 = (T)v[2]; cw.QF_EE2 = (T)v[3]; cw.R_EE = (T)v[4]; cw.Q_xEE = (T)v[5]; cw.QF_xEE = (T)v[6];
+        cw.Q_xdEE = (T)v[7]; cw.QF_xdEE = (T)v[8];
+        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; }
+        return 0;
+    }
     int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
                   int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) override {
         const size_t B = cfg.batch, N = cfg.N;
@@ -293,11 +317,15 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpyAsync(d_xActual, xActual, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(b.xGoal, xGoal, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(d_shift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
+        if (cfg.ee_cost && cfg.ee_cost_shift) HIPCHK(hipMemcpyAsync(b.tshift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
+        else HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
         hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
         const int saved_max_iter = sp.max_iter;
         sp.max_iter = max_iter;                                  // acceptRejectTrajGPU(..., max_iter)
-        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ifd, 0);
+        const int ee = cfg.ee_cost ? 1 : 0;
+        hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ifd, 0, ee, 1);   // keeps alphaIndex (runiLQR_MPC_GPU does not reset it)
         launch_nis(stream, 1);
+        if (ee) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), N * sizeof(T), stream, b, dm, cw, sp, ifd, 0, 2, 1);
         HIPCHK(hipGetLastError());
         std::vector<int> done(B);
         int rc = 0;
@@ -398,7 +426,7 @@ struct Solver : SolverBase {
         if (phase >= 0 && phase <= 3) launch_sweep(stream, phase);
         else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);
         else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);
-        else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0);
+        else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0, cfg.ee_cost ? 1 : 0, 0);
         else return fail(PDDP_EINVAL, "unknown phase");
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -451,6 +479,7 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.N < 4 || (c.N & (c.N - 1)) || c.N > 1024) return fail(PDDP_EINVAL, "N must be a power of two in [4,1024] (the reference's tree reductions assume it)");
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
+    if (c.ee_cost && c.plant != 4) return fail(PDDP_EINVAL, "ee_cost: the end-effector cost family belongs to the KUKA arm (plant 4)");
     if (c.plant == 4 && c.A * c.M > 128) return fail(PDDP_EINVAL, "KUKA arm: A * M must not exceed 128 (one workgroup rolls out all candidates of a problem)");
     if (c.plant == 4 && (double)c.batch * c.N * (c.A * 14 > 441 ? c.A * 14 : 441) >= 4294967296.0)
         return fail(PDDP_EINVAL, "KUKA arm: batch * N too large for the 32-bit element offsets of the lane-group kernels (split the batch over several handles)");
@@ -477,6 +506,10 @@ extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); retu
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { IMPL(h); return s->store(x, u, KT, Jout, alphaOut, dmax); }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
 extern "C" int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2) { IMPL(h); return s->set_cost(Q1, Q2, R, QF1, QF2); }
+extern "C" int pddp_set_cost_ee(pddp_handle h, double Q_EE1, double Q_EE2, double QF_EE1, double QF_EE2, double R_EE, double Q_xEE, double QF_xEE,
+                                double Q_xdEE, double QF_xdEE) {
+    IMPL(h); const double v[9] = {Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE}; return s->set_cost_ee(v);
+}
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { IMPL(h); s->bench_mode = on ? 1 : 0; return 0; }
 extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { IMPL(h); void* p; return s->array(name, &p, bytes); }
 extern "C" int pddp_array_ptr(pddp_handle h, const char* name, void** ptr, size_t* bytes) { IMPL(h); if (!ptr || !bytes) return fail(PDDP_EINVAL, "null argument"); return s->array(name, ptr, bytes); }

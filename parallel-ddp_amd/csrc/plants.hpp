@@ -15,6 +15,10 @@ namespace pddp {
 template <typename T>
 struct CostWeights {   // arm joint-space weights (plants/cost_arm.cuh:97-103); other plants use fixed macros
     T Q1, Q2, R, QF1, QF2;
+    // end-effector cost family (EE_COST 1, plants/cost_arm.cuh:206-389; ee_cost.hpp): xyz / rpy running and final weights, control weight,
+    // nominal-state weights on q and qd, and the tool point's offset along the last link's z axis (EE_ON_LINK_Z, dynamics_arm.cuh:53-65)
+    int ee;
+    T Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE, ee_z;
 };
 
 struct EmptyModel { int unused; };

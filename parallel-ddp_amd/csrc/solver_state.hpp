@@ -53,6 +53,9 @@ struct Buffers {
     T *xs, *us, *ds, *xb, *ucur, *dcur;
     T *P, *p, *Pp, *pp, *AB, *H, *g, *KT, *du, *ApBK, *Bdu;
     T *J, *dmax, *dJexp, *alpha, *xGoal, *Jout;
+    T *xTarget;          // [B][n] nominal-state target of the end-effector cost (zeros unless set)
+    T *costk;            // [B][N] per-knot cost of the loaded trajectory (end-effector cost: written by the setup kernel, d_JT[k] of initAlgGPU)
+    int *tshift;         // [B] finalCostShift of the end-effector cost (0 unless the MPC call shifts it)
     int *err, *alphaOut;
     SolverState<T>* state;
     const void* model;   // plant constants (P::Model) in device memory

@@ -21,6 +21,9 @@ class PddpConfig(C.Structure):
         ("total_time", C.c_double), ("alpha_base", C.c_double), ("rho_init", C.c_double), ("max_defect", C.c_double),
         ("tol_cost", C.c_double), ("exp_red_min", C.c_double), ("exp_red_max", C.c_double),
         ("Q1", C.c_double), ("Q2", C.c_double), ("R", C.c_double), ("QF1", C.c_double), ("QF2", C.c_double),
+        ("ee_cost", C.c_int), ("ee_cost_shift", C.c_int),
+        ("Q_EE1", C.c_double), ("Q_EE2", C.c_double), ("QF_EE1", C.c_double), ("QF_EE2", C.c_double), ("R_EE", C.c_double),
+        ("Q_xEE", C.c_double), ("QF_xEE", C.c_double), ("Q_xdEE", C.c_double), ("QF_xdEE", C.c_double), ("ee_on_link_z", C.c_double),
     ]
 
 
@@ -193,6 +196,11 @@ class Solver:
         """pddp_set_cost: joint-space cost weights for the following loads / solves."""
         self.lib.pddp_set_cost.argtypes = [C.c_void_p] + [C.c_double] * 5
         self._chk(self.lib.pddp_set_cost(self.h, Q1, Q2, R, QF1, QF2))
+
+    def set_cost_ee(self, Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE):
+        """pddp_set_cost_ee: end-effector cost weights for the following loads / solves."""
+        self.lib.pddp_set_cost_ee.argtypes = [C.c_void_p] + [C.c_double] * 9
+        self._chk(self.lib.pddp_set_cost_ee(self.h, Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE))
 
     # ---- measurement
     def set_benchmark_mode(self, on):

@@ -35,6 +35,8 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->rho_init = plant == 4 ? 12.5 : (plant == 3 ? 1.0 : 10.0); c->max_defect = plant == 2 ? 0.75 : 1.0;
     c->tol_cost = 0.0001; c->exp_red_min = 0.05; c->exp_red_max = 1.25;
     c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
+    c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
+    c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
     return 0;
 }
 
@@ -79,6 +81,8 @@ struct Sim : Base {
         sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
+        cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
+        cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
         dt = (T)(c.total_time / (c.N - 1));
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
 #define AL(name, count) al(#name, &b.name, (count))
@@ -88,6 +92,7 @@ struct Sim : Base {
         AL(AB, B * N * NX * NM); AL(H, B * N * NM * NM); AL(g, B * N * NM);
         AL(KT, B * N * NX * NU); AL(du, B * N * NU); AL(ApBK, B * N * NX * NX); AL(Bdu, B * N * NX);
         AL(J, B * A); AL(dmax, B * A); AL(dJexp, B * 2 * M); AL(alpha, A); AL(xGoal, B * NX);
+        AL(xTarget, B * NX); AL(costk, B * N); AL(tshift, B);
         AL(Jout, B * (c.max_iter + 2)); AL(err, B * M); AL(alphaOut, B * (c.max_iter + 2)); AL(state, B);
 #undef AL
         b.Pp = b.P + B * N * NX * NX; b.pp = b.p + B * N * NX;
@@ -111,12 +116,12 @@ struct Sim : Base {
             for (int pb = 0; pb < B; pb++) for (int blk = 0; blk < cfg.M; blk++) bp_body<P, T>(w, s, b, dm, blk, pb);
         } else if (ph == PDDP_PHASE_FP) {
             static SweepScratch<P, T> sw; static SimScratch<P, T> sim;
-            std::vector<T> cost_k(cfg.N), segx(cfg.M * NX), dnorm(cfg.M);
+            std::vector<T> cost_k(cfg.N), segx(cfg.M * NX), dnorm(cfg.M), segJ(cfg.M);
             for (int pb = 0; pb < B; pb++) {
                 if (!fp_active<T>(b, dm, pb)) continue;
                 for (int a = 0; a < cfg.A; a++) {
-                    const FpArgs<T> fa = fp_args<P, T>(b, dm, pb, a, dt, segx.data(), dnorm.data());
-                    if constexpr (P::PLANT == 4) {          // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
+                    const FpArgs<T> fa = fp_args<P, T>(b, dm, pb, a, dt, segx.data(), dnorm.data(), segJ.data());
+                    if constexpr (P::PLANT == 4) if (!cfg.ee_cost) {   // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
                         using L = LgHost<T>;
                         ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                         const FpLgArgs<T> la = fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data());
@@ -128,23 +133,23 @@ struct Sim : Base {
                     if (cfg.M > 1) forward_sweep<P, T>(w, sw, dm, fa);
                     P::load_model(w, sim.plant, &model);
                     for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + (size_t)pb * NX, cost_k.data());
-                    fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data());
+                    fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data(), cfg.ee_cost ? segJ.data() : nullptr);
                 }
             }
         } else if (ph == PDDP_PHASE_LS) {
             for (int pb = 0; pb < B; pb++) ls_body<T>(b, dm, sp, pb, bench);
         } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
-            if constexpr (P::PLANT == 4) {                    // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
+            if constexpr (P::PLANT == 4) if (!cfg.ee_cost) {   // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
                 using L = LgHost<T>;
                 ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                 for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) arm_lg_nis_body<L, T>(c, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
-            } else {
-                static NisScratch<P, INTEG, T> s;
-                for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) nis_body<P, INTEG, T>(w, s, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+                return;
             }
+            static NisScratch<P, INTEG, T> s;
+            for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) nis_body<P, INTEG, T>(w, s, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
         } else if (ph == PDDP_PHASE_INIT_COST) {
             std::vector<T> cost_k(cfg.N);
-            for (int pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, 1, 0, pb);
+            for (int pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, 1, 0, pb, cfg.ee_cost ? 1 : 0, 0);
         }
     }
     int load(const void* x0, const void* u0, const void* xg, const void* KT0, const void* P0, const void* p0, const void* d0, int rollout, int clear, int ifd) override {
@@ -164,29 +169,33 @@ struct Sim : Base {
         std::memset(b.du, 0, B * N * NU * sizeof(T)); std::memset(b.err, 0, B * cfg.M * sizeof(int)); std::memset(b.dmax, 0, B * cfg.A * sizeof(T));
         std::vector<T> cost_k(cfg.N); const Wave w = this_wave();
         if (rollout) {
-            static SimScratch<P, T> sim; std::vector<T> segx(cfg.M * NX), dnorm(cfg.M);
+            static SimScratch<P, T> sim; std::vector<T> segx(cfg.M * NX), dnorm(cfg.M), segJ(cfg.M);
             for (size_t pb = 0; pb < B; pb++) {
-                init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 1, (int)pb);
-                const FpArgs<T> fa = fp_args<P, T>(b, dm, (int)pb, 0, dt, segx.data(), dnorm.data());
-                if constexpr (P::PLANT == 4) {
+                init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 1, (int)pb, cfg.ee_cost ? 1 : 0, 0);
+                const FpArgs<T> fa = fp_args<P, T>(b, dm, (int)pb, 0, dt, segx.data(), dnorm.data(), segJ.data());
+                bool lane_groups = false;
+                if constexpr (P::PLANT == 4) lane_groups = !cfg.ee_cost;
+                if constexpr (P::PLANT == 4) if (lane_groups) {
                     using L = LgHost<T>;
                     ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                     const FpLgArgs<T> la = fp_lg_args<T>(b, dm, (int)pb, 0, dt, dnorm.data());
                     for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), true);
-                } else {
+                }
+                if (!lane_groups) {
                     for (int sg = 0; sg < cfg.M; sg++) rollout_seed_segment<P, T>(w, dm, fa, sg);
                     P::load_model(w, sim.plant, &model);
                     for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + pb * NX, cost_k.data());
                 }
-                fp_reduce<T>(w, b, dm, (int)pb, 0, cost_k.data(), dnorm.data());
+                fp_reduce<T>(w, b, dm, (int)pb, 0, cost_k.data(), dnorm.data(), cfg.ee_cost ? segJ.data() : nullptr);
                 const size_t slot = pb * cfg.A;
                 std::memcpy(b.xb + pb * 2 * N * NX, b.xs + slot * N * NX, N * NX * sizeof(T));
                 std::memcpy(b.ucur + pb * N * NU, b.us + slot * N * NU, N * NU * sizeof(T));
                 std::memcpy(b.dcur + pb * N * NX, b.ds + slot * N * NX, N * NX * sizeof(T));
             }
         }
-        for (size_t pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, rollout, (int)pb);
+        for (size_t pb = 0; pb < B; pb++) { b.tshift[pb] = 0; init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, rollout, (int)pb, cfg.ee_cost ? 1 : 0, 0); }
         phase(PDDP_PHASE_INIT_NIS);
+        if (cfg.ee_cost) for (size_t pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, rollout, (int)pb, 2, 0);
         return 0;
     }
     int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter,
@@ -198,9 +207,11 @@ struct Sim : Base {
         const int saved = sp.max_iter; sp.max_iter = max_iter;
         for (size_t pb = 0; pb < B; pb++) {
             mpc_load_body<P, INTEG, T>(w, ms, b, mb, dm, dt, (int)pb, (const T*)xActual + pb * NX, shift[pb], clear_vars, full_rollout);
-            init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 0, (int)pb);
+            b.tshift[pb] = (cfg.ee_cost && cfg.ee_cost_shift) ? shift[pb] : 0;
+            init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 0, (int)pb, cfg.ee_cost ? 1 : 0, 1);
         }
         phase(PDDP_PHASE_INIT_NIS);
+        if (cfg.ee_cost) for (size_t pb = 0; pb < B; pb++) init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 0, (int)pb, 2, 1);
         for (int guard = 0; guard < 100000; guard++) {
             iterate(1);
             bool all = true; for (size_t pb = 0; pb < B; pb++) all &= (b.state[pb].done != 0);

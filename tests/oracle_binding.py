@@ -22,6 +22,10 @@ class OraCfg(C.Structure):
         ("total_time", C.c_double), ("alpha_base", C.c_double), ("rho_init", C.c_double), ("max_defect", C.c_double),
         ("tol_cost", C.c_double), ("exp_red_min", C.c_double), ("exp_red_max", C.c_double),
         ("Q1", C.c_double), ("Q2", C.c_double), ("R", C.c_double), ("QF1", C.c_double), ("QF2", C.c_double),
+        ("ee_cost", C.c_int), ("ee_cost_shift", C.c_int),
+        ("Q_EE1", C.c_double), ("Q_EE2", C.c_double), ("QF_EE1", C.c_double), ("QF_EE2", C.c_double), ("R_EE", C.c_double),
+        ("Q_xEE", C.c_double), ("QF_xEE", C.c_double), ("Q_xdEE", C.c_double), ("QF_xdEE", C.c_double), ("ee_on_link_z", C.c_double),
+        ("xTarget", C.c_double * 14),
     ]
 
 
@@ -47,6 +51,8 @@ def lib():
         _LIB.ora_total_cost_f64.restype = C.c_double
         _LIB.ora_max_defect_f32.restype = C.c_float
         _LIB.ora_max_defect_f64.restype = C.c_double
+        _LIB.ora_ee_cost_f32.restype = C.c_float
+        _LIB.ora_ee_cost_f64.restype = C.c_double
     return _LIB
 
 
@@ -127,6 +133,23 @@ class Oracle:
         g = np.zeros(nm, self.dtype)
         self._f("cost_grad")(C.byref(self.c), _p(H), _p(g), _p(x), _p(u), _p(xg), int(k))
         return H, g
+
+    # ---- end-effector cost family (arm)
+    def ee_pos(self, x, jac=True):
+        x = self.arr(x)
+        pos, dpos = np.zeros(6, self.dtype), np.zeros(42, self.dtype)
+        self._f("ee_pos")(C.byref(self.c), _p(x), _p(pos), _p(dpos) if jac else None)
+        return pos, dpos.reshape(7, 6)
+
+    def ee_cost(self, x, u, goal, k, tshift=0):
+        x, u, goal = self.arr(x), self.arr(u), self.arr(goal)
+        return float(self._f("ee_cost")(C.byref(self.c), _p(x), _p(u), _p(goal), int(k), int(tshift)))
+
+    def ee_cost_grad(self, x, u, goal, k, tshift=0):
+        x, u, goal = self.arr(x), self.arr(u), self.arr(goal)
+        H, g = np.zeros(21 * 21, self.dtype), np.zeros(21, self.dtype)
+        self._f("ee_cost_grad")(C.byref(self.c), _p(H), _p(g), _p(x), _p(u), _p(goal), int(k), int(tshift))
+        return H.reshape(21, 21), g
 
     # ---- phase level (arrays are modified in place, like the reference)
     def backward_pass(self, sem_gpu, AB, P, p, Pp, pp, H, g, KT, du, d, ApBK, Bdu, x, xp2, rho):

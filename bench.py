@@ -157,6 +157,7 @@ def main():
 
     if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
         line["latency"] = latency_single_problem(ctx.local_rank)
+        line["widening"] = widening_rows(ctx.local_rank)
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     elif ctx.rank == 0:
@@ -209,6 +210,61 @@ def latency_single_problem(device):
                      "median_iterations_to_convergence": float(np.median(convs)),
                      "median_ms_to_convergence": round(float(np.median(np.asarray(convs) * np.asarray(mss) / np.asarray(its))), 3),
                      "ms_per_iteration": round(float(np.median(np.asarray(mss) / np.asarray(its))), 4)}
+        s.close()
+    return res
+
+
+def ee_inputs(N, rng, count):
+    """The MPC example's start (utils/exampleUtils.cuh:40-58: constant pose, u = 0.01, K = 0) with per-problem tool-point goals on a lemniscate --
+    SURVEY.md section 8(d) config 4: "64 rollouts" = 64 independent problems, goal r at phase r/64 of the figure."""
+    x = np.zeros((count, N, 14), np.float32); x[:, :, 1] = 0.7; x[:, :, 3] = -0.8; x[:, :, 5] = 0.75
+    x[:, :, :7] += rng.normal(0, 0.01, (count, 1, 7)).astype(np.float32)
+    u = np.full((count, N, 7), 0.01, np.float32)
+    ph = 2 * np.pi * np.arange(count) / count
+    g = np.zeros((count, 14), np.float32); g[:, 0] = 0.55; g[:, 1] = 0.20 * np.sin(ph); g[:, 2] = 0.45 + 0.12 * np.sin(2 * ph)
+    return x, u, g
+
+
+def widening_rows(device):
+    """SURVEY.md section 8(f) rows N1 / N2, measured: the receding-horizon wrapper and the end-effector cost family (EE_COST 1, MPC_MODE 1,
+    the configuration of examples/WAFR_MPC_examples.cu:4-37).  Not part of `value`."""
+    res = {}
+    rng = np.random.default_rng(77)
+    kw = dict(wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, ignore_max_rho_exit=0, device=device, use_graph=1)
+    # (1) BASELINE configs[3] stage 4b: 64 independent rollouts x 8 alphas, N=64, M=4, end-effector cost -- whole-batch sweeps/s
+    B, N = 64, 64
+    s = pyddp.Solver(pyddp.default_config(4, N=N, M=4, A=8, batch=B, max_iter=100, ee_cost=1, **kw))
+    x0, u0, xg = ee_inputs(N, rng, B)
+    s.load(x0, u0, xg)
+    s.set_benchmark_mode(1)
+    s.iterate(5); s.sync()
+    ms_tot, ms_phase = s.time_sweeps(30, phases=True)
+    ms_plain, _ = s.time_sweeps(30, phases=False)
+    s.set_benchmark_mode(0)
+    res["config4b_64_rollouts_ee_cost_N64_A8_M4"] = {"problems": B, "iterations_per_s": round(B * 30 / (ms_plain * 1e-3), 1), "ms_per_sweep": round(ms_plain / 30, 4),
+                                                      "per_phase_ms": {k: round(v / 30, 5) for k, v in zip(PHASES, ms_phase)}}
+    s.close()
+    # (2) the published shape with its own cost (test/WAFR_fig8.py:5-12: Kuka MPC, N=64, A=16, M=4, EE cost, ~1.36 ms per iteration published):
+    #     one problem, a warm start to convergence, then control cycles of 4 iterations shifted by one knot (runiLQR_MPC_GPU)
+    for name, ee in (("mpc_cycle_published_shape_ee_cost", 1), ("mpc_cycle_published_shape_joint_cost", 0)):
+        s = pyddp.Solver(pyddp.default_config(4, N=N, M=4, A=16, batch=1, max_iter=100, ee_cost=ee, **kw))
+        x0, u0, xg = ee_inputs(N, rng, 1)
+        if not ee:
+            xg[0, :7] = [0.5, 0.6, -0.3, -0.9, 0.2, 0.7, 0.1]
+        s.load(x0, u0, xg)
+        t0 = time.perf_counter()
+        first = s.mpc_solve(x0[0, 0], xg, 0, clear_vars=1, max_iter=100)
+        t_first = (time.perf_counter() - t0) * 1e3
+        cyc_ms, cyc_it, succ = [], [], 0
+        xa = first["x"][0][1]
+        for c in range(24):
+            t0 = time.perf_counter()
+            r = s.mpc_solve(xa + rng.normal(0, 0.0005, 14).astype(np.float32), xg, 1, max_iter=4)
+            cyc_ms.append((time.perf_counter() - t0) * 1e3); cyc_it.append(int(r["iters"][0])); succ += int(r["success"][0])
+            xa = r["x"][0][1]
+        res[name] = {"warm_start_iterations": int(first["iters"][0]), "warm_start_ms": round(t_first, 3), "cycles": len(cyc_ms), "iterations_per_cycle": 4,
+                     "median_cycle_ms": round(float(np.median(cyc_ms[2:])), 3), "ms_per_iteration": round(float(np.median(np.asarray(cyc_ms[2:]) / np.asarray(cyc_it[2:]))), 4),
+                     "successful_cycles": succ, "note": "wall clock around pddp_mpc_solve: includes H2D of the measured state and D2H of x, u, K every cycle"}
         s.close()
     return res
 

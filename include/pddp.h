@@ -124,6 +124,8 @@ int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xGoal, const 
  * handle created with ee_cost = 1. */
 int pddp_set_cost_ee(pddp_handle h, double Q_EE1, double Q_EE2, double QF_EE1, double QF_EE2, double R_EE, double Q_xEE, double QF_xEE,
                      double Q_xdEE, double QF_xdEE);
+/* use_cost_shift of runiLQR_MPC_GPU (MPCHelpers.cuh:866,876) for the following pddp_mpc_solve calls: same as config.ee_cost_shift. */
+int pddp_set_ee_cost_shift(pddp_handle h, int on);
 /* New joint-space cost weights for the following loads / solves (the reference passes Q1, Q2, R, QF1, QF2 on every call,
  * DDPWrappers.cuh:17-21, MPCHelpers.cuh:862-866 through costParams).  Takes effect at the next pddp_load / pddp_solve / pddp_mpc_solve:
  * the cost gradient and Hessian of the current trajectory are rebuilt there.  Arm plant only (the other plants' weights are

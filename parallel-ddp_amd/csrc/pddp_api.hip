@@ -506,6 +506,7 @@ extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); retu
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { IMPL(h); return s->store(x, u, KT, Jout, alphaOut, dmax); }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
 extern "C" int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2) { IMPL(h); return s->set_cost(Q1, Q2, R, QF1, QF2); }
+extern "C" int pddp_set_ee_cost_shift(pddp_handle h, int on) { IMPL(h); s->cfg.ee_cost_shift = on ? 1 : 0; return 0; }
 extern "C" int pddp_set_cost_ee(pddp_handle h, double Q_EE1, double Q_EE2, double QF_EE1, double QF_EE2, double R_EE, double Q_xEE, double QF_xEE,
                                 double Q_xdEE, double QF_xdEE) {
     IMPL(h); const double v[9] = {Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE}; return s->set_cost_ee(v);

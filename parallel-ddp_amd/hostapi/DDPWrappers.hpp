@@ -49,6 +49,7 @@ namespace pddp_hostapi {
 
 struct Context {
     pddp_handle h;
+    double cost[14];              // the weights the handle currently holds: Q1 Q2 R QF1 QF2 | Q_EE1 Q_EE2 QF_EE1 QF_EE2 R_EE Q_xEE QF_xEE Q_xdEE QF_xdEE
     std::vector<double> phase;    // [4][MAX_ITER+2]
     std::vector<char> Jtmp;       // [MAX_ITER+2] elements of T
     std::vector<int> atmp;
@@ -64,6 +65,18 @@ template <typename T> T* dev(pddp_handle h, const char* name) {
     void* p = nullptr; size_t nb = 0;
     check(pddp_array_ptr(h, name, &p, &nb), name);
     return static_cast<T*>(p);
+}
+// the reference takes the cost weights on every call (DDPWrappers.cuh:17-21): forward them when they changed
+template <typename T>
+void apply_cost(Context* ctx, T Q1, T Q2, T R, T QF1, T QF2, T Q_EE1, T Q_EE2, T QF_EE1, T QF_EE2, T R_EE, T Q_xEE, T QF_xEE, T Q_xdEE, T QF_xdEE) {
+    const double v[14] = {(double)Q1, (double)Q2, (double)R, (double)QF1, (double)QF2, (double)Q_EE1, (double)Q_EE2, (double)QF_EE1, (double)QF_EE2,
+                          (double)R_EE, (double)Q_xEE, (double)QF_xEE, (double)Q_xdEE, (double)QF_xdEE};
+    bool joint = false, ee = false;
+    for (int i = 0; i < 5; i++) joint |= (T)v[i] != (T)ctx->cost[i];
+    for (int i = 5; i < 14; i++) ee |= (T)v[i] != (T)ctx->cost[i];
+    if (joint) check(pddp_set_cost(ctx->h, v[0], v[1], v[2], v[3], v[4]), "pddp_set_cost");
+    if (ee && EE_COST) check(pddp_set_cost_ee(ctx->h, v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13]), "pddp_set_cost_ee");
+    for (int i = 0; i < 14; i++) ctx->cost[i] = v[i];
 }
 inline Context* find(const void* d_P) {
     auto it = registry().find(d_P);
@@ -90,9 +103,13 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
     c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX;
     c.Q1 = _Q1; c.Q2 = _Q2; c.R = _R; c.QF1 = _QF1; c.QF2 = _QF2;
+    c.ee_cost = EE_COST; c.Q_EE1 = _Q_EE1; c.Q_EE2 = _Q_EE2; c.QF_EE1 = _QF_EE1; c.QF_EE2 = _QF_EE2; c.R_EE = _R_EE;
+    c.Q_xEE = _Q_xEE; c.QF_xEE = _QF_xEE; c.Q_xdEE = _Q_xdEE; c.QF_xdEE = _QF_xdEE; c.ee_on_link_z = EE_ON_LINK_Z;
     Context* ctx = new Context();
     check(pddp_create(&c, &ctx->h), "allocateMemory_GPU");
     pddp_handle h = ctx->h;
+    const double w0[14] = {_Q1, _Q2, _R, _QF1, _QF2, _Q_EE1, _Q_EE2, _QF_EE1, _QF_EE2, _R_EE, _Q_xEE, _QF_xEE, _Q_xdEE, _QF_xdEE};
+    for (int i = 0; i < 14; i++) ctx->cost[i] = w0[i];
     ctx->phase.assign(4 * (MAX_ITER + 2), 0.0);
     ctx->Jtmp.assign(sizeof(T) * (MAX_ITER + 2), 0);
     ctx->atmp.assign(MAX_ITER + 2, 0);
@@ -145,14 +162,10 @@ void runiLQR_GPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, i
     (void)d_AB; (void)d_H; (void)d_g; (void)d_KT; (void)d_du; (void)d_d; (void)h_d_d; (void)d_dp; (void)d_dT; (void)d_ApBK; (void)d_Bdu; (void)d_dM;
     (void)alpha; (void)d_alpha; (void)d_JT; (void)d_dJexp; (void)d_xGoal; (void)d_err; (void)ld_x; (void)ld_u; (void)ld_P; (void)ld_p; (void)ld_AB;
     (void)ld_H; (void)ld_g; (void)ld_KT; (void)ld_du; (void)ld_d; (void)ld_A; (void)d_I; (void)d_Tbody;
-    (void)Q_EE1; (void)Q_EE2; (void)QF_EE1; (void)QF_EE2; (void)Q_EEV1; (void)Q_EEV2; (void)QF_EEV1; (void)QF_EEV2; (void)R_EE; (void)Q_xdEE;
-    (void)QF_xdEE; (void)Q_xEE; (void)QF_xEE;
+    (void)Q_EEV1; (void)Q_EEV2; (void)QF_EEV1; (void)QF_EEV2;
     Context* ctx = find(d_P);
     pddp_handle h = ctx->h;
-    if (Q1 != (T)_Q1 || Q2 != (T)_Q2 || R != (T)_R || QF1 != (T)_QF1 || QF2 != (T)_QF2) {
-        std::fprintf(stderr, "GPUassert: cost weights are fixed at allocateMemory_GPU time (define _Q1.._QF2 before the include)\n");
-        std::exit(1);
-    }
+    apply_cost<T>(ctx, Q1, Q2, R, QF1, QF2, Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE);
     double times[2] = {0, 0};
     int sweeps = 0;
     T* Jtmp = reinterpret_cast<T*>(ctx->Jtmp.data());

@@ -8,7 +8,8 @@
 //   loadTraj (trajVars and GPUVars overloads)                             utils/exampleUtils.cuh:49-58, 72-79
 //
 // so that the reference's lock-step loop (examples/WAFR_MPC_examples.cu:160-238, `testMPC_lockstep`) reads the same here.
-// Included by hostapi/config.hpp when MPC_MODE is 1.  Joint-space cost only (EE_COST 0): the goal is a full state.
+// Included by hostapi/config.hpp when MPC_MODE is 1.  With EE_COST 0 the goal gv->xGoal is a full state, with EE_COST 1 its first six
+// entries are the tool-point goal (x, y, z, roll, pitch, yaw) and gv->xTarget is the nominal-state target (zeros unless set).
 //
 // As in DDPWrappers.hpp, GPUVars' device pointers are the solver handle's own arrays (see there for which ones keep the
 // reference's layout); the handle lives in GPUVars::d_P's registry entry.  Bookkeeping kept exactly as the reference has it:
@@ -22,7 +23,7 @@
 //     iteration, :919,:941,:1001 -- it needs a host round trip per phase, this solver does not)
 //   * algTrace: J and alpha receive entries 0..iter of every solve, tTime the wall time of the call, initTime 0; the per-phase
 //     vectors stay empty unless the caller fills them from pddp_solve_ex (the sweeps of an MPC solve are graph replays)
-//   * use_cost_shift only acts on the end-effector cost in the reference (plants/cost_arm.cuh:212) and is ignored here.
+//   * use_cost_shift only acts on the end-effector cost (plants/cost_arm.cuh:212): final weights from knot N-1-shift on.
 #ifndef PDDP_HOSTAPI_MPCHELPERS_HPP
 #define PDDP_HOSTAPI_MPCHELPERS_HPP
 
@@ -184,8 +185,12 @@ void runiLQR_MPC_GPU(trajVars<T>* tv, GPUVars<T>* gv, matDimms* md, algTrace<T>*
     gettimeofday(&start, NULL);
     Context* ctx = find(gv->d_P);
     pddp_handle h = ctx->h;
-    if (cst->Q1 != (T)_Q1 || cst->Q2 != (T)_Q2 || cst->R != (T)_R || cst->QF1 != (T)_QF1 || cst->QF2 != (T)_QF2)
-        check(pddp_set_cost(h, cst->Q1, cst->Q2, cst->R, cst->QF1, cst->QF2), "pddp_set_cost");
+    apply_cost<T>(ctx, cst->Q1, cst->Q2, cst->R, cst->QF1, cst->QF2, cst->Q_EE1, cst->Q_EE2, cst->QF_EE1, cst->QF_EE2, cst->R_EE, cst->Q_xEE, cst->QF_xEE,
+                  cst->Q_xdEE, cst->QF_xdEE);
+#if EE_COST
+    check(pddp_set_ee_cost_shift(h, use_cost_shift ? 1 : 0), "pddp_set_ee_cost_shift");                       // finalCostShift, :876
+    check(pddp_set_array(h, "xTarget", gv->xTarget, STATE_SIZE * sizeof(T)), "xTarget");                       // d_xTarget, :612
+#endif
     int shift = get_time_steps_us_f(tv->t0_plant, tActual_plant);
     if (shift < 0) shift = 0;
     if (shift > NUM_TIME_STEPS - 2) shift = NUM_TIME_STEPS - 2;

@@ -133,9 +133,6 @@ typedef float algType;                //                                        
 #ifndef EE_COST
 #define EE_COST 0                     //                                                          config.cuh:165-167
 #endif
-#if EE_COST
-#error "the end-effector cost family (plants/cost_arm.cuh:206-389) is not provided yet (SURVEY.md section 8f, row N2)"
-#endif
 // joint-space cost weights (plants/cost_arm.cuh:97-103); the pendulum / cart-pole / quadrotor weights are fixed inside
 // the library exactly as plants/cost_{pend,cart,quad}.cuh fix them
 #ifndef _Q1
@@ -153,20 +150,65 @@ typedef float algType;                //                                        
 #ifndef _QF2
 #define _QF2 1000.0
 #endif
-// the end-effector weights exist only so that call sites that pass them keep compiling
-#define _Q_EE1 0.0
+// end-effector cost family (EE_COST 1; plants/cost_arm.cuh:104-115): xyz / rpy weights, control weight, nominal-state weights
+#ifndef _Q_EE1
+#define _Q_EE1 0.1
+#endif
+#ifndef _Q_EE2
 #define _Q_EE2 0.0
-#define _QF_EE1 0.0
+#endif
+#ifndef _R_EE
+#define _R_EE 0.0001
+#endif
+#ifndef _QF_EE1
+#define _QF_EE1 1000.0
+#endif
+#ifndef _QF_EE2
 #define _QF_EE2 0.0
+#endif
+#ifndef _Q_xdEE
+#define _Q_xdEE 0.1
+#endif
+#ifndef _QF_xdEE
+#define _QF_xdEE 1000.0
+#endif
+#ifndef _Q_xEE
+#define _Q_xEE 0.0
+#endif
+#ifndef _QF_xEE
+#define _QF_xEE 0.0
+#endif
+// the end-effector VELOCITY cost (USE_EE_VEL_COST, upstream: "broken at this time", dynamics_arm.cuh:67-69), the smooth-abs variant and
+// the joint-limit penalties are not provided; their weights exist only so that call sites that pass them keep compiling
 #define _Q_EEV1 0.0
 #define _Q_EEV2 0.0
 #define _QF_EEV1 0.0
 #define _QF_EEV2 0.0
-#define _R_EE 0.0
-#define _Q_xdEE 0.0
-#define _QF_xdEE 0.0
-#define _Q_xEE 0.0
-#define _QF_xEE 0.0
+#if defined(USE_EE_VEL_COST) && USE_EE_VEL_COST
+#error "USE_EE_VEL_COST is not provided (upstream marks it broken, plants/dynamics_arm.cuh:67-69)"
+#endif
+#if defined(USE_SMOOTH_ABS) && USE_SMOOTH_ABS
+#error "USE_SMOOTH_ABS is not provided"
+#endif
+#if defined(USE_LIMITS_FLAG) && USE_LIMITS_FLAG
+#error "USE_LIMITS_FLAG is not provided"
+#endif
+#if EE_COST && PLANT != 4
+#error "EE_COST belongs to the KUKA arm (PLANT 4)"
+#endif
+#ifndef EE_TYPE
+#define EE_TYPE 1                     // flange, no end effector                                  config.cuh:47, dynamics_arm.cuh:50-52
+#endif
+#if EE_TYPE == 0
+#define EE_ON_LINK_Z 0.0
+#elif EE_TYPE == 1
+#define EE_ON_LINK_Z 0.0635
+#elif EE_TYPE == 2
+#define EE_ON_LINK_Z 0.1524
+#endif
+#if EE_TYPE != 1
+#error "only EE_TYPE 1 (flange) is provided: the link-7 inertia of the robot tables includes its INERTIA_MODIFIER / WEIGHT_MODIFIER (dynamics_arm.cuh:53-65)"
+#endif
 
 // matrix dimensions (config.cuh:195-236), column-major, leading dimension = rows
 #define DIM_x_r STATE_SIZE

@@ -218,7 +218,7 @@ class Solver:
 
     # ---- teacher-forced hooks
     def _adtype(self, name):
-        return np.int32 if name in ("err", "alphaOut") else self.dtype
+        return np.int32 if name in ("err", "alphaOut", "tshift", "shift") else self.dtype
 
     def get(self, name):
         nb = C.c_size_t(0)

@@ -25,19 +25,6 @@
 
 namespace pddp {
 
-template <typename T> PDDP_HD T tatan2(T y, T x);
-template <> PDDP_HD float tatan2<float>(float y, float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return static_cast<float>(atan2(static_cast<double>(y), static_cast<double>(x)));   // as tsin/tcos: rounded once from double
-#else
-    return atan2f(y, x);
-#endif
-}
-template <> PDDP_HD double tatan2<double>(double y, double x) { return atan2(y, x); }
-template <typename T> PDDP_HD T tsqrt(T v);
-template <> PDDP_HD float tsqrt<float>(float v) { return sqrtf(v); }
-template <> PDDP_HD double tsqrt<double>(double v) { return sqrt(v); }
-
 template <typename T>
 struct EeScratch {
     T pos[6];        // tool point position and roll / pitch / yaw           (s_eePos)

@@ -10,6 +10,7 @@
 //              running cost as a chain over the lanes in the reference's summation order, arm_lg_dynamics, Euler step.
 #pragma once
 
+#include "ee_cost_lg.hpp"
 #include "fp.hpp"
 #include "plant_arm_lg.hpp"
 
@@ -48,6 +49,7 @@ struct FpLgArgs {
     unsigned oxg;                             // pb * NX
     T alpha, dt;
     T* dnorm;                                 // LDS [M] of this candidate
+    const T* xTarget; int tshift;             // end-effector cost: nominal-state target [B][14], finalCostShift of this problem
 };
 template <typename T>
 PDDP_HD FpLgArgs<T> fp_lg_args(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, T dt, T* dnorm) {
@@ -57,6 +59,7 @@ PDDP_HD FpLgArgs<T> fp_lg_args(const Buffers<T>& b, const Dims& dm, int pb, int 
     a.slotN = ((unsigned)pb * dm.A + a_idx) * dm.N; a.pbN = (unsigned)pb * dm.N;
     a.oxc = ((unsigned)pb * 2 + b.state[pb].cur) * dm.N * 14; a.oxg = (unsigned)pb * 14;
     a.alpha = b.alpha[a_idx]; a.dt = dt; a.dnorm = dnorm;
+    a.xTarget = b.xTarget; a.tshift = b.tshift[pb];
     return a;
 }
 
@@ -189,6 +192,86 @@ PDDP_HD void arm_lg_rollout_segment(const ArmLgConst<L>& c, const Dims& dm, cons
         }
         L::scatter(a.dnorm, [bInd](int) { return bInd; }, V(T(0)), last_lane);
     }
+}
+
+// The same rollout with the end-effector cost (forwardSimInner / forwardSimKern with EE_COST, fpHelpers.cuh:225-275, 279-301; fp.hpp's
+// `ee` branch): every segment runs NB steps -- the last step of the last segment only for the tool point of the final state --, the
+// cost is accumulated on the way (lane l = s_cost[l]) and the segment's sum s_cost[0] + ... + s_cost[6] goes to segJ[bInd].
+template <typename L, typename T>
+PDDP_HD void arm_lg_rollout_segment_ee(const ArmLgConst<L>& c, const Dims& dm, const FpLgArgs<T>& a, int bInd, const CostWeights<T>& cw,
+                                       T* segJ, bool init_rollout) {
+    using V = typename L::V;
+    constexpr int NX = 14, NU = 7, NP = 7;
+    const typename L::M act = L::all_true(), last_lane = L::lane_is(6), first_lane = L::lane_is(0);
+    const int NBk = dm.NB, kStart = bInd * NBk, N = dm.N;
+    V goal[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) goal[i] = L::gather_at(a.xGoal, a.oxg, [i](int) { return i; });
+    const V tq = L::gather_at(a.xTarget, a.oxg, [](int l) { return l; }), tv = L::gather_at(a.xTarget, a.oxg, [](int l) { return l + NP; });
+    const bool from_cur = (bInd == 0 || init_rollout);
+    const T* xstart = from_cur ? a.xb : a.xs;
+    const unsigned ostart = (from_cur ? a.oxc : a.slotN * NX) + NX * kStart;
+    V q = L::gather_at(xstart, ostart, [](int l) { return l; }), qd = L::gather_at(xstart, ostart, [](int l) { return l + NP; });
+    if (from_cur) {
+        L::scatter_at(a.xs, (a.slotN + kStart) * NX, [](int l) { return l; }, q, act);
+        L::scatter_at(a.xs, (a.slotN + kStart) * NX, [](int l) { return l + NP; }, qd, act);
+    }
+    ArmLgState<L> st;
+    V nxq, nxv, nK[NX], nuc, ndu;
+    auto fetch = [&](int kn) {
+        const unsigned oKT = (a.pbN + kn) * (NX * NU), oU = (a.pbN + kn) * NU;
+        nxq = L::gather_at(a.xb, a.oxc, [kn](int l) { return 14 * kn + l; });
+        nxv = L::gather_at(a.xb, a.oxc, [kn](int l) { return 14 * kn + l + 7; });
+#pragma unroll
+        for (int cc = 0; cc < NX; cc++) nK[cc] = L::gather_at(a.KT, oKT, [cc](int l) { return cc + l * 14; });
+        nuc = L::gather_at(a.ucur, oU, [](int l) { return l; });
+        ndu = L::gather_at(a.du, oU, [](int l) { return l; });
+    };
+    fetch(kStart);
+    V acc = V(T(0));
+    for (int k = 0; k < NBk; k++) {
+        const int kn = kStart + k;
+        const V dq = q - nxq, dv = qd - nxv;
+        V bc[14];
+        lg_bcast14<L>(bc, dq, dv);
+        V Kdx = nK[0] * bc[0];
+#pragma unroll
+        for (int cc = 1; cc < NX; cc++) Kdx = Kdx + nK[cc] * bc[cc];
+        V u = nuc;
+        u = u - (V(a.alpha) * ndu + Kdx);
+        if (kn + 1 < N) fetch(kn + 1);
+        L::scatter_at(a.us, (a.slotN + kn) * NU, [](int l) { return l; }, u, act);
+        const bool costed = (k < NBk - 1 || bInd == dm.M - 1);
+        const bool fin_ee = kn >= N - 1 - a.tshift;
+        V eeJ = V(T(0));
+        const V qdd = arm_lg_dynamics<L, true>(c, st, q, qd, u, [&](const V* Tw) {
+            if (costed) { V pos[6]; lg_tool_point<L, T>(cw, Tw, pos); eeJ = lg_ee_term<L, T>(cw, pos, goal, fin_ee); }   // meaningful in lane 6
+        });
+        if (costed) {
+            V cost = L::sel(first_lane, L::template bcast<6>(eeJ), V(T(0)));
+            acc = acc + lg_ee_joint_terms<L, T>(cw, q, qd, u, tq, tv, kn == N - 1, cost);
+        }
+        const V qn = q + V(a.dt) * qd, qdn = qd + V(a.dt) * qdd;       // Euler (utils/integrators.cuh:24-36)
+        if (k < NBk - 1) {
+            L::scatter_at(a.xs, (a.slotN + kn + 1) * NX, [](int l) { return l; }, qn, act);
+            L::scatter_at(a.xs, (a.slotN + kn + 1) * NX, [](int l) { return l + NP; }, qdn, act);
+            q = qn; qd = qdn;
+        } else if (bInd < dm.M - 1) {                        // defect against the next segment's start state
+            const int ks = (bInd + 1) * NBk;
+            const T* xnext = init_rollout ? a.xb : a.xs;
+            const unsigned onext = (init_rollout ? a.oxc : a.slotN * NX) + NX * ks;
+            const V eq = qn - L::gather_at(xnext, onext, [](int l) { return l; });
+            const V ev = qdn - L::gather_at(xnext, onext, [](int l) { return l + NP; });
+            L::scatter_at(a.ds, (a.slotN + ks - 1) * NX, [](int l) { return l; }, eq, act);
+            L::scatter_at(a.ds, (a.slotN + ks - 1) * NX, [](int l) { return l + NP; }, ev, act);
+            V sdef = lg_chain_sum<L>(V(T(0)), L::vabs(eq));
+            sdef = lg_chain_sum<L>(L::template bcast<6>(sdef), L::vabs(ev));
+            L::scatter(a.dnorm, [bInd](int) { return bInd; }, sdef, last_lane);
+        }
+    }
+    if (bInd == dm.M - 1) L::scatter(a.dnorm, [bInd](int) { return bInd; }, V(T(0)), last_lane);
+    const V Jseg = lg_chain_sum<L>(V(T(0)), acc);             // s_cost[0] + s_cost[1] + ... + s_cost[6], complete in lane 6
+    L::scatter(segJ, [bInd](int) { return bInd; }, Jseg, last_lane);
 }
 
 }  // namespace pddp

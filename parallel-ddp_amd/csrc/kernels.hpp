@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_sweep_lg(Buffers<T> b, Dims dm, T dt) {
 // k_fp_lg: grid (B), block 64 * ceil(A*M/8): group i of the block rolls out segment i / A of candidate i % A (the 8 groups
 // of a wave are 8 candidates of one segment: they read the same gains, which the memory pipeline coalesces); per-knot
 // costs meet in LDS and are tree-summed per candidate in the reference's pairing.  Dynamic LDS: A*(N+M) elements.
-template <typename T, int MAXT>
+template <typename T, int MAXT, bool EE = false>
 __global__ __launch_bounds__(MAXT, 1) void k_fp_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int pb = blockIdx.x;
@@ -106,12 +106,14 @@ __global__ __launch_bounds__(MAXT, 1) void k_fp_lg(Buffers<T> b, Dims dm, CostWe
         ArmLgConst<LgDevice<T>> c;
         arm_lg_load_const<LgDevice<T>, T>(c, &lds_model);
         const FpLgArgs<T> a = fp_lg_args<T>(b, dm, pb, a_idx, dt, dnorm + a_idx * dm.M);
-        arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
+        if constexpr (EE) arm_lg_rollout_segment_ee<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);   // segment sums in cost_k[a][0..M)
+        else arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
     }
     __syncthreads();
     const Wave w = this_wave();
     const int wave_id = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-    for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves) fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M);
+    for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves)
+        fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M, EE ? cost_k + (size_t)a_idx * dm.N : nullptr);
 }
 // k_bp_lg: grid (ceil(B*M/8)), block 64 -- one 8-lane group per (problem, block of knots) (bp_lg.hpp); 8 x 2.4 KB of LDS.
 template <typename T>
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64) void k_bp_lg(Buffers<T> b, Dims dm, int batch) 
 }
 
 // k_nis_lg: grid (ceil(N/32), B), block 256 -- one 8-lane group per knot, 32 knots per workgroup (nis_lg.hpp).
-template <typename T>
+template <typename T, bool EE = false>
 __global__ __launch_bounds__(256, 2) void k_nis_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode) {
     __shared__ ArmModel<T> lds_model;
     {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void k_nis_lg(Buffers<T> b, Dims dm, CostWe
     if (k >= dm.N || LgDevice<T>::lane() == 7) return;       // lane 7 of every group stays inactive (lanegroup.hpp)
     ArmLgConst<LgDevice<T>> c;
     arm_lg_load_const<LgDevice<T>, T>(c, &lds_model);
-    arm_lg_nis_body<LgDevice<T>, T>(c, b, dm, cw, dt, mode, k, pb);
+    arm_lg_nis_body<LgDevice<T>, T, EE>(c, b, dm, cw, dt, mode, k, pb);
 }
 
 // forward dynamics (grad = 0: out qdd[count][7]) or its gradient (grad = 1: out dqdd[count][7*21]) of `count` (x,u) samples,

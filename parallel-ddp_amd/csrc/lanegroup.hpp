@@ -102,6 +102,8 @@ struct LgDevice {
     static __device__ __forceinline__ V vcos(V v) { return tcos<T>(v); }
     static __device__ __forceinline__ void vsincos(V v, V& sn, V& cs) { double s_, c_; sincos(static_cast<double>(v), &s_, &c_); sn = static_cast<T>(s_); cs = static_cast<T>(c_); }
     static __device__ __forceinline__ V vabs(V v) { return tabs(v); }
+    static __device__ __forceinline__ V vatan2(V y, V x) { return tatan2<T>(y, x); }
+    static __device__ __forceinline__ V vsqrt(V v) { return tsqrt<T>(v); }
     static __device__ __forceinline__ M all_true() { return true; }
     // keeps the instruction scheduler from hoisting the next block's loads over this point (register pressure)
     static __device__ __forceinline__ void sched_fence() { __asm__ volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }

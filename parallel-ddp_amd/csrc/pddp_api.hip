@@ -98,6 +98,7 @@ struct Solver : SolverBase {
     // backward pass of the arm: the lane-group kernel carries 8 (problem, block) pairs per wave and wins once the GPU is
     // full; the wave-cooperative kernel has the shorter critical path for a handful of problems.  PDDP_BP=lg|coop overrides.
     bool bp_lane_groups = false;
+    bool fp_coop = false;          // PDDP_FP=coop
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
@@ -130,6 +131,7 @@ struct Solver : SolverBase {
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
+        if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); }
         sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init;
@@ -216,7 +218,7 @@ struct Solver : SolverBase {
     void launch_fp(hipStream_t s, int init_rollout) {
         const unsigned B = cfg.batch;
         bool lane_groups = false;
-        if constexpr (P::PLANT == 4) lane_groups = !cfg.ee_cost;   // the end-effector cost runs on the wave-cooperative kernels
+        if constexpr (P::PLANT == 4) lane_groups = !fp_coop;       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests)
         if (!lane_groups) {
             hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
             return;
@@ -226,7 +228,11 @@ struct Solver : SolverBase {
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
-            if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            if (cfg.ee_cost) {
+                if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256, true>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+                else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512, true>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+                else hipLaunchKernelGGL((k_fp_lg<T, 1024, true>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            } else if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
             else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
             else hipLaunchKernelGGL((k_fp_lg<T, 1024>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
         }
@@ -234,7 +240,11 @@ struct Solver : SolverBase {
     void launch_nis(hipStream_t s, int mode) {
         const unsigned B = cfg.batch;
         if constexpr (P::PLANT == 4) {
-            if (!cfg.ee_cost) { hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode); return; }
+            if (!fp_coop) {
+                if (cfg.ee_cost) hipLaunchKernelGGL((k_nis_lg<T, true>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
+                else hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
+                return;
+            }
         }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }

@@ -92,6 +92,20 @@ template <> PDDP_HD float tcos<float>(float v) {
 }
 template <> PDDP_HD double tsin<double>(double v) { return sin(v); }
 template <> PDDP_HD double tcos<double>(double v) { return cos(v); }
+// atan2 / sqrt of the end-effector cost family (ee_cost.hpp): atan2 like sin/cos above, sqrt is correctly rounded on both sides
+template <typename T> PDDP_HD T tatan2(T y, T x);
+template <> PDDP_HD float tatan2<float>(float y, float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<float>(atan2(static_cast<double>(y), static_cast<double>(x)));   // as tsin/tcos: rounded once from double
+#else
+    return atan2f(y, x);
+#endif
+}
+template <> PDDP_HD double tatan2<double>(double y, double x) { return atan2(y, x); }
+template <typename T> PDDP_HD T tsqrt(T v);
+template <> PDDP_HD float tsqrt<float>(float v) { return sqrtf(v); }
+template <> PDDP_HD double tsqrt<double>(double v) { return sqrt(v); }
+
 template <typename T> PDDP_HD T tabs(T v) { return v < T(0) ? -v : v; }
 template <typename T> PDDP_HD T tmax(T a, T b) { return a > b ? a : b; }
 template <typename T> PDDP_HD T tmin(T a, T b) { return a < b ? a : b; }

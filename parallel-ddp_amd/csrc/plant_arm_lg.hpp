@@ -78,12 +78,9 @@ struct ArmLgState {
     typename L::V Minv[7];        // row `lane` of M^-1
 };
 
-// q, qd, u: this lane's joint position, velocity, torque.  Returns this lane's qdd.
-// PACK: do the 6x6 products two rows at a time with packed instructions (v_pk_mul_f32 / v_pk_add_f32).  Same operations per element;
-// it shortens the rollout step by ~14 % but needs even-aligned register pairs, which costs the gradient kernel its second wave per
-// SIMD -- so the forward pass uses PACK = true and next-iteration setup PACK = false.
-template <typename L, bool PACK = false>
-PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st, typename L::V q, typename L::V qd, typename L::V u) {
+// World frame of every link: Tw[3*col + row], rows 0..2 of T_i = T_{i-1} Tb_i(q_i), Tb = F Rz(q) (lane = link).
+template <typename L>
+PDDP_HD void arm_lg_world_frames(const ArmLgConst<L>& c, typename L::V q, typename L::V* Tw) {
     using V = typename L::V;
     using T = typename L::Scalar;
     V sn, cs;
@@ -101,7 +98,6 @@ PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st,
     // ---- world transforms T_i = T_{i-1} Tb_i.  Every sweep EVERY lane recomputes from its predecessor's current value: lanes
     // below s already hold (and reproduce, bit for bit) their final value, lane s becomes final in sweep s.  Lane 0's
     // predecessor is the identity (up() gives 0, the diagonal gets +1), and I * Tb_0 = Tb_0 exactly.
-    V Tw[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) Tw[e] = Tb[e];
     const V e0 = L::sel(L::lane_is(0), V(T(1)), V(T(0)));
@@ -122,6 +118,23 @@ PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st,
                 Tw[3 * ky + kx] = val;
             }
     }
+}
+
+struct LgNoHook { template <typename V> PDDP_HD void operator()(const V*) const {} };
+
+// q, qd, u: this lane's joint position, velocity, torque.  Returns this lane's qdd.
+// PACK: do the 6x6 products two rows at a time with packed instructions (v_pk_mul_f32 / v_pk_add_f32).  Same operations per element;
+// it shortens the rollout step by ~14 % but needs even-aligned register pairs, which costs the gradient kernel its second wave per
+// SIMD -- so the forward pass uses PACK = true and next-iteration setup PACK = false.
+// frame_hook(Tw): called once with the link frames (the end-effector cost reads the tool point off lane 6 there, ee_cost_lg.hpp).
+template <typename L, bool PACK = false, typename Hook = LgNoHook>
+PDDP_HD typename L::V arm_lg_dynamics(const ArmLgConst<L>& c, ArmLgState<L>& st, typename L::V q, typename L::V qd, typename L::V u,
+                                      Hook frame_hook = Hook()) {
+    using V = typename L::V;
+    using T = typename L::Scalar;
+    V Tw[12];
+    arm_lg_world_frames<L>(c, q, Tw);
+    frame_hook(Tw);
     // R(row, col) = Tw[3*col + row]; p = Tw[9..11]
     // ---- Pluecker transform TA = [R' 0; K R'],  K = skew(-R'p) R'   (Rt[row][col] = R(col,row); Kb[row][col])
     V tt[3];

@@ -40,6 +40,8 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     return 0;
 }
 
+static bool fp_coop() { const char* v = std::getenv("PDDP_FP"); return v && std::string(v) == "coop"; }   // PDDP_FP=coop: wave-cooperative forward pass / setup (comparison tests)
+
 struct Base {
     pddp_config cfg; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
     virtual ~Base() {}
@@ -121,13 +123,16 @@ struct Sim : Base {
                 if (!fp_active<T>(b, dm, pb)) continue;
                 for (int a = 0; a < cfg.A; a++) {
                     const FpArgs<T> fa = fp_args<P, T>(b, dm, pb, a, dt, segx.data(), dnorm.data(), segJ.data());
-                    if constexpr (P::PLANT == 4) if (!cfg.ee_cost) {   // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
+                    if constexpr (P::PLANT == 4) if (!fp_coop()) {   // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
                         using L = LgHost<T>;
                         ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                         const FpLgArgs<T> la = fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data());
                         if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, la);
-                        for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), false);
-                        fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data());
+                        for (int sg = 0; sg < cfg.M; sg++) {
+                            if (cfg.ee_cost) arm_lg_rollout_segment_ee<L, T>(c, dm, la, sg, cw, segJ.data(), false);
+                            else arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), false);
+                        }
+                        fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data(), cfg.ee_cost ? segJ.data() : nullptr);
                         continue;
                     }
                     if (cfg.M > 1) forward_sweep<P, T>(w, sw, dm, fa);
@@ -139,10 +144,13 @@ struct Sim : Base {
         } else if (ph == PDDP_PHASE_LS) {
             for (int pb = 0; pb < B; pb++) ls_body<T>(b, dm, sp, pb, bench);
         } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
-            if constexpr (P::PLANT == 4) if (!cfg.ee_cost) {   // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
+            if constexpr (P::PLANT == 4) if (!fp_coop()) {   // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
                 using L = LgHost<T>;
                 ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
-                for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) arm_lg_nis_body<L, T>(c, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+                for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) {
+                    if (cfg.ee_cost) arm_lg_nis_body<L, T, true>(c, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+                    else arm_lg_nis_body<L, T, false>(c, b, dm, cw, dt, ph == PDDP_PHASE_INIT_NIS, k, pb);
+                }
                 return;
             }
             static NisScratch<P, INTEG, T> s;
@@ -174,12 +182,15 @@ struct Sim : Base {
                 init_cost_body<P, T>(w, cost_k.data(), b, dm, cw, sp, ifd, 1, (int)pb, cfg.ee_cost ? 1 : 0, 0);
                 const FpArgs<T> fa = fp_args<P, T>(b, dm, (int)pb, 0, dt, segx.data(), dnorm.data(), segJ.data());
                 bool lane_groups = false;
-                if constexpr (P::PLANT == 4) lane_groups = !cfg.ee_cost;
+                if constexpr (P::PLANT == 4) lane_groups = !fp_coop();
                 if constexpr (P::PLANT == 4) if (lane_groups) {
                     using L = LgHost<T>;
                     ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                     const FpLgArgs<T> la = fp_lg_args<T>(b, dm, (int)pb, 0, dt, dnorm.data());
-                    for (int sg = 0; sg < cfg.M; sg++) arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), true);
+                    for (int sg = 0; sg < cfg.M; sg++) {
+                        if (cfg.ee_cost) arm_lg_rollout_segment_ee<L, T>(c, dm, la, sg, cw, segJ.data(), true);
+                        else arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), true);
+                    }
                 }
                 if (!lane_groups) {
                     for (int sg = 0; sg < cfg.M; sg++) rollout_seed_segment<P, T>(w, dm, fa, sg);

@@ -61,6 +61,8 @@ struct LgHost {
     static V vcos(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tcos<T>(v.l[i]); return r; }
     static void vsincos(const V& v, V& sn, V& cs) { sn = vsin(v); cs = vcos(v); }
     static V vabs(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tabs(v.l[i]); return r; }
+    static V vatan2(const V& y, const V& x) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tatan2<T>(y.l[i], x.l[i]); return r; }
+    static V vsqrt(const V& v) { V r; for (int i = 0; i < kLg; i++) r.l[i] = tsqrt<T>(v.l[i]); return r; }
     static T lane_value(const V& v, int j) { return v.l[j]; }     // host-side extraction (tests)
     static M all_true() { M m; for (int i = 0; i < kLg; i++) m.l[i] = true; return m; }
     static void sched_fence() {}

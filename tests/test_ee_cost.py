@@ -236,8 +236,9 @@ def test_end_effector_cost_at_the_mpc_example_shape_batch():
     equals the same problem solved alone (bitwise), and the costs decrease."""
     kw = dict(N=64, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=10, ee_cost=1, ignore_max_rho_exit=0)
     B = 64
+    rng = np.random.default_rng(2024)      # own stream: the inputs must not depend on which tests ran before
     x0 = np.zeros((B, 64, 14), np.float32); x0[:, :, 1] = 0.7; x0[:, :, 3] = -0.8; x0[:, :, 5] = 0.75
-    x0 += RNG.normal(0, 0.01, (B, 1, 14)).astype(np.float32)
+    x0 += rng.normal(0, 0.01, (B, 1, 14)).astype(np.float32)
     u0 = np.full((B, 64, 7), 0.01, np.float32)
     t = np.linspace(0, 2 * np.pi, B, endpoint=False)
     xg = np.zeros((B, 14), np.float32); xg[:, 0] = 0.5 + 0.1 * np.cos(t); xg[:, 1] = 0.2 * np.sin(t); xg[:, 2] = 0.6 + 0.1 * np.sin(2 * t)
@@ -248,6 +249,7 @@ def test_end_effector_cost_at_the_mpc_example_shape_batch():
         o1 = s1.solve(x0[b], u0[b], xg[b])
         assert np.array_equal(o1["Jout"][0], out["Jout"][b]) and np.array_equal(o1["x"][0], out["x"][b])
     it = out["iters"]
-    assert all(out["Jout"][b][it[b]] <= out["Jout"][b][0] for b in range(B))
+    # (a rejected iteration records prevJ, which carries the 2 TOL_COST epsilon of initAlgGPU until the first acceptance, nisInitHelpers.cuh:393)
+    assert all(out["Jout"][b][it[b]] <= out["Jout"][b][0] + 3 * kw["tol_cost"] for b in range(B))
     improved = sum(out["Jout"][b][it[b]] < 0.98 * out["Jout"][b][0] for b in range(B))
     assert improved >= B // 4, (improved, [float(out["Jout"][b][0]) for b in range(4)], [float(out["Jout"][b][it[b]]) for b in range(4)])

@@ -104,3 +104,36 @@ def test_whole_solve_identical_with_either_backward_pass(backend):
     assert np.array_equal(outs["lg"]["x"], outs["coop"]["x"]) and np.array_equal(outs["lg"]["KT"], outs["coop"]["KT"])
     assert np.array_equal(outs["wide"]["Jout"], outs["coop"]["Jout"]) and np.array_equal(outs["wide"]["KT"], outs["coop"]["KT"])
     assert outs["lg"]["Jout"][0][10] < outs["lg"]["Jout"][0][0]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("rollout", [0, 1])
+def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(backend, rollout):
+    """The end-effector cost family (ee_cost_lg.hpp vs ee_cost.hpp): tool point, Jacobian, Gauss-Newton Hessian, in-rollout cost accumulation --
+    whole float32 solves on the lane-group kernels and on the wave-cooperative ones (PDDP_FP=coop) give the same bits."""
+    import os
+    kw = dict(N=32, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=8, ee_cost=1, ignore_max_rho_exit=0, batch=3,
+              Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)
+    B, N = 3, 32
+    x0 = np.zeros((B, N, 14), np.float32); x0[:, :, 1] = 0.7; x0[:, :, 3] = -0.8; x0[:, :, 5] = 0.75
+    x0 += RNG.normal(0, 0.02, (B, 1, 14)).astype(np.float32)
+    u0 = np.full((B, N, 7), 0.01, np.float32)
+    xg = np.zeros((B, 14), np.float32); xg[:, :6] = [0.45, 0.15, 0.75, 0.1, -0.2, 0.3]; xg[:, 1] += np.float32(0.05) * np.arange(B, dtype=np.float32)
+    outs, arrs = {}, {}
+    for mode in ("lg", "coop"):
+        if mode == "coop":
+            os.environ["PDDP_FP"] = "coop"
+        try:
+            s = make_solver(backend, 4, **kw)
+            s.load(x0, u0, xg, forward_rollout=rollout)
+            arrs[mode] = {k: s.get(k).copy() for k in ("H", "g", "AB", "costk")}
+            outs[mode] = s.solve(x0, u0, xg, forward_rollout=rollout)
+        finally:
+            os.environ.pop("PDDP_FP", None)
+    for k in ("H", "g", "AB"):
+        assert np.array_equal(arrs["lg"][k], arrs["coop"][k]), k
+    if not rollout:
+        assert np.array_equal(arrs["lg"]["costk"], arrs["coop"]["costk"])
+    for k in ("Jout", "alphaOut", "x", "u", "KT"):
+        assert np.array_equal(outs["lg"][k], outs["coop"][k]), k
+    assert any(outs["lg"]["alphaOut"][b][1: outs["lg"]["iters"][b] + 1].max() >= 0 for b in range(B))

@@ -58,6 +58,9 @@ typedef struct pddp_config {
     double Q_EE1, Q_EE2, QF_EE1, QF_EE2;   /* _Q_EE1 (xyz) _Q_EE2 (rpy) and the final ones                                   */
     double R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE;   /* control weight; nominal-state weights on q and qd (target: array "xTarget") */
     double ee_on_link_z;  /* EE_ON_LINK_Z: tool point on the last link's z axis (0.0635 = EE_TYPE 1, flange)   dynamics_arm.cuh:48-65 */
+    int ee_initial_cost_fix; /* 0 (default) = the reference: an MPC solve with the EE cost reads its initial cost from d_JT[alphaIndex]
+                              * (nisInitHelpers.cuh:392), i.e. the cost of ONE knot whenever the previous solve ended on a shortened step, and
+                              * then rejects every iteration; 1 = always the whole trajectory's cost (d_JT[0]).  Not a reference behaviour. */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */

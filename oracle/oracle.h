@@ -12,6 +12,9 @@
  * SURVEY.md §8(c) / Appendix E (values the survey session measured from the reference's host
  * instantiation): see tests/golden/survey_kat.json and tests/test_oracle_pins.py.
  *
+ * The end-effector cost family (ee_cost = 1; added for SURVEY.md section 8f row N2) is PARITY UNPINNED: the survey holds no reference
+ * outputs for it.  Its restatement follows the reference's index expressions and is cross-checked analytically only (tests/test_ee_cost.py).
+ *
  * Two instantiations are exported: suffix _f32 (algType float, config.cuh:74) and _f64.
  */
 #ifndef PDDP_ORACLE_H

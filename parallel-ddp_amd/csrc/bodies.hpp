@@ -147,7 +147,7 @@ PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const
         const size_t ho = (size_t)pb * (sp.max_iter + 2);
         if (rollout) J = b.J[(size_t)pb * dm.A];
         else {
-            const int a0 = b.state[pb].alphaIndex;
+            const int a0 = sp.ee_initial_cost_fix ? 0 : b.state[pb].alphaIndex;
             PDDP_FOR(k, N) cost_k[k] = b.costk[(size_t)pb * N + k];
             wsync();
             const T Jk = (a0 > 0 && a0 < N) ? cost_k[a0] : T(0);

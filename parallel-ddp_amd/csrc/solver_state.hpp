@@ -45,6 +45,7 @@ struct SolverParams {    // read-only per launch (reference macros, config.cuh)
     double exp_red_min, exp_red_max;   //                  :117-122
     double max_defect;          // MAX_DEFECT_SIZE         :124-126
     double rho_init;            // RHO_INIT                :99-101
+    int ee_initial_cost_fix;    // pddp_config.ee_initial_cost_fix (not a reference macro)
 };
 constexpr double kRhoMax = 10000000.0, kRhoMin = 0.01, kRhoFactor = 1.25;   // config.cuh:102-104
 

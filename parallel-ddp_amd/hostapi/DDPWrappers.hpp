@@ -44,6 +44,9 @@
 #ifndef PDDP_DEVICE
 #define PDDP_DEVICE 0
 #endif
+#ifndef PDDP_EE_INITIAL_COST_FIX
+#define PDDP_EE_INITIAL_COST_FIX 0   // 1: pddp_config.ee_initial_cost_fix (include/pddp.h) -- NOT the reference's behaviour
+#endif
 
 namespace pddp_hostapi {
 
@@ -105,6 +108,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     c.Q1 = _Q1; c.Q2 = _Q2; c.R = _R; c.QF1 = _QF1; c.QF2 = _QF2;
     c.ee_cost = EE_COST; c.Q_EE1 = _Q_EE1; c.Q_EE2 = _Q_EE2; c.QF_EE1 = _QF_EE1; c.QF_EE2 = _QF_EE2; c.R_EE = _R_EE;
     c.Q_xEE = _Q_xEE; c.QF_xEE = _QF_xEE; c.Q_xdEE = _Q_xdEE; c.QF_xdEE = _QF_xdEE; c.ee_on_link_z = EE_ON_LINK_Z;
+    c.ee_initial_cost_fix = PDDP_EE_INITIAL_COST_FIX;
     Context* ctx = new Context();
     check(pddp_create(&c, &ctx->h), "allocateMemory_GPU");
     pddp_handle h = ctx->h;

@@ -24,6 +24,7 @@ class PddpConfig(C.Structure):
         ("ee_cost", C.c_int), ("ee_cost_shift", C.c_int),
         ("Q_EE1", C.c_double), ("Q_EE2", C.c_double), ("QF_EE1", C.c_double), ("QF_EE2", C.c_double), ("R_EE", C.c_double),
         ("Q_xEE", C.c_double), ("QF_xEE", C.c_double), ("Q_xdEE", C.c_double), ("QF_xdEE", C.c_double), ("ee_on_link_z", C.c_double),
+        ("ee_initial_cost_fix", C.c_int),
     ]
 
 
@@ -41,15 +42,16 @@ class DeviceArray:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": dtype.str, "data": (ptr, False), "version": 2}
 
 
-def algorithmic_bytes(n, m, N, A, M, s):
+def algorithmic_bytes(n, m, N, A, M, s, ee_cost=False):
     """Algorithmic HBM bytes of ONE problem per launch of each sweep kernel: every array read/written once per phase
     that consumes/produces it, in the reference's phase decomposition (DESIGN.md "roofline").
-    k_fp = sweep + rollout + cost of all A candidates (the three reference kernels it fuses)."""
+    k_fp = sweep + rollout + cost of all A candidates (the three reference kernels it fuses).  ee_cost: the reference accumulates the
+    cost inside the rollout (fpHelpers.cuh:259-265), so there is no separate pass over x, u."""
     nm = n + m
     bp = (n * nm + nm * nm + nm) * (N - 1) + n * n + n + (M - 1) * (n * n + 4 * n) + (2 * n * n + n * m + 2 * n + m) * (N - 1)
     sweep = ((n * n + n) * (N - 1) + 3 * n * N + n * (M - 1)) if M > 1 else 0
     sim = (n * m + m) * (N - 1) + 3 * n * N + 2 * m * (N - 1) + n * (M - 1)
-    cost = n * N + m * (N - 1)
+    cost = 0 if ee_cost else n * N + m * (N - 1)
     nis = 2 * (n * N + m * (N - 1)) + n * nm * (N - 1) + (nm * nm + nm) * N + 2 * (n * n + n) * N + A * (2 * n + m) * N + (2 * n + m) * N + n * N
     return {"k_bp": bp * s, "k_fp": A * (sweep + sim + cost) * s, "k_ls": (3 * A + 2 * M + 16) * s, "k_nis": nis * s}
 

@@ -184,6 +184,26 @@ def test_receding_horizon_with_the_end_effector_cost(backend, cost_shift):
     assert step >= 1
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_initial_cost_fix_flag_is_opt_in_and_only_changes_the_quirk(backend):
+    """pddp_config.ee_initial_cost_fix = 1: the warm-started solve after a solve that ended on a shortened step starts from the whole
+    trajectory's cost and makes progress; with the default 0 it reproduces the reference (previous test)."""
+    kw = {**EE, "max_iter": 8}
+    N = kw["N"]
+    x0, u0, xg = start(N, np.float64)
+    res = {}
+    for fix in (0, 1):
+        s = make_solver(backend, 4, dtype=1, ee_initial_cost_fix=fix, **kw)
+        s.load(x0, u0, xg)
+        first = s.mpc_solve(x0[0], xg, 0, clear_vars=1, max_iter=8)
+        assert first["alphaOut"][0][first["iters"][0]] > 0          # ends on a shortened step: the quirk's precondition
+        res[fix] = (first, s.mpc_solve(first["x"][0][1], xg, 1, max_iter=4))
+    assert np.array_equal(res[0][0]["Jout"], res[1][0]["Jout"])        # the first solve (alphaIndex = 0 at its start) is untouched
+    q, f = res[0][1], res[1][1]
+    assert q["success"][0] == 0 and q["Jout"][0][0] < 1.0              # one knot's cost
+    assert f["success"][0] == 1 and f["Jout"][0][0] > 1.0 and f["Jout"][0][f["iters"][0]] < f["Jout"][0][0]
+
+
 def _replay(kw, plan, xacts, xg, x0, u0):
     o = OracleMpc(default_cfg(4, cores=8, spawn_threads=0, **kw), np.float64)
     o.set_traj(x0.ravel(), u0.ravel())

@@ -134,6 +134,17 @@ int pddp_set_ee_cost_shift(pddp_handle h, int on);
  * the cost gradient and Hessian of the current trajectory are rebuilt there.  Arm plant only (the other plants' weights are
  * constants of plants/cost_{pend,cart,quad}.cuh). */
 int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2);
+/* ---- the lock-step experiment around the solver ------------------------- */
+/* simulateForward<T, SUBSTEPS> (examples/WAFR_MPC_examples.cu:111-139): the simulated robot of the lock-step MPC experiment.  Starting
+ * from xActual at plant time t0_us (the plan's t0), integrates the plant IN DOUBLE for elapsed_us in `substeps` steps under the trajectory
+ * runner's control law getHardwareControls (MPCHelpers.cuh:819-858: zero-order hold on u and K, first-order hold on the nominal state,
+ * evaluated in the plan's precision).  x [N][n], u [N][m], KT [N][n*m] = the plan (host, the handle's dtype); xActual_inout [n].
+ * goal_xyz (3 values, arm only, may be NULL): *avg_err = (sum of |tool point - goal| over the substeps' start states and the final
+ * state) / substeps, sic (:137-138).  *failed = 1 when the time leaves the plan (k >= N-2): state untouched, error 0 (:129-130). */
+int pddp_simulate(pddp_handle h, const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps,
+                  const void* goal_xyz, void* xActual_inout, double* avg_err, int* failed);
+/* compute_eePos_scratch (plants/dynamics_arm.cuh:1953-1960): tool point (x, y, z, roll, pitch, yaw) of `count` states [count][n] -> [count][6]. */
+int pddp_ee_pos(pddp_handle h, int count, const void* x, void* eePos);
 /* The HIP stream every kernel of this handle is enqueued on (a hipStream_t). */
 int pddp_stream(pddp_handle h, void** hip_stream);
 

@@ -103,6 +103,10 @@ typedef struct ora_result {
     void ora_ee_pos_##SUF(const ora_cfg *c, const REAL *x, REAL *eePos, REAL *deePos);                        \
     REAL ora_ee_cost_##SUF(const ora_cfg *c, const REAL *xk, const REAL *uk, const REAL *goal, int k, int tshift); \
     void ora_ee_cost_grad_##SUF(const ora_cfg *c, REAL *Hk, REAL *gk, const REAL *xk, const REAL *uk, const REAL *goal, int k, int tshift); \
+    /* lock-step experiment (examples/WAFR_MPC_examples.cu:111-139, MPCHelpers.cuh:819-858): the simulated robot -- plan x,u,KT of REAL, */ \
+    /* plant in double; returns the average tracking error (0 and *failed = 1 when the time leaves the plan)                             */ \
+    REAL ora_simulate_##SUF(const ora_cfg *c, const REAL *x, const REAL *u, const REAL *KT, double t0_us, double elapsed_us,          \
+                            int substeps, const REAL *goal_xyz, REAL *xActual, int *failed);                                          \
     /* MPC wrapper, GPU semantics (DDPHelpers/MPCHelpers.cuh:602-655 load, :864-1016 loop, :755-774 store): a    */ \
     /* persistent state is seeded with a trajectory, then every solve shifts it by `shift` knots, rolls it out  */ \
     /* from the measured state and iterates; returns `iter`, *success = an accepted step with alpha index > 0   */ \
@@ -113,6 +117,9 @@ typedef struct ora_result {
     int ora_gs_mpc_solve_##SUF(void *h, const REAL *xActual, const REAL *xGoal, int shift, int clear_vars,    \
                                int full_rollout, int ignoreFirstDefect, int max_iter, REAL *Jout,            \
                                int *alphaOut, int *success);
+
+/* the double-precision plant step the simulator uses from either instantiation (exported by ora_f64.c) */
+void ora_internal_integrator_f64(const ora_cfg *c, double dt, double *xkp1, const double *x, const double *u);
 
 ORA_DECL(f32, float)
 ORA_DECL(f64, double)

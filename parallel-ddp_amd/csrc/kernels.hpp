@@ -10,6 +10,7 @@
 #include "nis_lg.hpp"
 #include "bp_lg.hpp"
 #include "mpc.hpp"
+#include "sim.hpp"
 
 namespace pddp {
 
@@ -230,6 +231,21 @@ __global__ __launch_bounds__(64) void k_plant_eval(const void* model, int what, 
         else { integrator_gradient<P, INTEG, T>(w, s.plant, s.pgrad, s.integ, out + (size_t)i * NX * NM, s.x, s.u, dt); }
         wsync();
     }
+}
+
+// ---------------------------------------------------------------------------------------------- lock-step plant simulator (sim.hpp): one wave
+template <typename PD, int INTEG, typename T>
+__global__ __launch_bounds__(64) void k_plant_sim(const void* model, PlantSimArgs<T> a) {
+    __shared__ PlantSimScratch<PD, T> s;
+    plant_sim_body<PD, INTEG, T>(this_wave(), s, model, a);
+}
+// tool point of `count` states: grid (count), block 64
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_ee_pos(const void* model, T ee_z, const T* x, T* out) {
+    __shared__ typename P::Scratch plant;
+    __shared__ EeScratch<T> ee;
+    __shared__ T xs[P::NX], us[P::NU], qdd[P::NPOS];
+    ee_pos_body<P, T>(this_wave(), plant, ee, xs, us, qdd, model, ee_z, x + (size_t)blockIdx.x * P::NX, out + (size_t)blockIdx.x * 6);
 }
 
 }  // namespace pddp

@@ -64,6 +64,9 @@ struct SolverBase {
     virtual int run_phase(int phase) = 0;
     virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
     virtual int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) = 0;
+    virtual int simulate(const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal, void* xActual,
+                         double* avg_err, int* failed) = 0;
+    virtual int ee_pos(int count, const void* x, void* out) = 0;
     virtual int set_cost(double Q1, double Q2, double R, double QF1, double QF2) = 0;
     virtual int set_cost_ee(const double* v) = 0;
     virtual int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
@@ -442,6 +445,53 @@ struct Solver : SolverBase {
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
     }
+    // ---- lock-step experiment helpers
+    using PD = typename P::template Rebind<double>;
+    void* model_d = nullptr;                           // the plant's constants in double (the simulated robot runs in double)
+    int simulate(const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal, void* xActual,
+                 double* avg_err, int* failed) override {
+        if (substeps < 1 || !(elapsed_us >= 0)) return fail(PDDP_EINVAL, "pddp_simulate: substeps >= 1 and elapsed_us >= 0");
+        const size_t N = cfg.N;
+        if (!model_d) {
+            typename PD::Model hm; fill_model(hm, cfg);
+            HIPCHK(hipMalloc(&model_d, sizeof(hm))); allocs.push_back(model_d);
+            HIPCHK(hipMemcpy(model_d, &hm, sizeof(hm), hipMemcpyHostToDevice));
+        }
+        const size_t nx = N * NX, nu = N * NU, nk = N * NX * NU;
+        T* buf = nullptr; double* dout = nullptr;
+        HIPCHK(hipMalloc((void**)&buf, (nx + nu + nk + NX + 3) * sizeof(T))); HIPCHK(hipMalloc((void**)&dout, 2 * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(buf, x, nx * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(buf + nx, u, nu * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(buf + nx + nu, KT, nk * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(buf + nx + nu + nk, xActual, NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (goal) HIPCHK(hipMemcpyAsync(buf + nx + nu + nk + NX, goal, 3 * sizeof(T), hipMemcpyHostToDevice, stream));
+        PlantSimArgs<T> a;
+        a.x = buf; a.u = buf + nx; a.KT = buf + nx + nu; a.N = cfg.N; a.step_us = cfg.total_time / (cfg.N - 1) * 1000.0 * 1000.0;
+        a.t0_us = t0_us; a.elapsed_us = elapsed_us; a.substeps = substeps; a.goal = goal ? buf + nx + nu + nk + NX : nullptr; a.ee_z = cfg.ee_on_link_z;
+        a.xActual = buf + nx + nu + nk; a.out = dout;
+        hipLaunchKernelGGL((k_plant_sim<PD, INTEG, T>), dim3(1), dim3(64), 0, stream, (const void*)model_d, a);
+        HIPCHK(hipGetLastError());
+        double ho[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(ho, dout, sizeof(ho), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(xActual, buf + nx + nu + nk, NX * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        hipFree(buf); hipFree(dout);
+        if (avg_err) *avg_err = ho[0];
+        if (failed) *failed = (int)ho[1];
+        return 0;
+    }
+    int ee_pos(int count, const void* x, void* out) override {
+        if (P::PLANT != 4 || count <= 0) return fail(PDDP_EINVAL, "pddp_ee_pos: KUKA arm only, count >= 1");
+        T *dx = nullptr, *dout = nullptr;
+        HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&dout, (size_t)count * 6 * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(dx, x, (size_t)count * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL((k_ee_pos<P, T>), dim3(count), dim3(64), 0, stream, b.model, (T)cfg.ee_on_link_z, (const T*)dx, dout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, dout, (size_t)count * 6 * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        hipFree(dx); hipFree(dout);
+        return 0;
+    }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
         if (what < 0 || what > 6 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
         const size_t osz = (what == 0 || what == 4 || what == 6 ? NP : (what == 1 || what == 5) ? NP * NM : what == 2 ? NX : NX * NM);
@@ -516,6 +566,12 @@ extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); retu
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { IMPL(h); return s->store(x, u, KT, Jout, alphaOut, dmax); }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
 extern "C" int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2) { IMPL(h); return s->set_cost(Q1, Q2, R, QF1, QF2); }
+extern "C" int pddp_simulate(pddp_handle h, const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal_xyz,
+                             void* xActual_inout, double* avg_err, int* failed) {
+    IMPL(h); if (!x || !u || !KT || !xActual_inout) return fail(PDDP_EINVAL, "null argument");
+    return s->simulate(x, u, KT, t0_us, elapsed_us, substeps, goal_xyz, xActual_inout, avg_err, failed);
+}
+extern "C" int pddp_ee_pos(pddp_handle h, int count, const void* x, void* eePos) { IMPL(h); if (!x || !eePos) return fail(PDDP_EINVAL, "null argument"); return s->ee_pos(count, x, eePos); }
 extern "C" int pddp_set_ee_cost_shift(pddp_handle h, int on) { IMPL(h); s->cfg.ee_cost_shift = on ? 1 : 0; return 0; }
 extern "C" int pddp_set_cost_ee(pddp_handle h, double Q_EE1, double Q_EE2, double QF_EE1, double QF_EE2, double R_EE, double Q_xEE, double QF_xEE,
                                 double Q_xdEE, double QF_xdEE) {

@@ -47,6 +47,7 @@ PDDP_HD void diag_cost_grad(T* Hk, T* gk, const T* xk, const T* uk, const T* xg,
     template <typename T>                                                                                                \
     struct NAME {                                                                                                        \
         static constexpr int PLANT = CODE, NPOS = NP, NX = 2 * NP, NU = NUv;                                             \
+        template <typename U> using Rebind = NAME<U>;                                                                    \
         using Model = EmptyModel;                                                                                        \
         using Scratch = EmptyScratch<T>;                                                                                 \
         using GradScratch = EmptyScratch<T>;                                                                             \
@@ -100,6 +101,7 @@ template <typename T> PDDP_HD double QuadPlant<T>::QF(int) { return 1000.0; }
 template <typename T>
 struct ArmPlant {
     static constexpr int PLANT = 4, NPOS = 7, NX = 14, NU = 7;
+    template <typename U> using Rebind = ArmPlant<U>;     // the same plant in another precision (the lock-step simulator runs it in double)
     using Model = ArmModel<T>;
     using Scratch = ArmScratch<T>;
     using GradScratch = ArmGradScratch<T>;

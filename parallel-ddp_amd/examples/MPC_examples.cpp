@@ -41,7 +41,6 @@ int main(int argc, char** argv) {
     costParams<T>* cst = new costParams<T>; loadCost(cst);
     GPUVars<T>* algvars = new GPUVars<T>; allocateMemory_GPU_MPC<T>(algvars, dimms, tvars);
 
-    const double PI = 3.14159;
     T xInit[STATE_SIZE] = {0}; xInit[1] = (T)(PI / 4.0); xInit[3] = (T)(-PI / 4.0); xInit[5] = (T)(PI / 4.0);   // loadInitialState mode 1
 #if EE_COST
     // a slow lemniscate in the y-z plane in front of the robot; (roll, pitch, yaw) goals are 0 and carry no weight (_Q_EE2 = 0)

@@ -194,6 +194,23 @@ class Solver:
                     iters=int(iters[0]) if B == 1 else iters, ms_total=times[0], ms_init=times[1], ms_loop=times[0] - times[1],
                     J_final=float(Jout[0][iters[0]]))
 
+    def simulate(self, x, u, KT, t0_us, elapsed_us, substeps=150, goal_xyz=None, xActual=None):
+        """pddp_simulate: the lock-step simulated robot (simulateForward).  Returns (xActual after elapsed_us, average tracking error, failed)."""
+        x, u, KT = self.arr(x), self.arr(u), self.arr(KT)
+        xa = self.arr(xActual).copy()
+        g = None if goal_xyz is None else self.arr(goal_xyz)
+        err, failed = C.c_double(0), C.c_int(0)
+        self.lib.pddp_simulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.pddp_simulate(self.h, _p(x), _p(u), _p(KT), float(t0_us), float(elapsed_us), int(substeps), _p(g), _p(xa), C.byref(err), C.byref(failed)))
+        return xa, err.value, failed.value
+
+    def ee_pos(self, x):
+        """pddp_ee_pos: tool point (x, y, z, roll, pitch, yaw) of states [count][n]."""
+        x = self.arr(x).reshape(-1, self.n)
+        out = np.zeros((x.shape[0], 6), self.dtype)
+        self._chk(self.lib.pddp_ee_pos(self.h, x.shape[0], _p(x), _p(out)))
+        return out
+
     def set_cost(self, Q1, Q2, R, QF1, QF2):
         """pddp_set_cost: joint-space cost weights for the following loads / solves."""
         self.lib.pddp_set_cost.argtypes = [C.c_void_p] + [C.c_double] * 5

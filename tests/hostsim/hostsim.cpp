@@ -14,6 +14,7 @@
 #include "../../include/pddp.h"
 #include "lanegroup_host.hpp"
 #include "../../parallel-ddp_amd/csrc/bodies.hpp"
+#include "../../parallel-ddp_amd/csrc/sim.hpp"
 #include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/nis_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/bp_lg.hpp"
@@ -55,6 +56,8 @@ struct Base {
     virtual int run_phase(int) = 0;
     virtual int plant_eval(int, int, const void*, const void*, void*) = 0;
     virtual int mpc_solve(const void*, const void*, const int*, int, int, int, int, void*, void*, void*, void*, int*, int*, int*) = 0;
+    virtual int simulate(const void*, const void*, const void*, double, double, int, const void*, void*, double*, int*) = 0;
+    virtual int ee_pos(int, const void*, void*) = 0;
 };
 struct pddp_solver { Base* impl; };
 
@@ -234,6 +237,25 @@ struct Sim : Base {
         for (size_t pb = 0; pb < B; pb++) { if (success) success[pb] = b.state[pb].took_step; if (iters) iters[pb] = b.state[pb].iter; }
         return 0;
     }
+    int simulate(const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal, void* xActual, double* avg_err,
+                 int* failed) override {
+        using PD = typename P::template Rebind<double>;
+        static PlantSimScratch<PD, T> sc;
+        typename PD::Model md; fill_model(md, cfg);
+        PlantSimArgs<T> a; double out[2] = {0, 0};
+        a.x = (const T*)x; a.u = (const T*)u; a.KT = (const T*)KT; a.N = cfg.N; a.step_us = cfg.total_time / (cfg.N - 1) * 1000.0 * 1000.0;
+        a.t0_us = t0_us; a.elapsed_us = elapsed_us; a.substeps = substeps; a.goal = (const T*)goal; a.ee_z = cfg.ee_on_link_z; a.xActual = (T*)xActual; a.out = out;
+        plant_sim_body<PD, INTEG, T>(this_wave(), sc, &md, a);
+        if (avg_err) *avg_err = out[0];
+        if (failed) *failed = (int)out[1];
+        return 0;
+    }
+    int ee_pos(int count, const void* x, void* out) override {
+        if (P::PLANT != 4) return fail(PDDP_EINVAL, "pddp_ee_pos: KUKA arm only");
+        static typename P::Scratch plant; static EeScratch<T> ee; T xs[NX], us[NU], qdd[NP];
+        for (int i = 0; i < count; i++) ee_pos_body<P, T>(this_wave(), plant, ee, xs, us, qdd, &model, (T)cfg.ee_on_link_z, (const T*)x + (size_t)i * NX, (T*)out + (size_t)i * 6);
+        return 0;
+    }
     int iterate(int sweeps) override { for (int i = 0; i < sweeps; i++) for (int ph = 0; ph < 4; ph++) phase(ph); return 0; }
     int status(int* done, int* iters) override {
         for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = b.state[i].done; if (iters) iters[i] = b.state[i].iter; }
@@ -384,4 +406,7 @@ extern "C" int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xG
                               int max_iter, double, int, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) {
     return h->impl->mpc_solve(xActual, xGoal, shift, clear_vars, full_rollout, ifd, max_iter, x, u, KT, Jout, alphaOut, success, iters);
 }
+extern "C" int pddp_simulate(pddp_handle h, const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal, void* xa,
+                             double* avg_err, int* failed) { return h->impl->simulate(x, u, KT, t0_us, elapsed_us, substeps, goal, xa, avg_err, failed); }
+extern "C" int pddp_ee_pos(pddp_handle h, int count, const void* x, void* out) { return h->impl->ee_pos(count, x, out); }
 extern "C" int pddp_stream(pddp_handle, void** st) { if (st) *st = nullptr; return 0; }

@@ -53,6 +53,8 @@ def lib():
         _LIB.ora_max_defect_f64.restype = C.c_double
         _LIB.ora_ee_cost_f32.restype = C.c_float
         _LIB.ora_ee_cost_f64.restype = C.c_double
+        _LIB.ora_simulate_f32.restype = C.c_float
+        _LIB.ora_simulate_f64.restype = C.c_double
     return _LIB
 
 
@@ -150,6 +152,15 @@ class Oracle:
         H, g = np.zeros(21 * 21, self.dtype), np.zeros(21, self.dtype)
         self._f("ee_cost_grad")(C.byref(self.c), _p(H), _p(g), _p(x), _p(u), _p(goal), int(k), int(tshift))
         return H.reshape(21, 21), g
+
+    def simulate(self, x, u, KT, t0_us, elapsed_us, substeps=150, goal_xyz=None, xActual=None):
+        x, u, KT, xa = self.arr(x), self.arr(u), self.arr(KT), self.arr(xActual).copy()
+        g = None if goal_xyz is None else self.arr(goal_xyz)
+        failed = C.c_int(0)
+        f = self._f("simulate")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        err = f(C.byref(self.c), _p(x), _p(u), _p(KT), float(t0_us), float(elapsed_us), int(substeps), None if g is None else _p(g), _p(xa), C.byref(failed))
+        return xa, float(err), failed.value
 
     # ---- phase level (arrays are modified in place, like the reference)
     def backward_pass(self, sem_gpu, AB, P, p, Pp, pp, H, g, KT, du, d, ApBK, Bdu, x, xp2, rho):

@@ -104,6 +104,26 @@ def test_mpc_lockstep_loop_through_the_struct_facade():
 
 
 @pytest.mark.gpu
+def test_lockstep_figure_eight_experiment_end_to_end():
+    """testMPC_lockstep (examples/WAFR_MPC_examples.cu:185-238) against hostapi/: solve -> simulated robot (pddp_simulate) -> goal moves along the
+    reference's 200-point figure (tests/golden/fig8_goals.csv) -> solve ...; fixed 8 ms control cycles and a 4 s figure so that the run is
+    reproducible.  The reference's own run of this experiment reports an average tracking error of 0.0878 m (test/WAFR_fig8.py:5-6, 10 s figure)."""
+    build_examples()
+    goals = os.path.join(ROOT, "tests", "golden", "fig8_goals.csv")
+    res = {}
+    for exe in ("MPC_lockstep", "MPC_lockstep_fix"):
+        r = subprocess.run([os.path.join(PKG, "examples", exe), "4", "10", "4", goals, "8000"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"cycles: (\d+)  figure completed: (\d)  reached the start of the figure: (\d)", r.stdout)
+        e = re.search(r"Average tracking error: \[([0-9.]+)\]", r.stdout)
+        assert m and e and m.group(2) == "1" and m.group(3) == "1", r.stdout[-400:]
+        assert "CRITICAL FAILURE" not in r.stdout
+        res[exe] = (int(m.group(1)), float(e.group(1)))
+        assert 0.0 < res[exe][1] < 0.2, res
+        assert 4.0e6 / 8000 <= res[exe][0] < 3 * 4.0e6 / 8000        # the figure itself takes 500 cycles; reaching its start takes some more
+
+
+@pytest.mark.gpu
 def test_set_cost_equals_creating_with_those_weights():
     x0, u0, xg = example_inputs(4, 32, np.float32)
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=15)

@@ -246,6 +246,7 @@ typedef struct ihipStream_t* pddpStream_t;
 #if MPC_MODE
 #include "MPCHelpers.hpp"             // config.cuh:264-270 includes MPCHelpers.cuh instead of DDPWrappers.cuh in MPC_MODE; here it adds to it
 #include "exampleUtils.hpp"           // config.cuh:281: utils/exampleUtils.cuh (the lock-step experiment's helpers)
+#include "LCMHelpers.hpp"             // config.cuh:272-279 (USE_LCM): message types, packing, trajectory runner -- without the LCM transport
 #endif
 
 #endif

@@ -1,0 +1,64 @@
+// TEST TOOL: exercises hostapi/LCMHelpers.hpp (message encoding, the MPC loop's packing, the trajectory runner) on the host and prints what
+// tests/test_wire_format.py checks.  No solver call: nothing here needs a GPU.
+#define USE_WAFR_URDF 1
+#define EE_COST 1
+#define MPC_MODE 1
+#define PLANT 4
+#define NUM_TIME_STEPS 8
+#include "../../parallel-ddp_amd/hostapi/config.hpp"
+
+static void hex(const char* name, const std::vector<uint8_t>& b) {
+    std::printf("%s ", name);
+    for (uint8_t v : b) std::printf("%02x", v);
+    std::printf("\n");
+}
+
+int main() {
+    using namespace pddp_wire;
+    typedef float T;
+    std::printf("hash_traj_f %lld\nhash_traj_d %lld\nhash_solver %lld\nhash_cost %lld\n", (long long)lcmt_trajectory_f::getHash(), (long long)lcmt_trajectory_d::getHash(),
+                (long long)lcmt_solver_params::getHash(), (long long)lcmt_cost_params::getHash());
+    // a small plan: x[k][i] = k + i/100, u[k][i] = -(k + i/10), KT = 0.01 * index
+    const int N = NUM_TIME_STEPS;
+    std::vector<T> x(N * STATE_SIZE), u(N * CONTROL_SIZE), KT(N * STATE_SIZE * CONTROL_SIZE);
+    for (int k = 0; k < N; k++) { for (int i = 0; i < STATE_SIZE; i++) x[k * STATE_SIZE + i] = k + i / 100.0f; for (int i = 0; i < CONTROL_SIZE; i++) u[k * CONTROL_SIZE + i] = -(k + i / 10.0f); }
+    for (size_t i = 0; i < KT.size(); i++) KT[i] = 0.01f * (float)(i % 97);
+    trajVars<T> tv; matDimms md;
+    md.ld_x = DIM_x_r; md.ld_u = DIM_u_r; md.ld_KT = DIM_KT_r;
+    tv.x = x.data(); tv.u = u.data(); tv.KT = KT.data(); tv.ld_x = md.ld_x; tv.ld_u = md.ld_u; tv.ld_KT = md.ld_KT; tv.t0_plant = 123456789012345LL;
+    lcmt_trajectory<T> m = trajectoryMessage<T>(&tv, &md);
+    std::printf("sizes %d %d %d elems %zu %zu %zu\n", m.x_size, m.u_size, m.KT_size, m.x.size(), m.u.size(), m.KT.size());
+    std::vector<uint8_t> wire = m.encode();
+    std::printf("wire_len %zu\n", wire.size());
+    hex("wire_head", std::vector<uint8_t>(wire.begin(), wire.begin() + 28 + 8));
+    lcmt_trajectory<T> back;
+    std::printf("decode_ok %d\n", (int)back.decode(wire.data(), wire.size()));
+    std::printf("roundtrip %d\n", (int)(back.utime == m.utime && back.x == m.x && back.u == m.u && back.KT == m.KT && back.x_size == m.x_size));
+    wire[3] ^= 1;
+    std::printf("bad_fingerprint_rejected %d\n", (int)!back.decode(wire.data(), wire.size()));
+    wire[3] ^= 1;
+    std::printf("truncated_rejected %d\n", (int)!back.decode(wire.data(), wire.size() - 5));
+    // trajectory runner: takes the message, answers a status
+    TrajRunner<T> tr(md.ld_x, md.ld_u, md.ld_KT, 0.0);
+    double q[NUM_POS], qd[NUM_POS], q_out[NUM_POS], tau[NUM_POS];
+    for (int i = 0; i < NUM_POS; i++) { q[i] = 2.0 + i / 100.0 + 0.001; qd[i] = 2.0 + (i + 7) / 100.0; }
+    std::printf("not_ready %d\n", tr.statusCallback(q, qd, tv.t0_plant, q_out, tau));
+    tr.newTrajCallback(m);
+    const int64_t t = tv.t0_plant + (int64_t)(2.25 * TIME_STEP_LENGTH_IN_us);
+    const int err = tr.statusCallback(q, qd, t, q_out, tau);
+    std::printf("runner_err %d tau", err);
+    for (int i = 0; i < NUM_POS; i++) std::printf(" %.9g", tau[i]);
+    std::printf("\nrunner_beyond %d\n", tr.statusCallback(q, qd, tv.t0_plant + (int64_t)(6.5 * TIME_STEP_LENGTH_IN_us), q_out, tau));
+    // parameters
+    lcmt_solver_params sp; sp.utime = 42; sp.iterLimit = 4; sp.timeLimit = 10; sp.clearVars = 0; sp.useCostShift = 1;
+    hex("solver_wire", sp.encode());
+    lcmt_solver_params sp2; std::vector<uint8_t> sw = sp.encode();
+    std::printf("solver_roundtrip %d\n", (int)(sp2.decode(sw.data(), sw.size()) && sp2.iterLimit == 4 && sp2.timeLimit == 10 && sp2.useCostShift == 1 && sp2.utime == 42));
+    lcmt_cost_params cp; cp.utime = 7; for (int i = 0; i < 18; i++) cp.fields()[i] = 0.5f + i;
+    std::vector<uint8_t> cwire = cp.encode();
+    lcmt_cost_params cp2; costParams<T> cst;
+    std::printf("cost_len %zu cost_roundtrip %d\n", cwire.size(), (int)(cp2.decode(cwire.data(), cwire.size()) && cp2.r == 17.5f && cp2.q_ee1 == 0.5f));
+    applyCostParams<T>(&cst, cp2);
+    std::printf("cost_applied %g %g %g %g\n", (double)cst.Q_EE1, (double)cst.R_EE, (double)cst.Q1, (double)cst.R);
+    return 0;
+}

@@ -93,12 +93,12 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
-    torch.cuda.set_device(ctx.local_rank)
+    torch.cuda.set_device(ctx.device)
     K, W, B = args.steps, args.warmup, args.batch
     N, M, A, n, m = 128, 4, 8, 14, 7
 
     cfg = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B,
-                               max_iter=max(100, K + W + 1), device=ctx.local_rank, use_graph=args.graph, _lib_path=args.lib)
+                               max_iter=max(100, K + W + 1), device=ctx.device, use_graph=args.graph, _lib_path=args.lib)
     s = pyddp.Solver(cfg, _lib_path=args.lib)
     rng = np.random.default_rng(1234 + ctx.rank)      # every rank owns different problems
     x0, u0, xg = example_inputs(N, rng, B)
@@ -158,7 +158,7 @@ def main():
     s.close()
     # ---- wall clock to convergence of the whole sharded batch (BASELINE metric, second half): TOL_COST 1e-4 (config.cuh:85-87), MAX_ITER 100;
     # every rank iterates its own problems, the ranks agree on "all done" with one max-reduce per poll (pyddp.shard.all_done)
-    cfg2 = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=1e-4, total_time=0.5, batch=B, max_iter=100, device=ctx.local_rank,
+    cfg2 = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=1e-4, total_time=0.5, batch=B, max_iter=100, device=ctx.device,
                                 use_graph=args.graph, _lib_path=args.lib)
     s2 = pyddp.Solver(cfg2, _lib_path=args.lib)
     s2.load(x0, u0, xg)
@@ -182,8 +182,8 @@ def main():
     s2.close()
 
     if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
-        line["latency"] = latency_single_problem(ctx.local_rank)
-        line["widening"] = widening_rows(ctx.local_rank)
+        line["latency"] = latency_single_problem(ctx.device)
+        line["widening"] = widening_rows(ctx.device)
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     elif ctx.rank == 0:

@@ -19,6 +19,7 @@ class ShardCtx:
     world: int = 1
     local_rank: int = 0
     backend: str = ""
+    device: int = 0          # HIP device ordinal of this rank: LOCAL_RANK, unless PDDP_FORCE_DEVICE overrides it (single-GPU dry runs of the N > 1 path)
 
 
 def owned_problems(total, rank, world):
@@ -31,37 +32,38 @@ def init_from_env(n_gpus_flag=1, backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = int(os.environ.get("PDDP_FORCE_DEVICE", local_rank))
     if world == 1:
-        return ShardCtx(0, 1, local_rank, "")
+        return ShardCtx(0, 1, local_rank, "", device)
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("PDDP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # PDDP_DIST_BACKEND=gloo: dry run of the N > 1 path on one GPU
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local_rank)     # binds the communicator to this rank's GPU (no guessing in barrier())
+            kw["device_id"] = torch.device("cuda", device)         # binds the communicator to this rank's GPU (no guessing in barrier())
         try:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         except TypeError:                                          # older torch without device_id
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return ShardCtx(rank, world, local_rank, backend)
+    return ShardCtx(rank, world, local_rank, backend, device)
 
 
 def _dev(ctx):
     import torch
-    return torch.device("cuda", ctx.local_rank) if ctx.backend == "nccl" else torch.device("cpu")
+    return torch.device("cuda", ctx.device) if ctx.backend == "nccl" else torch.device("cpu")
 
 
 def barrier(ctx):
     if ctx.world > 1:
         import torch.distributed as dist
         if ctx.backend == "nccl":
-            dist.barrier(device_ids=[ctx.local_rank])
+            dist.barrier(device_ids=[ctx.device])
         else:
             dist.barrier()
 
@@ -96,7 +98,7 @@ def allgather_costs(ctx, jout, batch, stride, last_col):
     if isinstance(jout, np.ndarray):
         local = torch.from_numpy(np.ascontiguousarray(jout)).reshape(batch, stride)
     else:
-        local = torch.as_tensor(jout, device=_dev(ctx) if ctx.world > 1 else torch.device("cuda", ctx.local_rank)).reshape(batch, stride)
+        local = torch.as_tensor(jout, device=torch.device("cuda", ctx.device)).reshape(batch, stride)       # zero-copy view of the solver's array in HBM
     cols = local[:, [0, last_col]].contiguous()
     if ctx.world == 1:
         return cols.cpu().numpy()

@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, "parallel-ddp_amd"); sys.path.insert(0, ".")
+import numpy as np, pyddp, bench
+rng = np.random.default_rng(1)
+for N, A, bp in ((128, 8, None), (128, 8, "coop"), (64, 16, None)):
+    if bp: os.environ["PDDP_BP"] = bp
+    else: os.environ.pop("PDDP_BP", None)
+    cfg = pyddp.default_config(4, N=N, M=4, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=1, max_iter=100, use_graph=1)
+    s = pyddp.Solver(cfg)
+    x0, u0, xg = bench.example_inputs(N, rng, 1)
+    s.load(x0, u0, xg); s.set_benchmark_mode(1); s.iterate(5); s.sync()
+    tot, ph = s.time_sweeps(50, phases=True)
+    plain, _ = s.time_sweeps(50, phases=False)
+    print(N, A, bp, "per-phase us", [round(v / 50 * 1e3, 1) for v in ph], "sum", round(tot / 50 * 1e3, 1), "graph replay us/sweep", round(plain / 50 * 1e3, 1))
+    s.close()

@@ -88,8 +88,37 @@ def solver_level(path):
     s.close()
 
 
+def ee_cost_level(path, N=64):
+    """End-effector cost family (oracle unpinned): per-knot H_k, g_k, cost of the setup kernel on a random trajectory, and the first costs of a solve."""
+    rng = np.random.default_rng(9)
+    kw = dict(N=N, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=10, ee_cost=1, ignore_max_rho_exit=0, Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)
+    s = pyddp.Solver(pyddp.default_config(4, _lib_path=path, dtype=0, **kw), _lib_path=path)
+    o32, o64 = Oracle(default_cfg(4, **kw), np.float32), Oracle(default_cfg(4, **kw), np.float64)
+    x = rng.normal(0, 0.8, (N, 14)).astype(np.float32); u = rng.normal(0, 5.0, (N, 7)).astype(np.float32)
+    goal = np.zeros(14, np.float32); goal[:6] = [0.4, -0.1, 0.7, 0.1, -0.2, 0.3]
+    s.load(x, u, goal)
+    H, g, ck = s.get("H").reshape(N, 21, 21), s.get("g").reshape(N, 21), s.get("costk")
+    r32 = [o32.ee_cost_grad(x[k], u[k], goal[:6], k) for k in range(N)]; r64 = [o64.ee_cost_grad(x[k], u[k], goal[:6], k) for k in range(N)]
+    c32 = [o32.ee_cost(x[k], u[k], goal[:6], k) for k in range(N)]; c64 = [o64.ee_cost(x[k], u[k], goal[:6], k) for k in range(N)]
+    for name, got, a, b in (("H", H, np.stack([r[0] for r in r32]), np.stack([r[0] for r in r64])), ("g", g, np.stack([r[1] for r in r32]), np.stack([r[1] for r in r64])),
+                            ("cost", ck, np.asarray(c32), np.asarray(c64))):
+        print(f"  ee    {name:20s} kernel-vs-oracle32 {nrel(got, a):.2e}   oracle32-vs-oracle64 {nrel(a, b):.2e}   kernel-vs-oracle64 {nrel(got, b):.2e}")
+    x0 = np.zeros((N, 14), np.float32); x0[:, 1] = 0.7; x0[:, 3] = -0.8; x0[:, 5] = 0.75
+    u0 = np.full((N, 7), 0.01, np.float32); xg = np.zeros(14, np.float32); xg[:3] = [0.45, 0.15, 0.75]
+    out = s.solve(x0, u0, xg)
+    a32 = o32.run_ilqr_gpusem(x0.ravel(), u0.ravel(), xg); a64 = o64.run_ilqr_gpusem(x0.astype(np.float64).ravel(), u0.astype(np.float64).ravel(), xg.astype(np.float64))
+    same = 0
+    while same < 10 and out["alphaOut"][0][same] == a32["alphaOut"][same]:
+        same += 1
+    same64 = 0
+    while same64 < 10 and a32["alphaOut"][same64] == a64["alphaOut"][same64]:
+        same64 += 1
+    print(f"  ee    solve N={N} f32: alpha sequence identical to oracle32 for {same} iterations (oracle32 vs oracle64: {same64});  "
+          f"J[1] kernel {out['Jout'][0][1]:.5f} oracle32 {a32['Jout'][1]:.5f} oracle64 {a64['Jout'][1]:.5f}")
+
+
 if __name__ == "__main__":
     paths = sys.argv[1:] or [pyddp.library_path()]
     for path in paths:
         print(os.path.basename(path))
-        plant_level(path); backward_pass_level(path); backward_pass_level(path, N=128, M=4); solver_level(path)
+        plant_level(path); backward_pass_level(path); backward_pass_level(path, N=128, M=4); solver_level(path); ee_cost_level(path)

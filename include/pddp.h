@@ -113,7 +113,7 @@ int pddp_solve(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal,
 int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal, const void* KT0, const void* P0, const void* p0,
                   const void* d0, void* Jout, int* alphaOut, int forward_rollout, int clear_vars, int ignore_first_defect,
                   int poll_every, double* times_ms, double* phase_ms, int* sweeps_out);
-/* runiLQR_MPC_GPU (DDPHelpers/MPCHelpers.cuh:864-1045) for the batch, joint-space cost.  The handle holds the previous solution (seed it
+/* runiLQR_MPC_GPU (DDPHelpers/MPCHelpers.cuh:864-1045) for the batch (joint-space or end-effector cost).  The handle holds the previous solution (seed it
  * with pddp_solve).  Per problem: loadVarsGPU_MPC (:602-655) shifts it by shift[b] knots (x, d, P, p hold their last knot; u, KT are
  * zero-filled), or clears u, KT, P, p when clear_vars, and rolls the trajectory out open loop from the measured state xActual
  * (full_rollout = FULL_ROLLOUT, :37-39: the whole horizon; otherwise the first shooting segment plus the last shift[b] knots with

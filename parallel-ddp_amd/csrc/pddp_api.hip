@@ -178,8 +178,21 @@ struct Solver : SolverBase {
             HIPCHK(hipMemcpy(tab[t], hp.data(), B * A * sizeof(void*), hipMemcpyHostToDevice));
         }
         fp_lds = FpLds<P, T>::bytes(c.M, c.N);
-        if (fp_lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint exceeds 160 KiB: reduce M");
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp<P, INTEG, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp_lds));
+        if constexpr (P::PLANT == 4) {                                 // lane-group forward pass: A * (N + M) elements of dynamic LDS per workgroup
+            const size_t lds = (size_t)c.A * (c.N + c.M) * sizeof(T);
+            if (lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint (A * (N + M) elements) exceeds 160 KiB: reduce A or N");
+            if (lds > 48 * 1024) {
+                const void* ks[6] = {reinterpret_cast<const void*>(&k_fp_lg<T, 256, false>), reinterpret_cast<const void*>(&k_fp_lg<T, 512, false>),
+                                     reinterpret_cast<const void*>(&k_fp_lg<T, 1024, false>), reinterpret_cast<const void*>(&k_fp_lg<T, 256, true>),
+                                     reinterpret_cast<const void*>(&k_fp_lg<T, 512, true>), reinterpret_cast<const void*>(&k_fp_lg<T, 1024, true>)};
+                for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+        }
+        const bool uses_coop_fp = (P::PLANT != 4) || fp_coop;      // the arm's forward pass runs on lane groups (no per-segment LDS scratch) unless PDDP_FP=coop
+        if (uses_coop_fp) {
+            if (fp_lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint exceeds 160 KiB: reduce M");
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp<P, INTEG, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp_lds));
+        }
         HIPCHK(hipDeviceSynchronize());
         return 0;
     }

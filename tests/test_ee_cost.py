@@ -110,9 +110,9 @@ def test_setup_kernel_cost_gradient_hessian_knot_by_knot(backend, dtype, tol):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("rollout", [0, 1])
-@pytest.mark.parametrize("M", [4, 1])
-def test_float64_whole_solve(backend, rollout, M):
-    kw = {**EE, "M": M}
+@pytest.mark.parametrize("M,A", [(4, 8), (1, 8), (2, 3)])
+def test_float64_whole_solve(backend, rollout, M, A):
+    kw = {**EE, "M": M, "A": A}
     N = kw["N"]
     s = make_solver(backend, 4, dtype=1, **kw)
     o = Oracle(default_cfg(4, cores=8, spawn_threads=0, **kw), np.float64)
@@ -122,7 +122,7 @@ def test_float64_whole_solve(backend, rollout, M):
     it = r["iters"]
     assert out["iters"][0] == it
     assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
-    if not (rollout and M == 1):        # (that one scenario is rejected throughout: the rho schedule and exit are what it exercises)
+    if not (rollout and M == 1) and A == 8:        # (the other scenarios may be rejected throughout: the rho schedule and exit are what they exercise)
         assert sum(a >= 0 for a in r["alphaOut"][1: it + 1]) >= 1, "the scenario must contain accepted steps"
     np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-8)
     np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-8 * np.abs(r["x"]).max())

@@ -241,3 +241,42 @@ def test_kuka_float64_headline_size_whole_solve(M):
     np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-7 * np.abs(r["x"]).max())
     np.testing.assert_allclose(out["u"][0].ravel(), r["u"], rtol=0, atol=1e-7 * np.abs(r["u"]).max())
     np.testing.assert_allclose(out["KT"][0].ravel(), r["KT"], rtol=0, atol=1e-6 * np.abs(r["KT"]).max())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("N,M,A", [(16, 1, 1), (16, 8, 1), (32, 2, 3), (64, 16, 5), (32, 1, 13)])
+def test_kuka_ragged_shapes_float64(backend, N, M, A):
+    """Edge shapes of the arm path: a single candidate, a single segment, segments of 2 knots (N/M = 2, the minimum), candidate counts that do not fill
+    the 8 lane groups of a wave, A*M not a multiple of 8 -- the block / segment / defect-boundary bookkeeping must stay the reference's."""
+    kw = dict(N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5 * N / 128, max_iter=6)
+    out, refs, _ = run_pair(backend, 4, np.float64, **kw)
+    r = refs[0]
+    it = r["iters"]
+    assert out["iters"][0] == it
+    assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-8)
+    np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-8 * np.abs(r["x"]).max())
+    np.testing.assert_allclose(out["KT"][0].ravel(), r["KT"], rtol=0, atol=1e-7 * max(np.abs(r["KT"]).max(), 1.0))
+
+
+@pytest.mark.gpu
+def test_kuka_long_horizon_needs_more_than_the_default_dynamic_lds():
+    """N = 512, A = 16 in float64: the forward pass's cost table takes 16 * (512 + 4) * 8 = 66 KB of dynamic LDS (above the 64 KB default limit)."""
+    kw = dict(N=512, M=4, A=16, wafr_urdf=1, tol_cost=0.0, total_time=2.0, max_iter=3)
+    out, refs, _ = run_pair("hip", 4, np.float64, **kw)
+    r = refs[0]
+    it = r["iters"]
+    assert out["iters"][0] == it and list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_kuka_maximum_candidate_grid_float64():
+    """The largest candidate grid one workgroup takes (A * M = 128: 16 alphas x 8 segments) on a long horizon (N = 256), float64, against the oracle."""
+    kw = dict(N=256, M=8, A=16, wafr_urdf=1, tol_cost=0.0, total_time=1.0, max_iter=5)
+    out, refs, _ = run_pair("hip", 4, np.float64, **kw)
+    r = refs[0]
+    it = r["iters"]
+    assert out["iters"][0] == it and list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-7)
+    np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-7 * np.abs(r["x"]).max())

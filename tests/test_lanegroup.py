@@ -107,14 +107,14 @@ def test_whole_solve_identical_with_either_backward_pass(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("rollout", [0, 1])
-def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(backend, rollout):
+@pytest.mark.parametrize("rollout,N,M,A", [(0, 32, 4, 8), (1, 32, 4, 8), (0, 64, 8, 16)])
+def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(backend, rollout, N, M, A):
     """The end-effector cost family (ee_cost_lg.hpp vs ee_cost.hpp): tool point, Jacobian, Gauss-Newton Hessian, in-rollout cost accumulation --
     whole float32 solves on the lane-group kernels and on the wave-cooperative ones (PDDP_FP=coop) give the same bits."""
     import os
-    kw = dict(N=32, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=8, ee_cost=1, ignore_max_rho_exit=0, batch=3,
+    kw = dict(N=N, M=M, A=A, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=8 if N == 32 else 4, ee_cost=1, ignore_max_rho_exit=0, batch=3,
               Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)
-    B, N = 3, 32
+    B = 3
     x0 = np.zeros((B, N, 14), np.float32); x0[:, :, 1] = 0.7; x0[:, :, 3] = -0.8; x0[:, :, 5] = 0.75
     x0 += RNG.normal(0, 0.02, (B, 1, 14)).astype(np.float32)
     u0 = np.full((B, N, 7), 0.01, np.float32)

@@ -84,15 +84,16 @@ __global__ __launch_bounds__(64) void k_sweep_lg(Buffers<T> b, Dims dm, T dt) {
     const FpLgArgs<T> a = fp_lg_args<T>(b, dm, pb, a_idx, dt, nullptr);
     arm_lg_forward_sweep<LgDevice<T>, T>(dm, a);
 }
-// k_fp_lg: grid (B), block 64 * ceil(A*M/8): group i of the block rolls out segment i / A of candidate i % A (the 8 groups
-// of a wave are 8 candidates of one segment: they read the same gains, which the memory pipeline coalesces); per-knot
-// costs meet in LDS and are tree-summed per candidate in the reference's pairing.  Dynamic LDS: A*(N+M) elements.
+// k_fp_lg: grid (B, C), block 64 * ceil(Ac*M/8) with Ac = A / C candidates per workgroup: group i of the block rolls out segment i / Ac of candidate
+// a0 + i % Ac (the 8 groups of a wave are 8 candidates of one segment: they read the same gains, which the memory pipeline coalesces); per-knot
+// costs meet in LDS and are tree-summed per candidate in the reference's pairing.  Dynamic LDS: Ac*(N+M) elements.  C > 1 (A a multiple of 8 above 8:
+// one workgroup per 8 candidates) spreads one problem over C compute units -- the same waves in total, half the latency per sweep for A = 16.
 template <typename T, int MAXT, bool EE = false>
 __global__ __launch_bounds__(MAXT, 1) void k_fp_lg(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int pb = blockIdx.x;
     if (!init_rollout && !fp_active<T>(b, dm, pb)) return;
-    const int A_eff = init_rollout ? 1 : dm.A, n_inst = A_eff * dm.M;
+    const int A_all = init_rollout ? 1 : dm.A, A_eff = A_all / (int)gridDim.y, a0 = (int)blockIdx.y * A_eff, n_inst = A_eff * dm.M;
     __shared__ ArmModel<T> lds_model;
     T* cost_k = reinterpret_cast<T*>(lds_raw);              // [A_eff][N]
     T* dnorm = cost_k + (size_t)A_eff * dm.N;               // [A_eff][M]
@@ -103,18 +104,18 @@ __global__ __launch_bounds__(MAXT, 1) void k_fp_lg(Buffers<T> b, Dims dm, CostWe
     __syncthreads();
     const int inst = threadIdx.x >> 3;
     if (inst < n_inst && LgDevice<T>::lane() < 7) {        // lane 7 of every group stays inactive (lanegroup.hpp)
-        const int a_idx = inst % A_eff, seg = inst / A_eff;
+        const int a_loc = inst % A_eff, seg = inst / A_eff;
         ArmLgConst<LgDevice<T>> c;
         arm_lg_load_const<LgDevice<T>, T>(c, &lds_model);
-        const FpLgArgs<T> a = fp_lg_args<T>(b, dm, pb, a_idx, dt, dnorm + a_idx * dm.M);
-        if constexpr (EE) arm_lg_rollout_segment_ee<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);   // segment sums in cost_k[a][0..M)
-        else arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_idx * dm.N, init_rollout != 0);
+        const FpLgArgs<T> a = fp_lg_args<T>(b, dm, pb, a0 + a_loc, dt, dnorm + a_loc * dm.M);
+        if constexpr (EE) arm_lg_rollout_segment_ee<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_loc * dm.N, init_rollout != 0);   // segment sums in cost_k[a][0..M)
+        else arm_lg_rollout_segment<LgDevice<T>, T>(c, dm, a, seg, cw, cost_k + (size_t)a_loc * dm.N, init_rollout != 0);
     }
     __syncthreads();
     const Wave w = this_wave();
     const int wave_id = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-    for (int a_idx = wave_id; a_idx < A_eff; a_idx += nwaves)
-        fp_reduce<T>(w, b, dm, pb, a_idx, cost_k + (size_t)a_idx * dm.N, dnorm + a_idx * dm.M, EE ? cost_k + (size_t)a_idx * dm.N : nullptr);
+    for (int a_loc = wave_id; a_loc < A_eff; a_loc += nwaves)
+        fp_reduce<T>(w, b, dm, pb, a0 + a_loc, cost_k + (size_t)a_loc * dm.N, dnorm + a_loc * dm.M, EE ? cost_k + (size_t)a_loc * dm.N : nullptr);
 }
 // k_bp_lg: grid (ceil(B*M/8)), block 64 -- one 8-lane group per (problem, block of knots) (bp_lg.hpp); 8 x 2.4 KB of LDS.
 template <typename T>

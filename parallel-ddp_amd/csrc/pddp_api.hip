@@ -179,8 +179,9 @@ struct Solver : SolverBase {
         }
         fp_lds = FpLds<P, T>::bytes(c.M, c.N);
         if constexpr (P::PLANT == 4) {                                 // lane-group forward pass: A * (N + M) elements of dynamic LDS per workgroup
-            const size_t lds = (size_t)c.A * (c.N + c.M) * sizeof(T);
-            if (lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint (A * (N + M) elements) exceeds 160 KiB: reduce A or N");
+            const size_t a_wg = (c.A > 8 && c.A % 8 == 0) ? 8 : c.A;       // candidates per workgroup (launch_fp)
+            const size_t lds = a_wg * (c.N + c.M) * sizeof(T);
+            if (lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint (candidates per workgroup * (N + M) elements) exceeds 160 KiB: reduce A or N");
             if (lds > 48 * 1024) {
                 const void* ks[6] = {reinterpret_cast<const void*>(&k_fp_lg<T, 256, false>), reinterpret_cast<const void*>(&k_fp_lg<T, 512, false>),
                                      reinterpret_cast<const void*>(&k_fp_lg<T, 1024, false>), reinterpret_cast<const void*>(&k_fp_lg<T, 256, true>),
@@ -240,17 +241,20 @@ struct Solver : SolverBase {
             return;
         }
         if constexpr (P::PLANT == 4) {
-            const int A_eff = init_rollout ? 1 : cfg.A;
+            const int A_all = init_rollout ? 1 : cfg.A;
+            const unsigned chunks = (A_all > 8 && A_all % 8 == 0) ? A_all / 8 : 1;      // one workgroup per 8 candidates when they tile exactly (see k_fp_lg)
+            const int A_eff = A_all / chunks;
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
+            const dim3 grid(B, chunks);
             if (cfg.ee_cost) {
-                if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256, true>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
-                else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512, true>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
-                else hipLaunchKernelGGL((k_fp_lg<T, 1024, true>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
-            } else if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
-            else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
-            else hipLaunchKernelGGL((k_fp_lg<T, 1024>), dim3(B), dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+                if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256, true>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+                else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512, true>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+                else hipLaunchKernelGGL((k_fp_lg<T, 1024, true>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            } else if (waves <= 4) hipLaunchKernelGGL((k_fp_lg<T, 256>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            else if (waves <= 8) hipLaunchKernelGGL((k_fp_lg<T, 512>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
+            else hipLaunchKernelGGL((k_fp_lg<T, 1024>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
         }
     }
     void launch_nis(hipStream_t s, int mode) {
@@ -553,7 +557,8 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     if (c.ee_cost && c.plant != 4) return fail(PDDP_EINVAL, "ee_cost: the end-effector cost family belongs to the KUKA arm (plant 4)");
-    if (c.plant == 4 && c.A * c.M > 128) return fail(PDDP_EINVAL, "KUKA arm: A * M must not exceed 128 (one workgroup rolls out all candidates of a problem)");
+    if (c.plant == 4 && ((c.A > 8 && c.A % 8 == 0) ? 8 : c.A) * c.M > 128)
+        return fail(PDDP_EINVAL, "KUKA arm: (candidates per workgroup) * M must not exceed 128 -- a workgroup rolls out 8 candidates when A is a multiple of 8, otherwise all A");
     if (c.plant == 4 && (double)c.batch * c.N * (c.A * 14 > 441 ? c.A * 14 : 441) >= 4294967296.0)
         return fail(PDDP_EINVAL, "KUKA arm: batch * N too large for the 32-bit element offsets of the lane-group kernels (split the batch over several handles)");
     SolverBase* s = c.dtype == 0 ? make_plant<float>(c) : c.dtype == 1 ? make_plant<double>(c) : nullptr;

@@ -147,7 +147,7 @@ def test_set_cost_equals_creating_with_those_weights():
     (dict(batch=0), "batch"),
     (dict(integrator=3), "Euler"),                       # the arm is Euler-only, like config.cuh:58
     (dict(dtype=2), "unsupported"),
-    (dict(N=128, M=16, A=16), "A * M"),                  # lane-group forward pass: one workgroup per problem
+    (dict(N=128, M=16, A=12), "must not exceed 128"),    # lane-group forward pass: a workgroup rolls out all 12 candidates x 16 segments (A not a multiple of 8)
 ])
 def test_create_rejects_bad_configurations_with_a_code_and_a_message(kw, msg):
     """Errors are codes + pddp_last_error(), never exit() (the reference's gpuAssert exits, utils/cudaUtils.cu:31-37).

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Per-phase kernel times of ONE problem in flight (the latency case): HIP-event times per phase and the replayed-graph time per sweep."""
 import sys, os
-sys.path.insert(0, "parallel-ddp_amd"); sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, ROOT)
 import numpy as np, pyddp, bench
 rng = np.random.default_rng(1)
 for N, A, bp in ((128, 8, None), (128, 8, "coop"), (64, 16, None)):

@@ -12,6 +12,8 @@
 // keeps the dJexp partial sums in LDS lanes exactly like the reference's per-thread partials (:326-328, :416).
 #pragma once
 
+#include "lanegroup.hpp"
+
 #include "plants.hpp"
 
 namespace pddp {
@@ -123,7 +125,36 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
                 PDDP_FOR(e, 16) { const int ky = e / 4, kx = e % 4; A2[kx * 4 + ky] = val * adj[ky * 4 + kx]; }
                 wsync(w);
                 Hinv = A2;
-            } else {                          // [Huu | I] unpivoted Gauss-Jordan, never reports failure (invHuu)
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            else if (w.block && NU == 7) {    // workgroup variant (k_bp_wide, the latency case): the 7 pivots cost 14 barriers below; here lane r of
+                // the first lane group keeps row r of [Huu | I] in registers and the pivot rows travel by DPP (lanegroup.hpp) -- the same
+                // operations per element (bp_lg.hpp uses the same scheme), no barrier per pivot
+                T* A = &s.Huu[0];
+                if (threadIdx.x < 7) {        // lane 7 of the group must be inactive for the broadcasts
+                    using L = LgDevice<T>;
+                    const int r = threadIdx.x;
+                    T R[14];
+#pragma unroll
+                    for (int kc = 0; kc < 7; kc++) { R[kc] = s.H[oHUU + r + NM * kc]; R[7 + kc] = T(r == kc ? 1 : 0); }
+#define PDDP_WIDE_PIV(PV)                                                                                   \
+                    {                                                                                       \
+                        T rowp[8];                                                                          \
+                        _Pragma("unroll") for (int kc = 0; kc < 8; kc++) rowp[kc] = L::template bcast<PV>(R[PV + kc]);  \
+                        const T colp = R[PV];                                                               \
+                        const T inv = T(1) / rowp[0];                                                       \
+                        _Pragma("unroll") for (int kc = 0; kc < 8; kc++) R[PV + kc] = (r == PV) ? R[PV + kc] * inv : R[PV + kc] - colp * inv * rowp[kc]; \
+                    }
+                    PDDP_WIDE_PIV(0) PDDP_WIDE_PIV(1) PDDP_WIDE_PIV(2) PDDP_WIDE_PIV(3) PDDP_WIDE_PIV(4) PDDP_WIDE_PIV(5) PDDP_WIDE_PIV(6)
+#undef PDDP_WIDE_PIV
+#pragma unroll
+                    for (int kc = 0; kc < 7; kc++) A[NU * NU + r + NU * kc] = R[7 + kc];
+                }
+                wsync(w);
+                Hinv = &A[NU * NU];
+            }
+#endif
+            else {                            // [Huu | I] unpivoted Gauss-Jordan, never reports failure (invHuu)
                 T* A = &s.Huu[0]; T* gjC = &s.Huu[2 * NU * NU]; T* gjR = gjC + NU;
                 PDDP_FOR(e, NU * NU) { const int ky = e / NU, kx = e % NU; A[e] = s.H[oHUU + kx + NM * ky]; A[NU * NU + e] = T(kx == ky ? 1 : 0); }
                 wsync(w);

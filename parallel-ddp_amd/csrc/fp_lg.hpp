@@ -71,29 +71,35 @@ PDDP_HD void arm_lg_forward_sweep(const Dims& dm, const FpLgArgs<T>& a) {
     const typename L::M act = L::all_true();
     V xq = L::gather_at(a.xb, a.oxc, [](int l) { return l; }), xv = L::gather_at(a.xb, a.oxc, [](int l) { return l + NP; });
     const int k_last = (dm.M - 1) * dm.NB - 1;             // last defect boundary
+    // operands of step k (none depends on the running state): fetched one step ahead, their latency hides behind the previous step's arithmetic
+    V Aq[NX], Av[NX], cq, cv, nq, nv, bq, bv, dq_, dv_;
+    auto fetch = [&](int k) {
+        const unsigned oA = (a.pbN + k) * 196, ob = (a.pbN + k) * 14;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { Aq[i] = L::gather_at(a.ApBK, oA, [i](int l) { return l + 14 * i; }); Av[i] = L::gather_at(a.ApBK, oA, [i](int l) { return l + 7 + 14 * i; }); }
+        cq = L::gather_at(a.xb, a.oxc, [k](int l) { return 14 * k + l; }); cv = L::gather_at(a.xb, a.oxc, [k](int l) { return 14 * k + l + 7; });
+        nq = L::gather_at(a.xb, a.oxc, [k](int l) { return 14 * (k + 1) + l; }); nv = L::gather_at(a.xb, a.oxc, [k](int l) { return 14 * (k + 1) + l + 7; });
+        bq = L::gather_at(a.Bdu, ob, [](int l) { return l; }); bv = L::gather_at(a.Bdu, ob, [](int l) { return l + 7; });
+        dq_ = L::gather_at(a.dcur, ob, [](int l) { return l; }); dv_ = L::gather_at(a.dcur, ob, [](int l) { return l + 7; });
+    };
+    if (k_last >= 0) fetch(0);
     for (int k = 0; k <= k_last; k++) {
-        const unsigned oA = (a.pbN + k) * (NX * NX), ob = (a.pbN + k) * NX;
-        const V dq = xq - L::gather_at(a.xb, a.oxc, [k](int l) { return NX * k + l; });
-        const V dv = xv - L::gather_at(a.xb, a.oxc, [k](int l) { return NX * k + l + NP; });
+        const V dq = xq - cq, dv = xv - cv;
         V bc[14];
         lg_bcast14<L>(bc, dq, dv);
-        V vq = L::gather_at(a.ApBK, oA, [](int l) { return l; }) * bc[0];
-        V vv = L::gather_at(a.ApBK, oA, [](int l) { return l + NP; }) * bc[0];
+        V vq = Aq[0] * bc[0];
+        V vv = Av[0] * bc[0];
 #pragma unroll
         for (int i = 1; i < NX; i++) {
-            vq = vq + L::gather_at(a.ApBK, oA, [i](int l) { return l + NX * i; }) * bc[i];
-            vv = vv + L::gather_at(a.ApBK, oA, [i](int l) { return l + NP + NX * i; }) * bc[i];
+            vq = vq + Aq[i] * bc[i];
+            vv = vv + Av[i] * bc[i];
         }
         const bool bnd = dm.on_defect_boundary(k);
-        V nq = L::gather_at(a.xb, a.oxc, [k](int l) { return NX * (k + 1) + l; });
-        V nv = L::gather_at(a.xb, a.oxc, [k](int l) { return NX * (k + 1) + l + NP; });
-        V aq = -V(a.alpha) * L::gather_at(a.Bdu, ob, [](int l) { return l; }) + vq;
-        V av = -V(a.alpha) * L::gather_at(a.Bdu, ob, [](int l) { return l + NP; }) + vv;
-        if (bnd) {
-            aq = aq + L::gather_at(a.dcur, ob, [](int l) { return l; });
-            av = av + L::gather_at(a.dcur, ob, [](int l) { return l + NP; });
-        }                                                  // the cooperative code adds an exact 0 off the boundaries
+        V aq = -V(a.alpha) * bq + vq;
+        V av = -V(a.alpha) * bv + vv;
+        if (bnd) { aq = aq + dq_; av = av + dv_; }         // the cooperative code adds an exact 0 off the boundaries
         xq = nq + aq; xv = nv + av;
+        if (k < k_last) fetch(k + 1);
         if (bnd) {
             L::scatter_at(a.xs, (a.slotN + k + 1) * NX, [](int l) { return l; }, xq, act);
             L::scatter_at(a.xs, (a.slotN + k + 1) * NX, [](int l) { return l + NP; }, xv, act);

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-convergence", action="store_true", help="skip the whole-batch time-to-convergence block (profiling runs: keeps the kernel statistics to the timed sweeps)")
     ap.add_argument("--lib", default=None, help="alternative libpddp build (measurement of build variants only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
@@ -156,6 +157,22 @@ def main():
             "roofline": roof}
 
     s.close()
+    if not args.no_convergence:
+        line["convergence"] = batch_convergence(ctx, args, torch, x0, u0, xg, B, N, M, A)
+
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
+        line["latency"] = latency_single_problem(ctx.device)
+        line["widening"] = widening_rows(ctx.device)
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    elif ctx.rank == 0:
+        line["cpu_baseline"] = None
+    if ctx.rank == 0:
+        print(json.dumps(line), flush=True)
+    shard.finalize(ctx)
+
+
+def batch_convergence(ctx, args, torch, x0, u0, xg, B, N, M, A):
     # ---- wall clock to convergence of the whole sharded batch (BASELINE metric, second half): TOL_COST 1e-4 (config.cuh:85-87), MAX_ITER 100;
     # every rank iterates its own problems, the ranks agree on "all done" with one max-reduce per poll (pyddp.shard.all_done)
     cfg2 = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=1e-4, total_time=0.5, batch=B, max_iter=100, device=ctx.device,
@@ -175,22 +192,12 @@ def main():
     t_conv = shard.max_over_ranks(ctx, time.perf_counter() - t0)
     out2 = s2.store()
     conv_it = [convergence_iteration(out2["Jout"][b], out2["alphaOut"][b], int(iters2[b])) for b in range(min(B, 256))]
-    line["convergence"] = {"tol_cost": 1e-4, "max_iter": 100, "problems_total": ctx.world * B, "ms_until_every_problem_exited": round(1e3 * t_conv, 3),
+    res = {"tol_cost": 1e-4, "max_iter": 100, "problems_total": ctx.world * B, "ms_until_every_problem_exited": round(1e3 * t_conv, 3),
                            "sweeps_enqueued": 8 * polls, "median_exit_iteration_rank0": float(np.median(iters2)),
                            "median_iterations_to_convergence_rank0": float(np.median(conv_it)),
                            "exit_reasons_rank0": {str(k): int((done2 == k).sum()) for k in (1, 2, 3)}}
     s2.close()
-
-    if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
-        line["latency"] = latency_single_problem(ctx.device)
-        line["widening"] = widening_rows(ctx.device)
-    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline()
-    elif ctx.rank == 0:
-        line["cpu_baseline"] = None
-    if ctx.rank == 0:
-        print(json.dumps(line), flush=True)
-    shard.finalize(ctx)
+    return res
 
 
 def convergence_iteration(J, alpha, iters):

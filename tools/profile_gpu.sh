@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-latency $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-latency --no-convergence $*"
 timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- $BENCH > $OUT/trace_bench.log 2>&1
 timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $BENCH --calibrate-hbm > $OUT/pmc_fetch_bench.log 2>&1
 timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $BENCH --calibrate-hbm > $OUT/pmc_write_bench.log 2>&1

@@ -242,6 +242,17 @@ def latency_single_problem(device):
                      "median_iterations_to_convergence": float(np.median(convs)),
                      "median_ms_to_convergence": round(float(np.median(np.asarray(convs) * np.asarray(mss) / np.asarray(its))), 3),
                      "ms_per_iteration": round(float(np.median(np.asarray(mss) / np.asarray(its))), 4)}
+        # per-phase medians like the reference prints them (BP / sweep+sim / line search / NIS; DDPWrappers.cuh:54-105) and the (time, J) trace of one
+        # solve, so that another convergence threshold can be applied: kernel durations from HIP events, launched kernel by kernel
+        x0, u0, xg = example_inputs(Nk, np.random.default_rng(4321), 1)
+        pt = s.solve_phase_timed(x0, u0, xg)
+        n_it = int(pt["iters"][0])
+        ph = pt["phase_ms"][:, :n_it]
+        res[name]["per_phase_median_us"] = {k: round(float(np.median(ph[i]) * 1e3), 1) for i, k in enumerate(PHASES)}
+        if name == "to_convergence_tol_1e-4":
+            cum = np.cumsum(ph.sum(axis=0))
+            res[name]["trace"] = {"J": [round(float(v), 4) for v in pt["Jout"][0][: n_it + 1]], "alpha": [int(v) for v in pt["alphaOut"][0][: n_it + 1]],
+                                  "cumulative_kernel_ms": [0.0] + [round(float(v), 4) for v in cum]}
         s.close()
     return res
 

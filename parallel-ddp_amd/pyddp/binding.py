@@ -194,6 +194,21 @@ class Solver:
                     iters=int(iters[0]) if B == 1 else iters, ms_total=times[0], ms_init=times[1], ms_loop=times[0] - times[1],
                     J_final=float(Jout[0][iters[0]]))
 
+    def solve_phase_timed(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1, poll_every=8):
+        """pddp_solve_ex with per-iteration phase timers (HIP events per kernel, like the reference's bpTime[] / simTime[] / nisTime[], DDPWrappers.cuh:54-105):
+        phase_ms[4][max_iter + 2] = backward pass, sweep + rollouts, line search, next-iteration setup of every iteration (batch 1)."""
+        B, mi = self.cfg.batch, self.cfg.max_iter
+        x0, u0, xGoal = self.arr(x0).copy(), self.arr(u0).copy(), self.arr(xGoal)
+        Jout, aout = np.zeros((B, mi + 2), self.dtype), np.zeros((B, mi + 2), np.int32)
+        times = (C.c_double * 2)()
+        phase = np.zeros((4, mi + 2), np.float64)
+        sweeps = C.c_int(0)
+        self.lib.pddp_solve_ex.argtypes = [C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.pddp_solve_ex(self.h, _p(x0), _p(u0), _p(xGoal), None, None, None, None, _p(Jout), _p(aout), 0, int(clear_vars), int(ignore_first_defect),
+                                         int(poll_every), times, _p(phase), C.byref(sweeps)))
+        done, iters = self.status()
+        return dict(Jout=Jout, alphaOut=aout, iters=iters, phase_ms=phase, ms_total=times[0], ms_init=times[1], sweeps=sweeps.value)
+
     def simulate(self, x, u, KT, t0_us, elapsed_us, substeps=150, goal_xyz=None, xActual=None):
         """pddp_simulate: the lock-step simulated robot (simulateForward).  Returns (xActual after elapsed_us, average tracking error, failed)."""
         x, u, KT = self.arr(x), self.arr(u), self.arr(KT)

@@ -14,6 +14,7 @@
 #pragma once
 
 #include "fp.hpp"
+#include "plant_arm_lg.hpp"
 #include "solver_state.hpp"
 
 namespace pddp {
@@ -92,7 +93,29 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
     PDDP_FOR(i, NX) { const T v = xActual[i]; s.x[i] = v; x0[i] = v; }
     wsync();
     const int n_roll = full_rollout ? N : dm.NB;
-    for (int k = 0; k < n_roll - 1; k++) {
+    bool rolled = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (P::PLANT == 4 && INTEG == 1) {
+        // the arm: this serial rollout is a third of an MPC control cycle; one lane group runs it with the register-resident dynamics of the forward
+        // pass (plant_arm_lg.hpp: the same numbers as P::dynamics, bit for bit), about half the time per step of the wave-cooperative evaluation
+        if (w.lane < 7) {                       // lane 7 and the rest of the wave stay out of the lane-group code (lanegroup.hpp)
+            using L = LgDevice<T>;
+            ArmLgConst<L> c; c.Itab = s.plant.I; c.Ftab = s.plant.F; c.grav = s.plant.grav;
+            ArmLgState<L> st;
+            const int l = w.lane;
+            T q = xActual[l], qd = xActual[l + 7];
+            for (int k = 0; k < n_roll - 1; k++) {
+                const T qdd = arm_lg_dynamics<L, true>(c, st, q, qd, u[NU * k + l]);
+                const T qn = q + dt * qd, qdn = qd + dt * qdd;       // Euler (utils/integrators.cuh:24-36)
+                x0[NX * (k + 1) + l] = qn; x0[NX * (k + 1) + l + 7] = qdn;
+                q = qn; qd = qdn;
+            }
+        }
+        wsync();
+        rolled = true;
+    }
+#endif
+    if (!rolled) for (int k = 0; k < n_roll - 1; k++) {
         PDDP_FOR(i, NU) s.u[i] = u[NU * k + i];
         wsync();
         integrator_step<P, INTEG>(w, s.plant, s.integ, s.xn, s.x, s.u, dt);

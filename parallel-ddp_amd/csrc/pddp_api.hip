@@ -360,36 +360,43 @@ struct Solver : SolverBase {
         std::vector<int> done(B);
         int rc = 0;
         const int chunk = poll_every > 0 ? poll_every : 4;
+        bool fresh = false;
         for (int guard = 0; guard < 100000; guard++) {
             if (budget_ms > 0 && now_ms() - t0 > budget_ms) break;   // time_budget (MPCHelpers.cuh:919,941,1001): checked between chunks of sweeps
+            fresh = false;
             if ((rc = iterate(chunk))) break;
             if ((rc = status(done.data(), nullptr))) break;
+            fresh = true;                                            // hstate reflects everything enqueued so far
             bool all = true;
             for (int v : done) all &= (v != 0);
             if (all) break;
         }
         sp.max_iter = saved_max_iter;
         if (rc) return rc;
-        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm);
+        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm);   // copies only: the states status() fetched above stay valid
         HIPCHK(hipGetLastError());
-        if ((rc = store(x, u, KT, Jout, alphaOut, nullptr))) return rc;
-        std::vector<SolverState<T>> st(B);
-        HIPCHK(hipMemcpy(st.data(), b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < B; i++) { if (success) success[i] = st[i].took_step; if (iters) iters[i] = st[i].iter; }
+        if ((rc = store_impl(x, u, KT, Jout, alphaOut, nullptr, fresh))) return rc;
+        for (size_t i = 0; i < B; i++) { if (success) success[i] = hstate[i].took_step; if (iters) iters[i] = hstate[i].iter; }
         return 0;
     }
+    std::vector<SolverState<T>> hstate;      // the solver states as last fetched by status()
     int status(int* done, int* iters) override {
-        std::vector<SolverState<T>> st(cfg.batch);
-        HIPCHK(hipMemcpyAsync(st.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
+        hstate.resize(cfg.batch);
+        HIPCHK(hipMemcpyAsync(hstate.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = st[i].done; if (iters) iters[i] = st[i].iter; }
+        for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = hstate[i].done; if (iters) iters[i] = hstate[i].iter; }
         return 0;
     }
-    int store(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) override {
+    int store(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) override { return store_impl(x, u, KT, Jout, alphaOut, dmax, false); }
+    // state_is_current: hstate was fetched after the last kernel that changes `cur` / `alphaIndex` (saves a round trip in the MPC cycle)
+    int store_impl(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax, bool state_is_current) {
         const size_t B = cfg.batch, N = cfg.N;
-        std::vector<SolverState<T>> st(B);
-        HIPCHK(hipMemcpyAsync(st.data(), b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        if (!state_is_current) {
+            hstate.resize(B);
+            HIPCHK(hipMemcpyAsync(hstate.data(), b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        const std::vector<SolverState<T>>& st = hstate;
         for (size_t pb = 0; pb < B; pb++) {
             if (x) HIPCHK(hipMemcpyAsync((T*)x + pb * N * NX, b.xb + (pb * 2 + st[pb].cur) * N * NX, N * NX * sizeof(T), hipMemcpyDeviceToHost, stream));
             if (dmax) HIPCHK(hipMemcpyAsync((T*)dmax + pb, b.dmax + pb * cfg.A + st[pb].alphaIndex, sizeof(T), hipMemcpyDeviceToHost, stream));

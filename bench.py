@@ -160,11 +160,18 @@ def main():
     if not args.no_convergence:
         line["convergence"] = batch_convergence(ctx, args, torch, x0, u0, xg, B, N, M, A)
 
+    # the secondary figures must never cost the headline line: a failure in one of them is reported in its place
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:      # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"}
+
     if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
-        line["latency"] = latency_single_problem(ctx.device)
-        line["widening"] = widening_rows(ctx.device)
+        line["latency"] = guarded(latency_single_problem, ctx.device)
+        line["widening"] = guarded(widening_rows, ctx.device)
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline()
+        line["cpu_baseline"] = guarded(cpu_baseline)
     elif ctx.rank == 0:
         line["cpu_baseline"] = None
     if ctx.rank == 0:

@@ -117,8 +117,27 @@ def ee_cost_level(path, N=64):
           f"J[1] kernel {out['Jout'][0][1]:.5f} oracle32 {a32['Jout'][1]:.5f} oracle64 {a64['Jout'][1]:.5f}")
 
 
+def quadrotor_tolerance_sweep(path, iters=25):
+    """BASELINE configs[4]: quadrotor, N=256, RK3, 16 alphas, M=4, T=4 s -- float32 and float64 from the same stored inputs:
+    per iteration the relative deviation of J and the max deviations of x and K^T at the end, and the first iteration where the step-size index differs."""
+    kw = dict(N=256, M=4, A=16, integrator=3, total_time=4.0, max_iter=iters, tol_cost=0.0)
+    noise = np.random.default_rng(11).normal(0, 0.001, (256, 12))
+    res = {}
+    for dt in (np.float32, np.float64):
+        s = pyddp.Solver(pyddp.default_config(3, _lib_path=path, dtype=0 if dt == np.float32 else 1, **kw), _lib_path=path)
+        x0, u0, xg = example_inputs(3, 256, dt, noise=noise)
+        res[dt] = s.solve(x0, u0, xg)
+    a32, a64 = res[np.float32]["alphaOut"][0], res[np.float64]["alphaOut"][0]
+    J32, J64 = res[np.float32]["Jout"][0], res[np.float64]["Jout"][0]
+    first = next((i for i in range(iters + 1) if a32[i] != a64[i]), iters + 1)
+    dev = [abs(float(J32[i]) / float(J64[i]) - 1) for i in range(iters + 1)]
+    print(f"  quad  N=256 RK3 A=16 M=4: float32 vs float64 step-size indices agree for {first} of {iters + 1} entries; J[0] {J64[0]:.4f} -> J[{iters}] f64 {J64[iters]:.4f} f32 {J32[iters]:.4f}")
+    print("        |J32/J64 - 1| per iteration: " + " ".join(f"{d:.1e}" for d in dev))
+    print(f"        final x: {nrel(res[np.float32]['x'][0], res[np.float64]['x'][0]):.2e}   final K^T: {nrel(res[np.float32]['KT'][0], res[np.float64]['KT'][0]):.2e}")
+
+
 if __name__ == "__main__":
     paths = sys.argv[1:] or [pyddp.library_path()]
     for path in paths:
         print(os.path.basename(path))
-        plant_level(path); backward_pass_level(path); backward_pass_level(path, N=128, M=4); solver_level(path); ee_cost_level(path)
+        plant_level(path); backward_pass_level(path); backward_pass_level(path, N=128, M=4); solver_level(path); ee_cost_level(path); quadrotor_tolerance_sweep(path)

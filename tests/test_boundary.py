@@ -145,6 +145,7 @@ def test_set_cost_equals_creating_with_those_weights():
     (dict(A=0), "A in"),
     (dict(A=65), "A in"),
     (dict(batch=0), "batch"),
+    (dict(N=128, batch=80000), "32-bit element offsets"),  # maximum size: 80000 * 128 * 441 elements of H do not fit the lane-group kernels' offsets
     (dict(integrator=3), "Euler"),                       # the arm is Euler-only, like config.cuh:58
     (dict(dtype=2), "unsupported"),
     (dict(N=128, M=16, A=12), "must not exceed 128"),    # lane-group forward pass: a workgroup rolls out all 12 candidates x 16 segments (A not a multiple of 8)

@@ -32,6 +32,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
 
 
+def test_header_is_plain_c99_and_links_from_c():
+    """include/pddp.h is the FFI surface: it must compile with a C compiler (-std=c99 -pedantic) and the library must link from C."""
+    exe = os.path.join(ROOT, "tests", "cabi", "cabi_min")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi", "cabi_min.c"),
+                           "-L" + os.path.join(PKG, "lib"), "-lpddp", "-Wl,-rpath," + os.path.join(PKG, "lib"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    import torch
+    assert r.returncode == 0
+    assert ("create rc 0" in r.stdout) if torch.cuda.is_available() else ("create rc -2" in r.stdout and "no HIP device" in r.stdout)
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():

@@ -135,6 +135,29 @@ def test_lockstep_figure_eight_experiment_end_to_end():
 
 
 @pytest.mark.gpu
+def test_two_handles_on_two_host_threads_do_not_disturb_each_other():
+    """The reference's MPC set-up runs the solver and the trajectory runner on different host threads (MPCHelpers.cuh:62): two handles (own streams, own
+    buffers, thread-local error string) driven concurrently from two threads give exactly what each gives alone."""
+    import threading
+    kw = dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=25)
+    inputs = [example_inputs(4, 64, np.float32, noise=np.random.default_rng(s).normal(0, 0.002, (64, 14))) for s in (1, 2)]
+    alone = []
+    for x0, u0, xg in inputs:
+        alone.append(pyddp.Solver(pyddp.default_config(4, **kw)).solve(x0, u0, xg))
+    solvers = [pyddp.Solver(pyddp.default_config(4, **kw)) for _ in inputs]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(3):                      # several solves each, interleaved by the scheduler
+            out[i] = solvers[i].solve(*inputs[i])
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    for i in range(2):
+        assert np.array_equal(out[i]["Jout"], alone[i]["Jout"]) and np.array_equal(out[i]["x"], alone[i]["x"]) and np.array_equal(out[i]["KT"], alone[i]["KT"])
+    assert not np.array_equal(out[0]["Jout"], out[1]["Jout"])
+
+
+@pytest.mark.gpu
 def test_set_cost_equals_creating_with_those_weights():
     x0, u0, xg = example_inputs(4, 32, np.float32)
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=15)

@@ -13,8 +13,14 @@ static void hex(const char* name, const std::vector<uint8_t>& b) {
     std::printf("\n");
 }
 
-int main() {
+int main(int argc, char** argv) {
     using namespace pddp_wire;
+    if (argc > 1) {   // goal generator: loadFig8Goal over the table in argv[1] at a few times of a 10 s figure (examples/WAFR_MPC_examples.cu:93-104)
+        if (!Fig8Goals::table().load(argv[1])) return 2;
+        const double total = 10.0e6, times[6] = {0.0, 1234567.0, 5000000.0, 9999999.0, 10050000.0, 10051000.0};
+        for (int i = 0; i < 6; i++) { float g[6]; const int rep = loadFig8Goal<float>(g, times[i], total); std::printf("goal %.1f %d %.9g %.9g %.9g\n", times[i], rep, g[0], g[1], g[2]); }
+        return 0;
+    }
     typedef float T;
     std::printf("hash_traj_f %lld\nhash_traj_d %lld\nhash_solver %lld\nhash_cost %lld\n", (long long)lcmt_trajectory_f::getHash(), (long long)lcmt_trajectory_d::getHash(),
                 (long long)lcmt_solver_params::getHash(), (long long)lcmt_cost_params::getHash());

@@ -56,6 +56,8 @@ typedef struct ora_cfg {
     double Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE;
     double ee_on_link_z;                /* EE_ON_LINK_Z (EE_TYPE 1: 0.0635)                         dynamics_arm.cuh:48-65 */
     double xTarget[14];                 /* nominal-state target (d_xTarget); zeros = the reference's xTarget == nullptr case */
+    int ee_type;                        /* EE_TYPE 0 none / 1 flange (default) / 2 flange + peg: link-7 INERTIA_MODIFIER, WEIGHT_MODIFIER
+                                           (default-URDF branch only)                              dynamics_arm.cuh:48-65,338-347 */
 } ora_cfg;
 
 /* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */

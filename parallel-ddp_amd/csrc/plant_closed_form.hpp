@@ -1,8 +1,9 @@
 // Closed-form plants: pendulum, cart-pole, quadrotor.  One lane evaluates them (they are a few dozen flops);
 // the expressions, constants and literal types follow plants/dynamics_pend.cuh:30-51, dynamics_cart.cuh:30-76 and
 // dynamics_quad.cuh:42-169 (double literals promote the arithmetic exactly as in the reference).
-// GENERATED by the snippet in DESIGN.md (section "closed-form plants") from the same restated formulas the oracle uses;
-// parity tests still compare the two builds because compilers, contraction and libm differ.
+// These closed-form polynomials (with their numeric coefficients) cannot be written differently and stay exact, so the oracle carries the
+// same expressions; what pins BOTH is tests/golden/closed_form_plants.json -- the reference's own statements executed in float64 on stored
+// inputs by tests/golden/make_closed_form_plants.py (tests/test_closed_form_pins.py: dynamics and every gradient entry, 25 states per plant).
 #pragma once
 #include "pddp_common.hpp"
 namespace pddp {

@@ -5,8 +5,9 @@
 //
 // Encoding (LCM wire format of a message body): 8-byte fingerprint, then the members in declaration order, every scalar big-endian, arrays as
 // consecutive scalars.  fingerprint = rotl1(base) with base = lcm-gen's hash over (member name, primitive type name, dimensions) starting from
-// 0x12345678 -- restated from the LCM generator's published algorithm.  PARITY UNPINNED: no LCM install or captured packet is available here to
-// check the fingerprints against; tests/test_wire_format.py holds an independent second implementation and the byte layout checks.
+// 0x12345678 -- restated from the LCM generator's published algorithm.  PINNED: the four fingerprints equal rotl1 of the base hashes in the
+// reference's own lcm-gen output (lcmtypes/drake/lcmt_trajectory_{f,d}.hpp:212, lcmtypes/kuka/lcmt_cost_params.hpp:304, lcmt_solver_params.hpp:178;
+// fixture tests/golden/lcm_hashes.json, test tests/test_wire_format.py).
 //
 // A reference quirk that IS the contract: the MPC loop stores BYTE counts in x_size / u_size / KT_size (ld * TRAJ_RUNNER_TIME_STEPS * sizeof(T),
 // :241-246) and sizes the arrays with them, so a message carries sizeof(T) times more elements than the trajectory has (the tail is zero); the

@@ -291,6 +291,12 @@ class Solver:
     def run_phase(self, phase):
         self._chk(self.lib.pddp_run_phase(self.h, int(phase)))
 
+    def plant_eval_paths(self):
+        """`what` codes of pddp_plant_eval per plant function: every implementation of the plant the library carries."""
+        if self.cfg.plant != 4:
+            return {"dynamics": [0], "gradient": [1]}
+        return {"dynamics": [0, 4, 6], "gradient": [1, 5]}    # cooperative wave; lane group; lane group, packed rows
+
     def plant_eval(self, what, x, u):
         x, u = self.arr(x).reshape(-1, self.n), self.arr(u).reshape(-1, self.m)
         count = x.shape[0]

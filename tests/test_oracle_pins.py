@@ -1,7 +1,12 @@
-"""Pin the oracle (oracle/, test infrastructure) against the known answers recorded in SURVEY.md.
+"""Solver-level cross-checks of the oracle against the numbers recorded in SURVEY.md section 8(c) (tests/golden/survey_kat.json).
 
-CPU-only.  The reference's own tests hold no golden vectors for this path; the survey session's
-measurements of the reference host path are the only known answers available (tests/golden/survey_kat.json).
+STATUS: NOT a pin of the reference.  Those numbers came from a build of the reference's host code against stand-in CUDA headers, and carry two
+artefacts of that build (integer min/max in the rho schedule, sin/cos bound to the double libm functions); the tests below therefore run the oracle
+in an EMULATION of that build (`survey_int_minmax`, `survey_double_trig`), a mode no parity test uses.  They guard the restatement of the driver
+logic (line search, accept/reject, rho schedule, multiple-shooting bookkeeping) against regressions -- nothing more.  The pins that count come from
+data the reference itself holds: tests/test_urdf_pins.py (iiwa14.urdf, the example's gravity-balancing torques, printDyn / testDynGrad states),
+tests/test_closed_form_pins.py (the reference's own pendulum / cart-pole / quadrotor formulas), tests/test_fig8_pins.py (the recorded figure-eight
+run) and tests/test_wire_format.py (lcm-gen hashes).  CPU-only.
 """
 import json
 import os

@@ -1,9 +1,11 @@
 """Trajectory wire format and the robot-side trajectory runner (lcmtypes/lcmt_trajectory_{f,d}.lcm, lcmt_solver_params.lcm,
 lcmt_cost_params.lcm, DDPHelpers/LCMHelpers.cuh:98-153, 203-262) -- hostapi/LCMHelpers.hpp, exercised by the C++ test tool tests/wire/wire_driver.cpp.
 
-PARITY UNPINNED: no LCM install or captured packet exists here, so the fingerprints cannot be compared with lcm-gen's output.  Checked instead: a second,
-independent implementation of the generator's hash (below), the byte layout (big-endian scalars in declaration order), the reference's byte-count
-size quirk, round trips, rejection of foreign / truncated buffers, and the trajectory runner's command against numpy."""
+Fingerprints are PINNED to the reference's own lcm-gen output: tests/golden/lcm_hashes.json holds the four base hash constants of
+lcmtypes/{drake,kuka}/*.hpp (extracted by the committed tests/golden/make_lcm_hashes.py); getHash() rotates them left by one bit.  Also checked: a
+second, independent implementation of the generator's hash (below), the byte layout (big-endian scalars in declaration order), the reference's
+byte-count size quirk, round trips, rejection of foreign / truncated buffers, and the trajectory runner's command against numpy."""
+import json
 import os
 import struct
 import subprocess
@@ -64,6 +66,16 @@ def out():
             k, _, v = line.partition(" ")
             d[k] = v
     return d
+
+
+def test_fingerprints_equal_the_reference_lcm_gen_constants(out):
+    """The four fingerprints on the wire == rotl1(base hash in the reference's generated headers)."""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "lcm_hashes.json")))
+    M = (1 << 64) - 1
+    for key, okey in (("traj_f", "hash_traj_f"), ("traj_d", "hash_traj_d"), ("solver", "hash_solver"), ("cost", "hash_cost")):
+        base = int(gold[key]["base_hash"], 16)
+        fp = ((base << 1) & M) + (base >> 63)
+        assert int(out[okey]) & M == fp, (key, gold[key]["source"])
 
 
 def test_fingerprints_agree_with_an_independent_implementation_of_the_generator_hash(out):

@@ -76,7 +76,7 @@ PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp
     const int* err = b.err + (size_t)pb * dm.M;
     int any = 0;
     for (int i = 0; i < dm.M; i++) any |= err[i];
-    const size_t ho = (size_t)pb * (sp.max_iter + 2);
+    const size_t ho = (size_t)pb * sp.out_stride;
     if (freeze_exit) {   // benchmark mode: never exit, keep writing the same Jout slot
         SolverParams sp2 = sp; sp2.tol_cost = -1e300; sp2.ignore_max_rho_exit = 1;
         const int it = st.iter;
@@ -144,7 +144,7 @@ PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const
         wsync();
         J = tree_sum<T>(w, cost_k, N);
     } else if (stage == 2) {
-        const size_t ho = (size_t)pb * (sp.max_iter + 2);
+        const size_t ho = (size_t)pb * sp.out_stride;
         if (rollout) J = b.J[(size_t)pb * dm.A];
         else {
             const int a0 = sp.ee_initial_cost_fix ? 0 : b.state[pb].alphaIndex;
@@ -169,7 +169,7 @@ PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const
         st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.took_step = 0;
         st.pw = b.state[pb].pw;        // a warm start must read the cost-to-go of the iteration before the previous exit: keep the buffer roles
         b.state[pb] = st;
-        const size_t ho = (size_t)pb * (sp.max_iter + 2);
+        const size_t ho = (size_t)pb * sp.out_stride;
         b.Jout[ho] = st.prevJ - T(2 * sp.tol_cost);
         b.alphaOut[ho] = rollout ? 0 : -1;
     }

@@ -136,7 +136,7 @@ struct Solver : SolverBase {
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); }
-        sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
+        sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
@@ -290,7 +290,13 @@ struct Solver : SolverBase {
                 hipGraph_t gr;
                 HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 launch_sweep(stream);
-                HIPCHK(hipStreamEndCapture(stream, &gr));
+                {   // a failed launch inside the capture must not leave the stream capturing
+                    const hipError_t le = hipGetLastError(), ce = hipStreamEndCapture(stream, &gr);
+                    if (le != hipSuccess || ce != hipSuccess) {
+                        if (ce == hipSuccess && gr) hipGraphDestroy(gr);
+                        return fail(PDDP_ENODEVICE, std::string("sweep capture failed: ") + hipGetErrorString(le != hipSuccess ? le : ce));
+                    }
+                }
                 HIPCHK(hipGraphInstantiate(&graph, gr, nullptr, nullptr, 0));
                 HIPCHK(hipGraphDestroy(gr));
                 graph_mode = bench_mode + 2 * sp.max_iter;
@@ -440,6 +446,7 @@ struct Solver : SolverBase {
     }
     int get_state(pddp_state* out) override {
         std::vector<SolverState<T>> st(cfg.batch);
+        HIPCHK(hipStreamSynchronize(stream));        // the solver stream is non-blocking: order the copy after every enqueued sweep
         HIPCHK(hipMemcpy(st.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost));
         for (int i = 0; i < cfg.batch; i++) {
             const auto& s = st[i]; pddp_state& o = out[i];
@@ -455,6 +462,7 @@ struct Solver : SolverBase {
             s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
             s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw;
         }
+        HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(b.state, st.data(), cfg.batch * sizeof(SolverState<T>), hipMemcpyHostToDevice));
         return 0;
     }
@@ -608,6 +616,7 @@ extern "C" int pddp_array_ptr(pddp_handle h, const char* name, void** ptr, size_
 extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes) {
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
     if (bytes > cap) return fail(PDDP_EINVAL, "set_array: too many bytes");
+    HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice)); return 0;
 }
 extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes) {

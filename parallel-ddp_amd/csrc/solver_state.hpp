@@ -39,7 +39,8 @@ struct SolverState {
 };
 
 struct SolverParams {    // read-only per launch (reference macros, config.cuh)
-    int max_iter;               // MAX_ITER                :83
+    int max_iter;               // MAX_ITER                :83  (an MPC call lowers it per solve)
+    int out_stride;             // row stride of Jout / alphaOut = config.max_iter + 2: fixed at allocation, NOT the per-call iteration limit
     int ignore_max_rho_exit;    // IGNORE_MAX_ROX_EXIT     :105-107
     double tol_cost;            // TOL_COST                :85-87
     double exp_red_min, exp_red_max;   //                  :117-122

@@ -19,8 +19,9 @@
 //     tv->last_successful_solve, which storeVarsGPU_MPC then increments; only when it is 1 afterwards is the new
 //     trajectory copied into trajVars (under tv->lock), otherwise the device falls back to the shifted previous solution
 //   * tv->t0_sys / t0_plant always advance to this call's clock values                                           (:756)
-//   * the time budget is checked between groups of PDDP_POLL_EVERY sweeps (the reference checks it three times per
-//     iteration, :919,:941,:1001 -- it needs a host round trip per phase, this solver does not)
+//   * the time budget: with USE_MAX_SOLVER_TIME and a finite budget the exit flags and the clock are polled after EVERY sweep (the
+//     overshoot is at most one iteration; the reference checks three times per iteration, :919,:941,:1001); without a budget the
+//     sweeps are enqueued in groups of PDDP_POLL_EVERY
 //   * algTrace: J and alpha receive entries 0..iter of every solve, tTime the wall time of the call, initTime 0; the per-phase
 //     vectors stay empty unless the caller fills them from pddp_solve_ex (the sweeps of an MPC solve are graph replays)
 //   * use_cost_shift only acts on the end-effector cost (plants/cost_arm.cuh:212): final weights from knot N-1-shift on.
@@ -200,7 +201,7 @@ void runiLQR_MPC_GPU(trajVars<T>* tv, GPUVars<T>* gv, matDimms* md, algTrace<T>*
     T* Jtmp = reinterpret_cast<T*>(ctx->Jtmp.data());
     int success = 0, iter = 0;
     check(pddp_mpc_solve(h, gv->xActual, gv->xGoal, &shift, clear, FULL_ROLLOUT, ignoreFirstDefectFlag, max_iter, USE_MAX_SOLVER_TIME ? time_budget : 0.0,
-                         PDDP_POLL_EVERY, x.data(), u.data(), KT.data(), Jtmp, ctx->atmp.data(), &success, &iter), "runiLQR_MPC_GPU");
+                         (USE_MAX_SOLVER_TIME && time_budget > 0) ? 1 : PDDP_POLL_EVERY, x.data(), u.data(), KT.data(), Jtmp, ctx->atmp.data(), &success, &iter), "runiLQR_MPC_GPU");
     pddp_state st;
     check(pddp_get_state(h, &st), "pddp_get_state");
     *gv->alphaIndex = st.alphaIndex;

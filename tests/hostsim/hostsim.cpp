@@ -83,7 +83,7 @@ struct Sim : Base {
     void init() {
         const pddp_config& c = cfg;
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
-        sp.max_iter = c.max_iter; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
+        sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;

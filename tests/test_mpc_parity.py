@@ -86,3 +86,29 @@ def test_mpc_batch_rollouts_are_independent(backend):
         f2 = s1.mpc_solve(f1["x"][0][shifts[b]], gs[b], int(shifts[b]))
         assert np.array_equal(f1["Jout"][0], first["Jout"][b]) and np.array_equal(f2["Jout"][0], second["Jout"][b])
         assert np.array_equal(f2["x"][0], second["x"][b]) and f2["success"][0] == second["success"][b]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_mpc_batch_with_a_per_call_iteration_limit_keeps_the_trace_rows(backend):
+    """A per-call max_iter below config.max_iter must not move the rows of Jout / alphaOut: their stride is fixed at allocation
+    (config.max_iter + 2).  Batch of 3 against single-problem handles, trace rows and iteration counts compared."""
+    kw = dict(N=32, M=4, A=8, wafr_urdf=1, mpc_mode=1, total_time=0.5, tol_cost=1e-5, max_iter=8)
+    B = 3
+    xs, us, gs = [], [], []
+    for b in range(B):
+        x0, u0, xg = example_inputs(4, 32, np.float32, noise=RNG.normal(0, 0.001, (32, 14)))
+        xs.append(x0); us.append(np.full(32 * 7, 0.01, np.float32)); gs.append(xg + np.float32(0.05 * b))
+    sb = make_solver(backend, 4, batch=B, **kw)
+    sb.load(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    xact = np.stack([x[:14] for x in xs]) + RNG.normal(0, 0.002, (B, 14)).astype(np.float32)
+    got = sb.mpc_solve(xact, np.stack(gs), 0, clear_vars=1, max_iter=3)
+    for b in range(B):
+        s1 = make_solver(backend, 4, batch=1, **kw)
+        s1.load(xs[b], us[b], gs[b])
+        one = s1.mpc_solve(xact[b], gs[b], 0, clear_vars=1, max_iter=3)
+        it = int(one["iters"][0])
+        assert it == int(got["iters"][b]) and it <= 3
+        assert np.array_equal(one["Jout"][0][:it + 1], got["Jout"][b][:it + 1]) and np.array_equal(one["alphaOut"][0][:it + 1], got["alphaOut"][b][:it + 1])
+        assert np.array_equal(one["x"][0], got["x"][b])
+        s1.close()
+    sb.close()

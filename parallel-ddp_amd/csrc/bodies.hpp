@@ -4,6 +4,7 @@
 
 #include "bp.hpp"
 #include "fp.hpp"
+#include "fp_tl.hpp"
 #include "nis.hpp"
 #include "solver_state.hpp"
 
@@ -76,6 +77,7 @@ PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp
     const int* err = b.err + (size_t)pb * dm.M;
     int any = 0;
     for (int i = 0; i < dm.M; i++) any |= err[i];
+    if (b.parts_fresh && b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }   // thread-lane forward pass: add the per-segment partial sums
     const size_t ho = (size_t)pb * sp.out_stride;
     if (freeze_exit) {   // benchmark mode: never exit, keep writing the same Jout slot
         SolverParams sp2 = sp; sp2.tol_cost = -1e300; sp2.ignore_max_rho_exit = 1;

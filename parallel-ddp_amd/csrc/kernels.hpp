@@ -160,6 +160,12 @@ __global__ __launch_bounds__(64) void k_plant_eval_lg(const void* model, int cou
     }
 }
 
+// teacher-forcing hook only (pddp_run_phase(FP)): the line-search kernel normally adds the thread-lane forward pass's per-segment partial sums
+template <typename T>
+__global__ __launch_bounds__(64) void k_reduce_parts(Buffers<T> b, Dims dm, int batch) {
+    const int pb = blockIdx.x * 64 + threadIdx.x;
+    if (pb < batch && b.parts_fresh && b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }
+}
 // line search + accept/reject: grid (B), block 64; one lane takes the decision the reference takes on the host
 // (fpHelpers.cuh:395-408, nisInitHelpers.cuh:489-518).
 template <typename T>

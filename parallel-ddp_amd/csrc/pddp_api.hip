@@ -11,6 +11,7 @@
 #include "../../include/pddp.h"
 #include "iiwa14_model_data.h"
 #include "kernels.hpp"
+#include "tl_launch.hpp"
 
 using namespace pddp;
 
@@ -63,6 +64,7 @@ struct SolverBase {
     virtual int set_state(const pddp_state* in) = 0;
     virtual int run_phase(int phase) = 0;
     virtual int plant_eval(int what, int count, const void* x, const void* u, void* out) = 0;
+    virtual int model_changed() = 0;
     virtual int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) = 0;
     virtual int simulate(const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal, void* xActual,
                          double* avg_err, int* failed) = 0;
@@ -102,6 +104,27 @@ struct Solver : SolverBase {
     // full; the wave-cooperative kernel has the shorter critical path for a handful of problems.  PDDP_BP=lg|coop overrides.
     bool bp_lane_groups = false;
     bool fp_coop = false;          // PDDP_FP=coop
+    FpPath fp_path = kFpLg;        // the arm's forward pass / next-iteration setup (fp_tl.hpp select_fp_path)
+    int tl_variant = -1;           // which built-in robot model the handle's tables equal (the thread-lane kernels fold it into literals); -1: neither
+    T tl_grav = T(0);
+    void derive_tl_model(const ArmModel<T>& hm) {
+        ArmTlModel<T> m;
+        tl_variant = -1;
+        if (arm_tl_model_from_tables(m, hm))
+            for (int v = 0; v < 2; v++) if (arm_tl_models_equal(m, arm_tl_builtin<T>(v))) tl_variant = v;
+        tl_grav = hm.grav;
+        fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0);
+        fp_coop = (fp_path == kFpCoop);
+    }
+    void derive_tl_model(const EmptyModel&) {}
+    // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
+    int model_changed() override {
+        typename P::Model hm;
+        HIPCHK(hipMemcpy(&hm, b.model, sizeof(hm), hipMemcpyDeviceToHost));
+        derive_tl_model(hm);
+        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; }
+        return 0;
+    }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
@@ -134,7 +157,7 @@ struct Solver : SolverBase {
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
-        if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");
+        if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); }
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
@@ -168,6 +191,8 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpy(dmodel, &hm, sizeof(hm), hipMemcpyHostToDevice));
         b.model = dmodel;
         register_model(dmodel, hm);
+        derive_tl_model(hm);
+        if ((rc = alloc("Jpart", &b.Jpart, B * A * M)) || (rc = alloc("dpart", &b.dpart, B * A * M)) || (rc = alloc("parts_fresh", &b.parts_fresh, B))) return rc;
         // device tables of per-alpha pointers, the reference's d_x / d_u / d_d (nisInitHelpers.cuh:777-789,808-813)
         void** tab[3]; const char* tn[3] = {"xs_ptrs", "us_ptrs", "ds_ptrs"};
         T* base[3] = {b.xs, b.us, b.ds}; const size_t per[3] = {N * NX, N * NU, N * NX};
@@ -246,6 +271,10 @@ struct Solver : SolverBase {
             const int A_eff = A_all / chunks;
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
+            if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
+                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
+                return;
+            }
             const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
             const dim3 grid(B, chunks);
             if (cfg.ee_cost) {
@@ -260,6 +289,10 @@ struct Solver : SolverBase {
     void launch_nis(hipStream_t s, int mode) {
         const unsigned B = cfg.batch;
         if constexpr (P::PLANT == 4) {
+            if (fp_path == kFpTl) {
+                launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);
+                return;
+            }
             if (!fp_coop) {
                 if (cfg.ee_cost) hipLaunchKernelGGL((k_nis_lg<T, true>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 else hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
@@ -468,7 +501,10 @@ struct Solver : SolverBase {
     }
     int run_phase(int phase) override {
         const unsigned B = cfg.batch;
-        if (phase >= 0 && phase <= 3) launch_sweep(stream, phase);
+        if (phase >= 0 && phase <= 3) {
+            launch_sweep(stream, phase);
+            if (phase == PDDP_PHASE_FP) hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);   // J / dmax readable right after the phase
+        }
         else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);
         else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);
         else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0, cfg.ee_cost ? 1 : 0, 0);
@@ -525,8 +561,8 @@ struct Solver : SolverBase {
         return 0;
     }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
-        if (what < 0 || what > 6 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
-        const size_t osz = (what == 0 || what == 4 || what == 6 ? NP : (what == 1 || what == 5) ? NP * NM : what == 2 ? NX : NX * NM);
+        if (what < 0 || what > 8 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
+        const size_t osz = (what == 0 || what == 4 || what == 6 || what == 7 ? NP : (what == 1 || what == 5 || what == 8) ? NP * NM : what == 2 ? NX : NX * NM);
         T *dx, *du_, *dout;
         HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&du_, (size_t)count * NU * sizeof(T)));
         HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
@@ -534,7 +570,13 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
         int grid = count < 4096 ? count : 4096;
         if (const char* g = std::getenv("PDDP_EVAL_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;   // micro-benchmarks (tools/)
-        if (what >= 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout, what == 5 ? 1 : (what == 6 ? 2 : 0)); }
+        if (what >= 7) {
+            if constexpr (P::PLANT == 4) {
+                if (tl_variant < 0) { hipFree(dx); hipFree(du_); hipFree(dout); return fail(PDDP_EINVAL, "plant_eval: the thread-lane kernels need one of the built-in robot models"); }
+                launch_plant_eval_tl<T>(stream, tl_variant, tl_grav, count, dx, du_, dout, what == 8 ? 1 : 0);
+            }
+        }
+        else if (what >= 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout, what == 5 ? 1 : (what == 6 ? 2 : 0)); }
         else hipLaunchKernelGGL((k_plant_eval<P, INTEG, T>), dim3(grid), dim3(64), 0, stream, b.model, what, count, dx, du_, dout, dt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -617,7 +659,9 @@ extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host,
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
     if (bytes > cap) return fail(PDDP_EINVAL, "set_array: too many bytes");
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice)); return 0;
+    HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    if (std::strncmp(name, "model_", 6) == 0) return s->model_changed();
+    return 0;
 }
 extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes) {
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;

@@ -1,0 +1,445 @@
+// KUKA iiwa14 forward dynamics and its analytic gradient, ONE THREAD PER EVALUATION ("thread lane", tl): a wave carries 64 independent
+// evaluations, no cross-lane traffic, no LDS in the arithmetic.
+//
+// Why a third formulation.  The lane-group kernels (plant_arm_lg.hpp) spread one evaluation over 8 lanes: every serial recursion over
+// the 7 links is executed as 6 sweeps by all lanes, every broadcast is 2-3 DPP moves, one lane of 8 idles -- ~3.0 k wave instructions
+// per forward-dynamics evaluation of 8 instances and 13.3 k per gradient.  With one evaluation per LANE the same wave instruction count
+// serves 64 instances, recursions cost what they cost serially, and the algorithm can be the cheapest one instead of the reference's:
+//
+//   * body coordinates (Featherstone): joint i's frame is F_i Rz(q_i) in its parent's; for the iiwa every F_i is a SIGNED PERMUTATION
+//     of the axes plus a translation along ONE parent axis (plants/iiwa14.urdf joint origins; plants/dynamics_arm.cuh:353-427), so a
+//     Pluecker transform of a motion / force vector is 8 multiply-adds for the rotation about z and 2 for the translation (a dense
+//     6x6 transform is 36), and a rigid-body inertia moves between frames in ~30;
+//   * rigid-body inertias stay in their 10-parameter form (m, h = m c, I about the frame origin) -- composite inertias are sums of
+//     rigid bodies, so the composite-inertia recursion never needs a 6x6;
+//   * bias torque by recursive Newton-Euler, mass matrix by the composite-rigid-body algorithm (M_ij = z-moment of Ic_i e_z carried
+//     to frame j), M = L D L' (no square roots), qdd = M^-1 (u - C - 0.5 qd)            -- same function as dynamics<T>
+//     (plants/dynamics_arm.cuh:2097-2163: world-frame composite inertias + unpivoted Gauss-Jordan on [M | I]);
+//   * gradient: d qdd / d(q, qd) = -M^-1 d ID/d(q, qd) at the computed qdd, d qdd/du = M^-1, with the derivatives of the inverse
+//     dynamics by forward-mode recursion over the chain: d/dq_j enters only through X_j(q_j) (d(X_j v)/dq_j = -e_z x (X_j v),
+//     d(X_j' f)/dq_j = X_j' (e_z x* f)), links above joint j are untouched, links below see a transported tangent
+//                                                                                         -- same function as dynamicsGradient<T> (:2167-2289).
+// Floating point: this is a different (shorter, better conditioned) operation sequence than the reference's, fused multiply-adds
+// allowed; parity is asserted against the URDF-derived float64 fixture and the oracle within the stated bar (tests/test_urdf_pins.py),
+// not bit for bit.
+#pragma once
+
+#include <type_traits>
+
+#include "iiwa14_model_data.h"
+#include "plant_arm.hpp"
+
+// fused multiply-adds for everything in this header (the rest of the library is built with -ffp-contract=off; see the header comment)
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+
+namespace pddp {
+
+// Joint-frame classes of the iiwa14 chain (validated against the loaded model on the host: arm_tl_model_from_tables).
+//   rotation of F_i:  ID = identity;  A = [-x, z, y] (columns -e_x, e_z, e_y);  B = [x, z, -y] (columns e_x, e_z, -e_y)
+//   translation of F_i along the parent's z (Z) or y (Y) axis
+enum ArmTlKind { kTlIdZ = 0, kTlAZ = 1, kTlAY = 2, kTlBZ = 3 };
+PDDP_HD constexpr int arm_tl_kind(int link) { return link == 0 ? kTlIdZ : link == 1 ? kTlAZ : (link == 3 || link == 5) ? kTlBZ : kTlAY; }
+
+template <typename T>
+struct ArmTlModel {          // compact robot data of the thread-lane kernels (derived from ArmModel on the host)
+    T m[kArmNB];             // link mass
+    T h[kArmNB][3];          // first moment m c (joint frame)
+    T I[kArmNB][6];          // rotational inertia about the joint-frame origin: xx, yy, zz, xy, xz, yz
+    T r[kArmNB];             // translation of F_i along its axis (z or y of the parent, by kind)
+};
+
+// The two robot models the reference ships (USE_WAFR_URDF 0 / 1; tools/gen_iiwa14_tables.py), as a constant expression: a kernel that
+// declares `constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V)` gets every robot constant as an instruction literal -- no registers, no
+// loads, and the structural zeros of the inertias disappear from the arithmetic.  A handle whose tables were edited (pddp_set_array) does
+// not match either and keeps the lane-group kernels.
+template <typename T>
+constexpr ArmTlModel<T> arm_tl_builtin(int variant) {
+    ArmTlModel<T> o{};
+    for (int b = 0; b < kArmNB; b++) {
+        const double* S = IIWA14_SPATIAL_INERTIA[variant][b];
+        const double* F = IIWA14_JOINT_FRAME[variant][b];
+        o.r[b] = (T)F[arm_tl_kind(b) != kTlAY ? 14 : 13];
+        o.m[b] = (T)S[21];
+        o.h[b][0] = (T)-S[31]; o.h[b][1] = (T)S[30]; o.h[b][2] = (T)-S[24];
+        o.I[b][0] = (T)S[0]; o.I[b][1] = (T)S[7]; o.I[b][2] = (T)S[14]; o.I[b][3] = (T)S[6]; o.I[b][4] = (T)S[12]; o.I[b][5] = (T)S[13];
+    }
+    return o;
+}
+template <typename T>
+inline bool arm_tl_models_equal(const ArmTlModel<T>& a, const ArmTlModel<T>& b) {
+    bool eq = true;
+    for (int i = 0; i < kArmNB; i++) {
+        eq &= a.m[i] == b.m[i] && a.r[i] == b.r[i];
+        for (int e = 0; e < 3; e++) eq &= a.h[i][e] == b.h[i][e];
+        for (int e = 0; e < 6; e++) eq &= a.I[i][e] == b.I[i][e];
+    }
+    return eq;
+}
+
+// ArmModel tables -> ArmTlModel.  Returns false when the tables are not of the structure the thread-lane kernels hard-wire (then the
+// caller keeps the lane-group kernels, which take any joint frames / spatial inertias).
+template <typename T>
+inline bool arm_tl_model_from_tables(ArmTlModel<T>& o, const ArmModel<T>& t) {
+    const double tol = 1e-9;
+    bool ok = true;
+    auto near = [&](double a, double b) { return std::fabs(a - b) <= tol * (1.0 + std::fabs(b)); };
+    for (int b = 0; b < kArmNB; b++) {
+        const T* F = t.F + 16 * b; const T* S = t.I + 36 * b;
+        const int kind = arm_tl_kind(b);
+        // rotation columns (column-major 4x4)
+        const double RA[9] = {-1, 0, 0, 0, 0, 1, 0, 1, 0}, RB[9] = {1, 0, 0, 0, 0, 1, 0, -1, 0}, RI[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double* R = kind == kTlIdZ ? RI : kind == kTlBZ ? RB : RA;
+        for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) ok &= near(F[4 * c + r], R[3 * c + r]);
+        const bool along_z = (kind != kTlAY);
+        ok &= near(F[12], 0) && near(F[along_z ? 13 : 14], 0);
+        o.r[b] = F[along_z ? 14 : 13];
+        // spatial inertia [I  skew(h); skew(h)'  m 1], column-major, [angular; linear]
+        o.m[b] = S[21];
+        o.h[b][0] = -S[31]; o.h[b][1] = S[30]; o.h[b][2] = -S[24];
+        o.I[b][0] = S[0]; o.I[b][1] = S[7]; o.I[b][2] = S[14]; o.I[b][3] = S[6]; o.I[b][4] = S[12]; o.I[b][5] = S[13];
+        const double hx = o.h[b][0], hy = o.h[b][1], hz = o.h[b][2], m = o.m[b];
+        const double full[36] = {o.I[b][0], o.I[b][3], o.I[b][4], 0, -hz, hy,   o.I[b][3], o.I[b][1], o.I[b][5], hz, 0, -hx,   o.I[b][4], o.I[b][5], o.I[b][2], -hy, hx, 0,
+                                 0, hz, -hy, m, 0, 0,   -hz, 0, hx, 0, m, 0,   hy, -hx, 0, 0, 0, m};
+        for (int e = 0; e < 36; e++) ok &= near(S[e], full[e]);
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------ frame changes (compile-time kind)
+// parent coordinates -> stage-1 child coordinates (before the joint rotation): w1 = R_F' w
+template <int KIND, typename T> PDDP_HD void tl_to_child_axes(T* o, const T* w) {
+    if (KIND == kTlIdZ) { o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; }
+    else if (KIND == kTlBZ) { o[0] = w[0]; o[1] = w[2]; o[2] = -w[1]; }
+    else { o[0] = -w[0]; o[1] = w[2]; o[2] = w[1]; }
+}
+// stage-1 child coordinates -> parent coordinates: w = R_F w1
+template <int KIND, typename T> PDDP_HD void tl_to_parent_axes(T* o, const T* w1) {
+    if (KIND == kTlIdZ) { o[0] = w1[0]; o[1] = w1[1]; o[2] = w1[2]; }
+    else if (KIND == kTlBZ) { o[0] = w1[0]; o[1] = -w1[2]; o[2] = w1[1]; }
+    else { o[0] = -w1[0]; o[1] = w1[2]; o[2] = w1[1]; }
+}
+// motion vector [w; v] of the parent frame -> child frame:  w_c = Rz' R_F' w,  v_c = Rz' R_F' (v + w x r)
+template <int KIND, typename T> PDDP_HD void tl_motion_to_child(T* o, const T* mv, T r, T c, T s) {
+    T vv[3] = {mv[3], mv[4], mv[5]};
+    if (KIND == kTlAY) { vv[0] = vv[0] - mv[2] * r; vv[2] = vv[2] + mv[0] * r; }         // w x (0, r, 0) = (-wz r, 0, wx r)
+    else { vv[0] = vv[0] + mv[1] * r; vv[1] = vv[1] - mv[0] * r; }                       // w x (0, 0, r) = (wy r, -wx r, 0)
+    T w1[3], v1[3];
+    tl_to_child_axes<KIND>(w1, mv); tl_to_child_axes<KIND>(v1, vv);
+    o[0] = c * w1[0] + s * w1[1]; o[1] = c * w1[1] - s * w1[0]; o[2] = w1[2];
+    o[3] = c * v1[0] + s * v1[1]; o[4] = c * v1[1] - s * v1[0]; o[5] = v1[2];
+}
+// force vector [n; f] of the child frame -> parent frame:  f_p = R_F Rz f,  n_p = R_F Rz n + r x f_p
+template <int KIND, typename T> PDDP_HD void tl_force_to_parent(T* o, const T* fv, T r, T c, T s) {
+    const T n1[3] = {c * fv[0] - s * fv[1], s * fv[0] + c * fv[1], fv[2]};
+    const T f1[3] = {c * fv[3] - s * fv[4], s * fv[3] + c * fv[4], fv[5]};
+    tl_to_parent_axes<KIND>(o, n1); tl_to_parent_axes<KIND>(o + 3, f1);
+    if (KIND == kTlAY) { o[0] = o[0] + r * o[5]; o[2] = o[2] - r * o[3]; }                // (0, r, 0) x f = (r fz, 0, -r fx)
+    else { o[0] = o[0] - r * o[4]; o[1] = o[1] + r * o[3]; }                             // (0, 0, r) x f = (-r fy, r fx, 0)
+}
+// rigid-body inertia (m, h, I: xx yy zz xy xz yz) of the child frame, expressed in the parent frame, ADDED to (mp, hp, Ip)
+template <int KIND, typename T> PDDP_HD void tl_inertia_add_to_parent(T& mp, T* hp, T* Ip, T m, const T* h, const T* I, T r, T c, T s) {
+    // rotate about z: h1 = Rz h, I1 = Rz I Rz'
+    const T h1[3] = {c * h[0] - s * h[1], s * h[0] + c * h[1], h[2]};
+    const T cc = c * c, ss = s * s, cs = c * s;
+    const T d = I[0] - I[1];
+    const T xx = cc * I[0] + ss * I[1] - (cs + cs) * I[3];
+    const T yy = ss * I[0] + cc * I[1] + (cs + cs) * I[3];
+    const T xy = cs * d + (cc - ss) * I[3];
+    const T xz = c * I[4] - s * I[5], yz = s * I[4] + c * I[5], zz = I[2];
+    // axis permutation R_F
+    T h2[3], J[6];
+    tl_to_parent_axes<KIND>(h2, h1);
+    if (KIND == kTlIdZ) { J[0] = xx; J[1] = yy; J[2] = zz; J[3] = xy; J[4] = xz; J[5] = yz; }
+    else if (KIND == kTlBZ) { J[0] = xx; J[1] = zz; J[2] = yy; J[3] = -xz; J[4] = xy; J[5] = -yz; }      // x' = x, y' = -z, z' = y
+    else { J[0] = xx; J[1] = zz; J[2] = yy; J[3] = -xz; J[4] = -xy; J[5] = yz; }                         // x' = -x, y' = z, z' = y
+    // shift the reference point by r along y (AY) or z: I_p = I' - (r h' + h r') + 2 (h.r) 1 - m (r r' - r.r 1)
+    const T mr = m * r;
+    if (KIND == kTlAY) {
+        const T t = (h2[1] + h2[1]) * r + mr * r;
+        Ip[0] += J[0] + t; Ip[1] += J[1]; Ip[2] += J[2] + t; Ip[3] += J[3] - r * h2[0]; Ip[4] += J[4]; Ip[5] += J[5] - r * h2[2];
+        hp[0] += h2[0]; hp[1] += h2[1] + mr; hp[2] += h2[2];
+    } else {
+        const T t = (h2[2] + h2[2]) * r + mr * r;
+        Ip[0] += J[0] + t; Ip[1] += J[1] + t; Ip[2] += J[2]; Ip[3] += J[3]; Ip[4] += J[4] - r * h2[0]; Ip[5] += J[5] - r * h2[1];
+        hp[0] += h2[0]; hp[1] += h2[1]; hp[2] += h2[2] + mr;
+    }
+    mp += m;
+}
+// f = I_spatial [w; v] = [I w + h x v ; m v - h x w]
+template <typename T> PDDP_HD void tl_inertia_mul(T* o, T m, const T* h, const T* I, const T* mv) {
+    const T* w = mv; const T* v = mv + 3;
+    o[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2] + (h[1] * v[2] - h[2] * v[1]);
+    o[1] = I[3] * w[0] + I[1] * w[1] + I[5] * w[2] + (h[2] * v[0] - h[0] * v[2]);
+    o[2] = I[4] * w[0] + I[5] * w[1] + I[2] * w[2] + (h[0] * v[1] - h[1] * v[0]);
+    o[3] = m * v[0] - (h[1] * w[2] - h[2] * w[1]);
+    o[4] = m * v[1] - (h[2] * w[0] - h[0] * w[2]);
+    o[5] = m * v[2] - (h[0] * w[1] - h[1] * w[0]);
+}
+// o += v x* f   (spatial force cross product: [w x n + v x f ; w x f])
+template <typename T> PDDP_HD void tl_crf_add(T* o, const T* mv, const T* fv) {
+    const T* w = mv; const T* v = mv + 3; const T* n = fv; const T* f = fv + 3;
+    o[0] += (w[1] * n[2] - w[2] * n[1]) + (v[1] * f[2] - v[2] * f[1]);
+    o[1] += (w[2] * n[0] - w[0] * n[2]) + (v[2] * f[0] - v[0] * f[2]);
+    o[2] += (w[0] * n[1] - w[1] * n[0]) + (v[0] * f[1] - v[1] * f[0]);
+    o[3] += w[1] * f[2] - w[2] * f[1];
+    o[4] += w[2] * f[0] - w[0] * f[2];
+    o[5] += w[0] * f[1] - w[1] * f[0];
+}
+
+template <typename T> PDDP_HD void tl_sincos(T q, T& s, T& c);
+// float: two-term Cody-Waite reduction by pi/2 (exact products through the fused multiply-add; joint angles are a few radians) and the
+// degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]: ~1 ulp, ~25 instructions, no branches (the library sincosf carries a
+// Payne-Hanek path that costs ~200 instructions per call when inlined seven times per evaluation).
+template <> PDDP_HD void tl_sincos<float>(float q, float& s, float& c) {
+    const float k = rintf(q * 0.636619772367581343f);
+    float r = fmaf(k, -1.57079637050628662109375f, q);
+    r = fmaf(k, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+    const int n = static_cast<int>(k) & 3;
+    const float ss = (n & 1) ? cp : sp, cc = (n & 1) ? sp : cp;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+template <> PDDP_HD void tl_sincos<double>(double q, double& s, double& c) { sincos(q, &s, &c); }
+
+// What one evaluation keeps for the gradient (all per thread).
+template <typename T>
+struct ArmTlState {
+    T c[kArmNB], s[kArmNB];
+    T v[kArmNB][6];          // link velocities (own frame)
+    T L[21];                 // unit lower factor of M = L D L' (row-major strict lower triangle: L[i(i-1)/2 + j], j < i)
+    T Dinv[kArmNB];          // 1 / D_i
+};
+
+// solve M x = b in place with the stored factors
+template <typename T> PDDP_HD void tl_ldl_solve(const ArmTlState<T>& st, T* x) {
+#pragma unroll
+    for (int i = 1; i < kArmNB; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) x[i] -= st.L[i * (i - 1) / 2 + j] * x[j];
+#pragma unroll
+    for (int i = 0; i < kArmNB; i++) x[i] *= st.Dinv[i];
+#pragma unroll
+    for (int i = kArmNB - 2; i >= 0; i--)
+#pragma unroll
+        for (int j = i + 1; j < kArmNB; j++) x[i] -= st.L[j * (j - 1) / 2 + i] * x[j];
+}
+
+// compile-time loop over the links with their frame kind as a template argument
+template <int I, int END, int STEP> struct TlFor {
+    template <typename F> static PDDP_HD void run(F&& f) { f(std::integral_constant<int, I>()); TlFor<I + STEP, END, STEP>::run(f); }
+};
+template <int END, int STEP> struct TlFor<END, END, STEP> { template <typename F> static PDDP_HD void run(F&&) {} };
+
+// Forward dynamics: qdd[7] from q[7], qd[7], u[7].  Fills st (sines, velocities, factors of M) for arm_tl_gradient.
+template <typename T>
+PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st, T* qdd, const T* q, const T* qd, const T* u) {
+    constexpr int NB = kArmNB;
+#pragma unroll
+    for (int i = 0; i < NB; i++) tl_sincos<T>(q[i], st.s[i], st.c[i]);
+    // ---- recursive Newton-Euler with qdd = 0: bias torque C (gravity as an upward acceleration of the base)
+    T f[NB][6];
+    {
+        T a[6] = {T(0), T(0), T(0), T(0), T(0), grav}, vp[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        TlFor<0, NB, 1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int K = arm_tl_kind(i);
+            T* v = st.v[i];
+            tl_motion_to_child<K>(v, vp, md.r[i], st.c[i], st.s[i]);
+            v[2] += qd[i];
+            T an[6];
+            tl_motion_to_child<K>(an, a, md.r[i], st.c[i], st.s[i]);
+            an[0] += qd[i] * v[1]; an[1] -= qd[i] * v[0];              // v x (e_z qd): [w x e_z; vl x e_z] qd
+            an[3] += qd[i] * v[4]; an[4] -= qd[i] * v[3];
+            T Iv[6];
+            tl_inertia_mul(f[i], md.m[i], md.h[i], md.I[i], an);
+            tl_inertia_mul(Iv, md.m[i], md.h[i], md.I[i], v);
+            tl_crf_add(f[i], v, Iv);
+#pragma unroll
+            for (int e = 0; e < 6; e++) { a[e] = an[e]; vp[e] = v[e]; }
+        });
+    }
+    T tau[NB];
+    TlFor<NB - 1, -1, -1>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int K = arm_tl_kind(i);
+        tau[i] = u[i] - (f[i][2] + T(0.5) * qd[i]);                   // joint damping 0.5 qd (plants/dynamics_arm.cuh:1433-1434; iiwa14.urdf)
+        if (i > 0) {
+            T fp[6];
+            tl_force_to_parent<K>(fp, f[i], md.r[i], st.c[i], st.s[i]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) f[i - 1][e] += fp[e];
+        }
+    });
+    // ---- composite rigid bodies and the mass matrix (lower triangle, row-major M[i(i+1)/2 + j])
+    T M[28];
+    {
+        T cm[NB], ch[NB][3], cI[NB][6];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            cm[i] = md.m[i];
+#pragma unroll
+            for (int e = 0; e < 3; e++) ch[i][e] = md.h[i][e];
+#pragma unroll
+            for (int e = 0; e < 6; e++) cI[i][e] = md.I[i][e];
+        }
+        TlFor<NB - 1, 0, -1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            tl_inertia_add_to_parent<arm_tl_kind(i)>(cm[i - 1], ch[i - 1], cI[i - 1], cm[i], ch[i], cI[i], md.r[i], st.c[i], st.s[i]);
+        });
+        TlFor<0, NB, 1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            // F = Ic_i [e_z; 0] = [I e_z ; -h x e_z]
+            T F[6] = {cI[i][4], cI[i][5], cI[i][2], -ch[i][1], ch[i][0], T(0)};
+            M[i * (i + 1) / 2 + i] = F[2];
+            TlFor<i, 0, -1>::run([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                T Fp[6];
+                tl_force_to_parent<arm_tl_kind(j)>(Fp, F, md.r[j], st.c[j], st.s[j]);
+#pragma unroll
+                for (int e = 0; e < 6; e++) F[e] = Fp[e];
+                M[i * (i + 1) / 2 + (j - 1)] = F[2];
+            });
+        });
+    }
+    // ---- M = L D L'
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            T sum = M[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) sum -= st.L[i * (i - 1) / 2 + k] * (st.L[j * (j - 1) / 2 + k] * M[k * (k + 1) / 2 + k]);   // M[k][k] holds D_k from here on
+            if (j < i) st.L[i * (i - 1) / 2 + j] = sum * st.Dinv[j];
+            else { M[i * (i + 1) / 2 + i] = sum; st.Dinv[i] = T(1) / sum; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) qdd[i] = tau[i];
+    tl_ldl_solve(st, qdd);
+}
+
+// Gradient of the forward dynamics at (q, qd, u) with qdd from arm_tl_dynamics (st as it left it).
+// emit(col, row, value): dqdd(row, col), col 0..6 d/dq, 7..13 d/dqd, 14..20 d/du   (the plug-in layout s_dqdd[col*7 + row]).
+template <typename T, typename Emit>
+PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit) {
+    constexpr int NB = kArmNB;
+    // ---- nominal inverse dynamics at the actual qdd: per link the acceleration, I v, and the total force through its joint
+    T a[NB][6], Iv[NB][6], Ft[NB][6];
+    {
+        T ap[6] = {T(0), T(0), T(0), T(0), T(0), grav};
+        TlFor<0, NB, 1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const T* v = st.v[i];
+            tl_motion_to_child<arm_tl_kind(i)>(a[i], ap, md.r[i], st.c[i], st.s[i]);
+            a[i][0] += qd[i] * v[1]; a[i][1] -= qd[i] * v[0]; a[i][2] += qdd[i];
+            a[i][3] += qd[i] * v[4]; a[i][4] -= qd[i] * v[3];
+            tl_inertia_mul(Ft[i], md.m[i], md.h[i], md.I[i], a[i]);
+            tl_inertia_mul(Iv[i], md.m[i], md.h[i], md.I[i], v);
+            tl_crf_add(Ft[i], v, Iv[i]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) ap[e] = a[i][e];
+        });
+        TlFor<NB - 1, 0, -1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            T fp[6];
+            tl_force_to_parent<arm_tl_kind(i)>(fp, Ft[i], md.r[i], st.c[i], st.s[i]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) Ft[i - 1][e] += fp[e];
+        });
+    }
+    // ---- tangents: for joint j, d/dq_j and d/dqd_j of the inverse dynamics, then -M^-1
+    TlFor<0, NB, 1>::run([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        T dFq[6], dFv[6];                 // tangent of the total force through the current joint (accumulated from the tip inwards)
+        T dtq[NB], dtv[NB];
+        // forward over the links at and below joint j
+        T dvq[NB][6], daq[NB][6], dvv[NB][6], dav[NB][6];
+        {
+            const T* v = st.v[j];
+            // d(X_j v_p)/dq_j = -e_z x (X_j v_p) = -e_z x v_j (e_z x e_z = 0):  -(e_z x w) = (w_y, -w_x, 0)
+            dvq[j][0] = v[1]; dvq[j][1] = -v[0]; dvq[j][2] = T(0); dvq[j][3] = v[4]; dvq[j][4] = -v[3]; dvq[j][5] = T(0);
+            // X_j a_p = a_j - e_z qdd_j - v_j x (e_z qd_j)
+            const T xa[6] = {a[j][0] - qd[j] * v[1], a[j][1] + qd[j] * v[0], a[j][2] - qdd[j], a[j][3] - qd[j] * v[4], a[j][4] + qd[j] * v[3], a[j][5]};
+            daq[j][0] = xa[1] + qd[j] * dvq[j][1]; daq[j][1] = -xa[0] - qd[j] * dvq[j][0]; daq[j][2] = T(0);
+            daq[j][3] = xa[4] + qd[j] * dvq[j][4]; daq[j][4] = -xa[3] - qd[j] * dvq[j][3]; daq[j][5] = T(0);
+            // d/dqd_j: dv_j = e_z, da_j = v_j x e_z  (the e_z x e_z qd term vanishes)
+            dvv[j][0] = T(0); dvv[j][1] = T(0); dvv[j][2] = T(1); dvv[j][3] = T(0); dvv[j][4] = T(0); dvv[j][5] = T(0);
+            dav[j][0] = v[1]; dav[j][1] = -v[0]; dav[j][2] = T(0); dav[j][3] = v[4]; dav[j][4] = -v[3]; dav[j][5] = T(0);
+        }
+        TlFor<j + 1, NB, 1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int K = arm_tl_kind(i);
+            tl_motion_to_child<K>(dvq[i], dvq[i - 1], md.r[i], st.c[i], st.s[i]);
+            tl_motion_to_child<K>(daq[i], daq[i - 1], md.r[i], st.c[i], st.s[i]);
+            daq[i][0] += qd[i] * dvq[i][1]; daq[i][1] -= qd[i] * dvq[i][0]; daq[i][3] += qd[i] * dvq[i][4]; daq[i][4] -= qd[i] * dvq[i][3];
+            tl_motion_to_child<K>(dvv[i], dvv[i - 1], md.r[i], st.c[i], st.s[i]);
+            tl_motion_to_child<K>(dav[i], dav[i - 1], md.r[i], st.c[i], st.s[i]);
+            dav[i][0] += qd[i] * dvv[i][1]; dav[i][1] -= qd[i] * dvv[i][0]; dav[i][3] += qd[i] * dvv[i][4]; dav[i][4] -= qd[i] * dvv[i][3];
+        });
+        // backward: df_i = I da_i + dv_i x* (I v_i) + v_i x* (I dv_i), accumulated towards the base; joint j adds e_z x* F_j to the q tangent
+        TlFor<NB - 1, -1, -1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int K = arm_tl_kind(i);
+            if (i >= j) {
+                T dfq[6], dfv[6], t6[6];
+                tl_inertia_mul(dfq, md.m[i], md.h[i], md.I[i], daq[i]);
+                tl_crf_add(dfq, dvq[i], Iv[i]);
+                tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvq[i]);
+                tl_crf_add(dfq, st.v[i], t6);
+                tl_inertia_mul(dfv, md.m[i], md.h[i], md.I[i], dav[i]);
+                tl_crf_add(dfv, dvv[i], Iv[i]);
+                tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvv[i]);
+                tl_crf_add(dfv, st.v[i], t6);
+                if (i == NB - 1) {
+#pragma unroll
+                    for (int e = 0; e < 6; e++) { dFq[e] = dfq[e]; dFv[e] = dfv[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 6; e++) { dFq[e] += dfq[e]; dFv[e] += dfv[e]; }
+                }
+            }
+            dtq[i] = dFq[2]; dtv[i] = dFv[2];
+            if (i > 0) {
+                if (i == j) {                          // d(X_j' F_j)/dq_j = X_j' (e_z x* F_j + dF_j):  e_z x (n; f) = (-n_y, n_x, 0; -f_y, f_x, 0)
+                    dFq[0] -= Ft[j][1]; dFq[1] += Ft[j][0]; dFq[3] -= Ft[j][4]; dFq[4] += Ft[j][3];
+                }
+                T fp[6];
+                tl_force_to_parent<K>(fp, dFq, md.r[i], st.c[i], st.s[i]);
+#pragma unroll
+                for (int e = 0; e < 6; e++) dFq[e] = fp[e];
+                tl_force_to_parent<K>(fp, dFv, md.r[i], st.c[i], st.s[i]);
+#pragma unroll
+                for (int e = 0; e < 6; e++) dFv[e] = fp[e];
+            }
+        });
+        dtv[j] += T(0.5);                              // d(0.5 qd)/dqd_j
+        // dqdd/dq_j = -M^-1 dtau/dq_j
+#pragma unroll
+        for (int i = 0; i < NB; i++) { dtq[i] = -dtq[i]; dtv[i] = -dtv[i]; }
+        tl_ldl_solve(st, dtq);
+        tl_ldl_solve(st, dtv);
+#pragma unroll
+        for (int i = 0; i < NB; i++) { emit(j, i, dtq[i]); emit(NB + j, i, dtv[i]); }
+    });
+    // ---- dqdd/du = M^-1
+    TlFor<0, NB, 1>::run([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        T e[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) e[i] = (i == j) ? T(1) : T(0);
+        tl_ldl_solve(st, e);
+#pragma unroll
+        for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
+    });
+}
+
+}  // namespace pddp
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif

@@ -295,13 +295,13 @@ class Solver:
         """`what` codes of pddp_plant_eval per plant function: every implementation of the plant the library carries."""
         if self.cfg.plant != 4:
             return {"dynamics": [0], "gradient": [1]}
-        return {"dynamics": [0, 4, 6], "gradient": [1, 5]}    # cooperative wave; lane group; lane group, packed rows
+        return {"dynamics": [0, 4, 6, 7], "gradient": [1, 5, 8]}    # cooperative wave; lane group; lane group, packed rows; one thread per evaluation
 
     def plant_eval(self, what, x, u):
         x, u = self.arr(x).reshape(-1, self.n), self.arr(u).reshape(-1, self.m)
         count = x.shape[0]
         nm = self.n + self.m
-        osz = [self.npos, self.npos * nm, self.n, self.n * nm, self.npos, self.npos * nm, self.npos][what]
+        osz = [self.npos, self.npos * nm, self.n, self.n * nm, self.npos, self.npos * nm, self.npos, self.npos, self.npos * nm][what]
         out = np.zeros((count, osz), self.dtype)
         self._chk(self.lib.pddp_plant_eval(self.h, int(what), count, _p(x), _p(u), _p(out)))
         return out

@@ -18,6 +18,7 @@
 #include "../../parallel-ddp_amd/csrc/fp_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/nis_lg.hpp"
 #include "../../parallel-ddp_amd/csrc/bp_lg.hpp"
+#include "../../parallel-ddp_amd/csrc/plant_arm_tl.hpp"
 #include "../../parallel-ddp_amd/csrc/mpc.hpp"
 #include "../../parallel-ddp_amd/csrc/iiwa14_model_data.h"
 
@@ -106,7 +107,14 @@ struct Sim : Base {
         al("x_old", &mb.x_old, B * N * NX); al("u_old", &mb.u_old, B * N * NU); al("KT_old", &mb.KT_old, B * N * NX * NU);
         for (size_t i = 0; i < A; i++) b.alpha[i] = (T)std::pow(c.alpha_base, (double)i);
         fill_model(model, c); b.model = &model;
+        al("Jpart", &b.Jpart, B * A * M); al("dpart", &b.dpart, B * A * M); al("parts_fresh", &b.parts_fresh, B);
+        derive_tl(model);
     }
+    // the library's choice of the arm's forward pass / setup implementation (fp_tl.hpp select_fp_path), evaluated per phase like fp_coop()
+    ArmTlModel<T> tl_model{}; bool tl_ok = false;
+    void derive_tl(const ArmModel<T>& m) { tl_ok = arm_tl_model_from_tables(tl_model, m); }
+    void derive_tl(const EmptyModel&) {}
+    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok) == kFpTl; }
     void phase(int ph) {
         const int B = cfg.batch; const Wave w = this_wave();
         if (ph == PDDP_PHASE_BP) {
@@ -124,6 +132,12 @@ struct Sim : Base {
             std::vector<T> cost_k(cfg.N), segx(cfg.M * NX), dnorm(cfg.M), segJ(cfg.M);
             for (int pb = 0; pb < B; pb++) {
                 if (!fp_active<T>(b, dm, pb)) continue;
+                if constexpr (P::PLANT == 4) if (fp_tl()) {          // one "thread" per (candidate, segment): plain scalar code (fp_tl.hpp)
+                    using L = LgHost<T>;
+                    for (int a = 0; a < cfg.A; a++) if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data()));
+                    for (int sg = 0; sg < cfg.M; sg++) for (int a = 0; a < cfg.A; a++) arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg);
+                    continue;
+                }
                 for (int a = 0; a < cfg.A; a++) {
                     const FpArgs<T> fa = fp_args<P, T>(b, dm, pb, a, dt, segx.data(), dnorm.data(), segJ.data());
                     if constexpr (P::PLANT == 4) if (!fp_coop()) {   // the arm's forward pass runs on lane groups (fp_lg.hpp), 8 lanes in lock step here
@@ -147,6 +161,15 @@ struct Sim : Base {
         } else if (ph == PDDP_PHASE_LS) {
             for (int pb = 0; pb < B; pb++) ls_body<T>(b, dm, sp, pb, bench);
         } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
+            if constexpr (P::PLANT == 4) if (fp_tl()) {
+                const int mode = ph == PDDP_PHASE_INIT_NIS;
+                for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) {
+                    T* AB = b.AB + ((size_t)pb * cfg.N + k) * (NX * NM);
+                    const bool valid = arm_tl_nis_knot<T>(tl_model, model.grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; });
+                    if (valid) for (int col = 0; col < NM; col++) for (int r = 0; r < 7; r++) AB[col * NX + r] = tl_AB_const<T>(r, col, dt);
+                }
+                return;
+            }
             if constexpr (P::PLANT == 4) if (!fp_coop()) {   // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
                 using L = LgHost<T>;
                 ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
@@ -296,7 +319,9 @@ struct Sim : Base {
     }
     int run_phase(int ph) override {
         if (ph == PDDP_PHASE_BP_COOP) { bp_coop = 1; phase(PDDP_PHASE_BP); bp_coop = 0; return 0; }
-        if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase"); phase(ph); return 0;
+        if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase"); phase(ph);
+        if (ph == PDDP_PHASE_FP) for (int pb = 0; pb < cfg.batch; pb++) if (b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }
+        return 0;
     }
     int plant_eval(int what, int count, const void* xv, const void* uv, void* outv) override {
         static NisScratch<P, INTEG, T> s; static IntegScratch<P, T> is;
@@ -305,7 +330,16 @@ struct Sim : Base {
         T qdd[NP], dq[NP * NM], xn[NX];
         for (int i = 0; i < count; i++) {
             const T* xi = x + (size_t)i * NX; const T* ui = u + (size_t)i * NU;
-            if (what >= 4) {
+            if (what >= 7) {                     // thread-lane formulation (plant_arm_tl.hpp): plain scalar code, one evaluation per call
+                if constexpr (P::PLANT == 4) {
+                    const ArmTlModel<T>& tm = tl_model;
+                    ArmTlState<T> ts; T qdd[7];
+                    arm_tl_dynamics<T>(tm, model.grav, ts, qdd, xi, xi + 7, ui);
+                    if (what == 7) std::memcpy(out + (size_t)i * NP, qdd, sizeof(qdd));
+                    else { T* o = out + (size_t)i * NP * NM; arm_tl_gradient<T>(tm, model.grav, ts, xi + 7, qdd, [o](int col, int row, T val) { o[7 * col + row] = val; }); }
+                }
+            }
+            else if (what >= 4) {
                 if constexpr (P::PLANT == 4) {
                     using L = LgHost<T>;
                     ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model); ArmLgState<L> st;

@@ -73,7 +73,7 @@ PDDP_HD void fp_reduce(const Wave& w, const Buffers<T>& b, const Dims& dm, int p
 template <typename T>
 PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp, int pb, int freeze_exit) {
     SolverState<T> st = b.state[pb];
-    if (st.done) return;
+    if (st.done) { if (st.win_pending) b.state[pb].win_pending = 0; return; }      // the final accepted step was adopted by the previous sweep's winner kernel
     const int* err = b.err + (size_t)pb * dm.M;
     int any = 0;
     for (int i = 0; i < dm.M; i++) any |= err[i];
@@ -168,7 +168,7 @@ PDDP_HD void init_cost_body(const Wave& w, T* cost_k, const Buffers<T>& b, const
         st.rho = T(sp.rho_init); st.drho = T(1.0); st.dJ = 0; st.z = 0;
         st.prevJ = J + T(2 * sp.tol_cost);
         st.iter = 1; st.alphaIndex = keep_alpha ? b.state[pb].alphaIndex : 0; st.ignore_defect = ignore_first_defect; st.accepted = 1; st.done = 0;
-        st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.took_step = 0;
+        st.cur = 0; st.cur2 = 0; st.bp_retries = 0; st.took_step = 0; st.win_pending = 0;
         st.pw = b.state[pb].pw;        // a warm start must read the cost-to-go of the iteration before the previous exit: keep the buffer roles
         b.state[pb] = st;
         const size_t ho = (size_t)pb * sp.out_stride;

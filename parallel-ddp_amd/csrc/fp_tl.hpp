@@ -65,75 +65,151 @@ PDDP_HD T arm_tl_cost(const CostWeights<T>& cw, const T* x, const T* u, const T*
     return T(0.5) * (cw.Q1 * sq + cw.Q2 * sv + cw.R * su);
 }
 
-// Rollout of shooting segment `seg` of candidate `a_idx` of problem pb.  Writes the candidate's x, u (and the boundary defect) and
-// the segment's partial cost / defect norm into b.Jpart / b.dpart [(pb*A + a)*M + seg].
+// One rollout = one (problem, candidate, shooting segment).  The per-step operands (gain K_k, reference state, nominal control, feed-forward)
+// are handed in as pointers: global memory on the host / in the winner kernel, the wave's LDS staging area in k_fp_tl.
+//   begin(): start state (the current state for segment 0, else what the linear sweep left in the candidate's slot)
+//   step():  control law, running cost, dynamics, Euler step; the last step of a non-final segment produces the boundary defect
+//   end():   terminal knot (last segment), partial sums out
+// Where the trajectory goes is the Sink's business: NoSink (production sweep: candidates are not stored -- only the winner's trajectory is
+// ever read again, and the winner kernel re-rolls it), CandidateSink (teacher-forcing hook: every candidate's x, u, d as the reference keeps
+// them), WinnerSink (the accepted candidate straight into the current-trajectory buffers).
 template <typename T>
-PDDP_HD void arm_tl_rollout_segment(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int pb, int a_idx, int seg) {
+struct TlRollout {
+    T x[14]; T J; T sdef;
+    int pb, a_idx, seg, kStart, iters;
+    T alpha;
+};
+struct TlNoSink {
+    template <typename T> PDDP_HD void x(int, const T*) const {}
+    template <typename T> PDDP_HD void u(int, const T*) const {}
+    template <typename T> PDDP_HD void d(int, const T*) const {}
+};
+template <typename T> struct TlCandidateSink {         // candidate slot of xs / us / ds
+    T* xs; T* us; T* ds;
+    PDDP_HD void x(int k, const T* v) const { tl_store14(xs + (size_t)k * 14, v); }
+    PDDP_HD void u(int k, const T* v) const {
+#pragma unroll
+        for (int i = 0; i < 7; i++) us[(size_t)k * 7 + i] = v[i];
+    }
+    PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
+};
+template <typename T> struct TlWinnerSink {            // new current trajectory: the other half of xb, ucur, dcur
+    T* xn; T* uc; T* dc;
+    PDDP_HD void x(int k, const T* v) const { tl_store14(xn + (size_t)k * 14, v); }
+    PDDP_HD void u(int k, const T* v) const {
+#pragma unroll
+        for (int i = 0; i < 7; i++) uc[(size_t)k * 7 + i] = v[i];
+    }
+    PDDP_HD void d(int k, const T* v) const { tl_store14(dc + (size_t)k * 14, v); }
+};
+
+template <typename T, typename Sink>
+PDDP_HD void tl_rollout_begin(TlRollout<T>& r, const Buffers<T>& b, const Dims& dm, int pb, int a_idx, int seg, const T* xcur, const Sink& sink) {
+    r.pb = pb; r.a_idx = a_idx; r.seg = seg; r.kStart = seg * dm.NB;
+    r.iters = (seg < dm.M - 1) ? dm.NB : dm.NB - 1;
+    r.alpha = b.alpha[a_idx]; r.J = T(0); r.sdef = T(0);
+    if (seg == 0) tl_load14(r.x, xcur);
+    else tl_load14(r.x, b.xs + (((size_t)pb * dm.A + a_idx) * dm.N + r.kStart) * 14);
+    sink.x(r.kStart, r.x);                                                // (a candidate slot already holds it for seg > 0; the winner's buffer does not)
+}
+// step k of the segment (knot kn = kStart + k): Kk[98] = K(r, c) at [c + 14 r], xr[14], uc[7], du[7] of knot kn, xg[14] the goal
+template <typename T, typename Sink>
+PDDP_HD void tl_rollout_step(TlRollout<T>& r, const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int k,
+                             const T* Kk, const T* xr, const T* uc, const T* du, const T* xg, const Sink& sink) {
     constexpr int NX = 14, NU = 7;
-    const int N = dm.N, NBk = dm.NB, kStart = seg * NBk;
-    const int iters = (seg < dm.M - 1) ? NBk : NBk - 1;
-    const size_t slot = (size_t)pb * dm.A + a_idx;
-    T* xs = b.xs + slot * N * NX; T* us = b.us + slot * N * NU; T* ds = b.ds + slot * N * NX;
-    const T* xc = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
+    const int kn = r.kStart + k;
+    T dx[NX], u[NU];
+#pragma unroll
+    for (int i = 0; i < NX; i++) dx[i] = r.x[i] - xr[i];
+#pragma unroll
+    for (int rr = 0; rr < NU; rr++) {
+        T acc = r.alpha * du[rr];
+#pragma unroll
+        for (int c = 0; c < NX; c++) acc += Kk[rr * NX + c] * dx[c];
+        u[rr] = uc[rr] - acc;
+    }
+    sink.u(kn, u);
+    r.J += arm_tl_cost<T>(cw, r.x, u, xg, false);
+    ArmTlState<T> st;
+    T qdd[7], xn[NX];
+    arm_tl_dynamics<T>(md, grav, st, qdd, r.x, r.x + 7, u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { xn[i] = r.x[i] + dt * r.x[7 + i]; xn[7 + i] = r.x[7 + i] + dt * qdd[i]; }     // Euler (utils/integrators.cuh:24-36)
+    if (k < dm.NB - 1) {
+        sink.x(kn + 1, xn);
+#pragma unroll
+        for (int i = 0; i < NX; i++) r.x[i] = xn[i];
+    } else {                                                          // last step of a non-final segment: defect against the next segment's start
+        const int ks = (r.seg + 1) * dm.NB;
+        T xnext[NX], e[NX], sdef = T(0);
+        tl_load14(xnext, b.xs + (((size_t)r.pb * dm.A + r.a_idx) * dm.N + ks) * NX);
+#pragma unroll
+        for (int i = 0; i < NX; i++) { e[i] = xn[i] - xnext[i]; sdef += tabs(e[i]); }
+        sink.d(ks - 1, e);
+        r.sdef = sdef;
+    }
+}
+// ucN: the nominal control of the terminal knot (carried along unchanged)
+template <typename T, typename Sink>
+PDDP_HD void tl_rollout_end(TlRollout<T>& r, const Dims& dm, const CostWeights<T>& cw, const T* ucN, const T* xg, const Sink& sink) {
+    if (r.seg == dm.M - 1) {
+        T u[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) u[i] = ucN[i];
+        sink.u(dm.N - 1, u);
+        r.J += arm_tl_cost<T>(cw, r.x, u, xg, true);
+        r.sdef = T(0);
+    }
+}
+
+// Whole segment with the operands read straight from global memory (host emulation; winner kernel).  part != 0: publish the partial sums.
+template <typename T, typename Sink>
+PDDP_HD void arm_tl_rollout_segment(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int pb, int a_idx, int seg,
+                                    const T* xcur, const Sink& sink, bool part) {
+    constexpr int NX = 14, NU = 7;
+    const int N = dm.N;
     const T* uc = b.ucur + (size_t)pb * N * NU; const T* du = b.du + (size_t)pb * N * NU; const T* KT = b.KT + (size_t)pb * N * NX * NU;
-    const T alpha = b.alpha[a_idx];
     T xg[NX];
     tl_load14(xg, b.xGoal + (size_t)pb * NX);
-    T x[NX];
-    if (seg == 0) { tl_load14(x, xc); tl_store14(xs, x); }                 // segment starts: the current state, or what the linear sweep left
-    else tl_load14(x, xs + (size_t)kStart * NX);
-    ArmTlState<T> st;
-    T J = T(0);
-    for (int k = 0; k < iters; k++) {
-        const int kn = kStart + k;
-        T dx[NX], u[NU];
-        {
-            T xr[NX];
-            tl_load14(xr, xc + (size_t)kn * NX);
+    TlRollout<T> r;
+    tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, sink);
+    for (int k = 0; k < r.iters; k++) {
+        const int kn = r.kStart + k;
+        T Kk[NX * NU], xr[NX], ucv[NU], duv[NU];
 #pragma unroll
-            for (int i = 0; i < NX; i++) dx[i] = x[i] - xr[i];
-        }
-        const T* Kk = KT + (size_t)kn * (NX * NU);                        // K(r, c) = KT[c + r*14]: row r contiguous
+        for (int rr = 0; rr < NU; rr++) tl_load14(Kk + rr * NX, KT + (size_t)kn * (NX * NU) + rr * NX);
+        tl_load14(xr, xcur + (size_t)kn * NX);
 #pragma unroll
-        for (int r = 0; r < NU; r++) {
-            T row[NX];
-            tl_load14(row, Kk + r * NX);
-            T acc = alpha * du[(size_t)kn * NU + r];
-#pragma unroll
-            for (int c = 0; c < NX; c++) acc += row[c] * dx[c];
-            u[r] = uc[(size_t)kn * NU + r] - acc;
-            us[(size_t)kn * NU + r] = u[r];
-        }
-        J += arm_tl_cost<T>(cw, x, u, xg, false);
-        T qdd[7];
-        arm_tl_dynamics<T>(md, grav, st, qdd, x, x + 7, u);
-        T xn[NX];
-#pragma unroll
-        for (int i = 0; i < 7; i++) { xn[i] = x[i] + dt * x[7 + i]; xn[7 + i] = x[7 + i] + dt * qdd[i]; }     // Euler (utils/integrators.cuh:24-36)
-        if (k < NBk - 1) {
-            tl_store14(xs + (size_t)(kn + 1) * NX, xn);
-#pragma unroll
-            for (int i = 0; i < NX; i++) x[i] = xn[i];
-        } else {                                                          // last step of a non-final segment: defect against the next segment's start
-            const int ks = (seg + 1) * NBk;
-            T xnext[NX], e[NX], sdef = T(0);
-            tl_load14(xnext, xs + (size_t)ks * NX);
-#pragma unroll
-            for (int i = 0; i < NX; i++) { e[i] = xn[i] - xnext[i]; sdef += tabs(e[i]); }
-            tl_store14(ds + (size_t)(ks - 1) * NX, e);
-            b.dpart[slot * dm.M + seg] = sdef;
-        }
+        for (int i = 0; i < NU; i++) { ucv[i] = uc[(size_t)kn * NU + i]; duv[i] = du[(size_t)kn * NU + i]; }
+        tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, Kk, xr, ucv, duv, xg, sink);
     }
-    if (seg == dm.M - 1) {                                                // terminal knot: its (unused) control is carried along
-        const int kn = N - 1;
-        T u[NU];
+    T ucN[NU];
 #pragma unroll
-        for (int r = 0; r < NU; r++) { u[r] = uc[(size_t)kn * NU + r]; us[(size_t)kn * NU + r] = u[r]; }
-        J += arm_tl_cost<T>(cw, x, u, xg, true);
-        b.dpart[slot * dm.M + seg] = T(0);
+    for (int i = 0; i < NU; i++) ucN[i] = uc[(size_t)(N - 1) * NU + i];
+    tl_rollout_end<T>(r, dm, cw, ucN, xg, sink);
+    if (part) {
+        const size_t slot = (size_t)pb * dm.A + a_idx;
+        b.Jpart[slot * dm.M + seg] = r.J; b.dpart[slot * dm.M + seg] = r.sdef;
+        b.parts_fresh[pb] = 1;                                            // every thread of the problem stores the same value
     }
-    b.Jpart[slot * dm.M + seg] = J;
-    b.parts_fresh[pb] = 1;                                                // every thread of the problem stores the same value
+}
+template <typename T>
+PDDP_HD TlCandidateSink<T> tl_candidate_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx) {
+    const size_t slot = (size_t)pb * dm.A + a_idx;
+    return TlCandidateSink<T>{b.xs + slot * dm.N * 14, b.us + slot * dm.N * 7, b.ds + slot * dm.N * 14};
+}
+// After the line search accepted candidate st.alphaIndex (st.cur already points at the NEW half of xb): roll the winner out again, straight into
+// the current-trajectory buffers -- x into the new half of xb, u over ucur (each knot is read before it is written, by the same thread), the
+// boundary defects into dcur.  Same code, same inputs, same order as the candidate's rollout: the same numbers.  Replaces memcpyCurrAKern x3 and
+// the winner -> xp / up / dp copies of nextIterationSetupGPU (nisInitHelpers.cuh:270-276).
+template <typename T>
+PDDP_HD void arm_tl_rollout_winner(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int pb, int seg) {
+    const SolverState<T>& st = b.state[pb];
+    if (!st.win_pending) return;                                          // rejected, failed backward pass, or already finished: nothing moves
+    const size_t N = dm.N;
+    const T* xold = b.xb + ((size_t)pb * 2 + (1 - st.cur)) * N * 14;
+    TlWinnerSink<T> sink{b.xb + ((size_t)pb * 2 + st.cur) * N * 14, b.ucur + (size_t)pb * N * 7, b.dcur + (size_t)pb * N * 14};
+    arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, st.alphaIndex, seg, xold, sink, false);
 }
 
 // the line-search kernel's first step when the thread-lane forward pass ran: J[a] = sum of the segment partial sums in order, dmax[a] = max
@@ -147,7 +223,7 @@ PDDP_HD void tl_reduce_parts(const Buffers<T>& b, const Dims& dm, int pb) {
     }
 }
 
-// Next-iteration setup of knot k of problem pb (nis_body / arm_lg_nis_body): adopt the winner, g_k, (mode 1: H_k), and the Jacobian of the
+// Next-iteration setup of knot k of problem pb (nis_body / arm_lg_nis_body) at the current trajectory: g_k, (mode 1: H_k), and the Jacobian of the
 // dynamics through emit(col, row, dqdd) -- the caller turns it into [A B] rows 7..13 (k_nis_tl stages it through LDS).  Returns false when
 // this knot has no Jacobian to write (rejected / failed iteration, final knot, finished problem).
 template <typename T, typename Emit>
@@ -159,22 +235,10 @@ PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& 
     T* xc = b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX;
     T* uc = b.ucur + knot * NU;
     T x[NX], u[NU];
-    if (mode == 0) {
-        if (st.accepted != 1) return false;                               // rejected, or the backward pass failed: nothing moved
-        const size_t wknot = ((size_t)pb * dm.A + st.alphaIndex) * N + k;
-        tl_load14(x, b.xs + wknot * NX);
+    if (mode == 0 && (!st.win_pending || st.done)) return false;         // rejected / failed: nothing moved; final accepted step: no derivatives needed
+    tl_load14(x, xc);                                                     // the winner kernel (arm_tl_rollout_winner) has already put the new trajectory here
 #pragma unroll
-        for (int i = 0; i < NU; i++) u[i] = b.us[wknot * NU + i];
-        tl_store14(xc, x);
-#pragma unroll
-        for (int i = 0; i < NU; i++) uc[i] = u[i];
-        if (dm.M > 1 && dm.on_defect_boundary(k)) { T d[NX]; tl_load14(d, b.ds + wknot * NX); tl_store14(b.dcur + knot * NX, d); }
-        if (st.done) return false;                                        // final accepted step: solution copied, no derivatives needed
-    } else {
-        tl_load14(x, xc);
-#pragma unroll
-        for (int i = 0; i < NU; i++) u[i] = uc[i];
-    }
+    for (int i = 0; i < NU; i++) u[i] = uc[i];
     const bool fin = (k == N - 1);
     const T w1 = fin ? cw.QF1 : cw.Q1, w2 = fin ? cw.QF2 : cw.Q2, w3 = fin ? T(0) : cw.R;       // ArmPlant::weight
     T xg[NX];

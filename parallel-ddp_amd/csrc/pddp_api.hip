@@ -257,7 +257,7 @@ struct Solver : SolverBase {
         return 0;
     }
     // forward pass: the arm runs on lane groups (fp_lg.hpp), the closed-form plants on the wave-cooperative kernel
-    void launch_fp(hipStream_t s, int init_rollout) {
+    void launch_fp(hipStream_t s, int init_rollout, int store_candidates = 0) {
         const unsigned B = cfg.batch;
         bool lane_groups = false;
         if constexpr (P::PLANT == 4) lane_groups = !fp_coop;       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests)
@@ -272,7 +272,7 @@ struct Solver : SolverBase {
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
-                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
+                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
                 return;
             }
             const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
@@ -290,6 +290,7 @@ struct Solver : SolverBase {
         const unsigned B = cfg.batch;
         if constexpr (P::PLANT == 4) {
             if (fp_path == kFpTl) {
+                if (mode == 0) launch_win_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);     // the accepted candidate becomes the current trajectory
                 launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);
                 return;
             }
@@ -301,7 +302,7 @@ struct Solver : SolverBase {
         }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
-    void launch_sweep(hipStream_t s, int only = -1) {
+    void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0) {
         const unsigned B = cfg.batch;
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
@@ -312,7 +313,7 @@ struct Solver : SolverBase {
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
             }
         }
-        if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0);
+        if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0, store_candidates);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
         if (only < 0 || only == PDDP_PHASE_NIS) launch_nis(s, 0);
     }
@@ -493,7 +494,7 @@ struct Solver : SolverBase {
         for (int i = 0; i < cfg.batch; i++) {
             auto& s = st[i]; const pddp_state& o = in[i];
             s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
-            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw;
+            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw; s.win_pending = (o.accepted == 1) ? 1 : 0;
         }
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(b.state, st.data(), cfg.batch * sizeof(SolverState<T>), hipMemcpyHostToDevice));
@@ -502,7 +503,7 @@ struct Solver : SolverBase {
     int run_phase(int phase) override {
         const unsigned B = cfg.batch;
         if (phase >= 0 && phase <= 3) {
-            launch_sweep(stream, phase);
+            launch_sweep(stream, phase, 1);                         // teacher-forcing hook: the forward pass also stores every candidate trajectory
             if (phase == PDDP_PHASE_FP) hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);   // J / dmax readable right after the phase
         }
         else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);

@@ -7,17 +7,117 @@
 
 namespace pddp {
 
-// k_fp_tl: grid ceil(B*M*A / 256), block 256.  Thread i rolls out segment (i / A) % M of candidate i % A of problem i / (M*A): the 8 candidates
-// of a (problem, segment) are adjacent lanes and share every gain / reference address.  The linear sweep (k_sweep_lg) runs before it, unchanged.
-// Replaces forwardSimKern<<<(M,A),(8,7)>>> + costKern<<<A,N>>> + defectKern<<<A,N>>> (fpHelpers.cuh:366,383,388).
-template <typename T, int V>
+// k_fp_tl: grid ceil(B*M*A / 256), block 256.  Thread i rolls out segment (i / A) % M of candidate i % A of problem i / (M*A): the A candidates
+// of a (problem, segment) PAIR are adjacent lanes and need the same per-step operands (gain K_k 98 floats, reference state 14, nominal control 7,
+// feed-forward 7).  A wave owns 64/A pairs; it fetches their operands of step k+1 cooperatively (every pair's block is contiguous: 8-byte accesses,
+// each byte fetched once per wave) while step k computes, parks them in its own double-buffered LDS area (132-float pair stride: the pairs land in
+// different banks), and every lane reads its pair's copy from there.  No workgroup barrier: a wave only ever touches its own area.
+// STORE = false (the sweep): candidates leave only their partial cost / defect sums -- the trajectory of the winner is re-rolled by k_win_tl.
+// STORE = true (pddp_run_phase(FP), teacher-forced tests): every candidate's x, u, d is also written to xs / us / ds, as the reference keeps them.
+// The linear sweep (k_sweep_lg) runs before it, unchanged.  Replaces forwardSimKern<<<(M,A),(8,7)>>> + costKern<<<A,N>>> + defectKern<<<A,N>>>
+// (fpHelpers.cuh:366,383,388).
+constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | xr 14 | uc 7 | du 7 | pad 6
+constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
+template <typename T, int V, bool STORE>
 __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
-    const int inst = blockIdx.x * 256 + threadIdx.x, per_pb = dm.M * dm.A;
-    if (inst >= batch * per_pb) return;
-    const int pb = inst / per_pb, rem = inst - pb * per_pb, seg = rem / dm.A, a_idx = rem - seg * dm.A;
-    if (!fp_active<T>(b, dm, pb)) return;
-    arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg);
+    constexpr int NX = 14, NU = 7, PS = kFpTlPS;
+    const int A = dm.A, M = dm.M, N = dm.N, NBk = dm.NB, per_pb = M * A, total = batch * per_pb;
+    const int inst = blockIdx.x * 256 + threadIdx.x;
+    if (A < 8 || (64 % A) != 0) {            // unstaged: operands straight from global memory
+        if (inst >= total) return;
+        const int pb = inst / per_pb, rem = inst - pb * per_pb, seg = rem / A, a_idx = rem - seg * A;
+        if (!fp_active<T>(b, dm, pb)) return;
+        const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
+        if (STORE) arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_candidate_sink<T>(b, dm, pb, a_idx), true);
+        else arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, TlNoSink(), true);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) T stage_all[4 * 2 * kFpTlMaxPairs * PS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* stg = stage_all + wave * (2 * kFpTlMaxPairs * PS);
+    const int ppw = 64 / A, npairs = batch * M;
+    const int gp0 = (blockIdx.x * 256 + wave * 64) / A;               // first pair of this wave
+    if (gp0 >= npairs) return;                                        // whole wave beyond the batch
+    // ---- this lane's share of the cooperative fetch: up to 7 eight-byte pieces (K and xr) and 2 four-byte pieces (uc, du) per step
+    constexpr int J2 = (kFpTlMaxPairs * 56 + 63) / 64, J1 = (kFpTlMaxPairs * 14 + 63) / 64;
+    const T* src2[J2]; int dst2[J2], str2[J2];
+    const T* src1[J1]; int dst1[J1];
+#pragma unroll
+    for (int j = 0; j < J2; j++) {
+        const int e = lane + 64 * j, q = e / 56, off = e - q * 56;
+        int gq = gp0 + (q < ppw ? q : ppw - 1); gq = gq < npairs ? gq : npairs - 1;
+        const int pbq = gq / M, k0 = (gq - pbq * M) * NBk;
+        const bool isK = off < 49;
+        src2[j] = isK ? b.KT + ((size_t)pbq * N + k0) * (NX * NU) + 2 * off
+                      : b.xb + (((size_t)pbq * 2 + b.state[pbq].cur) * N + k0) * NX + 2 * (off - 49);
+        str2[j] = isK ? NX * NU : NX;
+        dst2[j] = (e < ppw * 56) ? q * PS + (isK ? 2 * off : 98 + 2 * (off - 49)) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < J1; j++) {
+        const int e = lane + 64 * j, q = e / 14, off = e - q * 14;
+        int gq = gp0 + (q < ppw ? q : ppw - 1); gq = gq < npairs ? gq : npairs - 1;
+        const int pbq = gq / M, k0 = (gq - pbq * M) * NBk;
+        src1[j] = (off < 7 ? b.ucur : b.du) + ((size_t)pbq * N + k0) * NU + (off < 7 ? off : off - 7);
+        dst1[j] = (e < ppw * 14) ? q * PS + 112 + off : -1;
+    }
+    TlPair<T> pf2[J2]; T pf1[J1];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < J2; j++) pf2[j] = *reinterpret_cast<const TlPair<T>*>(src2[j] + (size_t)k * str2[j]);
+#pragma unroll
+        for (int j = 0; j < J1; j++) pf1[j] = src1[j][(size_t)k * NU];
+    };
+    auto park = [&](int buf) {
+        T* d = stg + buf * (kFpTlMaxPairs * PS);
+#pragma unroll
+        for (int j = 0; j < J2; j++) if (dst2[j] >= 0) *reinterpret_cast<TlPair<T>*>(d + dst2[j]) = pf2[j];
+#pragma unroll
+        for (int j = 0; j < J1; j++) if (dst1[j] >= 0) d[dst1[j]] = pf1[j];
+    };
+    // ---- this lane's rollout
+    const int p = lane / A, a_idx = lane - p * A, gp = gp0 + p;
+    const int pb = (gp < npairs ? gp : npairs - 1) / M, seg = (gp < npairs ? gp : npairs - 1) - pb * M;
+    const bool live = gp < npairs && fp_active<T>(b, dm, pb);
+    const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
+    T xg[NX];
+    tl_load14(xg, b.xGoal + (size_t)pb * NX);
+    TlRollout<T> r;
+    r.iters = 0;
+    const auto csink = tl_candidate_sink<T>(b, dm, pb, a_idx);
+    if (live) { if (STORE) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, TlNoSink()); }
+    fetch(0); park(0);
+    wsync();
+    for (int k = 0; k < NBk; k++) {
+        if (k + 1 < NBk) fetch(k + 1);                                // in flight while this step computes
+        if (live && k < r.iters) {
+            const T* o = stg + (k & 1) * (kFpTlMaxPairs * PS) + p * PS;
+            if (STORE) tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, csink);
+            else tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, TlNoSink());
+        }
+        if (k + 1 < NBk) park((k + 1) & 1);
+        wsync();
+    }
+    if (!live) return;
+    T ucN[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) ucN[i] = b.ucur[((size_t)pb * N + (N - 1)) * NU + i];
+    if (STORE) tl_rollout_end<T>(r, dm, cw, ucN, xg, csink); else tl_rollout_end<T>(r, dm, cw, ucN, xg, TlNoSink());
+    const size_t slot = (size_t)pb * A + a_idx;
+    b.Jpart[slot * M + seg] = r.J; b.dpart[slot * M + seg] = r.sdef;
+    b.parts_fresh[pb] = 1;
+}
+
+// k_win_tl: grid ceil(B*M / 64), block 64.  Thread = (problem, segment): after an accepting line search, the winner's rollout again, written straight
+// into the current-trajectory buffers (arm_tl_rollout_winner).  One wave per workgroup so that the B*M/64 waves spread over all compute units.
+template <typename T, int V>
+__global__ __launch_bounds__(64, 1) void k_win_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
+    constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= batch * dm.M) return;
+    const int pb = i / dm.M, seg = i - pb * dm.M;
+    arm_tl_rollout_winner<T>(md, grav, b, dm, cw, dt, pb, seg);
 }
 
 // k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  float: a wave's 64 knots x 147 Jacobian entries are
@@ -78,10 +178,17 @@ __global__ __launch_bounds__(256, 1) void k_plant_eval_tl(T grav, int count, con
 }
 
 template <typename T>
-void launch_fp_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch) {
+void launch_fp_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, int store_candidates) {
     const unsigned inst = (unsigned)batch * dm.M * dm.A;
-    if (variant == 0) hipLaunchKernelGGL((k_fp_tl<T, 0>), dim3((inst + 255) / 256), dim3(256), 0, s, b, dm, cw, dt, grav, batch);
-    else hipLaunchKernelGGL((k_fp_tl<T, 1>), dim3((inst + 255) / 256), dim3(256), 0, s, b, dm, cw, dt, grav, batch);
+    const dim3 g((inst + 255) / 256), t(256);
+    if (variant == 0) { if (store_candidates) hipLaunchKernelGGL((k_fp_tl<T, 0, true>), g, t, 0, s, b, dm, cw, dt, grav, batch); else hipLaunchKernelGGL((k_fp_tl<T, 0, false>), g, t, 0, s, b, dm, cw, dt, grav, batch); }
+    else { if (store_candidates) hipLaunchKernelGGL((k_fp_tl<T, 1, true>), g, t, 0, s, b, dm, cw, dt, grav, batch); else hipLaunchKernelGGL((k_fp_tl<T, 1, false>), g, t, 0, s, b, dm, cw, dt, grav, batch); }
+}
+template <typename T>
+void launch_win_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch) {
+    const unsigned n = (unsigned)batch * dm.M;
+    if (variant == 0) hipLaunchKernelGGL((k_win_tl<T, 0>), dim3((n + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, grav, batch);
+    else hipLaunchKernelGGL((k_win_tl<T, 1>), dim3((n + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, grav, batch);
 }
 template <typename T>
 void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch) {
@@ -94,8 +201,10 @@ void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T
     if (variant == 0) hipLaunchKernelGGL((k_plant_eval_tl<T, 0>), dim3((count + 255) / 256), dim3(256), 0, s, grav, count, x, u, out, grad);
     else hipLaunchKernelGGL((k_plant_eval_tl<T, 1>), dim3((count + 255) / 256), dim3(256), 0, s, grav, count, x, u, out, grad);
 }
-template void launch_fp_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int);
-template void launch_fp_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int);
+template void launch_fp_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, int);
+template void launch_fp_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, int);
+template void launch_win_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int);
+template void launch_win_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int);
 template void launch_nis_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, int);
 template void launch_nis_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, int);
 template void launch_plant_eval_tl<float>(hipStream_t, int, float, int, const float*, const float*, float*, int);

@@ -36,6 +36,7 @@ struct SolverState {
     int bp_retries;
     int pw;              // which half of the cost-to-go double buffer (P = 0, Pp = 1) the next backward pass WRITES; it reads the other one
     int took_step;       // MPC: an accepted iteration of this solve used a step-size index > 0 (MPCHelpers.cuh:986-991)
+    int win_pending;     // this sweep's line search accepted a candidate: the thread-lane winner kernel / setup kernel act on it (cleared by the next line search)
 };
 
 struct SolverParams {    // read-only per launch (reference macros, config.cuh)
@@ -83,6 +84,7 @@ template <typename T>
 PDDP_HD void line_search_accept(SolverState<T>& st, const SolverParams& sp, const Dims& dm, int any_bp_err, const T* alpha,
                                 const T* J, const T* dmax, T* dJexp, T* Jout, int* alphaOut) {
     if (st.done) return;
+    st.win_pending = 0;
     if (any_bp_err) {
         rho_increase(st);
         st.accepted = -1;
@@ -116,7 +118,7 @@ PDDP_HD void line_search_accept(SolverState<T>& st, const SolverParams& sp, cons
         dJ = dJ / st.prevJ; st.prevJ = J[aidx];
         st.alphaIndex = aidx; alphaOut[st.iter] = aidx; Jout[st.iter] = J[aidx];
         if (aidx > 0) st.took_step = 1;
-        st.accepted = 1; st.dJ = dJ;
+        st.accepted = 1; st.dJ = dJ; st.win_pending = 1;
         st.cur = 1 - st.cur;                            // the winner is copied into the other half of xb by the NIS launch
         if (dJ < T(sp.tol_cost)) { st.done = 1; return; }
     }

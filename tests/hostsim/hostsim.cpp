@@ -45,7 +45,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
 static bool fp_coop() { const char* v = std::getenv("PDDP_FP"); return v && std::string(v) == "coop"; }   // PDDP_FP=coop: wave-cooperative forward pass / setup (comparison tests)
 
 struct Base {
-    pddp_config cfg; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
+    pddp_config cfg; int store_candidates = 0; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
     virtual ~Base() {}
     virtual int load(const void*, const void*, const void*, const void*, const void*, const void*, const void*, int, int, int) = 0;
     virtual int iterate(int) = 0;
@@ -135,7 +135,11 @@ struct Sim : Base {
                 if constexpr (P::PLANT == 4) if (fp_tl()) {          // one "thread" per (candidate, segment): plain scalar code (fp_tl.hpp)
                     using L = LgHost<T>;
                     for (int a = 0; a < cfg.A; a++) if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data()));
-                    for (int sg = 0; sg < cfg.M; sg++) for (int a = 0; a < cfg.A; a++) arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg);
+                    const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * cfg.N * NX;
+                    for (int sg = 0; sg < cfg.M; sg++) for (int a = 0; a < cfg.A; a++) {
+                        if (store_candidates) arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_candidate_sink<T>(b, dm, pb, a), true);
+                        else arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, TlNoSink(), true);
+                    }
                     continue;
                 }
                 for (int a = 0; a < cfg.A; a++) {
@@ -163,6 +167,7 @@ struct Sim : Base {
         } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
             if constexpr (P::PLANT == 4) if (fp_tl()) {
                 const int mode = ph == PDDP_PHASE_INIT_NIS;
+                if (!mode) for (int pb = 0; pb < B; pb++) for (int sg = 0; sg < cfg.M; sg++) arm_tl_rollout_winner<T>(tl_model, model.grav, b, dm, cw, dt, pb, sg);
                 for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) {
                     T* AB = b.AB + ((size_t)pb * cfg.N + k) * (NX * NM);
                     const bool valid = arm_tl_nis_knot<T>(tl_model, model.grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; });
@@ -313,13 +318,14 @@ struct Sim : Base {
         for (int i = 0; i < cfg.batch; i++) {
             auto& s = b.state[i]; const pddp_state& o = in[i];
             s.rho = (T)o.rho; s.drho = (T)o.drho; s.prevJ = (T)o.prevJ; s.dJ = (T)o.dJ; s.z = (T)o.z; s.iter = o.iter; s.alphaIndex = o.alphaIndex;
-            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw;
+            s.ignore_defect = o.ignore_defect; s.accepted = o.accepted; s.done = o.done; s.cur = o.cur; s.cur2 = o.cur2; s.bp_retries = o.bp_retries; s.took_step = 0; s.pw = o.pw; s.win_pending = (o.accepted == 1) ? 1 : 0;
         }
         return 0;
     }
     int run_phase(int ph) override {
         if (ph == PDDP_PHASE_BP_COOP) { bp_coop = 1; phase(PDDP_PHASE_BP); bp_coop = 0; return 0; }
-        if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase"); phase(ph);
+        if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase");
+        store_candidates = 1; phase(ph); store_candidates = 0;      // teacher-forcing hook: the thread-lane forward pass also stores every candidate
         if (ph == PDDP_PHASE_FP) for (int pb = 0; pb < cfg.batch; pb++) if (b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }
         return 0;
     }

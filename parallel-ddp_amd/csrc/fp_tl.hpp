@@ -29,17 +29,20 @@ namespace pddp {
 
 // Which implementation of the arm's forward pass / next-iteration setup a handle uses.  PDDP_FP=coop|lg|tl overrides (comparison tests).
 //   coop: one wave per unit (fp.hpp, nis.hpp)   lg: 8-lane groups (fp_lg.hpp, nis_lg.hpp)   tl: one thread per instance (this file)
-// Default: tl for float handles with the joint-space cost and an iiwa-structured model; lg otherwise (float64 handles keep the reference's
-// operation order, which the 1e-9 parity tests rely on; the end-effector cost family and the initial rollout exist on lane groups only).
+// Default: tl for float handles of >= 512 problems with the joint-space cost and an iiwa-structured model; lg otherwise (float64 handles keep
+// the reference's operation order, which the 1e-9 parity tests rely on; the end-effector cost family and the initial rollout exist on lane
+// groups only; below ~512 problems a thread per knot leaves most of the GPU idle and the lane groups' shorter critical path wins:
+// profiles/r02_path_sweep.txt -- one problem: setup 33 us on lane groups, 145 us on thread lanes; 1024 problems: 0.37 ms vs 0.24 ms).
 enum FpPath { kFpCoop = 0, kFpLg = 1, kFpTl = 2 };
-inline FpPath select_fp_path(const char* env, bool is_float, bool ee_cost, bool tl_model_ok) {
+constexpr int kFpTlMinBatch = 512;
+inline FpPath select_fp_path(const char* env, bool is_float, bool ee_cost, bool tl_model_ok, int batch) {
     const bool tl_possible = !ee_cost && tl_model_ok;
     if (env) {
         if (env[0] == 'c') return kFpCoop;
         if (env[0] == 'l') return kFpLg;
         if (env[0] == 't' && tl_possible) return kFpTl;
     }
-    return (is_float && tl_possible) ? kFpTl : kFpLg;
+    return (is_float && tl_possible && batch >= kFpTlMinBatch) ? kFpTl : kFpLg;
 }
 
 // 14 floats of one knot as seven 8-byte accesses (every x / d / xGoal knot block is 56 bytes, 8-byte aligned)

@@ -113,7 +113,7 @@ struct Solver : SolverBase {
         if (arm_tl_model_from_tables(m, hm))
             for (int v = 0; v < 2; v++) if (arm_tl_models_equal(m, arm_tl_builtin<T>(v))) tl_variant = v;
         tl_grav = hm.grav;
-        fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0);
+        fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0, cfg.batch);
         fp_coop = (fp_path == kFpCoop);
     }
     void derive_tl_model(const EmptyModel&) {}

@@ -114,7 +114,7 @@ struct Sim : Base {
     ArmTlModel<T> tl_model{}; bool tl_ok = false;
     void derive_tl(const ArmModel<T>& m) { tl_ok = arm_tl_model_from_tables(tl_model, m); }
     void derive_tl(const EmptyModel&) {}
-    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok) == kFpTl; }
+    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok, cfg.batch) == kFpTl; }
     void phase(int ph) {
         const int B = cfg.batch; const Wave w = this_wave();
         if (ph == PDDP_PHASE_BP) {

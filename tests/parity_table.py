@@ -1,0 +1,25 @@
+"""Prints the float32 bar table of tests/test_fp32_bar.py (worst kernel error and the oracle32 error at that point, per phase and quantity)
+for a backend:  python tests/parity_table.py hip|hostsim   (the GPU run's output is committed under profiles/)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "parallel-ddp_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+
+import test_fp32_bar as t  # noqa: E402
+
+backend = sys.argv[1] if len(sys.argv) > 1 else "hostsim"
+np.seterr(all="ignore")
+cases = (("Kuka N=128 A=8 M=4 float32, large-batch kernels (k_bp_lg + thread-lane forward pass / setup)", 4, t.KUKA, {"PDDP_BP": "lg", "PDDP_FP": "tl"}, 40),
+         ("Kuka N=128 A=8 M=4 float32, single-problem kernels", 4, t.KUKA, {}, 40),
+         ("cart-pole N=128 A=8 M=4 RK3 float32", 2, t.CART, {}, 12))
+for name, plant, kw, env, its in cases:
+    rows, fails, ints = t.run_bar(backend, plant, kw, env, 5, its)
+    print(f"{name}: {its} iterations teacher-forced from oracle64, {len(rows)} comparisons, integers identical: {ints}, outside the bar: {len(fails)}")
+    print("   phase quantity   worst err(kernel32,oracle64)   err(oracle32,oracle64) there   iteration")
+    for k, v in sorted(t.summarize(rows).items()):
+        print("   %-5s %-8s %.2e   %.2e   %d %s" % (k[0], k[1], v[0], v[1], v[2], v[3]))
+    for f in fails[:10]:
+        print("   OUTSIDE", f)

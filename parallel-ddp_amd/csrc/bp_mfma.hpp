@@ -1,0 +1,308 @@
+// Backward (Riccati-like) pass of the KUKA-sized problem (n = 14, m = 7, float) on the MATRIX CORES: one wavefront walks one of the M
+// blocks of knots of one problem backwards and every dense product of a knot is a chain of v_mfma_f32_16x16x4_f32.
+//
+// Same function as bp_block() (bp.hpp) / arm_lg_bp_block() (bp_lg.hpp), which restate backPassKern and its inner routines
+// (DDPHelpers/bpHelpers.cuh:18-420: linearXfrmOrLoad, backprop, invHuu + invertMatrix, computeKTdu, computeCTG, computeFSVars,
+// computeExpRed) including the asymmetric placement of the regulariser (rho reaches Hxu and Huu, not the Hux block the gains are computed
+// from).  What differs is the arithmetic decomposition, so the float32 results agree with the oracle within the float32 bar
+// (tests/test_fp32_bar.py), not bit for bit: sums over the state index run in the matrix core's order (k = r, 4+r, 8+r, 12+r per
+// instruction, r = 0..3), rho B is added to AB'P instead of rho to P.
+//
+// Layout.  "RB tile" of a matrix X with <= 16 rows and <= 16 columns: four registers t[0..3] per lane; lane (g = lane >> 4, c = lane & 15)
+// holds X[4 g + r][c] in t[r].  That is the accumulator layout of the 16x16x4 instruction, and -- with the k index of step r taken as
+// 4 g + r -- it is at the same time the A operand of X' (.) and the B operand of (.) X.  So for two RB tiles X, Y with a common row index
+//          mfma4(X, Y, C) = C + X' Y        (four instructions, result again an RB tile, rows = columns of X)
+// and the whole knot is written as products of that one form; no operand is ever transposed through LDS or shuffled between lanes:
+//   W_x, W_u = P' [A | B]                                    (= AB2', rows i)                      8 instructions
+//   Hxx' = A' W_x + Hxx_cost    Hux = B' W_x + Hux_cost      -Hxu' = (-W_u)' A - Hxu_cost'    Huu = B' W_u + Huu_cost      16
+//   K    = (Huu^-1')' Hux                                    (rows a)                              4
+//   T1'  = Huu' K - Hxu'                                     (rows b)                              4
+//   P+   = Hxx + T1'' K - K' Hux                             (rows kx: the next knot's P)          8
+//   A-BK = A + (-B')' K                                                                           4
+// The vectors ride along as column 14 of the tiles: p is column 14 of P, so g_x = A'p + g_cost, g_u = B'p + g_cost come out as column 14
+// of Hxx and Hux, du = Huu^-1 g_u as column 14 of K, Huu'du as column 14 of T1', the new p as column 14 of P+, and -B du as column 14 of
+// A - BK.  Only the 7x7 Gauss-Jordan inversion (unpivoted, never failing -- utils/cudaUtils.h:236-292) runs on the vector ALU: lane j keeps
+// column j of [Huu | I], pivot-column entries travel through v_readlane (the wave owns ONE problem, so they are wave-uniform scalars).
+//
+// Global memory: every per-knot block is read / written straight in RB order -- 16-byte pieces per lane (4 consecutive rows of a column of
+// the column-major blocks) or 56-byte runs across lanes; the bytes are the same as the lane-group kernel's (algorithmic bytes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "solver_state.hpp"
+
+namespace pddp {
+
+typedef float mx4 __attribute__((ext_vector_type(4)));
+typedef float mx4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float mx2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ mx4 mx_mfma4(const mx4& X, const mx4& Y, mx4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[2], Y[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[3], Y[3], acc, 0, 0, 0);
+    return acc;
+}
+// 1 / d to within one unit in the last place: hardware reciprocal + one Newton step (the reference divides, nisInitHelpers / cudaUtils.h:262)
+__device__ __forceinline__ float mx_recip(float d) { const float x = __builtin_amdgcn_rcpf(d); return __builtin_fmaf(__builtin_fmaf(-d, x, 1.f), x, x); }
+__device__ __forceinline__ float mx_readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float mx_from_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+
+// RB tile whose rows 4g..4g+3 are CONSECUTIVE in memory at p (a column of a column-major block): rows below `nrows` are read, the rest are 0
+__device__ __forceinline__ mx4 mx_load_rows4(const float* p, int row0, int nrows, bool lane_ok) {
+    mx4 t = {0.f, 0.f, 0.f, 0.f};
+    if (lane_ok) {
+        const int left = nrows - row0;
+        if (left >= 4) t = *reinterpret_cast<const mx4u*>(p);
+        else if (left == 3) { const mx2u v = *reinterpret_cast<const mx2u*>(p); t[0] = v[0]; t[1] = v[1]; t[2] = p[2]; }
+        else if (left == 2) { const mx2u v = *reinterpret_cast<const mx2u*>(p); t[0] = v[0]; t[1] = v[1]; }
+        else if (left == 1) t[0] = p[0];
+    }
+    return t;
+}
+__device__ __forceinline__ void mx_store_rows4(float* p, int row0, int nrows, bool lane_ok, const mx4& t) {
+    if (lane_ok) {
+        const int left = nrows - row0;
+        if (left >= 4) *reinterpret_cast<mx4u*>(p) = t;
+        else if (left == 3) { mx2u v; v[0] = t[0]; v[1] = t[1]; *reinterpret_cast<mx2u*>(p) = v; p[2] = t[2]; }
+        else if (left == 2) { mx2u v; v[0] = t[0]; v[1] = t[1]; *reinterpret_cast<mx2u*>(p) = v; }
+        else if (left == 1) p[0] = t[0];
+    }
+}
+// RB tile whose row 4g+r lies at p + (4g+r)*ld, lanes c consecutive (a row of a column-major block read as a tile row)
+__device__ __forceinline__ mx4 mx_load_strided(const float* p, int ld, int row0, int nrows, bool lane_ok) {
+    mx4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (lane_ok && row0 + r < nrows) t[r] = p[(row0 + r) * ld];
+    return t;
+}
+
+// Control-indexed tiles.  A tile whose ROWS are a control index a = 0..6 comes out of the matrix core in accumulator rows = the lanes of the
+// X operand's columns.  Control column b is therefore kept in lane mx_pi(b) = 4 (b >> 1) + (b & 1) of every tile that has controls in its
+// columns (B, W_u, Huu, Huu^-1'), which puts control row b into register b & 1 of lane group b >> 1: a product that sums over the controls
+// then needs instructions r = 0, 1 only (mx_mfma2) instead of four half-empty ones.
+__device__ __forceinline__ mx4 mx_mfma2(const mx4& X, const mx4& Y, mx4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], acc, 0, 0, 0);
+    return acc;
+}
+__host__ __device__ constexpr int mx_pi(int b) { return 4 * (b >> 1) + (b & 1); }
+
+// the read-only operands of one knot as they come from memory
+template <bool FS, bool DIAGH>
+struct MxKnotIn {
+    mx4 A0, B1;            // A(i, kx = c), B(i, control of this lane)
+    float BT0, BT1;        // FS: B(kx = c, b = 2g + r)
+    mx4 CXX;               // full H: Hcost(kx, ky = c) | g_x in column 14;   diagonal H: g_x only (lane of column 14)
+    float CUX0, CUX1;      // full H: Hcost(14 + b, kx = c) | g_u;             diagonal H: g_u only
+    float CXU0, CXU1;      // full H: Hcost(kx = c, 14 + b)
+    float CUU0, CUU1;      // full H: Hcost(14 + a, 14 + control of this lane)
+    float hx, hu;          // unused
+};
+
+// Every lane reads UNCONDITIONALLY from an address clamped into the arrays (no divergent control flow around the loads: the compiler would turn
+// every predicated load into its own exec-masked branch region) and what a lane must not use is replaced by 0 afterwards.  The clamped
+// addresses stay inside the allocation because the loop never touches the last knot's blocks (ks <= N - 2): an over-read of up to one row / two
+// floats past a knot's block lands in the next knot's block.
+template <bool FS, bool DIAGH>
+__device__ __forceinline__ void mx_load_knot(MxKnotIn<FS, DIAGH>& k, const float* ABk, const float* Hk, const float* gk, int g, int c, int ub) {
+    constexpr int NX = 14, NU = 7, NM = 21;
+    const int row0 = 4 * g, u0 = 2 * g;
+    const bool cx = c < NX, cu = ub < NU, c14 = (c == NX);
+    const int cc = cx ? c : NX - 1, uc = cu ? ub : NU - 1;            // clamped column indices
+    const mx4 a0 = *reinterpret_cast<const mx4u*>(ABk + cc * NX + row0);
+    const mx4 b1 = *reinterpret_cast<const mx4u*>(ABk + (NX + uc) * NX + row0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { k.A0[r] = (cx && row0 + r < NX) ? a0[r] : 0.f; k.B1[r] = (cu && row0 + r < NX) ? b1[r] : 0.f; }
+    if (FS) {
+        const float t0 = ABk[NX * NX + cc + NX * u0], t1 = ABk[NX * NX + cc + NX * (u0 + 1)];
+        k.BT0 = cx ? t0 : 0.f; k.BT1 = (cx && u0 + 1 < NU) ? t1 : 0.f;
+    }
+    if (DIAGH) {
+        const mx4 gx = *reinterpret_cast<const mx4u*>(gk + row0);
+        const float gu0 = gk[NX + u0], gu1 = gk[NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && row0 + r < NX) ? gx[r] : 0.f;
+        k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
+        (void)Hk;                                                     // the diagonal comes from the cost weights (arm_mx_bp_block): no Hessian traffic at all
+        k.hx = 0.f; k.hu = 0.f;
+    } else {
+        const mx4 xx = *reinterpret_cast<const mx4u*>(c14 ? gk + row0 : Hk + cc * NM + row0);
+        const float* pu = c14 ? gk + NX + u0 : Hk + cc * NM + NX + u0;
+        const float ux0 = pu[0], ux1 = pu[1];
+        const float xu0 = Hk[(NX + u0) * NM + cc], xu1 = Hk[(NX + u0 + 1) * NM + cc];
+        const float uu0 = Hk[(NX + uc) * NM + NX + u0], uu1 = Hk[(NX + uc) * NM + NX + u0 + 1];
+        const bool v1 = u0 + 1 < NU;
+#pragma unroll
+        for (int r = 0; r < 4; r++) k.CXX[r] = ((cx || c14) && row0 + r < NX) ? xx[r] : 0.f;
+        k.CUX0 = (cx || c14) ? ux0 : 0.f; k.CUX1 = ((cx || c14) && v1) ? ux1 : 0.f;
+        k.CXU0 = cx ? xu0 : 0.f; k.CXU1 = (cx && v1) ? xu1 : 0.f;
+        k.CUU0 = cu ? uu0 : 0.f; k.CUU1 = (cu && v1) ? uu1 : 0.f;
+    }
+}
+
+// One (problem, block of knots).  lds: 96 floats of this wave.  FS: M > 1 (write the forward-sweep operands A - B K, B du).
+// DIAGH: the cost Hessian of every running knot is the joint-space cost's diag(Q1 x 7, Q2 x 7, R x 7) (plants/cost_arm.cuh:158-202, ArmPlant::weight):
+// the setup kernel wrote exactly those numbers into H, so they are taken from the launch arguments (hq1, hq2, hr) and H is not read in the loop.
+template <bool FS, bool DIAGH>
+__device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims& dm, int pb, int blk, float hq1, float hq2, float hr) {
+    constexpr int NX = 14, NU = 7, NM = 21, SZP = NX * NX, SZAB = NX * NM, SZH = NM * NM;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g, u0 = 2 * g;
+    const int ub = ((c & 3) < 2) ? 2 * (c >> 2) + (c & 3) : 8;       // the control whose column this lane holds in control-column tiles (8: none)
+    const SolverState<float>& st = b.state[pb];
+    if (st.done) return;
+    const int N = dm.N, NBk = dm.NB;
+    const float rho = st.rho;
+    const size_t halfP = (size_t)(b.Pp - b.P), halfp = (size_t)(b.pp - b.p), knot0 = (size_t)pb * N;
+    float* Pw = b.P + (st.pw ? halfP : 0) + knot0 * SZP;              // the half of the cost-to-go double buffer this pass writes ...
+    const float* Pr = b.P + (st.pw ? 0 : halfP) + knot0 * SZP;        // ... and the one whose block-boundary slots it reads (reference d_Pp)
+    float* pw = b.p + (st.pw ? halfp : 0) + knot0 * NX;
+    const float* pr = b.p + (st.pw ? 0 : halfp) + knot0 * NX;
+    const float* AB = b.AB + knot0 * SZAB; const float* H = b.H + knot0 * SZH; const float* gg = b.g + knot0 * NM;
+    float* KT = b.KT + knot0 * (NX * NU); float* du = b.du + knot0 * NU; float* ApBK = b.ApBK + knot0 * SZP; float* Bdu = b.Bdu + knot0 * NX;
+    const float* dcur = b.dcur + knot0 * NX;
+    const float* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const float* xp2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
+    const bool cx = c < NX, cu = ub < NU, c14 = (c == NX);            // lane holds a state column / a control column / the vector column
+
+    int ks = NBk * (blk + 1) - 1, iterCount;
+    mx4 Pa;                                                           // [P | p]: P(4g+r, c) for c < 14, p(4g+r) in column 14
+    if (ks == N - 1) {                                                // last block: the final cost (bpHelpers.cuh:362-367)
+        const float* Hf = H + (size_t)ks * SZH; const float* gf = gg + (size_t)ks * NM;
+        Pa = mx_load_rows4(cx ? Hf + c * NM + row0 : gf + row0, row0, NX, cx || c14);
+        mx_store_rows4(cx ? Pw + (size_t)(ks - 1) * SZP + c * NX + row0 : pw + (size_t)(ks - 1) * NX + row0, row0, NX, cx || c14, Pa);
+        ks--; iterCount = NBk - 2;
+    } else {                                                          // boundary cost-to-go of the previous iteration + linear transform (:18-34)
+        iterCount = NBk - 1;
+        const float* bP = Pr + (size_t)ks * SZP;
+        Pa = mx_load_rows4(bP + c * NX + row0, row0, NX, cx);
+        if (lane < NX) {                                              // p = (Pp dx + pp) + Pp d: lane = row (the block's first knot is a defect boundary, :73)
+            float dot = 0.f, val = 0.f;
+            for (int j = 0; j < NX; j++) {
+                const float pj = bP[lane + NX * j];
+                dot += pj * (xc[NX * (ks + 1) + j] - xp2[NX * (ks + 1) + j]);
+                val += dcur[(size_t)ks * NX + j] * pj;
+            }
+            lds[lane] = (dot + pr[(size_t)ks * NX + lane]) + val;
+        }
+        wsync();
+        if (c14) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Pa[r] = (row0 + r < NX) ? lds[row0 + r] : 0.f;
+        }
+        wsync();
+    }
+    float dJ00 = 0.f, dJ01 = 0.f, dJ10 = 0.f, dJ11 = 0.f;            // per-control partial sums of the expected reduction (lanes of column 14: controls 2g, 2g+1)
+    const mx4 zero = {0.f, 0.f, 0.f, 0.f};
+    float* ldsI = lds + 16;                                           // Huu^-1, entry (a, b) at [a * 8 + b]
+    lds[16 + lane] = 0.f;                                             // slot b = 7 of every row stays 0
+    wsync();
+    MxKnotIn<FS, DIAGH> in;
+    const float* ABk = AB + (size_t)ks * SZAB; const float* Hk = H + (size_t)ks * SZH; const float* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
+    float* KTk = KT + (size_t)ks * (NX * NU); float* duk = du + (size_t)ks * NU; float* Fk = ApBK + (size_t)ks * SZP; float* Bduk = Bdu + (size_t)ks * NX;
+    float* Pk = Pw + (size_t)(ks - 1) * SZP; float* pk = pw + (size_t)(ks - 1) * NX;
+    for (int iter = iterCount; iter >= 0; iter--, ks--) {
+        // No register prefetch of the next knot: measured on MI355X (profiles/r02_bp_mfma_experiments.md) the 18 registers it costs are worth more
+        // as a fifth resident wave per SIMD (95 registers -> 5 waves: 0.53 ms for 4096 problems, against 0.58 ms with prefetch and 4 waves).
+        mx_load_knot<FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
+        const MxKnotIn<FS, DIAGH>& k = in;
+        ABk -= SZAB; Hk -= SZH; gk -= NM;
+        // ---- cost blocks in tile form
+        mx4 CXX = k.CXX, CUX = {k.CUX0, k.CUX1, 0.f, 0.f}, CXU = zero, CUU = zero;
+        if (DIAGH) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (cx) CXX[r] = (row0 + r == c) ? (c < 7 ? hq1 : hq2) : 0.f;
+            CUU[0] = (cu && u0 == ub) ? hr : 0.f; CUU[1] = (cu && u0 + 1 == ub) ? hr : 0.f;
+        } else {
+            CXU[0] = k.CXU0; CXU[1] = k.CXU1; CUU[0] = k.CUU0; CUU[1] = k.CUU1;
+        }
+        // ---- W = P' [A | B]  (AB2', rows i = column of P); the B columns take rho B (backprop, :39-64)
+        const mx4 W0 = mx_mfma4(Pa, k.A0, zero);
+        mx4 W1 = mx_mfma4(Pa, k.B1, zero);
+        W1 = W1 + rho * k.B1;
+        const mx4 W0a = c14 ? Pa : W0;                                                            // column 14 := p
+        // ---- H blocks (:66-93): products first, cost added after, like the reference
+        const mx4 Hxx = mx_mfma4(k.A0, W0a, zero) + CXX;                                          // Hxx(kx, ky) | g_x
+        const mx4 Hux = mx_mfma4(k.B1, W0a, zero) + CUX;                                          // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
+        const mx4 HxuT = mx_mfma4(W1, k.A0, zero) + CXU;                                          // Hxu(kx, b) as [b][kx]   (with rho)
+        const mx4 Huu = mx_mfma4(k.B1, W1, zero) + CUU;                                           // Huu(a, b)               (with rho)
+        // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292): lane mx_pi(j) keeps column j of Huu,
+        //      lane mx_pi(j) + 2 column j of the identity part; register a = row a
+        float R[NU];
+        {
+            const int e = 2 * (c >> 2) + (c & 3) - 2;                 // identity column of this lane ((c & 3) >= 2)
+            const bool left = (c & 3) < 2;
+            const float h2 = mx_from_lane(Huu[0], c + 16), h3 = mx_from_lane(Huu[1], c + 16), h4 = mx_from_lane(Huu[0], c + 32), h5 = mx_from_lane(Huu[1], c + 32),
+                        h6 = mx_from_lane(Huu[0], c + 48);
+            R[0] = left ? Huu[0] : (e == 0 ? 1.f : 0.f); R[1] = left ? Huu[1] : (e == 1 ? 1.f : 0.f);
+            R[2] = left ? h2 : (e == 2 ? 1.f : 0.f); R[3] = left ? h3 : (e == 3 ? 1.f : 0.f);
+            R[4] = left ? h4 : (e == 4 ? 1.f : 0.f); R[5] = left ? h5 : (e == 5 ? 1.f : 0.f); R[6] = left ? h6 : (e == 6 ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int pv = 0; pv < NU; pv++) {
+            const float rowp = R[pv];
+            const float inv = mx_recip(mx_readlane(rowp, mx_pi(pv)));
+#pragma unroll
+            for (int a = 0; a < NU; a++) {
+                if (a == pv) continue;
+                const float f = mx_readlane(R[a], mx_pi(pv)) * inv;
+                R[a] = __builtin_fmaf(-f, rowp, R[a]);
+            }
+            R[pv] = rowp * inv;
+        }
+        if (lane < 16 && (c & 3) >= 2) {
+            const int e = 2 * (c >> 2) + (c & 3) - 2;
+            if (e < NU) {
+#pragma unroll
+                for (int a = 0; a < NU; a++) ldsI[a * 8 + e] = R[a];
+            }
+        }
+        wsync();
+        mx4 InvT = zero;                                                                          // [b = 2g + r][a = control of this lane] = Huu^-1(a, b)
+        if (cu) { InvT[0] = ldsI[ub * 8 + u0]; InvT[1] = ldsI[ub * 8 + u0 + 1]; }
+        wsync();
+        // ---- gains (computeKTdu :208-220): K(a, kx) | du(a), rows a = 2g + r
+        const mx4 Kp = mx_mfma2(InvT, Hux, zero);
+        if (c <= NX) {                                                // K row a = 2g + r: 14 consecutive floats of KT; du(a) from the lane of column 14
+            float* q0 = cx ? KTk + u0 * NX + c : duk + u0;
+            q0[0] = Kp[0];
+            if (u0 + 1 < NU) (cx ? q0 + NX : q0 + 1)[0] = Kp[1];
+        }
+        const bool do_ctg = (iter != 0 || blk != 0);                  // the cost-to-go in front of knot 0 is never used (:396)
+        // T1(kx, b) = sum_a K(a,kx) Huu(a,b) - Hxu(kx,b) as [b][kx]; its column 14 is Huu' du
+        const mx4 T1t = mx_mfma2(Huu, Kp, zero) - HxuT;
+        // ---- expected reduction (computeExpRed :317-334): du . g_u and du . Huu du, per control
+        dJ00 += Kp[0] * Hux[0]; dJ01 += Kp[1] * Hux[1];
+        dJ10 += Kp[0] * T1t[0]; dJ11 += Kp[1] * T1t[1];
+        if (FS) {                                                     // A - B K | B du  (computeFSVars :281-312)
+            const mx4 BT = {k.BT0, k.BT1, 0.f, 0.f};                                              // [b][kx = c] = B(kx, b)
+            const mx4 BK = mx_mfma2(BT, Kp, zero);
+            mx_store_rows4(cx ? Fk + c * NX + row0 : Bduk + row0, row0, NX, cx || c14, c14 ? BK : k.A0 - BK);
+        }
+        if (do_ctg) {                                                 // new cost-to-go (computeCTG :225-276): P(kx, ky) | p(kx)
+            mx4 val = mx_mfma2(T1t, Kp, zero);
+            val = mx_mfma2(-Kp, Hux, val);
+            mx4 Pn = Hxx + val;
+            if (g == 3) { Pn[2] = 0.f; Pn[3] = 0.f; }                 // rows 14, 15 carry by-products of column 14: keep the padding clean
+            mx_store_rows4(cx ? Pk + c * NX + row0 : pk + row0, row0, NX, cx || c14, Pn);
+            Pa = Pn;
+        }
+        KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;
+    }
+    // dJexp[2 blk], [2 blk + 1]: the 7 per-control partial sums in order (column-14 lanes 14, 30, 46, 62 hold controls 2g, 2g + 1)
+    {
+        float a0 = dJ00, a1 = dJ10;
+        a0 = a0 + mx_readlane(dJ01, 14); a1 = a1 + mx_readlane(dJ11, 14);
+        a0 = (a0 + mx_readlane(dJ00, 30)) + mx_readlane(dJ01, 30); a1 = (a1 + mx_readlane(dJ10, 30)) + mx_readlane(dJ11, 30);
+        a0 = (a0 + mx_readlane(dJ00, 46)) + mx_readlane(dJ01, 46); a1 = (a1 + mx_readlane(dJ10, 46)) + mx_readlane(dJ11, 46);
+        a0 = a0 + mx_readlane(dJ00, 62); a1 = a1 + mx_readlane(dJ10, 62);
+        if (lane == NX) {
+            float* dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
+            dJexp[2 * blk] = a0; dJexp[2 * blk + 1] = a1;
+            b.err[(size_t)pb * dm.M + blk] = 0;                       // the generic 7x7 inversion never reports failure (utils/cudaUtils.h:291)
+        }
+    }
+}
+
+}  // namespace pddp

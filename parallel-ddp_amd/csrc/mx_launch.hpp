@@ -1,0 +1,14 @@
+// Launcher of the matrix-core backward pass (pddp_mx.hip / bp_mfma.hpp): float handles of the KUKA arm.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "solver_state.hpp"
+
+namespace pddp {
+
+// diag_h: the cost Hessian of every running knot is the joint-space cost's own diag(hq1 x 7, hq2 x 7, hr x 7), as the setup kernel wrote it:
+// the kernel takes the three numbers from here and does not read H in its loop (the final knot's block is always read)
+void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr);
+
+}  // namespace pddp

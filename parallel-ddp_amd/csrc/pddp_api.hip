@@ -12,6 +12,7 @@
 #include "iiwa14_model_data.h"
 #include "kernels.hpp"
 #include "tl_launch.hpp"
+#include "mx_launch.hpp"
 
 using namespace pddp;
 
@@ -47,6 +48,8 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     return 0;
 }
 
+// (problem, block) pairs from which the matrix-core backward pass is the default for float handles of the arm (profiles/r02_path_sweep_mx.txt)
+static constexpr size_t kBpMfmaMinBlocks = 1;
 static double now_ms() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
 
 struct SolverBase {
@@ -74,6 +77,8 @@ struct SolverBase {
     virtual int mpc_solve(const void* xActual, const void* xGoal, const int* shift, int clear_vars, int full_rollout, int ifd, int max_iter, double budget_ms,
                           int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) = 0;
     int bench_mode = 0;
+    bool h_overridden = false;     // pddp_set_array("H"): the cost Hessian is no longer known to be the plant's own (diagonal for the joint-space cost)
+    virtual void drop_graph() = 0;
     hipStream_t stream = nullptr;
 };
 struct pddp_solver { SolverBase* impl; };
@@ -118,6 +123,7 @@ struct Solver : SolverBase {
     }
     void derive_tl_model(const EmptyModel&) {}
     // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
+    void drop_graph() override { if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; } }
     int model_changed() override {
         typename P::Model hm;
         HIPCHK(hipMemcpy(&hm, b.model, sizeof(hm), hipMemcpyDeviceToHost));
@@ -126,6 +132,7 @@ struct Solver : SolverBase {
         return 0;
     }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
+    bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
     size_t fp_lds = 0;
@@ -158,7 +165,8 @@ struct Solver : SolverBase {
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
-        if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); }
+        bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
+        if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
@@ -306,8 +314,9 @@ struct Solver : SolverBase {
         const unsigned B = cfg.batch;
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
-            if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups;
-            if constexpr (P::PLANT == 4) { if (lane_groups) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
+            if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups || bp_mfma;
+            if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (bp_mfma) launch_bp_mfma(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, (float)cw.Q1, (float)cw.Q2, (float)cw.R); }
+            if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
                 if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
@@ -662,6 +671,7 @@ extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host,
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
     if (std::strncmp(name, "model_", 6) == 0) return s->model_changed();
+    if (std::strcmp(name, "H") == 0 && !s->h_overridden) { s->h_overridden = true; s->drop_graph(); }
     return 0;
 }
 extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes) {

@@ -33,15 +33,30 @@ class OraResult(C.Structure):
     _fields_ = [("iters", C.c_int), ("t_total_ms", C.c_double), ("t_init_ms", C.c_double)]
 
 
-def build(force=False):
-    so = os.path.join(ORACLE_DIR, "liboracle.so")
+def build(force=False, variant="strict"):
+    so = os.path.join(ORACLE_DIR, "liboracle.so" if variant == "strict" else "liboracle_fma.so")
     if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "all"])
     return so
 
 
-def lib():
+_LIBS = {}
+
+
+def lib(variant="strict"):
+    """variant "strict": IEEE operation by operation (the default everywhere); "fma": the same restatement with contracted multiply-adds (only the
+    float32 noise-floor ensemble of test_fp32_bar.py uses it)."""
     global _LIB
+    if variant != "strict":
+        if variant not in _LIBS:
+            L = C.CDLL(build(variant=variant))
+            L.ora_default_cfg.argtypes = [C.POINTER(OraCfg), C.c_int]
+            L.ora_total_cost_f32.restype = C.c_float
+            L.ora_total_cost_f64.restype = C.c_double
+            L.ora_max_defect_f32.restype = C.c_float
+            L.ora_max_defect_f64.restype = C.c_double
+            _LIBS[variant] = L
+        return _LIBS[variant]
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.ora_default_cfg.argtypes = [C.POINTER(OraCfg), C.c_int]
@@ -86,14 +101,15 @@ def _r(dtype, v):
 class Oracle:
     """Thin, explicit wrapper: every array is a contiguous numpy array of `dtype`."""
 
-    def __init__(self, cfg, dtype=np.float32):
+    def __init__(self, cfg, dtype=np.float32, variant="strict"):
+        self.variant = variant
         self.c = cfg
         self.dtype = np.dtype(dtype)
         self.suf = _suf(dtype)
         self.npos, self.n, self.m = PLANT_DIMS[cfg.plant]
 
     def _f(self, name):
-        return getattr(lib(), f"ora_{name}_{self.suf}")
+        return getattr(lib(self.variant), f"ora_{name}_{self.suf}")
 
     def arr(self, a):
         return np.ascontiguousarray(a, dtype=self.dtype)

@@ -12,11 +12,16 @@ import test_fp32_bar as t  # noqa: E402
 
 backend = sys.argv[1] if len(sys.argv) > 1 else "hostsim"
 np.seterr(all="ignore")
-cases = (("Kuka N=128 A=8 M=4 float32, large-batch kernels (k_bp_lg + thread-lane forward pass / setup)", 4, t.KUKA, {"PDDP_BP": "lg", "PDDP_FP": "tl"}, 40),
-         ("Kuka N=128 A=8 M=4 float32, single-problem kernels", 4, t.KUKA, {}, 40),
-         ("cart-pole N=128 A=8 M=4 RK3 float32", 2, t.CART, {}, 12))
-for name, plant, kw, env, its in cases:
-    rows, fails, ints = t.run_bar(backend, plant, kw, env, 5, its)
+cases = (("Kuka N=128 A=8 M=4 float32, matrix-core backward pass (diagonal-H path) + thread-lane forward pass / setup", 4, t.KUKA, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, 40, False),
+         ("Kuka N=128 A=8 M=4 float32, matrix-core backward pass (full-H path) + lane-group forward pass / setup", 4, t.KUKA, {"PDDP_BP": "mx", "PDDP_FP": "lg"}, 40, True),
+         ("Kuka N=128 A=8 M=4 float32, lane-group backward pass + thread-lane forward pass / setup", 4, t.KUKA, {"PDDP_BP": "lg", "PDDP_FP": "tl"}, 40, False),
+         ("cart-pole N=128 A=8 M=4 RK3 float32", 2, t.CART, {}, 12, False))
+for name, plant, kw, env, its, full_h in cases:
+    ens = env.get("PDDP_BP") == "mx"
+    rows, fails, ints = t.run_bar(backend, plant, kw, env, 5, its, full_h=full_h, ensemble=ens)
+    if ens:
+        r = t._run_bar.bp_ratio
+        print("   backward pass against the float32 noise-floor ensemble (8 float32 evaluations of the reference algorithm: strict, FMA-contracted, each on 3 draws of one-ulp-jittered inputs): err(kernel)/max(ensemble): median %.2f, 90th pct %.2f, max %.2f; inside 1.5x: %.1f %%" % (np.median(r), np.percentile(r, 90), r.max(), 100 * np.mean(r <= 1.5)))
     print(f"{name}: {its} iterations teacher-forced from oracle64, {len(rows)} comparisons, integers identical: {ints}, outside the bar: {len(fails)}")
     print("   phase quantity   worst err(kernel32,oracle64)   err(oracle32,oracle64) there   iteration")
     for k, v in sorted(t.summarize(rows).items()):

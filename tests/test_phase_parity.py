@@ -36,6 +36,12 @@ def setup(backend, plant, N, M, A, integ, dtype, seed=1):
     return s, o, rng, x, u, xg
 
 
+def kw_of(s):
+    """the oracle configuration of a solver handle's problem (setup() builds both from the same keywords)"""
+    c = s.cfg
+    return dict(N=c.N, M=c.M, A=c.A, integrator=c.integrator, wafr_urdf=c.wafr_urdf, total_time=c.total_time)
+
+
 def tol_for(dtype):
     return 1e-9 if dtype == np.float64 else 1e-4
 
@@ -82,11 +88,28 @@ def test_sweep_phases_teacher_forced(backend, dtype, plant, N, M, A, integ):
     fail, dJexp, err = o.backward_pass(1, ABin, P, p, Pp.copy(), pp.copy(), Hin.copy(), gin.copy(), KT, du, d, ApBK, Bdu,
                                        np.ascontiguousarray(x), np.ascontiguousarray(xprev), rho)
     assert list(s.get("err")) == list(err) and fail == 0
-    for name, ref in (("KT", KT), ("du", du), ("P", P), ("p", p), ("dJexp", dJexp)):
-        assert nrel(s.get(name), ref) <= tol, name
-    if M > 1:
-        assert nrel(s.get("ApBK")[: (N - 1) * n * n], ApBK.ravel()[: (N - 1) * n * n]) <= tol
-        assert nrel(s.get("Bdu")[: (N - 1) * n], Bdu.ravel()[: (N - 1) * n]) <= tol
+    if plant == 4 and dtype == np.float32:
+        # The arm's float32 backward pass may run on the matrix cores (bp_mfma.hpp), which sum in another order than oracle32: it is held against
+        # the float32 noise floor of the reference algorithm measured against oracle64 on the same inputs (test_fp32_bar.bp_noise_floor).
+        from test_fp32_bar import bp_noise_floor, bp_quantities, bar
+        q = dict(AB=ABin, Pp=Pp, pp=pp, H=Hin, g=gin, d=d, x=x, xp2=xprev)
+        o64 = Oracle(default_cfg(plant, **kw_of(s)), np.float64)
+        q64 = {k_: np.ascontiguousarray(v, np.float64).ravel() for k_, v in q.items()}
+        z64 = lambda *sh: np.zeros(sh, np.float64)
+        r = dict(P=z64(N * n * n), p=z64(N * n), KT=z64(N * n * m), du=z64(N * m), ApBK=z64(N * n * n), Bdu=z64(N * n))
+        _, r["dJexp"], _ = o64.backward_pass(1, q64["AB"], r["P"], r["p"], q64["Pp"].copy(), q64["pp"].copy(), q64["H"].copy(), q64["g"].copy(), r["KT"], r["du"],
+                                             q64["d"], r["ApBK"], r["Bdu"], q64["x"], q64["xp2"], rho)
+        o32f = Oracle(default_cfg(plant, **kw_of(s)), np.float32, variant="fma")
+        floor, _, _ = bp_noise_floor(o, o32f, q, rho, r, 7, n, N, M)
+        kern = {name: s.get(name) for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
+        for name, v, ref in bp_quantities(kern, r, n, N, M):
+            assert bar(nrel(v, ref), floor[name]), (name, nrel(v, ref), floor[name])
+    else:
+        for name, ref in (("KT", KT), ("du", du), ("P", P), ("p", p), ("dJexp", dJexp)):
+            assert nrel(s.get(name), ref) <= tol, name
+        if M > 1:
+            assert nrel(s.get("ApBK")[: (N - 1) * n * n], ApBK.ravel()[: (N - 1) * n * n]) <= tol
+            assert nrel(s.get("Bdu")[: (N - 1) * n], Bdu.ravel()[: (N - 1) * n]) <= tol
 
     # ---- forward pass: sweep + rollout + cost + defect for every alpha, from the oracle's gains
     s.set("KT", KT); s.set("du", du); s.set("ApBK", ApBK); s.set("Bdu", Bdu)

@@ -18,8 +18,9 @@ for B in batches:
             bp, fp = name.split("+"); os.environ["PDDP_BP"] = bp; os.environ["PDDP_FP"] = fp
         if name.startswith("wide") and B * 4 > 8192: continue
         if name.startswith("coop") and B > 8192: continue
-        cfg = pyddp.default_config(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, max_iter=200, use_graph=1)
-        s = pyddp.Solver(cfg)
+        lib = os.environ.get("PDDP_LIB")
+        cfg = pyddp.default_config(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, max_iter=200, use_graph=1, _lib_path=lib)
+        s = pyddp.Solver(cfg, _lib_path=lib)
         s.load(x0, u0, xg); s.iterate(5); s.sync()
         K = 30 if B <= 4096 else 12
         tot, ph = s.time_sweeps(K, phases=True)

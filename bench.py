@@ -31,8 +31,9 @@ import pyddp  # noqa: E402
 from pyddp import shard  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
-PHASES = ("bp", "fp", "ls", "nis")                      # the four phases of a sweep, in launch order
-PHASE_KERNELS = {"bp": "k_bp_lg", "fp": "k_sweep_lg+k_fp_lg", "ls": "k_ls", "nis": "k_nis_lg"}   # kernels of each phase (KUKA arm, large batch)
+PHASES = ("bp", "fp", "ls", "nis")                      # the four phases of a sweep, in launch order (per-phase figures of the latency block)
+# reference phase whose algorithmic bytes a kernel covers, by kernel-name prefix
+KERNEL_BYTES = {"k_bp": ("k_bp", 1.0), "k_sweep": ("k_sweep", 1.0), "k_fp": ("k_sim", 1.0), "k_ls": ("k_ls", 1.0), "k_win": ("k_nis_copies", 1.0), "k_nis": ("k_nis_derivs", 1.0)}
 
 
 def example_inputs(N, rng, count):
@@ -122,29 +123,35 @@ def main():
     acc = np.mean([(out["alphaOut"][b][W + 1: W + K + 1] >= 0).mean() for b in range(min(B, 64))])
     J_all = shard.allgather_costs(ctx, s.device_array("Jout"), B, cfg.max_iter + 2, int(iters.min()) - 1)   # RCCL exchange
 
-    # ---- per-phase kernel durations with HIP events on the solver's own stream: the SAME sweeps again (reload, same warm-up),
-    # launched kernel by kernel with an event after every launch
+    # ---- per-KERNEL durations with HIP events on the solver's own stream: the SAME sweeps again (reload, same warm-up), launched kernel by kernel
+    # with an event after every launch (pddp_time_kernels); the names are the kernels this handle's selection launches
     s.load(x0, u0, xg)
     s.iterate(W); s.sync()
-    ms_tot, ms_phase = s.time_sweeps(K, phases=True)
-    per_launch_ms = [v / K for v in ms_phase]
-    dom = int(np.argmax(per_launch_ms))
-    alg = pyddp.algorithmic_bytes(n, m, N, A, M, 4)
-    alg_phase = {"bp": alg["k_bp"], "fp": alg["k_fp"], "ls": alg["k_ls"], "nis": alg["k_nis"]}
-    bytes_launch = alg_phase[PHASES[dom]] * B
-    achieved = bytes_launch / (per_launch_ms[dom] * 1e-3) / 1e9
+    kern = s.time_kernels(K)
+    alg = pyddp.algorithmic_bytes_per_kernel(n, m, N, A, M, 4)
+    def alg_of(name):
+        key = next(v for p_, v in KERNEL_BYTES.items() if name.startswith(p_))
+        return alg[key[0]] * key[1]
+    dom_name, dom_ms = max(kern, key=lambda kv: kv[1])
+    bytes_launch = alg_of(dom_name) * B
+    achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
     sweep_bytes = sum(alg.values()) * B
-    traffic = args.traffic_bytes
-    tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # HBM bytes per launch from the separate --pmc passes
+    # HBM traffic and issue counters of the dominant kernel: separate rocprofv3 --pmc passes of THIS command (tools/pmc_pass.sh), committed
+    # under profiles/ -- not measured inside this run (a counter pass serialises the kernels and cannot share a run with the timing)
+    traffic, counters, tsrc = args.traffic_bytes, None, "command line" if args.traffic_bytes else None
+    tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if traffic is None and os.path.exists(tfile):
         tj = json.load(open(tfile))
-        if tj.get("batch") == B:
-            traffic = tj.get("phase_bytes", {}).get(PHASES[dom])
-    roof = {"bound": "hbm", "kernel": PHASE_KERNELS[PHASES[dom]], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": round(per_launch_ms[dom], 5),
-            "per_phase_ms": {PHASE_KERNELS[k]: round(v, 5) for k, v in zip(PHASES, per_launch_ms)},
-            "whole_sweep_GBs": round(sweep_bytes / (t_local / K) / 1e9, 2)}
+        ent = tj.get("kernels", {}).get(dom_name)
+        if tj.get("batch") == B and ent:
+            traffic, counters, tsrc = ent.get("hbm_bytes_per_launch"), ent.get("counters"), tj.get("source")
+    roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "counters": counters,
+            "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": round(dom_ms, 5),
+            # every kernel of the sweep: its time and the rate at which it gets through the REFERENCE's bytes for that phase (per-alpha
+            # re-reads of the gains / sweep operands included -- the forward kernels read them once for all alphas, so their figure can exceed the HBM peak)
+            "per_kernel": {nm: {"ms": round(ms, 5), "reference_equivalent_GBs": round(alg_of(nm) * B / (ms * 1e-3) / 1e9, 1)} for nm, ms in kern},
+            "whole_sweep_reference_equivalent_GBs": round(sweep_bytes / (t_local / K) / 1e9, 2)}
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),
@@ -310,7 +317,7 @@ def widening_rows(device):
     ach = [alg["k_bp"], alg["k_fp"], alg["k_ls"], alg["k_nis"]][dom] * B2 / (per[dom] * 1e-3) / 1e9
     res["ee_cost_4096_problems_N64_A8_M4"] = {"problems": B2, "iterations_per_s": round(B2 * 20 / (ms_plain * 1e-3), 1), "ms_per_sweep": round(ms_plain / 20, 4),
                                               "per_phase_ms": {k: round(v, 5) for k, v in zip(PHASES, per)},
-                                              "roofline": {"bound": "hbm", "kernel": ("k_bp_lg", "k_sweep_lg+k_fp_lg<EE>", "k_ls", "k_nis_lg<EE>")[dom],
+                                              "roofline": {"bound": "hbm", "kernel": ("k_bp_mfma", "k_sweep_lg+k_fp_lg<EE>", "k_ls", "k_nis_lg<EE>")[dom],
                                                            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                                                            "algorithmic_bytes_per_sweep_per_problem": sum(alg.values())}}
     s.close()

@@ -154,6 +154,11 @@ int pddp_stream(pddp_handle h, void** hip_stream);
  * every launch: ms_phase[4] = summed durations of the four phases (backward pass, forward pass, line search, next-
  * iteration setup), ms_total = their sum. */
 int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase);
+/* Per KERNEL: `sweeps` sweeps launched kernel by kernel on the solver's stream with a HIP event after every launch; ms6[k] = average duration of
+ * slot k (0 backward pass, 1 linear sweep, 2 rollouts + cost + defect, 3 line search, 4 winner re-roll, 5 next-iteration setup); names (optional,
+ * 6 x name_stride chars) receives the kernels' names for the handle's kernel selection -- empty where the selection has no separate kernel.
+ * Measurement aid of bench.py (the reference prints per-phase times, DDPWrappers.cuh:54-105). */
+int pddp_time_kernels(pddp_handle h, int sweeps, float* ms6, char* names, int name_stride);
 /* Freeze / unfreeze the exit tests so a benchmark can time a fixed number of full-work sweeps. */
 int pddp_set_benchmark_mode(pddp_handle h, int on);
 

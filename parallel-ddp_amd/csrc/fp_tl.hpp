@@ -226,17 +226,18 @@ PDDP_HD void tl_reduce_parts(const Buffers<T>& b, const Dims& dm, int pb) {
     }
 }
 
-// Next-iteration setup of knot k of problem pb (nis_body / arm_lg_nis_body) at the current trajectory: g_k, (mode 1: H_k), and the Jacobian of the
-// dynamics through emit(col, row, dqdd) -- the caller turns it into [A B] rows 7..13 (k_nis_tl stages it through LDS).  Returns false when
-// this knot has no Jacobian to write (rejected / failed iteration, final knot, finished problem).
-template <typename T, typename Emit>
-PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, Emit emit) {
+// Next-iteration setup of knot k of problem pb (nis_body / arm_lg_nis_body) at the current trajectory, in two halves:
+//   arm_tl_nis_cost: g_k, (mode 1: H_k); returns false when this knot has no Jacobian to write (rejected / failed iteration, final knot, finished problem)
+//   arm_tl_nis_jac:  the Jacobian of the dynamics through emit(col, row, dqdd) -- the caller turns it into [A B] rows 7..13 (k_nis_tl stages it through
+//                    LDS in three pieces, flushed at mark(stage); see arm_tl_gradient)
+template <typename T>
+PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb) {
     constexpr int NX = 14, NU = 7, NM = 21;
     const int N = dm.N;
     const SolverState<T>& st = b.state[pb];
     const size_t knot = (size_t)pb * N + k;
-    T* xc = b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX;
-    T* uc = b.ucur + knot * NU;
+    const T* xc = b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX;
+    const T* uc = b.ucur + knot * NU;
     T x[NX], u[NU];
     if (mode == 0 && (!st.win_pending || st.done)) return false;         // rejected / failed: nothing moved; final accepted step: no derivatives needed
     tl_load14(x, xc);                                                     // the winner kernel (arm_tl_rollout_winner) has already put the new trajectory here
@@ -253,11 +254,28 @@ PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& 
         T* H = b.H + knot * (NM * NM);
         for (int e = 0; e < NM * NM; e++) { const int i = e / NM, j = e % NM; H[e] = i != j ? T(0) : (i < 7 ? w1 : (i < NX ? w2 : w3)); }
     }
-    if (fin) return false;
+    return !fin;
+}
+template <typename T, typename Emit, typename Mark>
+PDDP_HD void arm_tl_nis_jac(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, int k, int pb, Emit emit, Mark mark) {
+    constexpr int NX = 14, NU = 7;
+    const int N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    const T* xc = b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX;
+    const T* uc = b.ucur + ((size_t)pb * N + k) * NU;
+    T x[NX], u[NU];
+    tl_load14(x, xc);
+#pragma unroll
+    for (int i = 0; i < NU; i++) u[i] = uc[i];
     ArmTlState<T> ts;
     T qdd[7];
     arm_tl_dynamics<T>(md, grav, ts, qdd, x, x + 7, u);
-    arm_tl_gradient<T>(md, grav, ts, x + 7, qdd, emit);
+    arm_tl_gradient<T>(md, grav, ts, x + 7, qdd, emit, mark);
+}
+template <typename T, typename Emit>
+PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, Emit emit) {
+    if (!arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb)) return false;
+    arm_tl_nis_jac<T>(md, grav, b, dm, k, pb, emit, [](int) {});
     return true;
 }
 

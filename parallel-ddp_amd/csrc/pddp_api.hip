@@ -62,6 +62,7 @@ struct SolverBase {
     virtual int status(int* done, int* iters) = 0;
     virtual int store(void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) = 0;
     virtual int time_sweeps(int sweeps, float* ms_total, float* ms_phase) = 0;
+    virtual int time_kernels(int sweeps, float* ms, char* names, int name_stride) = 0;
     virtual int array(const char* name, void** ptr, size_t* bytes) = 0;
     virtual int get_state(pddp_state* out) = 0;
     virtual int set_state(const pddp_state* in) = 0;
@@ -265,12 +266,13 @@ struct Solver : SolverBase {
         return 0;
     }
     // forward pass: the arm runs on lane groups (fp_lg.hpp), the closed-form plants on the wave-cooperative kernel
-    void launch_fp(hipStream_t s, int init_rollout, int store_candidates = 0) {
+    // part: -1 everything; 0 only the linear sweep kernel (when the path has a separate one); 1 only the rollout kernel (per-kernel timing)
+    void launch_fp(hipStream_t s, int init_rollout, int store_candidates = 0, int part = -1) {
         const unsigned B = cfg.batch;
         bool lane_groups = false;
         if constexpr (P::PLANT == 4) lane_groups = !fp_coop;       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests)
         if (!lane_groups) {
-            hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
+            if (part != 0) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
             return;
         }
         if constexpr (P::PLANT == 4) {
@@ -278,7 +280,8 @@ struct Solver : SolverBase {
             const unsigned chunks = (A_all > 8 && A_all % 8 == 0) ? A_all / 8 : 1;      // one workgroup per 8 candidates when they tile exactly (see k_fp_lg)
             const int A_eff = A_all / chunks;
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
-            if (!init_rollout && cfg.M > 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
+            if (!init_rollout && cfg.M > 1 && part != 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
+            if (part == 0) return;
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
                 launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
                 return;
@@ -294,23 +297,26 @@ struct Solver : SolverBase {
             else hipLaunchKernelGGL((k_fp_lg<T, 1024>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
         }
     }
-    void launch_nis(hipStream_t s, int mode) {
+    // part: -1 everything; 0 only the winner kernel (thread-lane path); 1 only the setup kernel
+    void launch_nis(hipStream_t s, int mode, int part = -1) {
         const unsigned B = cfg.batch;
         if constexpr (P::PLANT == 4) {
             if (fp_path == kFpTl) {
-                if (mode == 0) launch_win_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);     // the accepted candidate becomes the current trajectory
-                launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);
+                if (mode == 0 && part != 1) launch_win_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);     // the accepted candidate becomes the current trajectory
+                if (part != 0) launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);
                 return;
             }
             if (!fp_coop) {
+                if (part == 0) return;
                 if (cfg.ee_cost) hipLaunchKernelGGL((k_nis_lg<T, true>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 else hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 return;
             }
         }
+        if (part == 0) return;
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
-    void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0) {
+    void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0, int part = -1) {
         const unsigned B = cfg.batch;
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
@@ -322,9 +328,34 @@ struct Solver : SolverBase {
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
             }
         }
-        if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0, store_candidates);
+        if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0, store_candidates, part);
         if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
-        if (only < 0 || only == PDDP_PHASE_NIS) launch_nis(s, 0);
+        if (only < 0 || only == PDDP_PHASE_NIS) launch_nis(s, 0, part);
+    }
+    // The kernels of one sweep in launch order, by name, and their average duration over `sweeps` sweeps (an event after every launch, one pass).
+    // Slots: 0 backward pass, 1 linear sweep, 2 rollouts, 3 line search, 4 winner re-roll, 5 next-iteration setup; a path without a separate kernel
+    // for a slot leaves its name empty and its time 0.
+    int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
+        const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
+        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
+                             (lg && cfg.M > 1) ? "k_sweep_lg" : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", tl ? "k_win_tl" : "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
+        static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
+        HIPCHK(hipStreamSynchronize(stream));
+        const size_t need = 7 * (size_t)sweeps;
+        while (trace_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); trace_ev.push_back(e); }
+        for (int i = 0; i < sweeps; i++) {
+            HIPCHK(hipEventRecord(trace_ev[7 * i], stream));
+            for (int k = 0; k < 6; k++) { if (nm[k][0]) launch_sweep(stream, phase_of[k], 0, part_of[k]); HIPCHK(hipEventRecord(trace_ev[7 * i + k + 1], stream)); }
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 6; k++) {
+            double sum = 0;
+            for (int i = 0; i < sweeps; i++) { float t = 0; HIPCHK(hipEventElapsedTime(&t, trace_ev[7 * i + k], trace_ev[7 * i + k + 1])); sum += t; }
+            ms[k] = nm[k][0] ? (float)(sum / sweeps) : 0.f;
+            if (names) { std::strncpy(names + (size_t)k * name_stride, nm[k], name_stride - 1); names[(size_t)k * name_stride + name_stride - 1] = 0; }
+        }
+        return 0;
     }
     int iterate(int sweeps) override {
         if (cfg.use_graph) {
@@ -650,6 +681,10 @@ extern "C" int pddp_sync(pddp_handle h) { IMPL(h); return s->sync(); }
 extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { IMPL(h); return s->status(done, iters); }
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { IMPL(h); return s->store(x, u, KT, Jout, alphaOut, dmax); }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* ms_total, float* ms_phase) { IMPL(h); return s->time_sweeps(sweeps, ms_total, ms_phase); }
+extern "C" int pddp_time_kernels(pddp_handle h, int sweeps, float* ms6, char* names, int name_stride) {
+    IMPL(h); if (sweeps < 1 || !ms6 || (names && name_stride < 8)) return fail(PDDP_EINVAL, "pddp_time_kernels: bad arguments");
+    return s->time_kernels(sweeps, ms6, names, name_stride);
+}
 extern "C" int pddp_set_cost(pddp_handle h, double Q1, double Q2, double R, double QF1, double QF2) { IMPL(h); return s->set_cost(Q1, Q2, R, QF1, QF2); }
 extern "C" int pddp_simulate(pddp_handle h, const void* x, const void* u, const void* KT, double t0_us, double elapsed_us, int substeps, const void* goal_xyz,
                              void* xActual_inout, double* avg_err, int* failed) {

@@ -120,13 +120,15 @@ __global__ __launch_bounds__(64, 1) void k_win_tl(Buffers<T> b, Dims dm, CostWei
     arm_tl_rollout_winner<T>(md, grav, b, dm, cw, dt, pb, seg);
 }
 
-// k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  float: a wave's 64 knots x 147 Jacobian entries are
-// staged in LDS (entry-major, padded to 65 so that both the per-thread writes and the transposed reads are conflict-free) and [A B] of the 64 knots
-// -- one contiguous 64 x 294 float run -- is written column by column, 64 consecutive columns per pass: every cache line is written once, completely.
+// k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  float: the Jacobian of a wave's 64 knots is staged in
+// LDS (entry-major, padded to 65 so that both the per-thread writes and the transposed reads are conflict-free) and written out in THREE pieces
+// as soon as their columns are complete (arm_tl_gradient's marks: columns {0..3, 7..10}, {4..6, 11..13}, {14..20}): 56 staged entries per knot at most,
+// 14.6 KB per wave, so that two workgroups (two waves per SIMD -- the kernel needs all 256 registers) share a compute unit; a piece is written as whole
+// 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
 // double: direct stores.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
-constexpr int kNisTlStage = 147 * 65;
+constexpr int kNisTlStage = 56 * 65;
 template <typename T, int V>
-__global__ __launch_bounds__(256, 1) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
+__global__ __launch_bounds__(256, 2) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NM = 21;
     const int g = blockIdx.x * 256 + threadIdx.x, total = batch * dm.N;
@@ -135,24 +137,35 @@ __global__ __launch_bounds__(256, 1) void k_nis_tl(Buffers<T> b, Dims dm, CostWe
         __shared__ T stage_all[4 * kNisTlStage];
         T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
         const int lane = threadIdx.x & 63;
-        bool valid = false;
-        if (g < total) valid = arm_tl_nis_knot<T>(md, grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { stage[(col * 7 + row) * 65 + lane] = val; });
-        const unsigned long long mask = __ballot(valid);
-        wsync();
-        if (!mask) return;
-        const int g0 = g - lane;                                    // first knot of this wave
-        T* AB0 = b.AB + (size_t)g0 * (NX * NM);
-        for (int it = 0; it < NM; it++) {                           // 21 passes x 64 lanes = 64 knots x 21 columns, consecutive in memory
-            const int pi = it * 64 + lane, kk = pi / NM, col = pi - kk * NM;
-            if (!((mask >> kk) & 1ull)) continue;
-            T out[NX];
+        const bool need = (g < total) && arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb);
+        const unsigned long long mask = __ballot(need);
+        if (!mask) return;                                          // (uniform) nothing to differentiate in this wave
+        // every lane differentiates SOME knot (its own, or a valid neighbour's when it has none) so that the whole wave reaches the flushes together
+        const int gs = need ? g : (blockIdx.x * 256 + (threadIdx.x & ~63) + (__ffsll((long long)mask) - 1));
+        const int pbs = gs / dm.N, kk_s = gs - pbs * dm.N;
+        T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot
+        auto slot = [](int col, int row) -> int {                  // staged position of dqdd(row, col) inside its piece
+            const int cc = col < 4 ? col : col < 7 ? col - 4 : col < 11 ? col - 3 : col < 14 ? col - 8 : col - 14;
+            return cc * 7 + row;
+        };
+        auto flush = [&](int piece) {
+            wsync();
+            const int ncols = piece == 0 ? 8 : piece == 1 ? 6 : 7;
+            for (int it = 0; it * 64 < 64 * ncols; it++) {
+                const int pi = it * 64 + lane, kk = pi / ncols, ci = pi - kk * ncols;
+                if (kk >= 64 || !((mask >> kk) & 1ull)) continue;
+                const int col = piece == 0 ? (ci < 4 ? ci : ci + 3) : piece == 1 ? (ci < 3 ? ci + 4 : ci + 8) : ci + 14;
+                T out[NX];
 #pragma unroll
-            for (int r = 0; r < 7; r++) {
-                out[r] = tl_AB_const<T>(r, col, dt);
-                out[7 + r] = T(col == 7 + r ? 1 : 0) + dt * stage[(col * 7 + r) * 65 + kk];
+                for (int r = 0; r < 7; r++) {
+                    out[r] = tl_AB_const<T>(r, col, dt);
+                    out[7 + r] = T(col == 7 + r ? 1 : 0) + dt * stage[(ci * 7 + r) * 65 + kk];
+                }
+                tl_store14(AB0 + ((size_t)kk * NM + col) * NX, out);
             }
-            tl_store14(AB0 + (size_t)pi * NX, out);
-        }
+            wsync();
+        };
+        arm_tl_nis_jac<T>(md, grav, b, dm, kk_s, pbs, [&](int col, int row, T val) { stage[slot(col, row) * 65 + lane] = val; }, flush);
     } else {
         if (g >= total) return;
         T* AB = b.AB + (size_t)g * (NX * NM);

@@ -325,8 +325,10 @@ PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st,
 
 // Gradient of the forward dynamics at (q, qd, u) with qdd from arm_tl_dynamics (st as it left it).
 // emit(col, row, value): dqdd(row, col), col 0..6 d/dq, 7..13 d/dqd, 14..20 d/du   (the plug-in layout s_dqdd[col*7 + row]).
-template <typename T, typename Emit>
-PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit) {
+// mark(stage): called after the columns of joints 0..3 (stage 0: columns 0..3 and 7..10 are complete), of joints 4..6 (stage 1: columns 4..6, 11..13) and
+// of the controls (stage 2: columns 14..20) have been emitted -- a caller that stages the columns somewhere small can flush in three pieces.
+template <typename T, typename Emit, typename Mark>
+PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark) {
     constexpr int NB = kArmNB;
     // ---- nominal inverse dynamics at the actual qdd: per link the acceleration, I v, and the total force through its joint
     T a[NB][6], Iv[NB][6], Ft[NB][6];
@@ -425,6 +427,8 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
         tl_ldl_solve(st, dtv);
 #pragma unroll
         for (int i = 0; i < NB; i++) { emit(j, i, dtq[i]); emit(NB + j, i, dtv[i]); }
+        if (j == 3) mark(0);
+        if (j == NB - 1) mark(1);
     });
     // ---- dqdd/du = M^-1
     TlFor<0, NB, 1>::run([&](auto jc) {
@@ -436,6 +440,11 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
 #pragma unroll
         for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
     });
+    mark(2);
+}
+template <typename T, typename Emit>
+PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit) {
+    arm_tl_gradient<T>(md, grav, st, qd, qdd, emit, [](int) {});
 }
 
 }  // namespace pddp

@@ -56,6 +56,18 @@ def algorithmic_bytes(n, m, N, A, M, s, ee_cost=False):
     return {"k_bp": bp * s, "k_fp": A * (sweep + sim + cost) * s, "k_ls": (3 * A + 2 * M + 16) * s, "k_nis": nis * s}
 
 
+def algorithmic_bytes_per_kernel(n, m, N, A, M, s):
+    """The same accounting split by KERNEL of the large-batch arm selection (joint-space cost): backward pass; linear sweep of the A candidates;
+    rollouts + cost + defect of the A candidates; line search; the copies of nextIterationSetupGPU (winner -> all slots, xp/up/dp, Pp/pp: what the
+    winner kernel and the index flips stand for); the derivative kernels of nextIterationSetupGPU (AB, H, g written, x, u read)."""
+    nm = n + m
+    tot = algorithmic_bytes(n, m, N, A, M, s)
+    sweep = ((n * n + n) * (N - 1) + 3 * n * N + n * (M - 1)) if M > 1 else 0
+    derivs = 2 * (n * N + m * (N - 1)) + n * nm * (N - 1) + (nm * nm + nm) * N
+    return {"k_bp": tot["k_bp"], "k_sweep": A * sweep * s, "k_sim": tot["k_fp"] - A * sweep * s, "k_ls": tot["k_ls"],
+            "k_nis_copies": tot["k_nis"] - derivs * s, "k_nis_derivs": derivs * s}
+
+
 def library_path():
     return os.path.join(os.path.dirname(_HERE), "lib", "libpddp.so")
 
@@ -249,6 +261,19 @@ class Solver:
         ph = (C.c_float * 4)()
         self._chk(self.lib.pddp_time_sweeps(self.h, int(sweeps), C.byref(tot), ph if phases else None))
         return tot.value, [v for v in ph]
+
+    def time_kernels(self, sweeps):
+        """pddp_time_kernels: [(kernel name, average ms per launch)] of one sweep in launch order (HIP events on the solver's stream)."""
+        ms = (C.c_float * 6)()
+        names = C.create_string_buffer(6 * 32)
+        self.lib.pddp_time_kernels.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        self._chk(self.lib.pddp_time_kernels(self.h, int(sweeps), ms, names, 32))
+        out = []
+        for k in range(6):
+            nm = names.raw[32 * k: 32 * k + 32].split(b"\0")[0].decode()
+            if nm:
+                out.append((nm, float(ms[k])))
+        return out
 
     # ---- teacher-forced hooks
     def _adtype(self, name):

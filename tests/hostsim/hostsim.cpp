@@ -407,6 +407,7 @@ extern "C" int pddp_iterate(pddp_handle h, int sweeps) { return h->impl->iterate
 extern "C" int pddp_sync(pddp_handle) { return 0; }
 extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { return h->impl->status(done, iters); }
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { return h->impl->store(x, u, KT, Jout, alphaOut, dmax); }
+extern "C" int pddp_time_kernels(pddp_handle h, int sweeps, float* ms6, char* names, int stride) { h->impl->iterate(sweeps); for (int i = 0; i < 6; i++) { ms6[i] = 0; if (names) names[(size_t)i * stride] = 0; } return 0; }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* t, float* ph) { h->impl->iterate(sweeps); if (t) *t = 0; if (ph) for (int i = 0; i < 4; i++) ph[i] = 0; return 0; }
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { h->impl->bench = on ? 1 : 0; return 0; }
 extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { void* p; return h->impl->array(name, &p, bytes); }

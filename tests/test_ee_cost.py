@@ -273,3 +273,30 @@ def test_end_effector_cost_at_the_mpc_example_shape_batch():
     assert all(out["Jout"][b][it[b]] <= out["Jout"][b][0] + 3 * kw["tol_cost"] for b in range(B))
     improved = sum(out["Jout"][b][it[b]] < 0.98 * out["Jout"][b][0] for b in range(B))
     assert improved >= B // 4, (improved, [float(out["Jout"][b][0]) for b in range(4)], [float(out["Jout"][b][it[b]]) for b in range(4)])
+
+
+@pytest.mark.gpu
+def test_baseline_config3_at_size_float64_every_rollout_follows_the_oracle():
+    """BASELINE configs[3] at its stated size (stage 4b): 64 concurrent rollouts x 8 alphas, N=64, M=4, T=0.5 s,
+    MPC_MODE (gravity 0), end-effector cost, TOL_COST 1e-5 -- as ONE float64 handle of 64 problems (goal r at phase r/64 of a figure, start
+    pose perturbed per rollout).  Every rollout must follow the oracle's GPU-semantics driver: identical step-size indices (rejections
+    included), J / x / u to 1e-8.  (Sharded 8 per GPU the same problems run independently: tests/test_shard.py covers the partition.)"""
+    kw = dict(N=64, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=8, ee_cost=1, ignore_max_rho_exit=0)
+    B = 64
+    rng = np.random.default_rng(64)
+    x0 = np.zeros((B, 64, 14)); x0[:, :, 1] = 0.7; x0[:, :, 3] = -0.8; x0[:, :, 5] = 0.75
+    x0[:, :, :7] += rng.normal(0, 0.01, (B, 1, 7))
+    u0 = np.full((B, 64, 7), 0.01)
+    t = np.linspace(0, 2 * np.pi, B, endpoint=False)
+    xg = np.zeros((B, 14)); xg[:, 0] = 0.5 + 0.1 * np.cos(t); xg[:, 1] = 0.2 * np.sin(t); xg[:, 2] = 0.6 + 0.1 * np.sin(2 * t)
+    s = make_solver("hip", 4, dtype=1, batch=B, **kw)
+    out = s.solve(x0, u0, xg)
+    o = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
+    for r in range(B):
+        ref = o.run_ilqr_gpusem(x0[r].ravel(), u0[r].ravel(), xg[r])
+        it = ref["iters"]
+        assert out["iters"][r] == it, r
+        assert list(out["alphaOut"][r][: it + 1]) == list(ref["alphaOut"][: it + 1]), r
+        np.testing.assert_allclose(out["Jout"][r][: it + 1], ref["Jout"][: it + 1], rtol=1e-8)
+        np.testing.assert_allclose(out["x"][r].ravel(), ref["x"], rtol=0, atol=1e-8 * max(np.abs(ref["x"]).max(), 1))
+        np.testing.assert_allclose(out["u"][r].ravel(), ref["u"], rtol=0, atol=1e-7 * max(np.abs(ref["u"]).max(), 1))

@@ -1,0 +1,45 @@
+/* pddp_cpu.h -- C ABI of libpddp_cpu.so: the reference's CPU entry points runiLQR_CPU / allocateMemory_CPU / freeMemory_CPU
+ * (DDPHelpers/DDPWrappers.cuh:142-248, DDPHelpers/nisInitHelpers.cuh:886-925, :950-958) behind plain pointers.
+ *
+ * The reference ships a multi-threaded CPU iLQR next to its GPU path and its example runs both (examples/WAFR_iLQR_examples.cu:231-299,
+ * 425-438).  This library is that CPU path for callers of the source-level facade (hostapi/DDPWrappers.hpp: allocateMemory_CPU<T>,
+ * runiLQR_CPU<T>, freeMemory_CPU<T>): the plant / integrator / cost / Riccati bodies are the SAME sources the HIP kernels are compiled from
+ * (parallel-ddp_amd/csrc, host instantiation, one "lane"), driven with the reference's CPU semantics -- std::thread per phase
+ * (BP_THREADS, FSIM_THREADS, COST_THREADS, INTEGRATOR_THREADS from the core count, config.cuh:146-161), serial first-acceptable line
+ * search, strided cost partial sums, in-place cost Hessian accumulation, multiplicative prevJ epsilon, defectComp's always-zero result.
+ * It is NOT a fallback of the GPU path: nothing in libpddp.so calls it, and runiLQR_GPU never routes here.
+ * Joint-space cost only (EE_COST 0: what the reference's CPU example configures).
+ */
+#ifndef PDDP_CPU_H
+#define PDDP_CPU_H
+
+#include "pddp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the caller-owned host buffers of allocateMemory_CPU (nisInitHelpers.cuh:886-925), all of the handle's float type */
+typedef struct pddp_cpu_buffers {
+    void *x, *xp, *xp2, *u, *up, *P, *p, *Pp, *pp, *AB, *H, *g, *KT, *du, *d, *dp, *ApBK, *Bdu, *alpha, *JT, *dJexp;
+    int* err;
+} pddp_cpu_buffers;
+
+/* thread counts the reference derives from CPU_CORES (config.cuh:155-161); cores <= 0: std::thread::hardware_concurrency() */
+int pddp_cpu_thread_counts(int M, int cores, int* bp_threads, int* fsim_threads, int* cost_threads, int* integrator_threads);
+
+/* runiLQR_CPU<T> (DDPWrappers.cuh:142-248): x0, u0 in/out [N*n], [N*m]; KT0, P0, p0, d0 warm-start arrays or NULL (clearVarsFlag = 1);
+ * Jout[MAX_ITER+1], alphaOut[MAX_ITER+1]; the six timing outputs as the reference fills them (ms; the per-iteration arrays need MAX_ITER entries).
+ * cfg: plant, N, M, A, integrator, dtype, max_iter, total_time, alpha_base, rho_init, max_defect, tol_cost, exp_red_*, cost weights, wafr_urdf,
+ * mpc_mode, ignore_max_rho_exit -- the same record pddp_create takes (batch is ignored).  Returns 0, or a negative PDDP_E* code. */
+int pddp_cpu_run_ilqr(const pddp_config* cfg, const pddp_cpu_buffers* buf, void* x0, void* u0, const void* KT0, const void* P0, const void* p0,
+                      const void* d0, const void* xGoal, void* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag,
+                      int ignoreFirstDefectFlag, double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime,
+                      double* initTime, int cores, int* iters_out);
+
+const char* pddp_cpu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -39,6 +39,8 @@ struct BpArgs {
     T* dJexp;   // [2*M]
     int* err;   // [M]
     T rho;
+    T* Hrw = nullptr; T* grw = nullptr;   // host CPU path only (cpu_twin.cpp): the reference's CPU backprop accumulates H, g of every knot IN PLACE
+                                          // (bpHelpers.cuh:90-91) where its GPU kernel writes shared memory (:86-87); the kernels leave these null
 };
 
 // returns 1 (uniformly over the wave) on a failed Huu inversion
@@ -96,6 +98,11 @@ PDDP_HD int bp_block(const Wave& w, BpScratch<P, T>& s, const Dims& dm, int blk,
             s.g[kx] = dot + bg[kx];
         }
         wsync(w);
+        if (a.Hrw) {
+            PDDP_FOR(e, NM * NM) a.Hrw[(size_t)NM * NM * ks + e] = s.H[e];
+            PDDP_FOR(kx, NM) a.grw[(size_t)NM * ks + kx] = s.g[kx];
+            wsync(w);
+        }
         T* bKT = a.KT + NX * NU * ks; T* bdu = a.du + NU * ks;
         if (NU == 1) {                        // scalar Huu (computeKTdu_dim1)
             if (s.H[oHUU] <= T(0)) return 1;

@@ -1,0 +1,284 @@
+// libpddp_cpu.so: the reference's CPU iLQR path (runiLQR_CPU, DDPHelpers/DDPWrappers.cuh:142-248) -- see include/pddp_cpu.h.
+// Host C++ only (g++); the numerical bodies are the headers the HIP kernels are compiled from, instantiated with a 1-lane "wave".
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <sys/time.h>
+#include <thread>
+#include <vector>
+
+#include "../../include/pddp_cpu.h"
+#include "bp.hpp"
+#include "fp.hpp"
+#include "nis.hpp"
+#include "solver_state.hpp"
+#include "iiwa14_model_data.h"
+
+using namespace pddp;
+
+static thread_local std::string g_cpu_err;
+static int cpu_fail(int code, const std::string& m) { g_cpu_err = m; return code; }
+extern "C" const char* pddp_cpu_last_error(void) { return g_cpu_err.c_str(); }
+
+static double wall_ms() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
+
+extern "C" int pddp_cpu_thread_counts(int M, int cores, int* bp, int* fsim, int* cost, int* integ) {
+    if (cores <= 0) cores = (int)std::thread::hardware_concurrency();
+    if (cores <= 0) cores = 1;
+    if (bp) *bp = std::max(std::min(M, cores), 1);          // config.cuh:158-159 (USE_HYPER_THREADING 0)
+    if (fsim) *fsim = std::max(std::min(M, cores), 1);
+    if (cost) *cost = std::max(cores / 2, 1);               // :156-157
+    if (integ) *integ = std::max(cores / 2, 1);
+    return 0;
+}
+
+namespace {
+
+template <typename T> void fill_model(ArmModel<T>& m, const pddp_config& c) {
+    const int v = c.wafr_urdf ? 1 : 0;
+    for (int b = 0; b < 7; b++) {
+        for (int i = 0; i < 36; i++) m.I[36 * b + i] = (T)IIWA14_SPATIAL_INERTIA[v][b][i];
+        for (int i = 0; i < 16; i++) m.F[16 * b + i] = (T)IIWA14_JOINT_FRAME[v][b][i];
+    }
+    m.grav = (T)(c.mpc_mode ? 0.0 : 9.81);                  // plants/dynamics_arm.cuh:42-46
+}
+void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
+
+// threads of one phase: the reference creates them per phase and joins them (e.g. fpHelpers.cuh:425-441)
+struct Phase {
+    std::vector<std::thread> th;
+    void go(std::function<void()> f) { th.emplace_back(std::move(f)); }
+    void join() { for (auto& t : th) t.join(); th.clear(); }
+};
+// compute_reps (utils/threadUtils.h:19): thread tid of dim handles items tid, tid + dim, ...
+inline int reps_of(int tid, int dim, int total) { return total / dim + (tid < total % dim ? 1 : 0); }
+
+template <typename P, int INTEG, typename T>
+int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const T* KT0, const T* P0, const T* p0, const T* d0, const T* xGoal, T* Jout,
+            int* alphaOut, int rollout, int clearVars, int ignoreFirstDefect, double* tTime, double* simTime, double* sweepTime, double* bpTime,
+            double* nisTime, double* initTime, int cores, int* iters_out) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    const int N = c.N, M = c.M, A = c.A;
+    Dims dm; dm.N = N; dm.M = M; dm.A = A; dm.NB = N / M;
+    CostWeights<T> cw{}; cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2; cw.ee = 0;
+    const T dt = (T)(c.total_time / (N - 1));                // TIME_STEP, config.cuh:136
+    typename P::Model model; fill_model(model, c);
+    int BP_T, FSIM_T, COST_T, INT_T;
+    pddp_cpu_thread_counts(M, cores, &BP_T, &FSIM_T, &COST_T, &INT_T);
+    T *x = (T*)B.x, *xp = (T*)B.xp, *xp2 = (T*)B.xp2, *u = (T*)B.u, *up = (T*)B.up, *Pm = (T*)B.P, *pv = (T*)B.p, *Pp = (T*)B.Pp, *pp = (T*)B.pp;
+    T *AB = (T*)B.AB, *H = (T*)B.H, *g = (T*)B.g, *KT = (T*)B.KT, *du = (T*)B.du, *d = (T*)B.d, *dp = (T*)B.dp, *ApBK = (T*)B.ApBK, *Bdu = (T*)B.Bdu;
+    T *alpha = (T*)B.alpha, *JT = (T*)B.JT, *dJexp = (T*)B.dJexp; int* err = B.err;
+    const size_t szx = (size_t)NX * N, szu = (size_t)NU * N, szP = (size_t)NX * NX * N;
+    const Wave w = this_wave();
+    Phase ph;
+    const double t_start = wall_ms();
+    double t2 = t_start;
+
+    // ---- phase bodies (each thread owns private scratch; the global arrays are the caller's)
+    auto sim_segments = [&](int tid, T al) {                 // forwardSim (fpHelpers.cuh:305-328): segments tid, tid + FSIM_T, ...
+        SimScratch<P, T> s; std::vector<T> segx((size_t)NX * M), dnorm(M);
+        P::load_model(w, s.plant, &model);
+        FpArgs<T> a{}; a.x = x; a.u = u; a.d = d; a.xcur = xp; a.ucur = up; a.dcur = dp; a.KT = KT; a.du = du; a.ApBK = ApBK; a.Bdu = Bdu; a.alpha = al; a.dt = dt;
+        a.segx = segx.data(); a.dnorm = dnorm.data();
+        for (int b = 0; b < M; b++) for (int i = 0; i < NX; i++) segx[(size_t)NX * b + i] = x[(size_t)NX * b * dm.NB + i];   // the sweep left the start states in x
+        const int r = reps_of(tid, FSIM_T, M);
+        for (int i = 0; i < r; i++) forward_sim_segment<P, INTEG, T>(w, s, dm, a, tid + i * FSIM_T, cw, xGoal, nullptr);
+    };
+    auto cost_part = [&](int tid) {                          // costThreaded (fpHelpers.cuh:156-163): knots tid, tid + COST_T, ...
+        T acc = 0;
+        const int r = reps_of(tid, COST_T, N);
+        for (int i = 0; i < r; i++) { const int k = tid + i * COST_T; acc += P::cost(cw, x + (size_t)k * NX, u + (size_t)k * NU, xGoal, k, N); }
+        JT[tid] = acc;
+    };
+    auto derivs = [&](int tid, int dim, bool cost_part_, bool dyn_part) {   // costGradientHessianThreaded / integratorGradientThreaded (nisInitHelpers.cuh:97-136, 225-242)
+        NisScratch<P, INTEG, T> s;
+        P::load_model(w, s.plant, &model);
+        const int total = cost_part_ ? N : N - 1, r = reps_of(tid, dim, total);
+        for (int i = 0; i < r; i++) {
+            const int k = tid + i * dim;
+            const T* xk = x + (size_t)k * NX; const T* uk = u + (size_t)k * NU;
+            if (cost_part_) {
+                T* Hk = H + (size_t)k * NM * NM; T* gk = g + (size_t)k * NM;
+                for (int e = 0; e < NM * NM; e++) { const int ii = e / NM, jj = e % NM; Hk[e] = (ii == jj) ? P::weight(cw, ii, k, N) : T(0); }
+                for (int ii = 0; ii < NM; ii++) gk[ii] = P::weight(cw, ii, k, N) * (ii < NX ? (xk[ii] - xGoal[ii]) : uk[ii - NX]);
+            }
+            if (dyn_part) {
+                for (int ii = 0; ii < NX; ii++) s.x[ii] = xk[ii];
+                for (int ii = 0; ii < NU; ii++) s.u[ii] = uk[ii];
+                integrator_gradient<P, INTEG>(w, s.plant, s.pgrad, s.integ, AB + (size_t)k * NX * NM, s.x, s.u, dt);
+            }
+        }
+    };
+    auto back_blocks = [&](int tid, T rho) {                 // backPassThreaded (bpHelpers.cuh:424-481): blocks tid, tid + BP_T, ...
+        BpScratch<P, T> s;
+        BpArgs<T> a{}; a.AB = AB; a.Pm = Pm; a.pv = pv; a.Pp = Pp; a.pp = pp; a.H = H; a.g = g; a.KT = KT; a.du = du; a.dcur = d; a.ApBK = ApBK; a.Bdu = Bdu;
+        a.xcur = x; a.xprev2 = xp2; a.dJexp = dJexp; a.rho = rho; a.Hrw = H; a.grw = g;       // CPU path: H, g accumulate in place (bpHelpers.cuh:90-91)
+        std::vector<int> e(M, 0); a.err = e.data();
+        int any = 0;
+        const int r = reps_of(tid, BP_T, M);
+        for (int i = 0; i < r; i++) any |= bp_block<P, T>(w, s, dm, tid + i * BP_T, a);
+        err[tid] = any;
+    };
+
+    // ---- loadVarsCPU (nisInitHelpers.cuh:656-736)
+    std::memcpy(x, x0, szx * sizeof(T)); std::memcpy(u, u0, szu * sizeof(T)); std::memcpy(xp, x0, szx * sizeof(T)); std::memcpy(up, u0, szu * sizeof(T));
+    if (clearVars) {
+        std::memset(Pm, 0, szP * sizeof(T)); std::memset(Pp, 0, szP * sizeof(T)); std::memset(pv, 0, szx * sizeof(T)); std::memset(pp, 0, szx * sizeof(T));
+        std::memset(KT, 0, (size_t)NX * NU * N * sizeof(T)); std::memset(d, 0, szx * sizeof(T));
+    } else {
+        if (!P0 || !p0 || !KT0 || !d0) return cpu_fail(PDDP_EINVAL, "runiLQR_CPU: clearVarsFlag = 0 needs KT0, P0, p0, d0");
+        std::memcpy(Pm, P0, szP * sizeof(T)); std::memcpy(Pp, P0, szP * sizeof(T)); std::memcpy(pv, p0, szx * sizeof(T)); std::memcpy(pp, p0, szx * sizeof(T));
+        std::memcpy(KT, KT0, (size_t)NX * NU * N * sizeof(T)); std::memcpy(d, d0, szx * sizeof(T));
+    }
+    std::memset(du, 0, szu * sizeof(T));
+    for (int i = 0; i < BP_T; i++) err[i] = 0;
+    std::memset(AB + (size_t)NX * NM * (N - 2), 0, (size_t)NX * NM * sizeof(T));
+    std::memcpy(dp, d, szx * sizeof(T));                     // (the rollout reads the defects through dcur; backwardPassCPU copies d -> dp again)
+    if (rollout) { for (int t = 0; t < FSIM_T; t++) ph.go([&, t] { sim_segments(t, alpha[0]); }); ph.join(); }
+    // ---- initAlgCPU (:401-457)
+    alphaOut[0] = rollout ? 0 : -1;
+    for (int t = 0; t < COST_T; t++) ph.go([&, t] { cost_part(t); });
+    for (int t = 0; t < COST_T; t++) ph.go([&, t] { derivs(t, COST_T, true, false); });
+    for (int t = 0; t < INT_T; t++) ph.go([&, t] { derivs(t, INT_T, false, true); });
+    ph.go([&] { std::memcpy(xp, x, szx * sizeof(T)); }); ph.go([&] { std::memcpy(xp2, x, szx * sizeof(T)); }); ph.go([&] { std::memcpy(up, u, szu * sizeof(T)); });
+    ph.join();
+    T prevJ = 0;
+    for (int t = 0; t < COST_T; t++) prevJ += JT[t];
+    Jout[0] = prevJ; prevJ *= (T)(1 + 2 * c.tol_cost);        // :456 (the GPU path ADDS 2 TOL_COST, :393)
+    T dJ = 0, J = 0, z = 0, maxd = 0; int iter = 1; T rho = (T)c.rho_init, drho = (T)1.0; int alphaIndex = 0;
+    (void)z;
+    *initTime = wall_ms() - t2;
+
+    while (true) {
+        // ---- backwardPassCPU (bpHelpers.cuh:522-566); its "rho maxed out" return value is ignored by the caller (DDPWrappers.cuh:177), as here
+        t2 = wall_ms();
+        while (true) {
+            for (int t = 0; t < BP_T; t++) ph.go([&, t] { back_blocks(t, rho); });
+            if (M > 1) ph.go([&] { std::memcpy(dp, d, szx * sizeof(T)); });
+            ph.join();
+            int fail = 0;
+            for (int t = 0; t < BP_T; t++) fail |= err[t];
+            if (!fail) break;
+            drho = std::max(drho * (T)kRhoFactor, (T)kRhoFactor); rho = std::min(rho * drho, (T)kRhoMax);
+            if (rho == (T)kRhoMax && !c.ignore_max_rho_exit) break;
+            std::memcpy(Pm, Pp, szP * sizeof(T)); std::memcpy(pv, pp, szx * sizeof(T));
+        }
+        bpTime[iter - 1] = wall_ms() - t2;
+        // ---- serial line search (DDPWrappers.cuh:187-207) over forwardSimCPU (fpHelpers.cuh:413-486)
+        dJ = (T)-1.0; alphaIndex = 0; sweepTime[iter - 1] = 0; simTime[iter - 1] = 0;
+        while (true) {
+            const T al = alpha[alphaIndex];
+            t2 = wall_ms();
+            if (M > 1) {                                     // forwardSweep: the segment start states of this candidate, into x
+                SweepScratch<P, T> ss; std::vector<T> segx((size_t)NX * M);
+                FpArgs<T> a{}; a.x = x; a.xcur = xp; a.dcur = d; a.ApBK = ApBK; a.Bdu = Bdu; a.alpha = al; a.segx = segx.data();
+                forward_sweep<P, T>(w, ss, dm, a);
+            }
+            sweepTime[iter - 1] += wall_ms() - t2;
+            t2 = wall_ms();
+            for (int t = 0; t < FSIM_T; t++) ph.go([&, t] { sim_segments(t, al); });
+            const bool first = (al == (T)1);
+            std::thread cpy;
+            if (first) {                                     // xp2 <- xp while the rollouts run; the expected reduction is summed over the backward-pass threads (sic, :438)
+                cpy = std::thread([&] { std::memcpy(xp2, xp, szx * sizeof(T)); });
+                for (int i = 1; i < BP_T; i++) { dJexp[0] += dJexp[2 * i]; dJexp[1] += dJexp[2 * i + 1]; }
+            }
+            ph.join();
+            for (int t = 0; t < COST_T; t++) ph.go([&, t] { cost_part(t); });
+            ph.join();
+            J = 0;
+            for (int t = 0; t < COST_T; t++) J += JT[t];
+            if (first) cpy.join();
+            dJ = prevJ - J;
+            const bool JFlag = dJ >= (T)0;
+            z = dJ / (al * dJexp[0] + (T)0.5 * al * al * dJexp[1]);
+            const bool zFlag = (T)c.exp_red_min < z && z < (T)c.exp_red_max;
+            bool dFlag = true;
+            if (M > 1) { maxd = 0; dFlag = maxd < (T)c.max_defect; }   // defectComp never updates its maximum (fpHelpers.cuh:123): always 0 on this path
+            bool failed;
+            if (JFlag && zFlag && dFlag) { if (ignoreFirstDefect && maxd < (T)c.max_defect) ignoreFirstDefect = 0; failed = false; }
+            else {
+                std::memcpy(x, xp, szx * sizeof(T)); std::memcpy(u, up, szu * sizeof(T)); if (M > 1) std::memcpy(d, dp, szx * sizeof(T));
+                failed = true;
+            }
+            simTime[iter - 1] += wall_ms() - t2;
+            if (failed) { if (alphaIndex < A - 1) { alphaIndex++; continue; } alphaIndex = -1; }
+            break;
+        }
+        // ---- acceptRejectTrajCPU (nisInitHelpers.cuh:520-555)
+        t2 = wall_ms();
+        bool exit_now = false;
+        if (alphaIndex == -1) {
+            drho = std::max(drho * (T)kRhoFactor, (T)kRhoFactor); rho = std::min(rho * drho, (T)kRhoMax);
+            alphaOut[iter] = -1; Jout[iter] = prevJ;
+            std::memcpy(x, xp, szx * sizeof(T)); std::memcpy(u, up, szu * sizeof(T)); if (M > 1) std::memcpy(d, dp, szx * sizeof(T));
+            if (rho == (T)kRhoMax && !c.ignore_max_rho_exit) exit_now = true;
+        } else {
+            drho = std::min(drho / (T)kRhoFactor, (T)(1.0 / kRhoFactor)); rho = std::max(rho * drho, (T)kRhoMin);
+            dJ = dJ / prevJ; prevJ = J; alphaOut[iter] = alphaIndex; Jout[iter] = J;
+            if (dJ < (T)c.tol_cost) exit_now = true;
+        }
+        if (!exit_now) { if (iter == c.max_iter) exit_now = true; else iter += 1; }
+        if (exit_now) { nisTime[iter - 1] = wall_ms() - t2; break; }
+        // ---- nextIterationSetupCPU (:281-325)
+        for (int t = 0; t < COST_T; t++) ph.go([&, t] { derivs(t, COST_T, true, false); });
+        for (int t = 0; t < INT_T; t++) ph.go([&, t] { derivs(t, INT_T, false, true); });
+        ph.go([&] { std::memcpy(Pp, Pm, szP * sizeof(T)); }); ph.go([&] { std::memcpy(pp, pv, szx * sizeof(T)); });
+        ph.go([&] { std::memcpy(xp, x, szx * sizeof(T)); }); ph.go([&] { std::memcpy(up, u, szu * sizeof(T)); });
+        ph.join();
+        nisTime[iter - 2] = wall_ms() - t2;
+    }
+    // ---- storeVarsCPU (:752-764)
+    t2 = wall_ms();
+    std::memcpy(x0, x, szx * sizeof(T)); std::memcpy(u0, u, szu * sizeof(T));
+    const double t_end = wall_ms();
+    *initTime += t_end - t2;
+    *tTime = t_end - t_start;
+    if (iters_out) *iters_out = iter;
+    return 0;
+}
+
+template <template <typename> class PT, typename T, typename... Args>
+int by_integrator(int integ, Args&&... args) {
+    switch (integ) {
+    case 1: return run_cpu<PT<T>, 1, T>(std::forward<Args>(args)...);
+    case 2: return run_cpu<PT<T>, 2, T>(std::forward<Args>(args)...);
+    case 3: return run_cpu<PT<T>, 3, T>(std::forward<Args>(args)...);
+    }
+    return cpu_fail(PDDP_EINVAL, "integrator must be 1 (Euler), 2 (midpoint) or 3 (RK3)");
+}
+template <typename T>
+int by_plant(const pddp_config& c, const pddp_cpu_buffers& B, void* x0, void* u0, const void* KT0, const void* P0, const void* p0, const void* d0, const void* xg,
+             void* Jout, int* alphaOut, int rollout, int clear, int ifd, double* tT, double* sT, double* swT, double* bT, double* nT, double* iT, int cores, int* it) {
+#define PDDP_CPU_ARGS c, B, (T*)x0, (T*)u0, (const T*)KT0, (const T*)P0, (const T*)p0, (const T*)d0, (const T*)xg, (T*)Jout, alphaOut, rollout, clear, ifd, tT, sT, swT, bT, nT, iT, cores, it
+    switch (c.plant) {
+    case 1: return by_integrator<PendPlant, T>(c.integrator, PDDP_CPU_ARGS);
+    case 2: return by_integrator<CartPlant, T>(c.integrator, PDDP_CPU_ARGS);
+    case 3: return by_integrator<QuadPlant, T>(c.integrator, PDDP_CPU_ARGS);
+    case 4: if (c.integrator != 1) return cpu_fail(PDDP_EINVAL, "the arm is Euler-only (config.cuh:58)");
+            return run_cpu<ArmPlant<T>, 1, T>(PDDP_CPU_ARGS);
+    }
+#undef PDDP_CPU_ARGS
+    return cpu_fail(PDDP_EINVAL, "plant must be 1..4");
+}
+
+}  // namespace
+
+extern "C" int pddp_cpu_run_ilqr(const pddp_config* cfg, const pddp_cpu_buffers* buf, void* x0, void* u0, const void* KT0, const void* P0, const void* p0,
+                                 const void* d0, const void* xGoal, void* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag,
+                                 int ignoreFirstDefectFlag, double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime,
+                                 double* initTime, int cores, int* iters_out) {
+    if (!cfg || !buf || !x0 || !u0 || !xGoal || !Jout || !alphaOut || !tTime || !simTime || !sweepTime || !bpTime || !nisTime || !initTime)
+        return cpu_fail(PDDP_EINVAL, "pddp_cpu_run_ilqr: null argument");
+    const pddp_config& c = *cfg;
+    if (c.ee_cost) return cpu_fail(PDDP_EINVAL, "pddp_cpu_run_ilqr: joint-space cost only (EE_COST 0)");
+    if (c.N < 4 || (c.N & (c.N - 1)) || c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.A < 1 || c.A > 64 || c.max_iter < 1)
+        return cpu_fail(PDDP_EINVAL, "pddp_cpu_run_ilqr: N a power of two >= 4, M dividing N with N/M >= 2, 1 <= A <= 64, max_iter >= 1");
+    return c.dtype == 1 ? by_plant<double>(c, *buf, x0, u0, KT0, P0, p0, d0, xGoal, Jout, alphaOut, forwardRolloutFlag, clearVarsFlag, ignoreFirstDefectFlag,
+                                           tTime, simTime, sweepTime, bpTime, nisTime, initTime, cores, iters_out)
+                        : by_plant<float>(c, *buf, x0, u0, KT0, P0, p0, d0, xGoal, Jout, alphaOut, forwardRolloutFlag, clearVarsFlag, ignoreFirstDefectFlag,
+                                          tTime, simTime, sweepTime, bpTime, nisTime, initTime, cores, iters_out);
+}

@@ -218,4 +218,76 @@ void freeMemory_GPU(T** d_x, T** h_d_x, T* d_xp, T* d_xp2, T** d_u, T** h_d_u, T
     std::free(alphaIndex); std::free(err); std::free(streams);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The reference's CPU twins (DDPHelpers/nisInitHelpers.cuh:886-925 allocateMemory_CPU, :950-958 freeMemory_CPU; DDPHelpers/DDPWrappers.cuh:142-248
+// runiLQR_CPU), same names and argument order, over libpddp_cpu.so (include/pddp_cpu.h): the caller owns plain host buffers, exactly as upstream.
+// Compiled in when the translation unit defines PDDP_WITH_CPU_PATH (link with -lpddp_cpu); examples/WAFR_iLQR_examples.cu:231-299 (`testCPU`, the
+// serial-alpha branch) then recompiles unchanged.  runiLQR_GPU never routes here, and this path never touches the GPU library.
+#ifdef PDDP_WITH_CPU_PATH
+#include "../../include/pddp_cpu.h"
+#include <cmath>
+#include <thread>
+
+template <typename T>
+void allocateMemory_CPU(T** x, T** xp, T** xp2, T** u, T** up, T** xGoal, T** P, T** Pp, T** p, T** pp, T** AB, T** H, T** g, T** KT, T** du, T** d, T** dp,
+                        T** ApBK, T** Bdu, T** JT, T** dJexp, T** alpha, int** err, int* ld_x, int* ld_u, int* ld_P, int* ld_p, int* ld_AB, int* ld_H,
+                        int* ld_g, int* ld_KT, int* ld_du, int* ld_d, int* ld_A, T** I = nullptr, T** Tbody = nullptr) {
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "algType must be float or double");
+    *ld_x = DIM_x_r; *ld_u = DIM_u_r; *ld_AB = DIM_AB_r; *ld_P = DIM_P_r; *ld_p = DIM_p_r; *ld_H = DIM_H_r; *ld_g = DIM_g_r; *ld_KT = DIM_KT_r;
+    *ld_du = DIM_du_r; *ld_d = DIM_d_r; *ld_A = DIM_A_r;
+    const size_t N = NUM_TIME_STEPS;
+    auto arr = [](size_t count) { return static_cast<T*>(std::calloc(count, sizeof(T))); };
+    *x = arr(DIM_x_r * N); *xp = arr(DIM_x_r * N); *xp2 = arr(DIM_x_r * N); *u = arr(DIM_u_r * N); *up = arr(DIM_x_r * N);
+    *xGoal = arr(EE_COST ? 6 : STATE_SIZE);
+    *P = arr(DIM_P_r * DIM_P_c * N); *Pp = arr(DIM_P_r * DIM_P_c * N); *p = arr(DIM_p_r * N); *pp = arr(DIM_p_r * N);
+    *AB = arr(DIM_AB_r * DIM_AB_c * N); *H = arr(DIM_H_r * DIM_H_c * N); *g = arr(DIM_g_r * N); *KT = arr(DIM_KT_r * DIM_KT_c * N); *du = arr(DIM_du_r * N);
+    *d = arr(DIM_d_r * N); *dp = arr(DIM_d_r * N); *Bdu = arr(DIM_d_r * N); *ApBK = arr(DIM_A_r * DIM_A_c * N);
+    int bp_t = 1, fsim_t = 1, cost_t = 1, integ_t = 1;
+    pddp_cpu_thread_counts(M_BLOCKS_B, 0, &bp_t, &fsim_t, &cost_t, &integ_t);
+    *JT = arr(fsim_t > cost_t ? fsim_t : cost_t);          // max(FSIM_THREADS, COST_THREADS) partial sums (:917)
+    *dJexp = arr(2 * (M_BLOCKS_B > bp_t ? M_BLOCKS_B : bp_t));
+    *alpha = arr(NUM_ALPHA);
+    for (int i = 0; i < NUM_ALPHA; i++) (*alpha)[i] = (T)std::pow((double)ALPHA_BASE, (double)i);   // :920
+    *err = static_cast<int*>(std::calloc(M_BLOCKS_B > bp_t ? M_BLOCKS_B : bp_t, sizeof(int)));
+    if (I) *I = arr(36 * NUM_POS);                          // opaque here: the robot constants live inside the library (wafr_urdf / mpc_mode select them)
+    if (Tbody) *Tbody = arr(36 * NUM_POS);
+}
+
+template <typename T>
+void runiLQR_CPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag, int ignoreFirstDefectFlag,
+                 double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime, double* initTime, T* x, T* xp, T* xp2, T* u, T* up, T* P,
+                 T* p, T* Pp, T* pp, T* AB, T* H, T* g, T* KT, T* du, T* d, T* dp, T* ApBK, T* Bdu, T* alpha, T* JT, T* dJexp, int* err, int ld_x, int ld_u,
+                 int ld_P, int ld_p, int ld_AB, int ld_H, int ld_g, int ld_KT, int ld_du, int ld_d, int ld_A, T* I = nullptr, T* Tbody = nullptr,
+                 T Q_EE1 = _Q_EE1, T Q_EE2 = _Q_EE2, T QF_EE1 = _QF_EE1, T QF_EE2 = _QF_EE2, T Q_EEV1 = _Q_EEV1, T Q_EEV2 = _Q_EEV2, T QF_EEV1 = _QF_EEV1,
+                 T QF_EEV2 = _QF_EEV2, T R_EE = _R_EE, T Q_xdEE = _Q_xdEE, T QF_xdEE = _QF_xdEE, T Q_xEE = _Q_xEE, T QF_xEE = _QF_xEE, T Q1 = _Q1, T Q2 = _Q2,
+                 T R = _R, T QF1 = _QF1, T QF2 = _QF2) {
+    (void)ld_x; (void)ld_u; (void)ld_P; (void)ld_p; (void)ld_AB; (void)ld_H; (void)ld_g; (void)ld_KT; (void)ld_du; (void)ld_d; (void)ld_A; (void)I; (void)Tbody;
+    (void)Q_EE1; (void)Q_EE2; (void)QF_EE1; (void)QF_EE2; (void)Q_EEV1; (void)Q_EEV2; (void)QF_EEV1; (void)QF_EEV2; (void)R_EE; (void)Q_xdEE; (void)QF_xdEE;
+    (void)Q_xEE; (void)QF_xEE;
+    pddp_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.plant = PLANT; c.dtype = std::is_same<T, double>::value ? 1 : 0;
+    c.N = NUM_TIME_STEPS; c.M = M_BLOCKS; c.A = NUM_ALPHA; c.integrator = INTEGRATOR; c.batch = 1; c.max_iter = MAX_ITER;
+    c.wafr_urdf = USE_WAFR_URDF; c.mpc_mode = MPC_MODE; c.ignore_max_rho_exit = IGNORE_MAX_ROX_EXIT;
+    c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
+    c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX; c.Q1 = Q1; c.Q2 = Q2; c.R = R; c.QF1 = QF1; c.QF2 = QF2; c.ee_cost = EE_COST;
+    pddp_cpu_buffers b = {x, xp, xp2, u, up, P, p, Pp, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, alpha, JT, dJexp, err};
+    int iter = 0;
+    const int rc = pddp_cpu_run_ilqr(&c, &b, x0, u0, KT0, P0, p0, d0, xGoal, Jout, alphaOut, forwardRolloutFlag, clearVarsFlag, ignoreFirstDefectFlag, tTime,
+                                     simTime, sweepTime, bpTime, nisTime, initTime, 0, &iter);
+    if (rc) { std::fprintf(stderr, "runiLQR_CPU: %s (code %d)\n", pddp_cpu_last_error(), rc); std::exit(rc < 0 ? -rc : rc); }
+    std::printf("CPU Parallel blocks:[%d] t:[%f] with FP[%f], FS[%f], BP[%f], NIU[%f] Xf:[%.4f, %.4f] iters:[%d] cost:[%f] max_d[%f]\n", M_BLOCKS_B, *tTime,
+                *simTime, *sweepTime, *bpTime, *nisTime, (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1)], (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1) + 1], iter,
+                (double)Jout[iter], 0.0);
+}
+
+template <typename T>
+void freeMemory_CPU(T* x, T* xp, T* xp2, T* u, T* up, T* P, T* Pp, T* p, T* pp, T* AB, T* H, T* g, T* KT, T* du, T* d, T* dp, T* Bdu, T* ApBK, T* dJexp, int* err,
+                    T* alpha, T* JT, T* xGoal, T* I = nullptr, T* Tbody = nullptr) {
+    std::free(x); std::free(xp); std::free(xp2); std::free(u); std::free(up); std::free(P); std::free(Pp); std::free(p); std::free(pp); std::free(AB); std::free(H);
+    std::free(g); std::free(KT); std::free(du); std::free(d); std::free(dp); std::free(Bdu); std::free(ApBK); std::free(dJexp); std::free(err); std::free(alpha);
+    std::free(JT); std::free(xGoal); if (I) std::free(I); if (Tbody) std::free(Tbody);
+}
+#endif   // PDDP_WITH_CPU_PATH
+
 #endif

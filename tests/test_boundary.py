@@ -65,6 +65,17 @@ def test_facade_compiles_with_plain_gxx_and_fails_loudly_without_gpu():
     assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
+def test_reference_example_cpu_branch_through_the_facade():
+    """testCPU of examples/WAFR_iLQR_examples.cu:231-299 (serial-alpha branch) against hostapi/: allocateMemory_CPU / runiLQR_CPU / freeMemory_CPU over
+    libpddp_cpu.so, Kuka N=128, A=8, M=4, TOL_COST 0, 1 solve.  Runs without a GPU (it is the reference's CPU path, not a fallback of the GPU one)."""
+    exe = build_examples()
+    r = subprocess.run([exe, "C", "1", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("CPU Parallel blocks:[4]") == 1 and "<<<TESTING CPU 1/1>>>" in r.stdout
+    m = re.search(r"solve 0: (\d+) iterations, J ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert m and int(m.group(1)) == 100 and float(m.group(3)) < 0.5 * float(m.group(2))      # the first-acceptable line search stalls around 600-750 on this problem (SURVEY.md 8c, G3 trace)
+
+
 @pytest.mark.gpu
 def test_reference_example_shape_through_the_facade():
     """testGPU of examples/WAFR_iLQR_examples.cu:303-361 against hostapi/: Kuka N=128, A=8, M=4, TOL_COST 0, 2 solves."""

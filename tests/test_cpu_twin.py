@@ -1,0 +1,84 @@
+"""The CPU entry points of the boundary (allocateMemory_CPU / runiLQR_CPU / freeMemory_CPU; include/pddp_cpu.h,
+parallel-ddp_amd/csrc/cpu_twin.cpp): product host code built from the kernels' own bodies with the reference's CPU semantics, checked against
+the oracle's independent restatement of runiLQR_CPU (oracle/ora_core.inc run_ilqr_cpu, pinned to the reference's recorded traces).
+float64: identical step-size indices and iteration count, J / x / u / K to 1e-8.  float32: leading iterations."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import pyddp
+from oracle_binding import Oracle, default_cfg, example_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "parallel-ddp_amd", "lib", "libpddp_cpu.so")
+
+
+class CpuBuffers(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x", "xp", "xp2", "u", "up", "P", "p", "Pp", "pp", "AB", "H", "g", "KT", "du", "d", "dp", "ApBK", "Bdu", "alpha", "JT", "dJexp")] + [("err", C.c_void_p)]
+
+
+def run_cpu_twin(plant, dtype, x0, u0, xg, cores=8, rollout=0, **kw):
+    lib = C.CDLL(LIB)
+    lib.pddp_cpu_last_error.restype = C.c_char_p
+    cfg = pyddp.default_config(plant, dtype=0 if dtype == np.float32 else 1, **kw)
+    npos, n, m = pyddp.PLANT_DIMS[plant]
+    N, M, A, mi = cfg.N, cfg.M, cfg.A, cfg.max_iter
+    nm = n + m
+    sizes = dict(x=n * N, xp=n * N, xp2=n * N, u=m * N, up=n * N, P=n * n * N, p=n * N, Pp=n * n * N, pp=n * N, AB=n * nm * N, H=nm * nm * N, g=nm * N, KT=n * m * N,
+                 du=m * N, d=n * N, dp=n * N, ApBK=n * n * N, Bdu=n * N, alpha=A, JT=max(M, cores), dJexp=2 * max(M, 1))
+    arrs = {k: np.zeros(v, dtype) for k, v in sizes.items()}
+    arrs["alpha"][:] = [cfg.alpha_base ** i for i in range(A)]           # allocateMemory_CPU, nisInitHelpers.cuh:920
+    err = np.zeros(max(M, cores), np.int32)
+    buf = CpuBuffers(**{k: v.ctypes.data for k, v in arrs.items()}, err=err.ctypes.data)
+    x, u, g_ = np.ascontiguousarray(x0, dtype).copy(), np.ascontiguousarray(u0, dtype).copy(), np.ascontiguousarray(xg, dtype)
+    Jout, aout = np.zeros(mi + 2, dtype), np.full(mi + 2, -99, np.int32)
+    tt = [np.zeros(1), np.zeros(mi + 1), np.zeros(mi + 1), np.zeros(mi + 1), np.zeros(mi + 1), np.zeros(1)]
+    iters = C.c_int(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.pddp_cpu_run_ilqr(C.byref(cfg), C.byref(buf), p(x), p(u), None, None, None, None, p(g_), p(Jout), p(aout), int(rollout), 1, 1,
+                               p(tt[0]), p(tt[1]), p(tt[2]), p(tt[3]), p(tt[4]), p(tt[5]), int(cores), C.byref(iters))
+    assert rc == 0, lib.pddp_cpu_last_error()
+    return dict(x=x, u=u, KT=arrs["KT"], Jout=Jout, alphaOut=aout, iters=iters.value, t_total_ms=float(tt[0][0]), t_init_ms=float(tt[5][0]), bpTime=tt[3])
+
+
+CASES = [
+    pytest.param(4, dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=12), id="kuka-N128-M4"),      # the reference example's configuration
+    pytest.param(4, dict(N=64, M=1, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=10), id="kuka-N64-M1"),
+    pytest.param(2, dict(N=64, M=4, A=8, integrator=3, total_time=2.0, tol_cost=0.0, max_iter=10), id="cart-N64-M4-rk3"),
+    pytest.param(1, dict(N=64, M=1, A=1, integrator=1, total_time=4.0, tol_cost=0.0, max_iter=10), id="pend-N64-A1"),     # BASELINE configs[0]
+    pytest.param(3, dict(N=64, M=4, A=16, integrator=3, total_time=2.0, tol_cost=0.0, max_iter=6), id="quad-N64-rk3"),
+]
+
+
+@pytest.mark.parametrize("plant,kw", CASES)
+def test_cpu_entry_point_follows_the_oracles_cpu_path_float64(plant, kw):
+    o = Oracle(default_cfg(plant, cores=8, spawn_threads=0, **kw), np.float64)
+    x0, u0, xg = example_inputs(plant, kw["N"], np.float64, noise=np.random.default_rng(9).normal(0, 0.001, (kw["N"], o.n)))
+    ref = o.run_ilqr_cpu(x0, u0, xg)
+    got = run_cpu_twin(plant, np.float64, x0, u0, xg, cores=8, **kw)
+    it = ref["iters"]
+    assert got["iters"] == it
+    assert list(got["alphaOut"][: it + 1]) == list(ref["alphaOut"][: it + 1])
+    np.testing.assert_allclose(got["Jout"][: it + 1], ref["Jout"][: it + 1], rtol=1e-8)
+    np.testing.assert_allclose(got["x"], ref["x"], rtol=0, atol=1e-8 * max(np.abs(ref["x"]).max(), 1))
+    np.testing.assert_allclose(got["u"], ref["u"], rtol=0, atol=1e-7 * max(np.abs(ref["u"]).max(), 1))
+    np.testing.assert_allclose(got["KT"], ref["KT"], rtol=0, atol=1e-6 * max(np.abs(ref["KT"]).max(), 1))
+    assert got["t_total_ms"] > 0 and got["bpTime"][0] > 0
+
+
+def test_cpu_entry_point_float32_and_thread_counts():
+    kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=8)
+    o = Oracle(default_cfg(4, cores=8, spawn_threads=0, **kw), np.float32)
+    x0, u0, xg = example_inputs(4, 128, np.float32)
+    ref = o.run_ilqr_cpu(x0, u0, xg)
+    got = run_cpu_twin(4, np.float32, x0, u0, xg, cores=8, **kw)
+    assert list(got["alphaOut"][:4]) == list(ref["alphaOut"][:4])
+    np.testing.assert_allclose(got["Jout"][:4], ref["Jout"][:4], rtol=2e-3)
+    lib = C.CDLL(LIB)
+    t = [C.c_int(0) for _ in range(4)]
+    lib.pddp_cpu_thread_counts(4, 8, *[C.byref(v) for v in t])
+    assert [v.value for v in t] == [4, 4, 4, 4]                        # config.cuh:156-159 with CPU_CORES 8
+    lib.pddp_cpu_thread_counts(4, 256, *[C.byref(v) for v in t])
+    assert [v.value for v in t] == [4, 4, 128, 128]

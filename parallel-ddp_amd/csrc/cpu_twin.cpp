@@ -260,9 +260,12 @@ int by_plant(const pddp_config& c, const pddp_cpu_buffers& B, void* x0, void* u0
     case 3: return by_integrator<QuadPlant, T>(c.integrator, PDDP_CPU_ARGS);
     case 4: if (c.integrator != 1) return cpu_fail(PDDP_EINVAL, "the arm is Euler-only (config.cuh:58)");
             return run_cpu<ArmPlant<T>, 1, T>(PDDP_CPU_ARGS);
+#ifdef PDDP_USER_PLANT_HEADER
+    case 5: return by_integrator<UserPlant, T>(c.integrator, PDDP_CPU_ARGS);
+#endif
     }
 #undef PDDP_CPU_ARGS
-    return cpu_fail(PDDP_EINVAL, "plant must be 1..4");
+    return cpu_fail(PDDP_EINVAL, "plant must be 1..4 (5: the user plant of a `make user PLANT_POLICY=...` build)");
 }
 
 }  // namespace

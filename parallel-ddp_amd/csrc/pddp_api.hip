@@ -25,15 +25,20 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 extern "C" const char* pddp_last_error(void) { return g_err.c_str(); }
-extern "C" int pddp_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 4 ? 14 : -1; }
-extern "C" int pddp_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 4 ? 7 : -1; }
+#ifdef PDDP_USER_PLANT_HEADER
+static constexpr int kMaxPlant = 5, kUserNX = 2 * pddp::kUserPlantNPOS, kUserNU = pddp::kUserPlantNU;
+#else
+static constexpr int kMaxPlant = 4, kUserNX = -1, kUserNU = -1;
+#endif
+extern "C" int pddp_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 4 ? 14 : plant == 5 ? kUserNX : -1; }
+extern "C" int pddp_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 4 ? 7 : plant == 5 ? kUserNU : -1; }
 
 // Reference defaults: config.cuh:24-61 per plant, :78-136 algorithm, plants/cost_arm.cuh:97-103 weights.
 extern "C" int pddp_default_config(pddp_config* c, int plant) {
-    if (!c || plant < 1 || plant > 4) return fail(PDDP_EINVAL, "plant must be 1..4");
+    if (!c || plant < 1 || plant > kMaxPlant) return fail(PDDP_EINVAL, "plant must be 1..4 (5: the user plant of a `make user PLANT_POLICY=...` build)");
     std::memset(c, 0, sizeof(*c));
     c->plant = plant; c->dtype = 0;
-    c->N = plant == 4 ? 64 : 128; c->M = 4;
+    c->N = plant == 4 ? 64 : 128; c->M = 4;                      // plant 5 (a user plant) starts from the pendulum's defaults
     c->A = (plant == 3 || plant == 4) ? 16 : 32;
     c->integrator = plant == 4 ? 1 : 3;
     c->batch = 1; c->max_iter = 100; c->ignore_max_rho_exit = 1;
@@ -643,6 +648,9 @@ static SolverBase* make_plant(const pddp_config& c) {
     case 2: return make_integ<CartPlant, T>(c.integrator);
     case 3: return make_integ<QuadPlant, T>(c.integrator);
     case 4: return c.integrator == 1 ? new Solver<ArmPlant<T>, 1, T>() : nullptr;   // the arm is Euler-only, as config.cuh:58
+#ifdef PDDP_USER_PLANT_HEADER
+    case 5: return make_integ<UserPlant, T>(c.integrator);
+#endif
     }
     return nullptr;
 }
@@ -650,7 +658,7 @@ static SolverBase* make_plant(const pddp_config& c) {
 extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (!cfg || !out) return fail(PDDP_EINVAL, "null argument");
     const pddp_config& c = *cfg;
-    if (c.plant < 1 || c.plant > 4) return fail(PDDP_EINVAL, "plant must be 1..4");
+    if (c.plant < 1 || c.plant > kMaxPlant) return fail(PDDP_EINVAL, "plant must be 1..4 (5: the user plant of a `make user PLANT_POLICY=...` build)");
     if (c.N < 4 || (c.N & (c.N - 1)) || c.N > 1024) return fail(PDDP_EINVAL, "N must be a power of two in [4,1024] (the reference's tree reductions assume it)");
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");

@@ -79,6 +79,18 @@ PDDP_HD void diag_cost_grad(T* Hk, T* gk, const T* xk, const T* uk, const T* xg,
 PDDP_CLOSED_FORM_PLANT(PendPlant, 1, 1, 1, pend_dynamics_eval, pend_gradient_eval)
 PDDP_CLOSED_FORM_PLANT(CartPlant, 2, 2, 1, cart_dynamics_eval, cart_gradient_eval)
 PDDP_CLOSED_FORM_PLANT(QuadPlant, 3, 6, 4, quad_dynamics_eval, quad_gradient_eval)
+}  // namespace pddp
+// A user plant compiled in as plant 5 (make user PLANT_POLICY=<header>; examples/plants/damped_pendulum.hpp documents what the header provides).
+#ifdef PDDP_USER_PLANT_HEADER
+#include PDDP_USER_PLANT_HEADER
+namespace pddp {
+PDDP_CLOSED_FORM_PLANT(UserPlant, 5, kUserPlantNPOS, kUserPlantNU, user_plant_dynamics, user_plant_gradient)
+template <typename T> PDDP_HD double UserPlant<T>::QR(int i, int N) { return user_plant_QR(i, N); }
+template <typename T> PDDP_HD double UserPlant<T>::Rw(int N) { return user_plant_R(N); }
+template <typename T> PDDP_HD double UserPlant<T>::QF(int N) { return user_plant_QF(N); }
+}  // namespace pddp
+#endif
+namespace pddp {
 #undef PDDP_CLOSED_FORM_PLANT
 
 // cost_pend.cuh:19-24 (QR(1) falls through to R, QR(2) is the control's Q2)

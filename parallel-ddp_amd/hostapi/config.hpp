@@ -67,8 +67,17 @@
 #ifndef INTEGRATOR
 #define INTEGRATOR 1                  // the arm's dynamics are only provided for Euler, as upstream (README.md:33)
 #endif
+#elif PLANT == 5                      // a user plant compiled into the library: make user PLANT_POLICY=<header>; link -lpddp_user (-lpddp_cpu_user)
+#ifndef PDDP_USER_PLANT_NUM_POS       // the two sizes of the policy header (kUserPlantNPOS, kUserPlantNU), given to this translation unit as macros
+#error "PLANT 5: define PDDP_USER_PLANT_NUM_POS and PDDP_USER_PLANT_CONTROL_SIZE (the policy header's kUserPlantNPOS / kUserPlantNU)"
+#endif
+#define NUM_POS PDDP_USER_PLANT_NUM_POS
+#define CONTROL_SIZE PDDP_USER_PLANT_CONTROL_SIZE
+#ifndef RHO_INIT
+#define RHO_INIT 10.0
+#endif
 #else
-#error "PLANT must be 1 (pendulum), 2 (cart-pole), 3 (quadrotor) or 4 (KUKA iiwa14)"
+#error "PLANT must be 1 (pendulum), 2 (cart-pole), 3 (quadrotor), 4 (KUKA iiwa14) or 5 (the user plant of a `make user` build)"
 #endif
 #define STATE_SIZE (2 * NUM_POS)
 

@@ -112,7 +112,11 @@ class Solver:
         self.lib = _load(self.path)
         self.cfg = cfg
         self.dtype = np.dtype(np.float32 if cfg.dtype == 0 else np.float64)
-        self.npos, self.n, self.m = PLANT_DIMS[cfg.plant]
+        if cfg.plant in PLANT_DIMS:
+            self.npos, self.n, self.m = PLANT_DIMS[cfg.plant]
+        else:                                      # a user plant (make user PLANT_POLICY=...): the library knows its sizes
+            self.n, self.m = self.lib.pddp_state_size(cfg.plant), self.lib.pddp_control_size(cfg.plant)
+            self.npos = self.n // 2
         self.h = C.c_void_p()
         self._chk(self.lib.pddp_create(C.byref(cfg), C.byref(self.h)))
 

@@ -27,11 +27,16 @@ using namespace pddp;
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
 extern "C" const char* pddp_last_error(void) { return g_err.c_str(); }
-extern "C" int pddp_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 4 ? 14 : -1; }
-extern "C" int pddp_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 4 ? 7 : -1; }
+#ifdef PDDP_USER_PLANT_HEADER
+static constexpr int kMaxPlant = 5, kUserNX = 2 * pddp::kUserPlantNPOS, kUserNU = pddp::kUserPlantNU;
+#else
+static constexpr int kMaxPlant = 4, kUserNX = -1, kUserNU = -1;
+#endif
+extern "C" int pddp_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 4 ? 14 : plant == 5 ? kUserNX : -1; }
+extern "C" int pddp_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 4 ? 7 : plant == 5 ? kUserNU : -1; }
 extern "C" int pddp_default_config(pddp_config* c, int plant) {
     std::memset(c, 0, sizeof(*c));
-    c->plant = plant; c->N = plant == 4 ? 64 : 128; c->M = 4; c->A = (plant == 3 || plant == 4) ? 16 : 32;
+    c->plant = plant; c->N = plant == 4 ? 64 : 128; c->M = 4; c->A = (plant == 3 || plant == 4) ? 16 : 32;   /* plant 5 (user plant): the pendulum's defaults */
     c->integrator = plant == 4 ? 1 : 3; c->batch = 1; c->max_iter = 100; c->ignore_max_rho_exit = 1;
     c->total_time = plant == 4 ? 0.5 : 4.0; c->alpha_base = (plant == 3 || plant == 4) ? 0.5 : 0.75;
     c->rho_init = plant == 4 ? 12.5 : (plant == 3 ? 1.0 : 10.0); c->max_defect = plant == 2 ? 0.75 : 1.0;
@@ -382,12 +387,15 @@ template <typename T> static Base* mk(const pddp_config& c) {
     case 2: return mk_integ<CartPlant, T>(c);
     case 3: return mk_integ<QuadPlant, T>(c);
     case 4: if (c.integrator == 1) { auto* s = new Sim<ArmPlant<T>, 1, T>(); s->cfg = c; s->init(); return s; } return nullptr;
+#ifdef PDDP_USER_PLANT_HEADER
+    case 5: return mk_integ<UserPlant, T>(c);
+#endif
     }
     return nullptr;
 }
 extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     const pddp_config& c = *cfg;
-    if (c.plant < 1 || c.plant > 4) return fail(PDDP_EINVAL, "plant must be 1..4");
+    if (c.plant < 1 || c.plant > kMaxPlant) return fail(PDDP_EINVAL, "plant must be 1..4 (5: the user plant of a `make user PLANT_POLICY=...` build)");
     if (c.N < 4 || (c.N & (c.N - 1)) || c.N > 1024) return fail(PDDP_EINVAL, "N must be a power of two in [4,1024]");
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");

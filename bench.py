@@ -89,7 +89,12 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
     ap.add_argument("--calibrate-hbm", action="store_true", help="also launch the known-byte-count copy kernel (for --pmc passes)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+                    help="config2 (default, the headline): BASELINE configs[2]; config3: BASELINE configs[3] -- 64 Kuka MPC rollouts with the end-effector cost, "
+                         "64 / N per GPU, exchanges through the C ABI's own RCCL collectives (pddp_comm_*)")
     args = ap.parse_args()
+    if args.workload == "config3":
+        return config3_sharded(args)
 
     ctx = shard.init_from_env(args.gpus)              # rank, world, local_rank; torch.distributed if world > 1
     import torch
@@ -184,6 +189,43 @@ def main():
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
     shard.finalize(ctx)
+
+
+def config3_sharded(args):
+    """BASELINE configs[3]: 64 concurrent rollouts x 8 alphas (Kuka, N=64, M=4, MPC_MODE, end-effector cost), rank g owns the rollouts {r : r % N == g}
+    (64 / N per GPU), no collective per sweep; the exit poll (all-reduce) and the cost table (all-gather) go through the C ABI's native RCCL
+    exchanges (include/pddp.h "multi-GPU").  STRONG scaling: the 64 rollouts are the whole job.  Not the headline line (that is configs[2])."""
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    total, N = 64, 64
+    if total % world:
+        raise SystemExit("config3: 64 rollouts must split evenly over the ranks")
+    B = total // world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    comm = pyddp.Comm(rank, world, local, id_path=f"/tmp/pddp_bench_{os.environ.get('MASTER_PORT', 'solo')}.id" if world > 1 else None)
+    K, W = args.steps, args.warmup
+    cfg = pyddp.default_config(4, N=N, M=4, A=8, batch=B, max_iter=max(100, K + W + 1), ee_cost=1, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5,
+                               ignore_max_rho_exit=0, device=local, use_graph=args.graph)
+    s = pyddp.Solver(cfg)
+    x_all, u_all, g_all = ee_inputs(N, np.random.default_rng(77), total)
+    mine = list(range(rank, total, world))
+    s.load(x_all[mine], u_all[mine], g_all[mine])
+    s.set_benchmark_mode(1)                     # keep every rollout iterating through the timed sweeps (no early exit changes the work per step)
+    s.iterate(W); s.sync(); comm.barrier()
+    t0 = time.perf_counter()
+    s.iterate(K); s.sync(); comm.barrier()
+    t = comm.max_over_ranks(time.perf_counter() - t0)
+    s.set_benchmark_mode(0)
+    done = comm.all_done(s)
+    costs = comm.allgather_costs(s)
+    if rank == 0:
+        print(json.dumps({"metric": "DDP iterations/sec (Kuka MPC shape N=64, 64 rollouts x 8 alphas x 4 segments, end-effector cost)", "value": round(total * K / t, 1),
+                          "unit": "DDP iterations/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[3]: 64 concurrent Kuka MPC rollouts (N=64, 8 alphas x 4 segments, MPC_MODE, end-effector cost), "
+                                                 f"{B} per GPU, round-robin", "problems_total": total, "sharding": "batch axis; RCCL all-reduce per poll + all-gather of the cost table (pddp_comm_*)"},
+                          "rccl_ranks_seen": comm.world, "all_done_after_timed_sweeps": bool(done),
+                          "J_first_last_mean": [round(float(costs[:, 0].mean()), 4), round(float(costs[:, 1].mean()), 4)]}), flush=True)
+    s.close(); comm.close()
 
 
 def batch_convergence(ctx, args, torch, x0, u0, xg, B, N, M, A):

@@ -176,6 +176,29 @@ int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes);
  * lets the host layer run an RCCL collective on the cost table without staging it through the host. */
 int pddp_array_ptr(pddp_handle h, const char* name, void** device_ptr, size_t* bytes);
 
+/* ---- multi-GPU (mode R): one process per GPU, rank g owns the problems {r : r % world == g} in its own handle; a sweep needs
+ * no exchange.  The two exchanges a caller needs -- "has every problem on every rank exited?" and the cost table of all rollouts -- are RCCL
+ * collectives issued on the solver's own stream (ncclAllReduce(max) of one int, ncclAllGather of [batch][2] costs), straight from HBM.
+ * The reference has no multi-GPU path (no NCCL / MPI anywhere in its tree); this is the batch-axis shard BASELINE configs[3] asks for.
+ * Rendezvous: rank 0 calls pddp_comm_unique_id and ships the PDDP_COMM_ID_BYTES bytes to the other ranks by whatever means the caller has
+ * (a file, an environment variable, MPI, a TCP store); every rank then calls pddp_comm_init with the same bytes. */
+#define PDDP_COMM_ID_BYTES 128
+typedef struct pddp_comm* pddp_comm_handle;
+int pddp_comm_unique_id(void* id /* PDDP_COMM_ID_BYTES */);
+int pddp_comm_init(pddp_comm_handle* out, int rank, int world, const void* id, int device);
+int pddp_comm_destroy(pddp_comm_handle c);
+int pddp_comm_ranks(pddp_comm_handle c, int* rank, int* world);
+/* *all_done = 1 when every problem of every rank's handle has met an exit condition (one all-reduce(max) over the ranks, after everything
+ * already enqueued on the handle's stream) */
+int pddp_comm_all_done(pddp_comm_handle c, pddp_handle h, int* all_done);
+/* costs[world * batch][2] (double, host) = (J_initial, J at the problem's last iteration) of every problem of every rank in GLOBAL problem order
+ * (problem g lives on rank g % world at local index g / world); every rank's handle must have the same batch */
+int pddp_comm_allgather_costs(pddp_comm_handle c, pddp_handle h, double* costs);
+/* value = max over the ranks of value (a host double; doubles as a barrier: it returns when every rank has entered) */
+int pddp_comm_allreduce_max(pddp_comm_handle c, double* value);
+/* the configuration a handle was created with */
+int pddp_get_config(pddp_handle h, pddp_config* out);
+
 typedef struct pddp_state {      /* per problem, all scalars as double regardless of dtype */
     double rho, drho, prevJ, dJ, z;
     int iter, alphaIndex, ignore_defect, accepted, done, cur, cur2, bp_retries;

@@ -25,6 +25,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 extern "C" const char* pddp_last_error(void) { return g_err.c_str(); }
+int pddp_internal_fail(int code, const std::string& msg) { return fail(code, msg); }      // for the library's other translation units (pddp_comm.hip)
 #ifdef PDDP_USER_PLANT_HEADER
 static constexpr int kMaxPlant = 5, kUserNX = 2 * pddp::kUserPlantNPOS, kUserNU = pddp::kUserPlantNU;
 #else
@@ -746,6 +747,7 @@ extern "C" int pddp_mpc_solve(pddp_handle h, const void* xActual, const void* xG
     if (!xActual || !xGoal || !shift) return fail(PDDP_EINVAL, "pddp_mpc_solve: null argument");
     return s->mpc_solve(xActual, xGoal, shift, clear_vars, full_rollout, ifd, max_iter, time_budget_ms, poll_every, x, u, KT, Jout, alphaOut, success, iters);
 }
+extern "C" int pddp_get_config(pddp_handle h, pddp_config* out) { IMPL(h); if (!out) return fail(PDDP_EINVAL, "null argument"); *out = s->cfg; return 0; }
 extern "C" int pddp_stream(pddp_handle h, void** hip_stream) { IMPL(h); if (!hip_stream) return fail(PDDP_EINVAL, "null argument"); *hip_stream = (void*)s->stream; return 0; }
 
 // runiLQR_GPU (DDPWrappers.cuh:10-138) for the batch.

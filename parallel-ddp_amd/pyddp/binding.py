@@ -102,6 +102,64 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class Comm:
+    """The C ABI's multi-GPU communicator (include/pddp.h "multi-GPU"): RCCL collectives on the solvers' own streams.  One per process / GPU.
+    Rendezvous through a file: rank 0 writes the unique id, the others wait for it (any other transport of the 128 bytes works as well)."""
+
+    def __init__(self, rank, world, device, id_path=None, timeout_s=120.0, _lib_path=None):
+        import time
+        self.lib = _load(_lib_path or library_path())
+        self.rank, self.world = rank, world
+        blob = C.create_string_buffer(128)
+        if world > 1 and id_path is None:
+            raise PddpError("Comm: a world > 1 needs a rendezvous file path shared by the ranks")
+        if rank == 0:
+            if self.lib.pddp_comm_unique_id(blob):
+                raise PddpError(self.lib.pddp_last_error().decode())
+            if id_path:
+                tmp = id_path + ".tmp"
+                with open(tmp, "wb") as f:
+                    f.write(blob.raw)
+                os.replace(tmp, id_path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(id_path):
+                if time.time() - t0 > timeout_s:
+                    raise PddpError("Comm: timed out waiting for the rendezvous file " + id_path)
+                time.sleep(0.01)
+            blob = C.create_string_buffer(open(id_path, "rb").read(), 128)
+        self.h = C.c_void_p()
+        if self.lib.pddp_comm_init(C.byref(self.h), int(rank), int(world), blob, int(device)):
+            raise PddpError(self.lib.pddp_last_error().decode())
+
+    def _chk(self, rc):
+        if rc:
+            raise PddpError(f"pddp error {rc}: {self.lib.pddp_last_error().decode()}")
+
+    def all_done(self, solver):
+        flag = C.c_int(0)
+        self._chk(self.lib.pddp_comm_all_done(self.h, solver.h, C.byref(flag)))
+        return bool(flag.value)
+
+    def allgather_costs(self, solver):
+        out = np.zeros((self.world * solver.cfg.batch, 2), np.float64)
+        self._chk(self.lib.pddp_comm_allgather_costs(self.h, solver.h, _p(out)))
+        return out
+
+    def max_over_ranks(self, value):
+        v = C.c_double(float(value))
+        self._chk(self.lib.pddp_comm_allreduce_max(self.h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        self.max_over_ranks(0.0)
+
+    def close(self):
+        if self.h:
+            self.lib.pddp_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Solver:
     """One pddp handle = the buffers of allocateMemory_GPU for `batch` problems + the solver kernels."""
 

@@ -415,6 +415,15 @@ extern "C" int pddp_iterate(pddp_handle h, int sweeps) { return h->impl->iterate
 extern "C" int pddp_sync(pddp_handle) { return 0; }
 extern "C" int pddp_status(pddp_handle h, int* done, int* iters) { return h->impl->status(done, iters); }
 extern "C" int pddp_store(pddp_handle h, void* x, void* u, void* KT, void* Jout, int* alphaOut, void* dmax) { return h->impl->store(x, u, KT, Jout, alphaOut, dmax); }
+// multi-GPU exchanges: the host emulation is a single "rank" without a device; the entry points exist so that the symbol check passes
+extern "C" int pddp_comm_unique_id(void*) { return fail(PDDP_ENODEVICE, "host emulation: no RCCL"); }
+extern "C" int pddp_comm_init(pddp_comm_handle*, int, int, const void*, int) { return fail(PDDP_ENODEVICE, "host emulation: no RCCL"); }
+extern "C" int pddp_comm_destroy(pddp_comm_handle) { return 0; }
+extern "C" int pddp_comm_ranks(pddp_comm_handle, int*, int*) { return fail(PDDP_ENODEVICE, "host emulation: no RCCL"); }
+extern "C" int pddp_comm_all_done(pddp_comm_handle, pddp_handle, int*) { return fail(PDDP_ENODEVICE, "host emulation: no RCCL"); }
+extern "C" int pddp_comm_allgather_costs(pddp_comm_handle, pddp_handle, double*) { return fail(PDDP_ENODEVICE, "host emulation: no RCCL"); }
+extern "C" int pddp_comm_allreduce_max(pddp_comm_handle, double*) { return fail(PDDP_ENODEVICE, "host emulation: no RCCL"); }
+extern "C" int pddp_get_config(pddp_handle h, pddp_config* out) { *out = h->impl->cfg; return 0; }
 extern "C" int pddp_time_kernels(pddp_handle h, int sweeps, float* ms6, char* names, int stride) { h->impl->iterate(sweeps); for (int i = 0; i < 6; i++) { ms6[i] = 0; if (names) names[(size_t)i * stride] = 0; } return 0; }
 extern "C" int pddp_time_sweeps(pddp_handle h, int sweeps, float* t, float* ph) { h->impl->iterate(sweeps); if (t) *t = 0; if (ph) for (int i = 0; i < 4; i++) ph[i] = 0; return 0; }
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { h->impl->bench = on ? 1 : 0; return 0; }

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -66,3 +67,78 @@ def test_world_size_2_gloo_matches_single_process(tmp_path):
     assert np.array_equal(costs[:, 0].astype(np.float32), J0) and np.array_equal(costs[:, 1].astype(np.float32), Jf)
     assert res["best"][0] == int(np.argmin(Jf))
     assert res["sweeps"] % 3 == 0
+
+
+WORKER4 = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, os.path.join(%(root)r, "parallel-ddp_amd"))
+import pyddp
+from pyddp import shard
+from backends import hostsim_path
+from oracle_binding import example_inputs
+ctx = shard.init_from_env(4, backend="gloo")
+assert ctx.world == 4
+kw = dict(N=16, M=2, A=2, wafr_urdf=1, tol_cost=1e-3, total_time=0.25, max_iter=6)
+rng = np.random.default_rng(4)
+path = hostsim_path()
+mk = lambda batch: pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=batch, **kw), _lib_path=path)
+def problems(total):
+    out = [example_inputs(4, 16, np.float32, noise=rng.normal(0, 0.01 * (b + 1), (16, 14))) for b in range(total)]
+    return [p[0] for p in out], [p[1] for p in out], [p[2] for p in out]
+rejected = False
+try:
+    shard.solve_sharded(ctx, mk, *problems(6), poll_every=2)          # 6 problems do not split over 4 ranks
+except ValueError as e:
+    rejected = "multiple of the number of ranks" in str(e)
+assert rejected
+res = shard.solve_sharded(ctx, mk, *problems(8), poll_every=2)       # 2 per rank
+assert shard.owned_problems(8, ctx.rank, 4) == [ctx.rank, ctx.rank + 4]
+assert res["costs"].shape == (8, 2) and (res["costs"][:, 1] <= res["costs"][:, 0] + 3e-3).all()   # (a solve that rejects everything records prevJ = J + 2 TOL_COST, nisInitHelpers.cuh:393)
+if ctx.rank == 0:
+    json.dump(dict(costs=res["costs"].tolist(), best=res["best"]), open(sys.argv[1], "w"))
+shard.finalize(ctx)
+'''
+
+
+def test_world_size_4_gloo_uneven_batch_is_rejected_and_an_even_one_gathers_in_global_order(tmp_path):
+    out = tmp_path / "res4.json"
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4 % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                           "--master-port", "29614", str(script), str(out)], env=env, timeout=900)
+    import json
+    res = json.load(open(out))
+    costs = np.asarray(res["costs"])
+    assert costs.shape == (8, 2) and res["best"][0] == int(np.argmin(costs[:, 1]))
+    assert len(set(np.round(costs[:, 0], 3))) == 8              # eight different problems, each reported once
+
+
+@pytest.mark.gpu
+def test_native_rccl_exchanges_of_the_c_abi_world_of_one():
+    """include/pddp.h "multi-GPU": pddp_comm_init / pddp_comm_all_done / pddp_comm_allgather_costs / pddp_comm_allreduce_max with RCCL on the solver's
+    stream.  The GPU box has one device, so the communicator has one rank: the collectives run for real (ncclAllReduce, ncclAllGather) and must
+    return exactly what the handle holds."""
+    import pyddp
+    from oracle_binding import example_inputs
+    kw = dict(N=32, M=4, A=4, wafr_urdf=1, tol_cost=1e-3, total_time=0.5, max_iter=12)
+    B = 6
+    s = pyddp.Solver(pyddp.default_config(4, batch=B, **kw))
+    rng = np.random.default_rng(5)
+    xs, us, gs = zip(*[example_inputs(4, 32, np.float32, noise=rng.normal(0, 0.01 * (b + 1), (32, 14))) for b in range(B)])
+    s.load(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    c = pyddp.Comm(0, 1, 0)
+    assert not c.all_done(s)
+    polls = 0
+    while not c.all_done(s) and polls < 100:
+        s.iterate(4); polls += 1
+    done, iters = s.status()
+    assert done.all() and c.all_done(s)
+    costs = c.allgather_costs(s)
+    out = s.store()
+    assert costs.shape == (B, 2)
+    np.testing.assert_array_equal(costs[:, 0], out["Jout"][:, 0].astype(np.float64))
+    np.testing.assert_array_equal(costs[:, 1], out["Jout"][np.arange(B), iters].astype(np.float64))
+    assert c.max_over_ranks(3.5) == 3.5
+    c.close(); s.close()

@@ -139,6 +139,8 @@ struct Solver : SolverBase {
         return 0;
     }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
+    bool tl_store = false;         // thread-lane path: the rollouts store every candidate and the winner is copied (PDDP_TL_STORE=1) instead of re-rolled
+    bool sweep_per_alpha = false;  // PDDP_SWEEP=alpha: the per-candidate lane-group sweep also on the thread-lane path (comparison)
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
@@ -172,6 +174,9 @@ struct Solver : SolverBase {
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
+        if (const char* v = std::getenv("PDDP_SWEEP")) sweep_per_alpha = (std::string(v) == "alpha");
+        tl_store = c.batch <= 2048;         // measured (profiles/r02_kernel_times.txt): 1024 problems 0.47 ms per sweep stored vs 0.56 re-rolled; 4096: 1.19 vs 1.18; 8192: 2.30 vs 2.10
+        if (const char* v = std::getenv("PDDP_TL_STORE")) tl_store = (std::string(v) == "1");
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
@@ -286,10 +291,14 @@ struct Solver : SolverBase {
             const unsigned chunks = (A_all > 8 && A_all % 8 == 0) ? A_all / 8 : 1;      // one workgroup per 8 candidates when they tile exactly (see k_fp_lg)
             const int A_eff = A_all / chunks;
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
-            if (!init_rollout && cfg.M > 1 && part != 1) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
+            if (!init_rollout && cfg.M > 1 && part != 1) {
+                bool st = false;
+                if constexpr (sizeof(T) == 4) { if (fp_path == kFpTl && !sweep_per_alpha) { launch_sweep_st(s, b, dm, (int)B); st = true; } }
+                if (!st) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
+            }
             if (part == 0) return;
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
-                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
+                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates || tl_store);
                 return;
             }
             const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
@@ -308,7 +317,9 @@ struct Solver : SolverBase {
         const unsigned B = cfg.batch;
         if constexpr (P::PLANT == 4) {
             if (fp_path == kFpTl) {
-                if (mode == 0 && part != 1) launch_win_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);     // the accepted candidate becomes the current trajectory
+                if (mode == 0 && part != 1) {                      // the accepted candidate becomes the current trajectory: re-rolled, or copied from its stored slot
+                    if (tl_store) launch_adopt_tl<T>(s, b, dm, (int)B); else launch_win_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
+                }
                 if (part != 0) launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);
                 return;
             }
@@ -344,7 +355,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? "k_sweep_lg" : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", tl ? "k_win_tl" : "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
+                             (lg && cfg.M > 1) ? ((tl && sizeof(T) == 4 && !sweep_per_alpha) ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", tl ? (tl_store ? "k_adopt_tl" : "k_win_tl") : "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bodies.hpp"
+#include "fp_lg.hpp"
 #include "tl_launch.hpp"
 
 namespace pddp {
@@ -109,6 +110,71 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
     b.parts_fresh[pb] = 1;
 }
 
+// k_sweep_st: grid ceil(2 B / 8), block 64.  The linear sweep of forwardSweepKern (fpHelpers.cuh:19-63) for ALL candidates of a problem at once.
+// The sweep is affine in the step size: with e_k = x_k - xcur_k,  e_{k+1} = F_k e_k - alpha (B du)_k + [boundary] d_k,  e_0 = 0,  so
+//     e_k(alpha) = t_k - alpha s_k      with   s_{k+1} = F_k s_k + (B du)_k,   t_{k+1} = F_k t_k + [boundary] d_k,   s_0 = t_0 = 0,
+// and two sequences serve every alpha: group 2 pb walks s, group 2 pb + 1 walks t (8-lane groups as in fp_lg.hpp: lane l owns entries l and l + 7,
+// F_k's rows stream through registers one step ahead, the running vector is broadcast inside the group by DPP), and at the M - 1 segment
+// boundaries the two groups swap their vectors and write x_start(alpha_a) = xcur + (t - alpha_a s) into every candidate's slot -- a quarter of
+// the lane-group sweep's work for 8 alphas, and the same numbers up to rounding (float handles only; the float32 bar covers it).
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+__global__ __launch_bounds__(64) void k_sweep_st(Buffers<float> b, Dims dm, int batch) {
+    using L = LgDevice<float>;
+    constexpr int NX = 14, NP = 7;
+    const int gi = blockIdx.x * kLgPerWave + (threadIdx.x >> 3), pb = gi >> 1, which = gi & 1;
+    if (pb >= batch || L::lane() == 7 || !fp_active<float>(b, dm, pb)) return;       // lane 7 of every group stays inactive (lanegroup.hpp)
+    const unsigned pbN = (unsigned)pb * dm.N, oxc = ((unsigned)pb * 2 + b.state[pb].cur) * dm.N * NX;
+    const int k_last = (dm.M - 1) * dm.NB - 1, A = dm.A, a0 = which ? (A + 1) / 2 : 0, a1 = which ? A : (A + 1) / 2;
+    float eq = 0.f, ev = 0.f;                                          // entries l, l + 7 of s (which = 0) or t (which = 1)
+    // F_k's two rows and the inhomogeneous term of step k, fetched kDepth steps ahead into a ring of register sets (the chain is serial and short on
+    // arithmetic: what it waits for is the ~1 us latency of these gathers, so several steps of them have to be in flight)
+    constexpr int kDepth = 4;
+    float Aq[kDepth][NX], Av[kDepth][NX], cq[kDepth], cv[kDepth];
+    const float* add = which ? b.dcur : b.Bdu;                        // the inhomogeneous term of this group's sequence
+    auto fetch = [&](int slot, int k) {
+        const unsigned oA = (pbN + k) * 196, ob = (pbN + k) * 14;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { Aq[slot][i] = L::gather_at(b.ApBK, oA, [i](int l) { return l + 14 * i; }); Av[slot][i] = L::gather_at(b.ApBK, oA, [i](int l) { return l + 7 + 14 * i; }); }
+        cq[slot] = L::gather_at(add, ob, [](int l) { return l; }); cv[slot] = L::gather_at(add, ob, [](int l) { return l + 7; });
+    };
+    auto step = [&](int slot, int k) {
+        float bc[14];
+        lg_bcast14<L>(bc, eq, ev);
+        float vq = Aq[slot][0] * bc[0], vv = Av[slot][0] * bc[0];
+#pragma unroll
+        for (int i = 1; i < NX; i++) { vq += Aq[slot][i] * bc[i]; vv += Av[slot][i] * bc[i]; }
+        const bool bnd = dm.on_defect_boundary(k);
+        if (which == 0 || bnd) { vq += cq[slot]; vv += cv[slot]; }
+        eq = vq; ev = vv;
+        if (k + kDepth <= k_last) fetch(slot, k + kDepth);
+        if (bnd) {                                                    // segment start states of every candidate
+            const float oq = __shfl_xor(eq, 8), ov = __shfl_xor(ev, 8);
+            const float sq = which ? oq : eq, sv = which ? ov : ev, tq = which ? eq : oq, tv = which ? ev : ov;
+            const float nq = L::gather_at(b.xb, oxc, [k](int l) { return 14 * (k + 1) + l; }), nv = L::gather_at(b.xb, oxc, [k](int l) { return 14 * (k + 1) + l + 7; });
+            for (int a = a0; a < a1; a++) {
+                const float al = b.alpha[a];
+                const unsigned o = (((unsigned)pb * A + a) * dm.N + k + 1) * NX;
+                L::scatter_at(b.xs, o, [](int l) { return l; }, nq + (tq - al * sq), true);
+                L::scatter_at(b.xs, o, [](int l) { return l + NP; }, nv + (tv - al * sv), true);
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < kDepth; j++) if (j <= k_last) fetch(j, j);
+    for (int k0 = 0; k0 <= k_last; k0 += kDepth) {
+#pragma unroll
+        for (int j = 0; j < kDepth; j++) if (k0 + j <= k_last) step(j, k0 + j);
+    }
+}
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+void launch_sweep_st(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch) {
+    hipLaunchKernelGGL(k_sweep_st, dim3((2 * (unsigned)batch + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, batch);
+}
+
 // k_win_tl: grid ceil(B*M / 64), block 64.  Thread = (problem, segment): after an accepting line search, the winner's rollout again, written straight
 // into the current-trajectory buffers (arm_tl_rollout_winner).  One wave per workgroup so that the B*M/64 waves spread over all compute units.
 template <typename T, int V>
@@ -119,6 +185,31 @@ __global__ __launch_bounds__(64, 1) void k_win_tl(Buffers<T> b, Dims dm, CostWei
     const int pb = i / dm.M, seg = i - pb * dm.M;
     arm_tl_rollout_winner<T>(md, grav, b, dm, cw, dt, pb, seg);
 }
+
+// k_adopt_tl: grid ceil(B*N / 256), block 256.  Thread = knot.  When the sweep's rollout kernel stored every candidate (k_fp_tl<STORE>), the accepted
+// candidate becomes the current trajectory by a copy of its slot: x into the new half of xb, u into ucur, the boundary defects into dcur -- the
+// reference's memcpyCurrAKern / xp, up, dp copies (nisInitHelpers.cuh:24-32, 270-276), for the winner only.
+template <typename T>
+__global__ __launch_bounds__(256) void k_adopt_tl(Buffers<T> b, Dims dm, int batch) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= batch * dm.N) return;
+    const int pb = g / dm.N, k = g - pb * dm.N;
+    const SolverState<T>& st = b.state[pb];
+    if (!st.win_pending) return;
+    const size_t src = ((size_t)pb * dm.A + st.alphaIndex) * dm.N + k;
+    T v[14];
+    tl_load14(v, b.xs + src * 14);
+    tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * dm.N + k) * 14, v);
+#pragma unroll
+    for (int i = 0; i < 7; i++) b.ucur[((size_t)pb * dm.N + k) * 7 + i] = b.us[src * 7 + i];
+    if (dm.M > 1 && dm.on_defect_boundary(k)) { tl_load14(v, b.ds + src * 14); tl_store14(b.dcur + ((size_t)pb * dm.N + k) * 14, v); }
+}
+template <typename T>
+void launch_adopt_tl(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batch) {
+    hipLaunchKernelGGL((k_adopt_tl<T>), dim3(((unsigned)batch * dm.N + 255) / 256), dim3(256), 0, s, b, dm, batch);
+}
+template void launch_adopt_tl<float>(hipStream_t, const Buffers<float>&, const Dims&, int);
+template void launch_adopt_tl<double>(hipStream_t, const Buffers<double>&, const Dims&, int);
 
 // k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  float: the Jacobian of a wave's 64 knots is staged in
 // LDS (entry-major, padded to 65 so that both the per-thread writes and the transposed reads are conflict-free) and written out in THREE pieces

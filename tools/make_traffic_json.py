@@ -10,7 +10,7 @@ src = os.path.join(root, "gpurun_out", "pmc_" + tag)
 d = collections.defaultdict(list)
 for f in sorted(glob.glob(src + "/*/run_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("void pddp::", "").split("<")[0].split("(")[0]
+        k = r["Kernel_Name"].replace("void ", "").replace("pddp::", "").split("<")[0].split("(")[0]
         if k.startswith("k_"):
             d[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kern = sorted({k for k, _ in d})

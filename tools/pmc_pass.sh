@@ -16,7 +16,7 @@ for f in sorted(glob.glob("$OUT/*/run_counter_collection.csv")):
     d=collections.defaultdict(list)
     try:
         for r in csv.DictReader(open(f)):
-            k=r["Kernel_Name"].replace("void pddp::","").split("(")[0]
+            k=r["Kernel_Name"].replace("void ","").replace("pddp::","").split("(")[0]
             if k.startswith("k_"): d[(k,r["Counter_Name"])].append(float(r["Counter_Value"]))
     except Exception as e: print(f, e); continue
     names=sorted({c for _,c in d})

@@ -5,15 +5,22 @@
  * `cpu_baseline` leg may load it, and only as the checker / the reported CPU baseline.
  * The product path (parallel-ddp_amd/) never includes, links or calls anything in oracle/.
  *
- * Pinning status: the reference's own tests hold no golden vectors for this path
- * (SURVEY.md §4), and the reference cannot be compiled here without stand-in CUDA headers
- * (it includes cuda.h / cuda_runtime.h / cublas_v2.h / cusolverDn.h, absent from this image),
- * so no oracle/_ref build exists.  The oracle is pinned against the known answers recorded in
- * SURVEY.md §8(c) / Appendix E (values the survey session measured from the reference's host
- * instantiation): see tests/golden/survey_kat.json and tests/test_oracle_pins.py.
+ * Pinning status: no oracle/_ref build exists -- the reference cannot be compiled here without stand-in CUDA
+ * headers (cuda.h / cuda_runtime.h / cublas_v2.h / cusolverDn.h are absent from this image).
+ *   PINNED by reference-held data, through generators committed under tests/golden/: the KUKA plant functions (an independent
+ *   RNEA/CRBA on plants/iiwa14.urdf, the gravity-balancing torques the example holds, the probe states of test/printDyn.cu:
+ *   tests/test_urdf_pins.py); the pendulum / cart-pole / quadrotor plug-ins and cost weights (the reference's own statements
+ *   executed in float64: tests/test_closed_form_pins.py); tool-point kinematics and the error metric (the recorded run of
+ *   test/WAFR_fig8.py: tests/test_fig8_pins.py).
+ *   PARITY UNPINNED: the iLQR loop itself (backward pass, line search, bookkeeping; runiLQR_CPU and GPU semantics).  The
+ *   reference's tests hold no golden vectors for it; the J / alpha traces in tests/golden/survey_kat.json were recorded from
+ *   a build of the reference host code against stand-in CUDA headers and are kept only as a quarantined regression check
+ *   (two artefacts of that build are emulated by ora_cfg.survey_* flags that no parity test uses).
+ *   PARITY UNPINNED: the end-effector cost family (ee_cost = 1): its restatement follows the reference's index expressions and is
+ *   cross-checked against finite differences and an independent forward kinematics only (tests/test_ee_cost.py).
  *
- * The end-effector cost family (ee_cost = 1; added for SURVEY.md section 8f row N2) is PARITY UNPINNED: the survey holds no reference
- * outputs for it.  Its restatement follows the reference's index expressions and is cross-checked analytically only (tests/test_ee_cost.py).
+ * liboracle_fma.so is the same source compiled with contracted multiply-adds (how nvcc compiles the reference's device code): a member of
+ * the float32 noise-floor ensemble of tests/test_fp32_bar.py, never a reference by itself.
  *
  * Two instantiations are exported: suffix _f32 (algType float, config.cuh:74) and _f64.
  */

@@ -82,3 +82,17 @@ def test_cpu_entry_point_float32_and_thread_counts():
     assert [v.value for v in t] == [4, 4, 4, 4]                        # config.cuh:156-159 with CPU_CORES 8
     lib.pddp_cpu_thread_counts(4, 256, *[C.byref(v) for v in t])
     assert [v.value for v in t] == [4, 4, 128, 128]
+
+
+def test_cpu_library_exports_every_declared_symbol_and_the_header_is_c99():
+    import re
+    import subprocess
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pddp_cpu.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(pddp_cpu_[a-z_0-9]+)\s*\(", text)))
+    lib = C.CDLL(LIB)
+    assert len(syms) >= 3
+    for s in syms:
+        assert hasattr(lib, s), s
+    src = os.path.join(ROOT, "tests", "cabi", "cpu_hdr.c")
+    open(src, "w").write('#include "pddp_cpu.h"\nint main(void) { return pddp_cpu_last_error() == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", os.devnull])

@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "ab_compact.hpp"
 #include "solver_state.hpp"
 
 namespace pddp {
@@ -143,11 +144,50 @@ __device__ __forceinline__ void mx_load_knot(MxKnotIn<FS, DIAGH>& k, const float
     }
 }
 
+// The same operands from the COMPACT [A B] (ab_compact.hpp): only state rows 7..13 of a column are in memory, seven consecutive floats.  One 16-byte
+// load per tile and lane at an offset that depends on the lane's row group g -- g = 1: the column's first float (row 7, wanted in register 3), g = 2:
+// floats 1..4 (rows 8..11), g = 3: floats 5, 6 (rows 12, 13; the two floats read beyond the column are discarded), g = 0: nothing wanted -- and the
+// constant rows {1, dt, 0} of the Euler step come from compares.  pA / pB: this lane's column of the knot's share of its piece (wave-uniform knot part
+// already added), pT0 / pT1: B(row c, controls 2g, 2g + 1).
+template <bool FS, bool DIAGH>
+__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<FS, DIAGH>& k, const float* pA, const float* pB, const float* pT0, const float* pT1, const float* gk,
+                                                     int g, int c, int ub, float dt) {
+    constexpr int NX = 14, NU = 7;
+    const int row0 = 4 * g, u0 = 2 * g;
+    const bool cx = c < NX, cu = ub < NU, c14 = (c == NX);
+    const mx4 ta = *reinterpret_cast<const mx4u*>(pA);
+    const mx4 tb = *reinterpret_cast<const mx4u*>(pB);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = row0 + r;
+        const float ca = (c == row) ? 1.f : ((c == row + 7) ? dt : 0.f);              // rows < 7 of A; B has zeros there
+        const float da = (g == 1) ? ta[0] : ta[r], db = (g == 1) ? tb[0] : tb[r];     // the dynamic row this register holds, if any
+        const bool dyn = (row >= 7) && (row < NX);
+        k.A0[r] = cx ? (dyn ? da : (row < 7 ? ca : 0.f)) : 0.f;
+        k.B1[r] = (cu && dyn) ? db : 0.f;
+    }
+    if (FS) {
+        const float t0 = *pT0, t1 = *pT1;
+        k.BT0 = (cx && c >= 7) ? t0 : 0.f; k.BT1 = (cx && c >= 7 && u0 + 1 < NU) ? t1 : 0.f;
+    }
+    static_assert(DIAGH, "the compact [A B] is produced by the thread-lane setup kernel, whose cost Hessian is the joint-space diagonal");
+    const mx4 gx = *reinterpret_cast<const mx4u*>(gk + row0);
+    const float gu0 = gk[NX + u0], gu1 = gk[NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)];
+#pragma unroll
+    for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && row0 + r < NX) ? gx[r] : 0.f;
+    k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
+    k.hx = 0.f; k.hu = 0.f;
+}
+
 // One (problem, block of knots).  lds: 96 floats of this wave.  FS: M > 1 (write the forward-sweep operands A - B K, B du).
 // DIAGH: the cost Hessian of every running knot is the joint-space cost's diag(Q1 x 7, Q2 x 7, R x 7) (plants/cost_arm.cuh:158-202, ArmPlant::weight):
 // the setup kernel wrote exactly those numbers into H, so they are taken from the launch arguments (hq1, hq2, hr) and H is not read in the loop.
-template <bool FS, bool DIAGH>
-__device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims& dm, int pb, int blk, float hq1, float hq2, float hr) {
+// CAB: [A B] comes from the compact array b.ABc (ab_compact.hpp; dt rebuilds the constant rows).  keepP = 0: only the cost-to-go slots a later pass reads are
+// written -- the one in front of the block's first knot, which the neighbouring block's next pass starts from (the reference's d_Pp / d_pp boundary slots); the
+// per-knot P, p of the interior are by-products nobody reads (not an output of runiLQR_GPU).  The phase hook and MPC handles (whose warm start shifts the
+// whole array, MPCHelpers.cuh:602-655) pass keepP = 1.
+template <bool FS, bool DIAGH, bool CAB>
+__device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims& dm, int pb, int blk, float hq1, float hq2, float hr, float dt, int keepP) {
     constexpr int NX = 14, NU = 7, NM = 21, SZP = NX * NX, SZAB = NX * NM, SZH = NM * NM;
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g, u0 = 2 * g;
     const int ub = ((c & 3) < 2) ? 2 * (c >> 2) + (c & 3) : 8;       // the control whose column this lane holds in control-column tiles (8: none)
@@ -171,7 +211,7 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     if (ks == N - 1) {                                                // last block: the final cost (bpHelpers.cuh:362-367)
         const float* Hf = H + (size_t)ks * SZH; const float* gf = gg + (size_t)ks * NM;
         Pa = mx_load_rows4(cx ? Hf + c * NM + row0 : gf + row0, row0, NX, cx || c14);
-        mx_store_rows4(cx ? Pw + (size_t)(ks - 1) * SZP + c * NX + row0 : pw + (size_t)(ks - 1) * NX + row0, row0, NX, cx || c14, Pa);
+        if (keepP) mx_store_rows4(cx ? Pw + (size_t)(ks - 1) * SZP + c * NX + row0 : pw + (size_t)(ks - 1) * NX + row0, row0, NX, cx || c14, Pa);
         ks--; iterCount = NBk - 2;
     } else {                                                          // boundary cost-to-go of the previous iteration + linear transform (:18-34)
         iterCount = NBk - 1;
@@ -202,10 +242,26 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     const float* ABk = AB + (size_t)ks * SZAB; const float* Hk = H + (size_t)ks * SZH; const float* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
     float* KTk = KT + (size_t)ks * (NX * NU); float* duk = du + (size_t)ks * NU; float* Fk = ApBK + (size_t)ks * SZP; float* Bduk = Bdu + (size_t)ks * NX;
     float* Pk = Pw + (size_t)(ks - 1) * SZP; float* pk = pw + (size_t)(ks - 1) * NX;
+    // compact [A B]: per-lane float offsets of this lane's columns inside a knot's share of their pieces, and the per-knot strides of those pieces
+    int oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
+    if (CAB) {
+        const int cc = cx ? c : NX - 1, uc = cu ? ub : NU - 1, roff = g == 2 ? 1 : g == 3 ? 5 : 0;
+        const int pa = abc_piece(cc);
+        sA = abc_piece_cols(pa) * 7;
+        oA = abc_piece_off(pa) + abc_col_in_piece(cc) * 7 + roff;
+        oB = abc_piece_off(2) + uc * 7 + roff;
+        const int tr = cx && c >= 7 ? c - 7 : 0, u1 = u0 + 1 < NU ? u0 + 1 : NU - 1;
+        oT0 = abc_piece_off(2) + u0 * 7 + tr; oT1 = abc_piece_off(2) + u1 * 7 + tr;
+    }
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
         // No register prefetch of the next knot: measured on MI355X (profiles/r02_bp_mfma_experiments.md) the 18 registers it costs are worth more
         // as a fifth resident wave per SIMD (95 registers -> 5 waves: 0.53 ms for 4096 problems, against 0.58 ms with prefetch and 4 waves).
-        mx_load_knot<FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
+        if constexpr (CAB) {
+            const size_t G = knot0 + (size_t)ks;
+            const float* ch = b.ABc + (G >> 6) * kAbcChunk;
+            const int kk = (int)(G & 63);
+            mx_load_knot_compact<FS, DIAGH>(in, ch + oA + kk * sA, ch + oB + kk * 49, ch + oT0 + kk * 49, ch + oT1 + kk * 49, gk, g, c, ub, dt);
+        } else mx_load_knot<FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
         const MxKnotIn<FS, DIAGH>& k = in;
         ABk -= SZAB; Hk -= SZH; gk -= NM;
         // ---- cost blocks in tile form
@@ -285,7 +341,7 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
             val = mx_mfma2(-Kp, Hux, val);
             mx4 Pn = Hxx + val;
             if (g == 3) { Pn[2] = 0.f; Pn[3] = 0.f; }                 // rows 14, 15 carry by-products of column 14: keep the padding clean
-            mx_store_rows4(cx ? Pk + c * NX + row0 : pk + row0, row0, NX, cx || c14, Pn);
+            if (keepP || iter == 0) mx_store_rows4(cx ? Pk + c * NX + row0 : pk + row0, row0, NX, cx || c14, Pn);
             Pa = Pn;
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;

@@ -68,24 +68,39 @@ PDDP_HD T arm_tl_cost(const CostWeights<T>& cw, const T* x, const T* u, const T*
     return T(0.5) * (cw.Q1 * sq + cw.Q2 * sv + cw.R * su);
 }
 
+// The control law of one knot, u = uc - (alpha du + K (x - xr))   (computeControlKT, DDPHelpers/fpHelpers.cuh:202-221): ONE definition with explicit
+// fused multiply-adds, because two kernels evaluate it for the accepted candidate -- the rollout that produced its states and the setup kernel that
+// adopts them (arm_tl_adopt_knot) -- and both must get the same bits.  Kk[98] = K(r, c) at [c + 14 r].
+template <typename T> PDDP_HD T tl_fma(T a, T b, T c);
+template <> PDDP_HD float tl_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> PDDP_HD double tl_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T>
+PDDP_HD void tl_control_law(T* u, T alpha, const T* du, const T* Kk, const T* x, const T* xr, const T* uc) {
+    T dx[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) dx[i] = x[i] - xr[i];
+#pragma unroll
+    for (int rr = 0; rr < 7; rr++) {
+        T acc = alpha * du[rr];
+#pragma unroll
+        for (int c = 0; c < 14; c++) acc = tl_fma(Kk[rr * 14 + c], dx[c], acc);
+        u[rr] = uc[rr] - acc;
+    }
+}
+
 // One rollout = one (problem, candidate, shooting segment).  The per-step operands (gain K_k, reference state, nominal control, feed-forward)
-// are handed in as pointers: global memory on the host / in the winner kernel, the wave's LDS staging area in k_fp_tl.
+// are handed in as pointers: global memory on the host, the wave's LDS staging area in k_fp_tl.
 //   begin(): start state (the current state for segment 0, else what the linear sweep left in the candidate's slot)
 //   step():  control law, running cost, dynamics, Euler step; the last step of a non-final segment produces the boundary defect
 //   end():   terminal knot (last segment), partial sums out
-// Where the trajectory goes is the Sink's business: NoSink (production sweep: candidates are not stored -- only the winner's trajectory is
-// ever read again, and the winner kernel re-rolls it), CandidateSink (teacher-forcing hook: every candidate's x, u, d as the reference keeps
-// them), WinnerSink (the accepted candidate straight into the current-trajectory buffers).
+// Where the trajectory goes is the Sink's business: StateSink (production sweep: every candidate's STATES and boundary defects go to its slot of
+// xs / ds -- 56 bytes per step; the controls are not stored: the setup kernel recomputes the accepted candidate's from its states with the same
+// control law, arm_tl_adopt_knot), CandidateSink (teacher-forcing hook: x, u, d of every candidate as the reference keeps them).
 template <typename T>
 struct TlRollout {
     T x[14]; T J; T sdef;
     int pb, a_idx, seg, kStart, iters;
     T alpha;
-};
-struct TlNoSink {
-    template <typename T> PDDP_HD void x(int, const T*) const {}
-    template <typename T> PDDP_HD void u(int, const T*) const {}
-    template <typename T> PDDP_HD void d(int, const T*) const {}
 };
 template <typename T> struct TlCandidateSink {         // candidate slot of xs / us / ds
     T* xs; T* us; T* ds;
@@ -96,14 +111,11 @@ template <typename T> struct TlCandidateSink {         // candidate slot of xs /
     }
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
-template <typename T> struct TlWinnerSink {            // new current trajectory: the other half of xb, ucur, dcur
-    T* xn; T* uc; T* dc;
-    PDDP_HD void x(int k, const T* v) const { tl_store14(xn + (size_t)k * 14, v); }
-    PDDP_HD void u(int k, const T* v) const {
-#pragma unroll
-        for (int i = 0; i < 7; i++) uc[(size_t)k * 7 + i] = v[i];
-    }
-    PDDP_HD void d(int k, const T* v) const { tl_store14(dc + (size_t)k * 14, v); }
+template <typename T> struct TlStateSink {             // candidate slot of xs / ds; controls dropped
+    T* xs; T* ds;
+    PDDP_HD void x(int k, const T* v) const { tl_store14(xs + (size_t)k * 14, v); }
+    PDDP_HD void u(int, const T*) const {}
+    PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
 
 template <typename T, typename Sink>
@@ -121,16 +133,8 @@ PDDP_HD void tl_rollout_step(TlRollout<T>& r, const ArmTlModel<T>& md, T grav, c
                              const T* Kk, const T* xr, const T* uc, const T* du, const T* xg, const Sink& sink) {
     constexpr int NX = 14, NU = 7;
     const int kn = r.kStart + k;
-    T dx[NX], u[NU];
-#pragma unroll
-    for (int i = 0; i < NX; i++) dx[i] = r.x[i] - xr[i];
-#pragma unroll
-    for (int rr = 0; rr < NU; rr++) {
-        T acc = r.alpha * du[rr];
-#pragma unroll
-        for (int c = 0; c < NX; c++) acc += Kk[rr * NX + c] * dx[c];
-        u[rr] = uc[rr] - acc;
-    }
+    T u[NU];
+    tl_control_law<T>(u, r.alpha, du, Kk, r.x, xr, uc);
     sink.u(kn, u);
     r.J += arm_tl_cost<T>(cw, r.x, u, xg, false);
     ArmTlState<T> st;
@@ -165,7 +169,7 @@ PDDP_HD void tl_rollout_end(TlRollout<T>& r, const Dims& dm, const CostWeights<T
     }
 }
 
-// Whole segment with the operands read straight from global memory (host emulation; winner kernel).  part != 0: publish the partial sums.
+// Whole segment with the operands read straight from global memory (host emulation; candidate counts that do not tile a wave).  part != 0: publish the partial sums.
 template <typename T, typename Sink>
 PDDP_HD void arm_tl_rollout_segment(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int pb, int a_idx, int seg,
                                     const T* xcur, const Sink& sink, bool part) {
@@ -201,18 +205,59 @@ PDDP_HD TlCandidateSink<T> tl_candidate_sink(const Buffers<T>& b, const Dims& dm
     const size_t slot = (size_t)pb * dm.A + a_idx;
     return TlCandidateSink<T>{b.xs + slot * dm.N * 14, b.us + slot * dm.N * 7, b.ds + slot * dm.N * 14};
 }
-// After the line search accepted candidate st.alphaIndex (st.cur already points at the NEW half of xb): roll the winner out again, straight into
-// the current-trajectory buffers -- x into the new half of xb, u over ucur (each knot is read before it is written, by the same thread), the
-// boundary defects into dcur.  Same code, same inputs, same order as the candidate's rollout: the same numbers.  Replaces memcpyCurrAKern x3 and
-// the winner -> xp / up / dp copies of nextIterationSetupGPU (nisInitHelpers.cuh:270-276).
 template <typename T>
-PDDP_HD void arm_tl_rollout_winner(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int pb, int seg) {
+PDDP_HD TlStateSink<T> tl_state_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx) {
+    const size_t slot = (size_t)pb * dm.A + a_idx;
+    return TlStateSink<T>{b.xs + slot * dm.N * 14, b.ds + slot * dm.N * 14};
+}
+// After the line search accepted candidate st.alphaIndex (st.cur already points at the NEW half of xb): knot k of the winner becomes the current
+// trajectory -- its state from the candidate's slot of xs into the new half of xb, its control recomputed from that state with the rollout's own
+// control law (same operands: the gain, the OLD current state / control of this knot, the feed-forward; the same tl_control_law, so the same
+// bits the rollout used) over ucur, the boundary defect from ds into dcur.  Every knot is independent: this is the first step of the setup
+// kernel's thread.  Replaces memcpyCurrAKern x3 and the winner -> xp / up / dp copies of nextIterationSetupGPU (nisInitHelpers.cuh:24-32, 270-276).
+// Leaves the adopted x[14], u[7] with the caller.
+template <typename T>
+PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int pb, T* x, T* u) {
+    constexpr int NX = 14, NU = 7;
     const SolverState<T>& st = b.state[pb];
-    if (!st.win_pending) return;                                          // rejected, failed backward pass, or already finished: nothing moves
-    const size_t N = dm.N;
-    const T* xold = b.xb + ((size_t)pb * 2 + (1 - st.cur)) * N * 14;
-    TlWinnerSink<T> sink{b.xb + ((size_t)pb * 2 + st.cur) * N * 14, b.ucur + (size_t)pb * N * 7, b.dcur + (size_t)pb * N * 14};
-    arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, st.alphaIndex, seg, xold, sink, false);
+    const size_t N = dm.N, knot = (size_t)pb * N + k;
+    const size_t src = ((size_t)pb * dm.A + st.alphaIndex) * N + k;
+    tl_load14(x, b.xs + src * NX);
+    T* uc = b.ucur + knot * NU;
+    T ucv[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) ucv[i] = uc[i];
+    if (k < dm.N - 1) {
+        T xr[NX], duv[NU];
+        tl_load14(xr, b.xb + (((size_t)pb * 2 + (1 - st.cur)) * N + k) * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) duv[i] = b.du[knot * NU + i];
+        const T* Kg = b.KT + knot * (NX * NU);
+        const T alpha = b.alpha[st.alphaIndex];
+        T dx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) dx[i] = x[i] - xr[i];
+#pragma unroll
+        for (int rr = 0; rr < NU; rr++) {                                 // tl_control_law, one gain row in registers at a time
+            T Kr[NX];
+            tl_load14(Kr, Kg + rr * NX);
+            T acc = alpha * duv[rr];
+#pragma unroll
+            for (int c = 0; c < NX; c++) acc = tl_fma(Kr[c], dx[c], acc);
+            u[rr] = ucv[rr] - acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NU; i++) uc[i] = u[i];
+    } else {                                                              // the terminal knot carries its nominal control along unchanged (tl_rollout_end)
+#pragma unroll
+        for (int i = 0; i < NU; i++) u[i] = ucv[i];
+    }
+    tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX, x);
+    if (dm.M > 1 && dm.on_defect_boundary(k)) {
+        T d[NX];
+        tl_load14(d, b.ds + src * NX);
+        tl_store14(b.dcur + knot * NX, d);
+    }
 }
 
 // the line-search kernel's first step when the thread-lane forward pass ran: J[a] = sum of the segment partial sums in order, dmax[a] = max
@@ -226,23 +271,27 @@ PDDP_HD void tl_reduce_parts(const Buffers<T>& b, const Dims& dm, int pb) {
     }
 }
 
-// Next-iteration setup of knot k of problem pb (nis_body / arm_lg_nis_body) at the current trajectory, in two halves:
-//   arm_tl_nis_cost: g_k, (mode 1: H_k); returns false when this knot has no Jacobian to write (rejected / failed iteration, final knot, finished problem)
+// Next-iteration setup of knot k of problem pb (nis_body / arm_lg_nis_body), in two halves:
+//   arm_tl_nis_cost: (mode 0: adopt the accepted candidate's knot, arm_tl_adopt_knot), g_k, (mode 1: H_k); returns false when this knot has no Jacobian to
+//                    write (rejected / failed iteration, final knot, finished problem)
 //   arm_tl_nis_jac:  the Jacobian of the dynamics through emit(col, row, dqdd) -- the caller turns it into [A B] rows 7..13 (k_nis_tl stages it through
 //                    LDS in three pieces, flushed at mark(stage); see arm_tl_gradient)
+// x[14], u[7]: out -- the current state / control of the knot (mode 0: just adopted from the accepted candidate).
 template <typename T>
-PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb) {
+PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, T* x, T* u) {
     constexpr int NX = 14, NU = 7, NM = 21;
     const int N = dm.N;
     const SolverState<T>& st = b.state[pb];
     const size_t knot = (size_t)pb * N + k;
-    const T* xc = b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX;
-    const T* uc = b.ucur + knot * NU;
-    T x[NX], u[NU];
-    if (mode == 0 && (!st.win_pending || st.done)) return false;         // rejected / failed: nothing moved; final accepted step: no derivatives needed
-    tl_load14(x, xc);                                                     // the winner kernel (arm_tl_rollout_winner) has already put the new trajectory here
+    if (mode == 0) {
+        if (!st.win_pending) return false;                                // rejected / failed: nothing moved
+        arm_tl_adopt_knot<T>(b, dm, k, pb, x, u);
+        if (st.done) return false;                                        // final accepted step: the trajectory is adopted, no derivatives needed
+    } else {
+        tl_load14(x, b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX);
 #pragma unroll
-    for (int i = 0; i < NU; i++) u[i] = uc[i];
+        for (int i = 0; i < NU; i++) u[i] = b.ucur[knot * NU + i];
+    }
     const bool fin = (k == N - 1);
     const T w1 = fin ? cw.QF1 : cw.Q1, w2 = fin ? cw.QF2 : cw.Q2, w3 = fin ? T(0) : cw.R;       // ArmPlant::weight
     T xg[NX];
@@ -256,17 +305,9 @@ PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeig
     }
     return !fin;
 }
+// the Jacobian of the dynamics at (x, u) through emit(col, row, dqdd)
 template <typename T, typename Emit, typename Mark>
-PDDP_HD void arm_tl_nis_jac(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, int k, int pb, Emit emit, Mark mark) {
-    constexpr int NX = 14, NU = 7;
-    const int N = dm.N;
-    const SolverState<T>& st = b.state[pb];
-    const T* xc = b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX;
-    const T* uc = b.ucur + ((size_t)pb * N + k) * NU;
-    T x[NX], u[NU];
-    tl_load14(x, xc);
-#pragma unroll
-    for (int i = 0; i < NU; i++) u[i] = uc[i];
+PDDP_HD void arm_tl_nis_jac(const ArmTlModel<T>& md, T grav, const T* x, const T* u, Emit emit, Mark mark) {
     ArmTlState<T> ts;
     T qdd[7];
     arm_tl_dynamics<T>(md, grav, ts, qdd, x, x + 7, u);
@@ -274,8 +315,9 @@ PDDP_HD void arm_tl_nis_jac(const ArmTlModel<T>& md, T grav, const Buffers<T>& b
 }
 template <typename T, typename Emit>
 PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, Emit emit) {
-    if (!arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb)) return false;
-    arm_tl_nis_jac<T>(md, grav, b, dm, k, pb, emit, [](int) {});
+    T x[14], u[7];
+    if (!arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u)) return false;
+    arm_tl_nis_jac<T>(md, grav, x, u, emit, [](int) {});
     return true;
 }
 

@@ -9,6 +9,8 @@ namespace pddp {
 
 // diag_h: the cost Hessian of every running knot is the joint-space cost's own diag(hq1 x 7, hq2 x 7, hr x 7), as the setup kernel wrote it:
 // the kernel takes the three numbers from here and does not read H in its loop (the final knot's block is always read)
-void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr);
+// b.ABc non-null (and diag_h): [A B] is read from the compact array (ab_compact.hpp), dt rebuilds its constant rows.  keep_P: write every knot's cost-to-go
+// (phase hook, MPC handles); otherwise only the block-boundary slots the next pass reads.
+void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr, float dt, bool keep_P);
 
 }  // namespace pddp

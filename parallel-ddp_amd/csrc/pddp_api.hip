@@ -86,6 +86,8 @@ struct SolverBase {
     int bench_mode = 0;
     bool h_overridden = false;     // pddp_set_array("H"): the cost Hessian is no longer known to be the plant's own (diagonal for the joint-space cost)
     virtual void drop_graph() = 0;
+    virtual int ab_view(int to_compact) = 0;       // compact [A B] handles (ab_compact.hpp): refresh the reference-layout array "AB" from the compact one (0) or the reverse (1)
+    virtual int ab_keep_reference_layout() = 0;   // leave the compact mode for good (the cost Hessian was overridden: the backward pass reads the reference layout then)
     hipStream_t stream = nullptr;
 };
 struct pddp_solver { SolverBase* impl; };
@@ -131,6 +133,18 @@ struct Solver : SolverBase {
     void derive_tl_model(const EmptyModel&) {}
     // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
     void drop_graph() override { if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; } }
+    int ab_view(int to_compact) override {
+        if constexpr (P::PLANT == 4 && sizeof(T) == 4) {
+            if (b.ABc) { launch_abc_convert(stream, b, (int)(cfg.batch * cfg.N), cfg.N, (float)dt, to_compact); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream)); }
+        }
+        return 0;
+    }
+    int ab_keep_reference_layout() override {
+        if (!b.ABc) return 0;
+        int rc = ab_view(0);
+        b.ABc = nullptr; drop_graph();
+        return rc;
+    }
     int model_changed() override {
         typename P::Model hm;
         HIPCHK(hipMemcpy(&hm, b.model, sizeof(hm), hipMemcpyDeviceToHost));
@@ -139,8 +153,8 @@ struct Solver : SolverBase {
         return 0;
     }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
-    bool tl_store = false;         // thread-lane path: the rollouts store every candidate and the winner is copied (PDDP_TL_STORE=1) instead of re-rolled
     bool sweep_per_alpha = false;  // PDDP_SWEEP=alpha: the per-candidate lane-group sweep also on the thread-lane path (comparison)
+    bool mpc_used = false;         // pddp_mpc_solve ran on this handle: its warm start shifts every cost-to-go slot, so the backward pass keeps writing all of them
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
@@ -175,8 +189,6 @@ struct Solver : SolverBase {
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
         if (const char* v = std::getenv("PDDP_SWEEP")) sweep_per_alpha = (std::string(v) == "alpha");
-        tl_store = c.batch <= 2048;         // measured (profiles/r02_kernel_times.txt): 1024 problems 0.47 ms per sweep stored vs 0.56 re-rolled; 4096: 1.19 vs 1.18; 8192: 2.30 vs 2.10
-        if (const char* v = std::getenv("PDDP_TL_STORE")) tl_store = (std::string(v) == "1");
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
@@ -212,6 +224,10 @@ struct Solver : SolverBase {
         b.model = dmodel;
         register_model(dmodel, hm);
         derive_tl_model(hm);
+        if constexpr (P::PLANT == 4 && sizeof(T) == 4) {
+            const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
+            if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) { if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc; }
+        }
         if ((rc = alloc("Jpart", &b.Jpart, B * A * M)) || (rc = alloc("dpart", &b.dpart, B * A * M)) || (rc = alloc("parts_fresh", &b.parts_fresh, B))) return rc;
         // device tables of per-alpha pointers, the reference's d_x / d_u / d_d (nisInitHelpers.cuh:777-789,808-813)
         void** tab[3]; const char* tn[3] = {"xs_ptrs", "us_ptrs", "ds_ptrs"};
@@ -298,7 +314,7 @@ struct Solver : SolverBase {
             }
             if (part == 0) return;
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
-                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates || tl_store);
+                launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
                 return;
             }
             const size_t lds = (size_t)A_eff * (cfg.N + cfg.M) * sizeof(T);
@@ -312,15 +328,12 @@ struct Solver : SolverBase {
             else hipLaunchKernelGGL((k_fp_lg<T, 1024>), grid, dim3(64 * waves), lds, s, b, dm, cw, dt, init_rollout);
         }
     }
-    // part: -1 everything; 0 only the winner kernel (thread-lane path); 1 only the setup kernel
+    // part: -1 everything; 0 nothing (slot of a former separate winner kernel in the per-kernel timing); 1 only the setup kernel
     void launch_nis(hipStream_t s, int mode, int part = -1) {
         const unsigned B = cfg.batch;
         if constexpr (P::PLANT == 4) {
             if (fp_path == kFpTl) {
-                if (mode == 0 && part != 1) {                      // the accepted candidate becomes the current trajectory: re-rolled, or copied from its stored slot
-                    if (tl_store) launch_adopt_tl<T>(s, b, dm, (int)B); else launch_win_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
-                }
-                if (part != 0) launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);
+                if (part != 0) launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);   // mode 0: adopts the accepted candidate first (arm_tl_adopt_knot)
                 return;
             }
             if (!fp_coop) {
@@ -338,7 +351,7 @@ struct Solver : SolverBase {
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
             if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups || bp_mfma;
-            if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (bp_mfma) launch_bp_mfma(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, (float)cw.Q1, (float)cw.Q2, (float)cw.R); }
+            if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (bp_mfma) launch_bp_mfma(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, (float)cw.Q1, (float)cw.Q2, (float)cw.R, (float)dt, store_candidates || cfg.mpc_mode || mpc_used); }
             if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
                 if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
@@ -355,7 +368,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? ((tl && sizeof(T) == 4 && !sweep_per_alpha) ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", tl ? (tl_store ? "k_adopt_tl" : "k_win_tl") : "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
+                             (lg && cfg.M > 1) ? ((tl && sizeof(T) == 4 && !sweep_per_alpha) ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;
@@ -439,6 +452,7 @@ struct Solver : SolverBase {
                   int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) override {
         const size_t B = cfg.batch, N = cfg.N;
         if (max_iter < 1 || max_iter > cfg.max_iter) return fail(PDDP_EINVAL, "mpc_solve: max_iter must be in [1, config.max_iter]");
+        if (!mpc_used) { mpc_used = true; drop_graph(); }
         for (size_t i = 0; i < B; i++) if (shift[i] < 0 || shift[i] >= (int)N - 1) return fail(PDDP_EINVAL, "mpc_solve: shift must be in [0, N-2]");
         const double t0 = now_ms();
         HIPCHK(hipMemcpyAsync(d_xActual, xActual, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
@@ -724,15 +738,18 @@ extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host,
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
     if (bytes > cap) return fail(PDDP_EINVAL, "set_array: too many bytes");
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (std::strcmp(name, "AB") == 0 && bytes < cap && (rc = s->ab_view(0))) return rc;      // a partial write lands on the current values
     HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
     if (std::strncmp(name, "model_", 6) == 0) return s->model_changed();
-    if (std::strcmp(name, "H") == 0 && !s->h_overridden) { s->h_overridden = true; s->drop_graph(); }
+    if (std::strcmp(name, "AB") == 0) return s->ab_view(1);
+    if (std::strcmp(name, "H") == 0 && !s->h_overridden) { s->h_overridden = true; s->drop_graph(); return s->ab_keep_reference_layout(); }
     return 0;
 }
 extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes) {
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
     if (bytes > cap) return fail(PDDP_EINVAL, "get_array: too many bytes");
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (std::strcmp(name, "AB") == 0 && (rc = s->ab_view(0))) return rc;
     HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost)); return 0;
 }
 extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { IMPL(h); return s->get_state(out); }

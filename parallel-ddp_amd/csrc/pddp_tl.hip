@@ -2,6 +2,7 @@
 // Built with -ffp-contract=fast semantics inside the tl headers and -fno-slp-vectorize (Makefile).
 #include <hip/hip_runtime.h>
 
+#include "ab_compact.hpp"
 #include "bodies.hpp"
 #include "fp_lg.hpp"
 #include "tl_launch.hpp"
@@ -13,13 +14,14 @@ namespace pddp {
 // feed-forward 7).  A wave owns 64/A pairs; it fetches their operands of step k+1 cooperatively (every pair's block is contiguous: 8-byte accesses,
 // each byte fetched once per wave) while step k computes, parks them in its own double-buffered LDS area (132-float pair stride: the pairs land in
 // different banks), and every lane reads its pair's copy from there.  No workgroup barrier: a wave only ever touches its own area.
-// STORE = false (the sweep): candidates leave only their partial cost / defect sums -- the trajectory of the winner is re-rolled by k_win_tl.
-// STORE = true (pddp_run_phase(FP), teacher-forced tests): every candidate's x, u, d is also written to xs / us / ds, as the reference keeps them.
-// The linear sweep (k_sweep_lg) runs before it, unchanged.  Replaces forwardSimKern<<<(M,A),(8,7)>>> + costKern<<<A,N>>> + defectKern<<<A,N>>>
+// ALL = false (the sweep): every candidate writes its states and boundary defects into its slot of xs / ds (56 bytes per step) next to its partial
+// cost / defect sums; the setup kernel adopts the accepted candidate from there and recomputes its controls (arm_tl_adopt_knot).
+// ALL = true (pddp_run_phase(FP), teacher-forced tests): the controls go to us as well, as the reference keeps them.
+// The linear sweep (k_sweep_st) runs before it.  Replaces forwardSimKern<<<(M,A),(8,7)>>> + costKern<<<A,N>>> + defectKern<<<A,N>>>
 // (fpHelpers.cuh:366,383,388).
 constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | xr 14 | uc 7 | du 7 | pad 6
 constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
-template <typename T, int V, bool STORE>
+template <typename T, int V, bool ALL>
 __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NU = 7, PS = kFpTlPS;
@@ -30,8 +32,8 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
         const int pb = inst / per_pb, rem = inst - pb * per_pb, seg = rem / A, a_idx = rem - seg * A;
         if (!fp_active<T>(b, dm, pb)) return;
         const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
-        if (STORE) arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_candidate_sink<T>(b, dm, pb, a_idx), true);
-        else arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, TlNoSink(), true);
+        if (ALL) arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_candidate_sink<T>(b, dm, pb, a_idx), true);
+        else arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_state_sink<T>(b, dm, pb, a_idx), true);
         return;
     }
     __shared__ __attribute__((aligned(16))) T stage_all[4 * 2 * kFpTlMaxPairs * PS];
@@ -87,15 +89,16 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
     TlRollout<T> r;
     r.iters = 0;
     const auto csink = tl_candidate_sink<T>(b, dm, pb, a_idx);
-    if (live) { if (STORE) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, TlNoSink()); }
+    const auto ssink = tl_state_sink<T>(b, dm, pb, a_idx);
+    if (live) { if (ALL) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, ssink); }
     fetch(0); park(0);
     wsync();
     for (int k = 0; k < NBk; k++) {
         if (k + 1 < NBk) fetch(k + 1);                                // in flight while this step computes
         if (live && k < r.iters) {
             const T* o = stg + (k & 1) * (kFpTlMaxPairs * PS) + p * PS;
-            if (STORE) tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, csink);
-            else tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, TlNoSink());
+            if (ALL) tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, csink);
+            else tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, ssink);
         }
         if (k + 1 < NBk) park((k + 1) & 1);
         wsync();
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
     T ucN[NU];
 #pragma unroll
     for (int i = 0; i < NU; i++) ucN[i] = b.ucur[((size_t)pb * N + (N - 1)) * NU + i];
-    if (STORE) tl_rollout_end<T>(r, dm, cw, ucN, xg, csink); else tl_rollout_end<T>(r, dm, cw, ucN, xg, TlNoSink());
+    if (ALL) tl_rollout_end<T>(r, dm, cw, ucN, xg, csink); else tl_rollout_end<T>(r, dm, cw, ucN, xg, ssink);
     const size_t slot = (size_t)pb * A + a_idx;
     b.Jpart[slot * M + seg] = r.J; b.dpart[slot * M + seg] = r.sdef;
     b.parts_fresh[pb] = 1;
@@ -175,47 +178,13 @@ void launch_sweep_st(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
     hipLaunchKernelGGL(k_sweep_st, dim3((2 * (unsigned)batch + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, batch);
 }
 
-// k_win_tl: grid ceil(B*M / 64), block 64.  Thread = (problem, segment): after an accepting line search, the winner's rollout again, written straight
-// into the current-trajectory buffers (arm_tl_rollout_winner).  One wave per workgroup so that the B*M/64 waves spread over all compute units.
-template <typename T, int V>
-__global__ __launch_bounds__(64, 1) void k_win_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
-    constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= batch * dm.M) return;
-    const int pb = i / dm.M, seg = i - pb * dm.M;
-    arm_tl_rollout_winner<T>(md, grav, b, dm, cw, dt, pb, seg);
-}
-
-// k_adopt_tl: grid ceil(B*N / 256), block 256.  Thread = knot.  When the sweep's rollout kernel stored every candidate (k_fp_tl<STORE>), the accepted
-// candidate becomes the current trajectory by a copy of its slot: x into the new half of xb, u into ucur, the boundary defects into dcur -- the
-// reference's memcpyCurrAKern / xp, up, dp copies (nisInitHelpers.cuh:24-32, 270-276), for the winner only.
-template <typename T>
-__global__ __launch_bounds__(256) void k_adopt_tl(Buffers<T> b, Dims dm, int batch) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= batch * dm.N) return;
-    const int pb = g / dm.N, k = g - pb * dm.N;
-    const SolverState<T>& st = b.state[pb];
-    if (!st.win_pending) return;
-    const size_t src = ((size_t)pb * dm.A + st.alphaIndex) * dm.N + k;
-    T v[14];
-    tl_load14(v, b.xs + src * 14);
-    tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * dm.N + k) * 14, v);
-#pragma unroll
-    for (int i = 0; i < 7; i++) b.ucur[((size_t)pb * dm.N + k) * 7 + i] = b.us[src * 7 + i];
-    if (dm.M > 1 && dm.on_defect_boundary(k)) { tl_load14(v, b.ds + src * 14); tl_store14(b.dcur + ((size_t)pb * dm.N + k) * 14, v); }
-}
-template <typename T>
-void launch_adopt_tl(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batch) {
-    hipLaunchKernelGGL((k_adopt_tl<T>), dim3(((unsigned)batch * dm.N + 255) / 256), dim3(256), 0, s, b, dm, batch);
-}
-template void launch_adopt_tl<float>(hipStream_t, const Buffers<float>&, const Dims&, int);
-template void launch_adopt_tl<double>(hipStream_t, const Buffers<double>&, const Dims&, int);
-
 // k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  float: the Jacobian of a wave's 64 knots is staged in
 // LDS (entry-major, padded to 65 so that both the per-thread writes and the transposed reads are conflict-free) and written out in THREE pieces
 // as soon as their columns are complete (arm_tl_gradient's marks: columns {0..3, 7..10}, {4..6, 11..13}, {14..20}): 56 staged entries per knot at most,
-// 14.6 KB per wave, so that two workgroups (two waves per SIMD -- the kernel needs all 256 registers) share a compute unit; a piece is written as whole
-// 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
+// 14.6 KB per wave, so that two workgroups (two waves per SIMD -- the kernel needs all 256 registers) share a compute unit.
+//   b.ABc != null (the sweep's default): the piece goes to the compact [A B] (ab_compact.hpp) -- the wave's 64 knots x the piece's columns x 7 dynamic rows are ONE
+//                  contiguous 16-byte aligned run of the chunk, written with 16 bytes per lane; the constant rows are not written at all;
+//   b.ABc == null: the reference layout, whole 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
 // double: direct stores.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
 constexpr int kNisTlStage = 56 * 65;
 template <typename T, int V>
@@ -228,41 +197,78 @@ __global__ __launch_bounds__(256, 2) void k_nis_tl(Buffers<T> b, Dims dm, CostWe
         __shared__ T stage_all[4 * kNisTlStage];
         T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
         const int lane = threadIdx.x & 63;
-        const bool need = (g < total) && arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb);
+        T x[NX], u[7];
+#pragma unroll
+        for (int i = 0; i < NX; i++) x[i] = T(0);                    // a lane without a knot differentiates the zero state (its columns are never flushed)
+#pragma unroll
+        for (int i = 0; i < 7; i++) u[i] = T(0);
+        const bool need = (g < total) && arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u);
         const unsigned long long mask = __ballot(need);
         if (!mask) return;                                          // (uniform) nothing to differentiate in this wave
-        // every lane differentiates SOME knot (its own, or a valid neighbour's when it has none) so that the whole wave reaches the flushes together
-        const int gs = need ? g : (blockIdx.x * 256 + (threadIdx.x & ~63) + (__ffsll((long long)mask) - 1));
-        const int pbs = gs / dm.N, kk_s = gs - pbs * dm.N;
-        T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot
+        T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot (reference layout)
+        T* ABc0 = b.ABc ? b.ABc + (size_t)((g - lane) >> 6) * kAbcChunk : nullptr;   // the wave's chunk of the compact array
         auto slot = [](int col, int row) -> int {                  // staged position of dqdd(row, col) inside its piece
-            const int cc = col < 4 ? col : col < 7 ? col - 4 : col < 11 ? col - 3 : col < 14 ? col - 8 : col - 14;
-            return cc * 7 + row;
+            return abc_col_in_piece(col) * 7 + row;
         };
         auto flush = [&](int piece) {
             wsync();
-            const int ncols = piece == 0 ? 8 : piece == 1 ? 6 : 7;
-            for (int it = 0; it * 64 < 64 * ncols; it++) {
-                const int pi = it * 64 + lane, kk = pi / ncols, ci = pi - kk * ncols;
-                if (kk >= 64 || !((mask >> kk) & 1ull)) continue;
-                const int col = piece == 0 ? (ci < 4 ? ci : ci + 3) : piece == 1 ? (ci < 3 ? ci + 4 : ci + 8) : ci + 14;
-                T out[NX];
+            const int ncols = abc_piece_cols(piece);
+            if (ABc0) {
+                const int per = ncols * 7, count = 64 * per;        // floats of this piece per knot / per wave (a multiple of 4)
+                T* dst = ABc0 + abc_piece_off(piece);
+                for (int e0 = 4 * lane; e0 < count; e0 += 256) {
+                    T out[4]; bool ok[4], all = true;
 #pragma unroll
-                for (int r = 0; r < 7; r++) {
-                    out[r] = tl_AB_const<T>(r, col, dt);
-                    out[7 + r] = T(col == 7 + r ? 1 : 0) + dt * stage[(ci * 7 + r) * 65 + kk];
+                    for (int j = 0; j < 4; j++) {
+                        const int e = e0 + j, kk = e / per, ent = e - kk * per, ci = ent / 7, r = ent - ci * 7;
+                        out[j] = T(abc_piece_col(piece, ci) == 7 + r ? 1 : 0) + dt * stage[ent * 65 + kk];
+                        ok[j] = (mask >> kk) & 1ull; all = all && ok[j];
+                    }
+                    if (all) { float4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3]; *reinterpret_cast<float4*>(dst + e0) = v; }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) if (ok[j]) dst[e0 + j] = out[j];
+                    }
                 }
-                tl_store14(AB0 + ((size_t)kk * NM + col) * NX, out);
+            } else {
+                for (int it = 0; it * 64 < 64 * ncols; it++) {
+                    const int pi = it * 64 + lane, kk = pi / ncols, ci = pi - kk * ncols;
+                    if (kk >= 64 || !((mask >> kk) & 1ull)) continue;
+                    const int col = abc_piece_col(piece, ci);
+                    T out[NX];
+#pragma unroll
+                    for (int r = 0; r < 7; r++) {
+                        out[r] = tl_AB_const<T>(r, col, dt);
+                        out[7 + r] = T(col == 7 + r ? 1 : 0) + dt * stage[(ci * 7 + r) * 65 + kk];
+                    }
+                    tl_store14(AB0 + ((size_t)kk * NM + col) * NX, out);
+                }
             }
             wsync();
         };
-        arm_tl_nis_jac<T>(md, grav, b, dm, kk_s, pbs, [&](int col, int row, T val) { stage[slot(col, row) * 65 + lane] = val; }, flush);
+        arm_tl_nis_jac<T>(md, grav, x, u, [&](int col, int row, T val) { stage[slot(col, row) * 65 + lane] = val; }, flush);
     } else {
         if (g >= total) return;
         T* AB = b.AB + (size_t)g * (NX * NM);
         const bool valid = arm_tl_nis_knot<T>(md, grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; });
         if (valid) for (int col = 0; col < NM; col++) for (int r = 0; r < 7; r++) AB[col * NX + r] = tl_AB_const<T>(r, col, dt);
     }
+}
+
+// API view of the compact [A B]: grid ceil(B*N*21 / 256), block 256, thread = (knot, column).  expand: compact -> the reference layout (pddp_get_array("AB"));
+// compact: the reference layout -> compact (pddp_set_array("AB"): teacher-forced tests hand in the oracle's derivatives).
+__global__ __launch_bounds__(256) void k_abc_convert(Buffers<float> b, int knots, int N, float dt, int to_compact) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= knots * 21) return;
+    const int G = i / 21, col = i - G * 21;
+    if (!to_compact && (G % N) == N - 1) return;                      // the terminal knot has no [A B]: the kernels never write it, the view keeps what it holds
+    float* full = b.AB + ((size_t)G * 21 + col) * 14;
+    float* cmp = b.ABc + abc_index((size_t)G, col, 0);
+    if (to_compact) { for (int r = 0; r < 7; r++) cmp[r] = full[7 + r]; }
+    else { for (int r = 0; r < 7; r++) { full[r] = abc_const(r, col, dt); full[7 + r] = cmp[r]; } }
+}
+void launch_abc_convert(hipStream_t s, const Buffers<float>& b, int knots, int N, float dt, int to_compact) {
+    hipLaunchKernelGGL(k_abc_convert, dim3(((unsigned)knots * 21 + 255) / 256), dim3(256), 0, s, b, knots, N, dt, to_compact);
 }
 
 // forward dynamics / gradient of `count` (x, u) samples, one thread each (tests, micro-benchmarks)
@@ -289,12 +295,6 @@ void launch_fp_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& d
     else { if (store_candidates) hipLaunchKernelGGL((k_fp_tl<T, 1, true>), g, t, 0, s, b, dm, cw, dt, grav, batch); else hipLaunchKernelGGL((k_fp_tl<T, 1, false>), g, t, 0, s, b, dm, cw, dt, grav, batch); }
 }
 template <typename T>
-void launch_win_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch) {
-    const unsigned n = (unsigned)batch * dm.M;
-    if (variant == 0) hipLaunchKernelGGL((k_win_tl<T, 0>), dim3((n + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, grav, batch);
-    else hipLaunchKernelGGL((k_win_tl<T, 1>), dim3((n + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, grav, batch);
-}
-template <typename T>
 void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch) {
     const unsigned knots = (unsigned)batch * dm.N;
     if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0>), dim3((knots + 255) / 256), dim3(256), 0, s, b, dm, cw, dt, grav, mode, batch);
@@ -307,8 +307,6 @@ void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T
 }
 template void launch_fp_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, int);
 template void launch_fp_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, int);
-template void launch_win_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int);
-template void launch_win_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int);
 template void launch_nis_tl<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, int);
 template void launch_nis_tl<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, int);
 template void launch_plant_eval_tl<float>(hipStream_t, int, float, int, const float*, const float*, float*, int);

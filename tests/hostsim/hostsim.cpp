@@ -143,7 +143,7 @@ struct Sim : Base {
                     const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * cfg.N * NX;
                     for (int sg = 0; sg < cfg.M; sg++) for (int a = 0; a < cfg.A; a++) {
                         if (store_candidates) arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_candidate_sink<T>(b, dm, pb, a), true);
-                        else arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, TlNoSink(), true);
+                        else arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_state_sink<T>(b, dm, pb, a), true);
                     }
                     continue;
                 }
@@ -172,7 +172,6 @@ struct Sim : Base {
         } else if (ph == PDDP_PHASE_NIS || ph == PDDP_PHASE_INIT_NIS) {
             if constexpr (P::PLANT == 4) if (fp_tl()) {
                 const int mode = ph == PDDP_PHASE_INIT_NIS;
-                if (!mode) for (int pb = 0; pb < B; pb++) for (int sg = 0; sg < cfg.M; sg++) arm_tl_rollout_winner<T>(tl_model, model.grav, b, dm, cw, dt, pb, sg);
                 for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) {
                     T* AB = b.AB + ((size_t)pb * cfg.N + k) * (NX * NM);
                     const bool valid = arm_tl_nis_knot<T>(tl_model, model.grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; });

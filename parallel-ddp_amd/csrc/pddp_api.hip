@@ -153,7 +153,7 @@ struct Solver : SolverBase {
         return 0;
     }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
-    bool sweep_per_alpha = false;  // PDDP_SWEEP=alpha: the per-candidate lane-group sweep also on the thread-lane path (comparison)
+    int sweep_kind = 0;            // the arm's linear sweep: 0 one lane group per candidate (k_sweep_lg), 1 two sequences on lane groups (k_sweep_st), 2 two sequences, workgroup per problem (k_sweep_wg); PDDP_SWEEP=alpha|st|wg
     bool mpc_used = false;         // pddp_mpc_solve ran on this handle: its warm start shifts every cost-to-go slot, so the backward pass keeps writing all of them
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
     hipGraphExec_t graph = nullptr;
@@ -188,7 +188,10 @@ struct Solver : SolverBase {
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
-        if (const char* v = std::getenv("PDDP_SWEEP")) sweep_per_alpha = (std::string(v) == "alpha");
+        if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
+            sweep_kind = c.batch <= 512 ? 2 : 1;
+            if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
+        }
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
@@ -309,7 +312,10 @@ struct Solver : SolverBase {
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1 && part != 1) {
                 bool st = false;
-                if constexpr (sizeof(T) == 4) { if (fp_path == kFpTl && !sweep_per_alpha) { launch_sweep_st(s, b, dm, (int)B); st = true; } }
+                if constexpr (sizeof(T) == 4) {
+                    if (sweep_kind == 2) { launch_sweep_wg(s, b, dm, (int)B); st = true; }
+                    else if (sweep_kind == 1) { launch_sweep_st(s, b, dm, (int)B); st = true; }
+                }
                 if (!st) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             }
             if (part == 0) return;
@@ -368,7 +374,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? ((tl && sizeof(T) == 4 && !sweep_per_alpha) ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

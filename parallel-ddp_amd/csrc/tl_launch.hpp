@@ -15,6 +15,8 @@ namespace pddp {
 template <typename T> void launch_fp_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, int store_candidates);
 // the linear sweep of all candidates from two sequences (k_sweep_st, float handles)
 void launch_sweep_st(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch);
+// the same sweep with one workgroup per problem and the chain's operands staged in LDS up front (k_sweep_wg: few problems in flight)
+void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch);
 template <typename T> void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch);
 // compact [A B] (ab_compact.hpp) <-> the reference layout b.AB, for the API view of a handle that keeps the compact array
 void launch_abc_convert(hipStream_t s, const Buffers<float>& b, int knots, int N, float dt, int to_compact);

@@ -339,8 +339,8 @@ def test_bench_batch_4096_whole_solves_equal_single_problem_solves():
     assert (out["iters"] == 10).all()
     o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)
     o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
-    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP")}
-    os.environ.update({"PDDP_BP": "mx", "PDDP_FP": "tl"})
+    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP", "PDDP_SWEEP")}
+    os.environ.update({"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "st"})
     try:
         s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw)
     finally:

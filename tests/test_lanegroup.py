@@ -123,13 +123,14 @@ def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(back
     for mode in ("lg", "coop"):
         if mode == "coop":
             os.environ["PDDP_FP"] = "coop"
+        os.environ["PDDP_SWEEP"] = "alpha"       # the per-candidate linear sweep (k_sweep_lg): the one whose operation order equals the cooperative kernel's
         try:
             s = make_solver(backend, 4, **kw)
             s.load(x0, u0, xg, forward_rollout=rollout)
             arrs[mode] = {k: s.get(k).copy() for k in ("H", "g", "AB", "costk")}
             outs[mode] = s.solve(x0, u0, xg, forward_rollout=rollout)
         finally:
-            os.environ.pop("PDDP_FP", None)
+            os.environ.pop("PDDP_FP", None); os.environ.pop("PDDP_SWEEP", None)
     for k in ("H", "g", "AB"):
         assert np.array_equal(arrs["lg"][k], arrs["coop"][k]), k
     if not rollout:

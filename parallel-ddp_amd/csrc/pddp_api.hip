@@ -118,6 +118,7 @@ struct Solver : SolverBase {
     // full; the wave-cooperative kernel has the shorter critical path for a handful of problems.  PDDP_BP=lg|coop overrides.
     bool bp_lane_groups = false;
     bool fp_coop = false;          // PDDP_FP=coop
+    bool fp_split = false;         // rollouts of a lane-group handle on the split thread-lane kernel (k_fp_tl2)
     FpPath fp_path = kFpLg;        // the arm's forward pass / next-iteration setup (fp_tl.hpp select_fp_path)
     int tl_variant = -1;           // which built-in robot model the handle's tables equal (the thread-lane kernels fold it into literals); -1: neither
     T tl_grav = T(0);
@@ -129,6 +130,10 @@ struct Solver : SolverBase {
         tl_grav = hm.grav;
         fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0, cfg.batch);
         fp_coop = (fp_path == kFpCoop);
+        // few problems in flight, joint-space cost, float, built-in robot model: the rollouts run on k_fp_tl2 (every step split over two wavefronts);
+        // sweep, line search and setup stay on the lane-group kernels.  PDDP_FP=lg keeps the lane-group rollouts (bit-identity tests), PDDP_FP=tl2 asks for the split.
+        const char* fpenv = std::getenv("PDDP_FP");
+        fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.ee_cost && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
     }
     void derive_tl_model(const EmptyModel&) {}
     // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
@@ -319,6 +324,7 @@ struct Solver : SolverBase {
                 if (!st) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             }
             if (part == 0) return;
+            if constexpr (sizeof(T) == 4) { if (!init_rollout && fp_split) { launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); return; } }
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
                 launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
                 return;
@@ -374,7 +380,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

@@ -113,6 +113,125 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
     b.parts_fresh[pb] = 1;
 }
 
+// k_fp_tl2: grid ceil(B*M*A / 64), block 128.  The rollouts of a handle with FEW problems in flight (one MPC solve: 32 rollouts on a 256-CU device), where only the
+// length of one step's instruction stream counts.  Lane = rollout as in k_fp_tl, but a step is split over the workgroup's TWO wavefronts (two SIMDs of one CU),
+// which carry the same 64 rollouts:
+//     wave 0: control law, running cost, sines / cosines, recursive Newton-Euler -> tau = u - bias        (arm_tl_bias)        ~ 900 instructions
+//     wave 1: sines / cosines, composite rigid bodies, mass matrix, L D L'                                 (arm_tl_factor)      ~ 950 instructions
+//     barrier; wave 1: tau from LDS, two triangular solves, Euler step, new state to LDS and to xs; barrier; wave 0 picks the new state up
+// instead of ~1700 instructions in a row on one wave (a lone wave issues a dependent instruction every ~6 cycles: tools/probes/single_wave_clock.hip).
+// The next step's operands (gain, reference state, nominal control, feed-forward) are fetched into registers while the current step computes.
+// Candidates are stored like the reference's (x, u, d: the lane-group setup kernel adopts the winner from there); cost / defect leave as per-segment
+// partial sums (k_ls adds them in order, as after k_fp_tl).  Same arithmetic as k_fp_tl (fp_tl.hpp, plant_arm_tl.hpp): under the float32 bar.
+template <int V>
+__global__ __launch_bounds__(128, 1) void k_fp_tl2(Buffers<float> b, Dims dm, CostWeights<float> cw, float dt, float grav, int batch) {
+    using T = float;
+    constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+    constexpr int NX = 14, NU = 7, ST = 9, SX = 15;                   // odd LDS strides: 64 lanes, 64 banks apart
+    __shared__ T s_tau[64 * ST];
+    __shared__ T s_x[64 * SX];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int A = dm.A, M = dm.M, N = dm.N, NBk = dm.NB, total = batch * M * A;
+    const int inst_raw = blockIdx.x * 64 + lane, inst = inst_raw < total ? inst_raw : total - 1;
+    const int pb = inst / (M * A), rem = inst - pb * (M * A), seg = rem / A, a_idx = rem - seg * A;
+    const bool live = inst_raw < total && fp_active<T>(b, dm, pb);
+    const int kStart = seg * NBk, iters = (seg < M - 1) ? NBk : NBk - 1;
+    const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
+    const size_t slot = (size_t)pb * A + a_idx;
+    T* xs = b.xs + slot * N * NX; T* us = b.us + slot * N * NU; T* ds = b.ds + slot * N * NX;
+    T x[NX];
+    if (seg == 0) tl_load14(x, xcur); else tl_load14(x, xs + (size_t)kStart * NX);
+    if (wave == 0) {
+        // ---------------------------------------------------------------- wave 0: control law, cost, bias torque
+        const T alpha = b.alpha[a_idx];
+        const T* KT = b.KT + (size_t)pb * N * NX * NU; const T* uc = b.ucur + (size_t)pb * N * NU; const T* du = b.du + (size_t)pb * N * NU;
+        T xg[NX];
+        tl_load14(xg, b.xGoal + (size_t)pb * NX);
+        T J = T(0);
+        T nK[NX * NU], nxr[NX], nuc[NU], ndu[NU];
+        auto fetch = [&](int kn) {
+#pragma unroll
+            for (int rr = 0; rr < NU; rr++) tl_load14(nK + rr * NX, KT + (size_t)kn * (NX * NU) + rr * NX);
+            tl_load14(nxr, xcur + (size_t)kn * NX);
+#pragma unroll
+            for (int i = 0; i < NU; i++) { nuc[i] = uc[(size_t)kn * NU + i]; ndu[i] = du[(size_t)kn * NU + i]; }
+        };
+        fetch(kStart);
+        for (int k = 0; k < NBk; k++) {
+            const int kn = kStart + k;
+            const bool act = live && k < iters;
+            if (act) {
+                T u[NU];
+                tl_control_law<T>(u, alpha, ndu, nK, x, nxr, nuc);
+                if (k + 1 < NBk) fetch(kn + 1);                         // in flight while this step computes (kn + 1 <= N - 1)
+#pragma unroll
+                for (int i = 0; i < NU; i++) us[(size_t)kn * NU + i] = u[i];
+                J += arm_tl_cost<T>(cw, x, u, xg, false);
+                ArmTlState<T> st;
+                T bias[NU];
+                arm_tl_trig<T>(st, x);
+                arm_tl_bias<T>(md, grav, st, x + 7, bias);
+#pragma unroll
+                for (int i = 0; i < NU; i++) s_tau[lane * ST + i] = u[i] - bias[i];
+            }
+            __syncthreads();                                            // tau is in LDS
+            __syncthreads();                                            // the new state is in LDS
+            if (act && k < NBk - 1) {
+#pragma unroll
+                for (int i = 0; i < NX; i++) x[i] = s_x[lane * SX + i];
+            }
+        }
+        if (live) {
+            if (seg == M - 1) {                                         // terminal knot: its (unused) control is carried along (tl_rollout_end)
+                T u[NU];
+#pragma unroll
+                for (int i = 0; i < NU; i++) { u[i] = uc[(size_t)(N - 1) * NU + i]; us[(size_t)(N - 1) * NU + i] = u[i]; }
+                J += arm_tl_cost<T>(cw, x, u, xg, true);
+            }
+            b.Jpart[slot * M + seg] = J;
+            b.parts_fresh[pb] = 1;
+        }
+    } else {
+        // ---------------------------------------------------------------- wave 1: factors of the mass matrix, solve, Euler step, trajectory out
+        if (live) tl_store14(xs + (size_t)kStart * NX, x);             // (a candidate slot already holds it for seg > 0)
+        T sdef = T(0);
+        for (int k = 0; k < NBk; k++) {
+            const int kn = kStart + k;
+            const bool act = live && k < iters;
+            ArmTlState<T> st;
+            if (act) { arm_tl_trig<T>(st, x); arm_tl_factor<T>(md, st); }
+            __syncthreads();                                            // tau is in LDS
+            if (act) {
+                T qdd[NU], xn[NX];
+#pragma unroll
+                for (int i = 0; i < NU; i++) qdd[i] = s_tau[lane * ST + i];
+                tl_ldl_solve(st, qdd);
+#pragma unroll
+                for (int i = 0; i < 7; i++) { xn[i] = x[i] + dt * x[7 + i]; xn[7 + i] = x[7 + i] + dt * qdd[i]; }     // Euler (utils/integrators.cuh:24-36)
+                if (k < NBk - 1) {
+#pragma unroll
+                    for (int i = 0; i < NX; i++) { x[i] = xn[i]; s_x[lane * SX + i] = xn[i]; }
+                    tl_store14(xs + (size_t)(kn + 1) * NX, xn);
+                } else {                                                // last step of a non-final segment: defect against the next segment's start
+                    const int ks = (seg + 1) * NBk;
+                    T xnext[NX], e[NX];
+                    tl_load14(xnext, xs + (size_t)ks * NX);
+#pragma unroll
+                    for (int i = 0; i < NX; i++) { e[i] = xn[i] - xnext[i]; sdef += tabs(e[i]); }
+                    tl_store14(ds + (size_t)(ks - 1) * NX, e);
+                }
+            }
+            __syncthreads();                                            // the new state is in LDS
+        }
+        if (live) b.dpart[slot * M + seg] = (seg == M - 1) ? T(0) : sdef;
+    }
+}
+void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int batch) {
+    const unsigned inst = (unsigned)batch * dm.M * dm.A;
+    if (variant == 0) hipLaunchKernelGGL((k_fp_tl2<0>), dim3((inst + 63) / 64), dim3(128), 0, s, b, dm, cw, dt, grav, batch);
+    else hipLaunchKernelGGL((k_fp_tl2<1>), dim3((inst + 63) / 64), dim3(128), 0, s, b, dm, cw, dt, grav, batch);
+}
+
 // k_sweep_st: grid ceil(2 B / 8), block 64.  The linear sweep of forwardSweepKern (fpHelpers.cuh:19-63) for ALL candidates of a problem at once.
 // The sweep is affine in the step size: with e_k = x_k - xcur_k,  e_{k+1} = F_k e_k - alpha (B du)_k + [boundary] d_k,  e_0 = 0,  so
 //     e_k(alpha) = t_k - alpha s_k      with   s_{k+1} = F_k s_k + (B du)_k,   t_{k+1} = F_k t_k + [boundary] d_k,   s_0 = t_0 = 0,

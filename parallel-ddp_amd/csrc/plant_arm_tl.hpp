@@ -235,13 +235,20 @@ template <int I, int END, int STEP> struct TlFor {
 };
 template <int END, int STEP> struct TlFor<END, END, STEP> { template <typename F> static PDDP_HD void run(F&&) {} };
 
-// Forward dynamics: qdd[7] from q[7], qd[7], u[7].  Fills st (sines, velocities, factors of M) for arm_tl_gradient.
+// Forward dynamics in three parts (arm_tl_dynamics below runs them in order; the split rollout kernel k_fp_tl2 runs the bias and the factor parts
+// on two different wavefronts):
+//   arm_tl_trig:    sines / cosines of the joint angles
+//   arm_tl_bias:    recursive Newton-Euler with qdd = 0 -> bias[i] = C_i + 0.5 qd_i (gravity as an upward acceleration of the base; joint damping 0.5 qd,
+//                   plants/dynamics_arm.cuh:1433-1434; iiwa14.urdf); fills st.v
+//   arm_tl_factor:  composite rigid bodies, mass matrix, M = L D L' -> st.L, st.Dinv
 template <typename T>
-PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st, T* qdd, const T* q, const T* qd, const T* u) {
-    constexpr int NB = kArmNB;
+PDDP_HD void arm_tl_trig(ArmTlState<T>& st, const T* q) {
 #pragma unroll
-    for (int i = 0; i < NB; i++) tl_sincos<T>(q[i], st.s[i], st.c[i]);
-    // ---- recursive Newton-Euler with qdd = 0: bias torque C (gravity as an upward acceleration of the base)
+    for (int i = 0; i < kArmNB; i++) tl_sincos<T>(q[i], st.s[i], st.c[i]);
+}
+template <typename T>
+PDDP_HD void arm_tl_bias(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st, const T* qd, T* bias) {
+    constexpr int NB = kArmNB;
     T f[NB][6];
     {
         T a[6] = {T(0), T(0), T(0), T(0), T(0), grav}, vp[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -263,11 +270,10 @@ PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st,
             for (int e = 0; e < 6; e++) { a[e] = an[e]; vp[e] = v[e]; }
         });
     }
-    T tau[NB];
     TlFor<NB - 1, -1, -1>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int K = arm_tl_kind(i);
-        tau[i] = u[i] - (f[i][2] + T(0.5) * qd[i]);                   // joint damping 0.5 qd (plants/dynamics_arm.cuh:1433-1434; iiwa14.urdf)
+        bias[i] = f[i][2] + T(0.5) * qd[i];
         if (i > 0) {
             T fp[6];
             tl_force_to_parent<K>(fp, f[i], md.r[i], st.c[i], st.s[i]);
@@ -275,6 +281,10 @@ PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st,
             for (int e = 0; e < 6; e++) f[i - 1][e] += fp[e];
         }
     });
+}
+template <typename T>
+PDDP_HD void arm_tl_factor(const ArmTlModel<T>& md, ArmTlState<T>& st) {
+    constexpr int NB = kArmNB;
     // ---- composite rigid bodies and the mass matrix (lower triangle, row-major M[i(i+1)/2 + j])
     T M[28];
     {
@@ -318,8 +328,17 @@ PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st,
             else { M[i * (i + 1) / 2 + i] = sum; st.Dinv[i] = T(1) / sum; }
         }
     }
+}
+// Forward dynamics: qdd[7] from q[7], qd[7], u[7].  Fills st (sines, velocities, factors of M) for arm_tl_gradient.
+template <typename T>
+PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st, T* qdd, const T* q, const T* qd, const T* u) {
+    constexpr int NB = kArmNB;
+    arm_tl_trig<T>(st, q);
+    T bias[NB];
+    arm_tl_bias<T>(md, grav, st, qd, bias);
+    arm_tl_factor<T>(md, st);
 #pragma unroll
-    for (int i = 0; i < NB; i++) qdd[i] = tau[i];
+    for (int i = 0; i < NB; i++) qdd[i] = u[i] - bias[i];
     tl_ldl_solve(st, qdd);
 }
 

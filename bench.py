@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd"))
 import pyddp  # noqa: E402
 from pyddp import shard  # noqa: E402
 
+BENCH_BATCH = 16384       # independent problems per GPU of the headline line (tests/test_fp32_bar.py runs its what-the-bench-runs cases at this size)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 PHASES = ("bp", "fp", "ls", "nis")                      # the four phases of a sweep, in launch order (per-phase figures of the latency block)
 # reference phase whose algorithmic bytes a kernel covers, by kernel-name prefix
@@ -80,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="independent problems per GPU")
+    ap.add_argument("--batch", type=int, default=BENCH_BATCH, help="independent problems per GPU")
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")

@@ -102,18 +102,21 @@ struct TlRollout {
     int pb, a_idx, seg, kStart, iters;
     T alpha;
 };
-template <typename T> struct TlCandidateSink {         // candidate slot of xs / us / ds
-    T* xs; T* us; T* ds;
-    PDDP_HD void x(int k, const T* v) const { tl_store14(xs + (size_t)k * 14, v); }
+// xw: the candidates' states KNOT-major, [problem][knot][candidate][14] (null: not kept).  The 8 candidates of a (problem, segment) sit in adjacent lanes, so one
+// step of a wave's rollouts fills whole 448-byte runs -- the candidate-major slots of xs get 56-byte pieces 7 KB apart, which cost 1.8 x their bytes in HBM writes
+// (profiles/r02b_b16384: 105 KB written per problem for 57 KB of states).  xwk = xw + ((problem * N) * A + candidate) * 14, knot stride A * 14.
+template <typename T> struct TlCandidateSink {         // candidate slot of xs / us / ds (the reference's arrays) and of xw
+    T* xs; T* us; T* ds; T* xwk; int xw_stride;
+    PDDP_HD void x(int k, const T* v) const { tl_store14(xs + (size_t)k * 14, v); if (xwk) tl_store14(xwk + (size_t)k * xw_stride, v); }
     PDDP_HD void u(int k, const T* v) const {
 #pragma unroll
         for (int i = 0; i < 7; i++) us[(size_t)k * 7 + i] = v[i];
     }
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
-template <typename T> struct TlStateSink {             // candidate slot of xs / ds; controls dropped
-    T* xs; T* ds;
-    PDDP_HD void x(int k, const T* v) const { tl_store14(xs + (size_t)k * 14, v); }
+template <typename T> struct TlStateSink {             // states to xw (xs without it), boundary defects to the candidate's slot of ds; controls dropped
+    T* xs; T* ds; T* xwk; int xw_stride;
+    PDDP_HD void x(int k, const T* v) const { if (xwk) tl_store14(xwk + (size_t)k * xw_stride, v); else tl_store14(xs + (size_t)k * 14, v); }
     PDDP_HD void u(int, const T*) const {}
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
@@ -203,12 +206,13 @@ PDDP_HD void arm_tl_rollout_segment(const ArmTlModel<T>& md, T grav, const Buffe
 template <typename T>
 PDDP_HD TlCandidateSink<T> tl_candidate_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx) {
     const size_t slot = (size_t)pb * dm.A + a_idx;
-    return TlCandidateSink<T>{b.xs + slot * dm.N * 14, b.us + slot * dm.N * 7, b.ds + slot * dm.N * 14};
+    return TlCandidateSink<T>{b.xs + slot * dm.N * 14, b.us + slot * dm.N * 7, b.ds + slot * dm.N * 14,
+                              b.xw ? b.xw + ((size_t)pb * dm.N * dm.A + a_idx) * 14 : nullptr, dm.A * 14};
 }
 template <typename T>
 PDDP_HD TlStateSink<T> tl_state_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx) {
     const size_t slot = (size_t)pb * dm.A + a_idx;
-    return TlStateSink<T>{b.xs + slot * dm.N * 14, b.ds + slot * dm.N * 14};
+    return TlStateSink<T>{b.xs + slot * dm.N * 14, b.ds + slot * dm.N * 14, b.xw ? b.xw + ((size_t)pb * dm.N * dm.A + a_idx) * 14 : nullptr, dm.A * 14};
 }
 // After the line search accepted candidate st.alphaIndex (st.cur already points at the NEW half of xb): knot k of the winner becomes the current
 // trajectory -- its state from the candidate's slot of xs into the new half of xb, its control recomputed from that state with the rollout's own
@@ -222,7 +226,7 @@ PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int p
     const SolverState<T>& st = b.state[pb];
     const size_t N = dm.N, knot = (size_t)pb * N + k;
     const size_t src = ((size_t)pb * dm.A + st.alphaIndex) * N + k;
-    tl_load14(x, b.xs + src * NX);
+    if (b.xw) tl_load14(x, b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * NX); else tl_load14(x, b.xs + src * NX);
     T* uc = b.ucur + knot * NU;
     T ucv[NU];
 #pragma unroll

@@ -232,6 +232,7 @@ struct Solver : SolverBase {
         b.model = dmodel;
         register_model(dmodel, hm);
         derive_tl_model(hm);
+        if constexpr (P::PLANT == 4) { if (fp_path == kFpTl && !std::getenv("PDDP_NO_XW")) { if ((rc = alloc("xw", &b.xw, B * N * A * NX))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
         if constexpr (P::PLANT == 4 && sizeof(T) == 4) {
             const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
             if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) { if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc; }

@@ -32,6 +32,11 @@ import numpy as np
 import pytest
 
 import pyddp
+sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys
+if sys_path_root not in sys.path:
+    sys.path.insert(0, sys_path_root)
+from bench import BENCH_BATCH
 from backends import BACKENDS, make_solver
 from gpusem_steps import gpusem_iterations
 from oracle_binding import Oracle, default_cfg, example_inputs
@@ -309,10 +314,11 @@ def test_cartpole_config_float32_bar_every_iteration(backend):
 
 
 @pytest.mark.gpu
-def test_bench_batch_4096_every_phase_under_the_bar():
-    """What bench.py runs: ONE handle of 4096 Kuka problems (N=128, A=8, M=4, float32), the library's own kernel selection at that size.
-    The slots hold the states of every iteration of three different solves (120 distinct records, each replicated ~34 times across the
-    batch); every phase is one launch over all 4096 -- the distinct records under the float32 bar, every replica bit-identical to its
+def test_bench_batch_every_phase_under_the_bar():
+    """What bench.py runs: ONE handle of 4096 Kuka problems (N=128, A=8, M=4, float32) -- the library's kernel selection and launch shapes are the same from 4096
+    problems up (bench.BENCH_BATCH is a multiple; teacher-forcing that many slots would move 4 GB of cost Hessians per phase) -- at its own selection.
+    The slots hold the states of every iteration of three different solves (120 distinct records, each replicated across the
+    batch); every phase is one launch over all of them -- the distinct records under the float32 bar, every replica bit-identical to its
     record's first slot (the batch axis must not leak between problems)."""
     rows, fails, ints_ok = run_bar("hip", 4, KUKA, {}, 21, 40, batch=4096, seeds=3, ensemble=True)
     assert ints_ok
@@ -323,12 +329,12 @@ def test_bench_batch_4096_every_phase_under_the_bar():
 
 
 @pytest.mark.gpu
-def test_bench_batch_4096_whole_solves_equal_single_problem_solves():
-    """10 production sweeps (hipGraph replay) of 4096 problems; 16 problems drawn at random must equal, bit for bit, single-problem solves
+def test_bench_batch_whole_solves_equal_single_problem_solves():
+    """10 production sweeps (hipGraph replay) of bench.BENCH_BATCH problems; 16 problems drawn at random must equal, bit for bit, single-problem solves
     run on the same kernels (PDDP_BP=mx, PDDP_FP=tl force the large-batch selection for a batch of one), and follow the float32 oracle's
     step-size decisions over the leading iterations with J inside the bar measured against oracle64."""
     kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=10)
-    B = 4096
+    B = BENCH_BATCH
     rng = np.random.default_rng(2024)
     xs, us = [], []
     for b_ in range(B):

@@ -118,6 +118,7 @@ struct Solver : SolverBase {
     // full; the wave-cooperative kernel has the shorter critical path for a handful of problems.  PDDP_BP=lg|coop overrides.
     bool bp_lane_groups = false;
     bool fp_coop = false;          // PDDP_FP=coop
+    static constexpr int kNisTl7MaxBatch = 128;   // measured crossover against k_nis_lg (profiles/)
     bool fp_split = false;         // rollouts of a lane-group handle on the split thread-lane kernel (k_fp_tl2)
     FpPath fp_path = kFpLg;        // the arm's forward pass / next-iteration setup (fp_tl.hpp select_fp_path)
     int tl_variant = -1;           // which built-in robot model the handle's tables equal (the thread-lane kernels fold it into literals); -1: neither
@@ -351,6 +352,7 @@ struct Solver : SolverBase {
             }
             if (!fp_coop) {
                 if (part == 0) return;
+                if constexpr (sizeof(T) == 4) { if (fp_split && cfg.batch <= kNisTl7MaxBatch) { launch_nis_tl7(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B); return; } }
                 if (cfg.ee_cost) hipLaunchKernelGGL((k_nis_lg<T, true>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 else hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 return;
@@ -381,7 +383,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : lg ? "k_nis_lg" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

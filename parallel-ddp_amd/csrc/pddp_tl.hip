@@ -456,6 +456,78 @@ __global__ __launch_bounds__(256, 2) void k_nis_tl(Buffers<T> b, Dims dm, CostWe
     }
 }
 
+// k_nis_tl7: grid (ceil(B*N / 64), 7), block 64.  Next-iteration setup of a handle with FEW problems in flight (one MPC solve: 127 knots on a 256-CU device):
+// thread = (knot, joint J); blockIdx.y = J, so a wave differentiates ONE joint of 64 knots -- every thread recomputes the knot's forward dynamics and nominal inverse
+// dynamics (~2.3 k instructions) and then only joint J's tangent pass (columns J, 7 + J, 14 + J of [A B]): the longest instruction stream is ~4.5 k instead of the
+// ~11 k of a whole knot on one thread (k_nis_tl), on 7 x as many waves.  Joint 0's threads also adopt the accepted candidate (a copy of its x, u, d from the
+// candidate-major arrays the split rollout kernel k_fp_tl2 wrote) and write the cost gradient (mode 1: the cost Hessian).  Reference layout of [A B].
+// Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279), like k_nis_lg.
+template <int V>
+__global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostWeights<float> cw, float dt, float grav, int mode, int batch) {
+    using T = float;
+    constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+    constexpr int NX = 14, NU = 7, NM = 21;
+    const int J = blockIdx.y, g = blockIdx.x * 64 + threadIdx.x, N = dm.N;
+    if (g >= batch * N) return;
+    const int pb = g / N, k = g - pb * N;
+    const SolverState<T>& st = b.state[pb];
+    const size_t knot = (size_t)pb * N + k;
+    T x[NX], u[NU];
+    if (mode == 0) {
+        if (!st.win_pending) return;                                      // rejected / failed backward pass: trajectory and derivatives are unchanged
+        const size_t src = ((size_t)pb * dm.A + st.alphaIndex) * N + k;   // this knot in the winner's candidate slot
+        tl_load14(x, b.xs + src * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) u[i] = b.us[src * NU + i];
+        if (J == 0) {
+            tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX, x);
+#pragma unroll
+            for (int i = 0; i < NU; i++) b.ucur[knot * NU + i] = u[i];
+            if (dm.M > 1 && dm.on_defect_boundary(k)) { T d[NX]; tl_load14(d, b.ds + src * NX); tl_store14(b.dcur + knot * NX, d); }
+        }
+        if (st.done) return;                                              // final accepted step: solution copied, no derivatives needed
+    } else {
+        tl_load14(x, b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) u[i] = b.ucur[knot * NU + i];
+    }
+    const bool fin = (k == N - 1);
+    if (J == 0) {
+        const T w1 = fin ? cw.QF1 : cw.Q1, w2 = fin ? cw.QF2 : cw.Q2, w3 = fin ? T(0) : cw.R;   // ArmPlant::weight
+        T xg[NX];
+        tl_load14(xg, b.xGoal + (size_t)pb * NX);
+        T* gk = b.g + knot * NM;
+#pragma unroll
+        for (int i = 0; i < 7; i++) { gk[i] = w1 * (x[i] - xg[i]); gk[7 + i] = w2 * (x[7 + i] - xg[7 + i]); gk[14 + i] = w3 * u[i]; }
+        if (mode == 1) {
+            T* H = b.H + knot * (NM * NM);
+            for (int e = 0; e < NM * NM; e++) { const int i = e / NM, j = e % NM; H[e] = i != j ? T(0) : (i < 7 ? w1 : (i < NX ? w2 : w3)); }
+        }
+    }
+    if (fin) return;
+    ArmTlState<T> ts;
+    T qdd[7];
+    arm_tl_dynamics<T>(md, grav, ts, qdd, x, x + 7, u);
+    T* AB = b.AB + knot * (NX * NM);
+    auto emit = [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; };
+    ArmTlNominal<T> nm;
+    arm_tl_grad_nominal<T>(md, grav, ts, x + 7, qdd, nm);
+    switch (J) {                                                          // uniform over the wave
+#define PDDP_TL7_CASE(JJ) case JJ: arm_tl_grad_joint<JJ, T>(md, ts, x + 7, qdd, nm, emit); arm_tl_grad_control<JJ, T>(ts, emit); break;
+        PDDP_TL7_CASE(0) PDDP_TL7_CASE(1) PDDP_TL7_CASE(2) PDDP_TL7_CASE(3) PDDP_TL7_CASE(4) PDDP_TL7_CASE(5) PDDP_TL7_CASE(6)
+#undef PDDP_TL7_CASE
+    }
+#pragma unroll
+    for (int r = 0; r < 7; r++) {                                         // the constant rows of this thread's three columns
+        AB[J * NX + r] = tl_AB_const<T>(r, J, dt); AB[(7 + J) * NX + r] = tl_AB_const<T>(r, 7 + J, dt); AB[(14 + J) * NX + r] = tl_AB_const<T>(r, 14 + J, dt);
+    }
+}
+void launch_nis_tl7(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int mode, int batch) {
+    const dim3 grid(((unsigned)batch * dm.N + 63) / 64, 7);
+    if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<0>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+    else hipLaunchKernelGGL((k_nis_tl7<1>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+}
+
 // API view of the compact [A B]: grid ceil(B*N*21 / 256), block 256, thread = (knot, column).  expand: compact -> the reference layout (pddp_get_array("AB"));
 // compact: the reference layout -> compact (pddp_set_array("AB"): teacher-forced tests hand in the oracle's derivatives).
 __global__ __launch_bounds__(256) void k_abc_convert(Buffers<float> b, int knots, int N, float dt, int to_compact) {

@@ -346,11 +346,17 @@ PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st,
 // emit(col, row, value): dqdd(row, col), col 0..6 d/dq, 7..13 d/dqd, 14..20 d/du   (the plug-in layout s_dqdd[col*7 + row]).
 // mark(stage): called after the columns of joints 0..3 (stage 0: columns 0..3 and 7..10 are complete), of joints 4..6 (stage 1: columns 4..6, 11..13) and
 // of the controls (stage 2: columns 14..20) have been emitted -- a caller that stages the columns somewhere small can flush in three pieces.
-template <typename T, typename Emit, typename Mark>
-PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark) {
+// The gradient in three reusable parts (arm_tl_gradient runs them for every joint; the setup kernel for few problems in flight, k_nis_tl7, gives every
+// joint's columns to a different thread):
+//   arm_tl_grad_nominal:  the nominal inverse dynamics at the actual qdd -- per link the acceleration a, I v, and the total force Ft through its joint
+//   arm_tl_grad_joint<J>: columns J (d/dq_J) and 7 + J (d/dqd_J)         arm_tl_grad_control<J>: column 14 + J (d/du_J = column J of M^-1)
+template <typename T>
+struct ArmTlNominal { T a[kArmNB][6], Iv[kArmNB][6], Ft[kArmNB][6]; };
+template <typename T>
+PDDP_HD void arm_tl_grad_nominal(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, ArmTlNominal<T>& nm) {
     constexpr int NB = kArmNB;
+    auto& a = nm.a; auto& Iv = nm.Iv; auto& Ft = nm.Ft;
     // ---- nominal inverse dynamics at the actual qdd: per link the acceleration, I v, and the total force through its joint
-    T a[NB][6], Iv[NB][6], Ft[NB][6];
     {
         T ap[6] = {T(0), T(0), T(0), T(0), T(0), grav};
         TlFor<0, NB, 1>::run([&](auto ic) {
@@ -373,92 +379,104 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
             for (int e = 0; e < 6; e++) Ft[i - 1][e] += fp[e];
         });
     }
-    // ---- tangents: for joint j, d/dq_j and d/dqd_j of the inverse dynamics, then -M^-1
+}
+template <int j, typename T, typename Emit>
+PDDP_HD void arm_tl_grad_joint(const ArmTlModel<T>& md, const ArmTlState<T>& st, const T* qd, const T* qdd, const ArmTlNominal<T>& nm, Emit emit) {
+    constexpr int NB = kArmNB;
+    const auto& a = nm.a; const auto& Iv = nm.Iv; const auto& Ft = nm.Ft;
+    T dFq[6], dFv[6];                 // tangent of the total force through the current joint (accumulated from the tip inwards)
+    T dtq[NB], dtv[NB];
+    // forward over the links at and below joint j
+    T dvq[NB][6], daq[NB][6], dvv[NB][6], dav[NB][6];
+    {
+        const T* v = st.v[j];
+        // d(X_j v_p)/dq_j = -e_z x (X_j v_p) = -e_z x v_j (e_z x e_z = 0):  -(e_z x w) = (w_y, -w_x, 0)
+        dvq[j][0] = v[1]; dvq[j][1] = -v[0]; dvq[j][2] = T(0); dvq[j][3] = v[4]; dvq[j][4] = -v[3]; dvq[j][5] = T(0);
+        // X_j a_p = a_j - e_z qdd_j - v_j x (e_z qd_j)
+        const T xa[6] = {a[j][0] - qd[j] * v[1], a[j][1] + qd[j] * v[0], a[j][2] - qdd[j], a[j][3] - qd[j] * v[4], a[j][4] + qd[j] * v[3], a[j][5]};
+        daq[j][0] = xa[1] + qd[j] * dvq[j][1]; daq[j][1] = -xa[0] - qd[j] * dvq[j][0]; daq[j][2] = T(0);
+        daq[j][3] = xa[4] + qd[j] * dvq[j][4]; daq[j][4] = -xa[3] - qd[j] * dvq[j][3]; daq[j][5] = T(0);
+        // d/dqd_j: dv_j = e_z, da_j = v_j x e_z  (the e_z x e_z qd term vanishes)
+        dvv[j][0] = T(0); dvv[j][1] = T(0); dvv[j][2] = T(1); dvv[j][3] = T(0); dvv[j][4] = T(0); dvv[j][5] = T(0);
+        dav[j][0] = v[1]; dav[j][1] = -v[0]; dav[j][2] = T(0); dav[j][3] = v[4]; dav[j][4] = -v[3]; dav[j][5] = T(0);
+    }
+    TlFor<j + 1, NB, 1>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int K = arm_tl_kind(i);
+        tl_motion_to_child<K>(dvq[i], dvq[i - 1], md.r[i], st.c[i], st.s[i]);
+        tl_motion_to_child<K>(daq[i], daq[i - 1], md.r[i], st.c[i], st.s[i]);
+        daq[i][0] += qd[i] * dvq[i][1]; daq[i][1] -= qd[i] * dvq[i][0]; daq[i][3] += qd[i] * dvq[i][4]; daq[i][4] -= qd[i] * dvq[i][3];
+        tl_motion_to_child<K>(dvv[i], dvv[i - 1], md.r[i], st.c[i], st.s[i]);
+        tl_motion_to_child<K>(dav[i], dav[i - 1], md.r[i], st.c[i], st.s[i]);
+        dav[i][0] += qd[i] * dvv[i][1]; dav[i][1] -= qd[i] * dvv[i][0]; dav[i][3] += qd[i] * dvv[i][4]; dav[i][4] -= qd[i] * dvv[i][3];
+    });
+    // backward: df_i = I da_i + dv_i x* (I v_i) + v_i x* (I dv_i), accumulated towards the base; joint j adds e_z x* F_j to the q tangent
+    TlFor<NB - 1, -1, -1>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int K = arm_tl_kind(i);
+        if (i >= j) {
+            T dfq[6], dfv[6], t6[6];
+            tl_inertia_mul(dfq, md.m[i], md.h[i], md.I[i], daq[i]);
+            tl_crf_add(dfq, dvq[i], Iv[i]);
+            tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvq[i]);
+            tl_crf_add(dfq, st.v[i], t6);
+            tl_inertia_mul(dfv, md.m[i], md.h[i], md.I[i], dav[i]);
+            tl_crf_add(dfv, dvv[i], Iv[i]);
+            tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvv[i]);
+            tl_crf_add(dfv, st.v[i], t6);
+            if (i == NB - 1) {
+#pragma unroll
+                for (int e = 0; e < 6; e++) { dFq[e] = dfq[e]; dFv[e] = dfv[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 6; e++) { dFq[e] += dfq[e]; dFv[e] += dfv[e]; }
+            }
+        }
+        dtq[i] = dFq[2]; dtv[i] = dFv[2];
+        if (i > 0) {
+            if (i == j) {                          // d(X_j' F_j)/dq_j = X_j' (e_z x* F_j + dF_j):  e_z x (n; f) = (-n_y, n_x, 0; -f_y, f_x, 0)
+                dFq[0] -= Ft[j][1]; dFq[1] += Ft[j][0]; dFq[3] -= Ft[j][4]; dFq[4] += Ft[j][3];
+            }
+            T fp[6];
+            tl_force_to_parent<K>(fp, dFq, md.r[i], st.c[i], st.s[i]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) dFq[e] = fp[e];
+            tl_force_to_parent<K>(fp, dFv, md.r[i], st.c[i], st.s[i]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) dFv[e] = fp[e];
+        }
+    });
+    dtv[j] += T(0.5);                              // d(0.5 qd)/dqd_j
+    // dqdd/dq_j = -M^-1 dtau/dq_j
+#pragma unroll
+    for (int i = 0; i < NB; i++) { dtq[i] = -dtq[i]; dtv[i] = -dtv[i]; }
+    tl_ldl_solve(st, dtq);
+    tl_ldl_solve(st, dtv);
+#pragma unroll
+    for (int i = 0; i < NB; i++) { emit(j, i, dtq[i]); emit(NB + j, i, dtv[i]); }
+}
+template <int j, typename T, typename Emit>
+PDDP_HD void arm_tl_grad_control(const ArmTlState<T>& st, Emit emit) {
+    constexpr int NB = kArmNB;
+        T e[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) e[i] = (i == j) ? T(1) : T(0);
+    tl_ldl_solve(st, e);
+#pragma unroll
+    for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
+}
+template <typename T, typename Emit, typename Mark>
+PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark) {
+    constexpr int NB = kArmNB;
+    ArmTlNominal<T> nm;
+    arm_tl_grad_nominal<T>(md, grav, st, qd, qdd, nm);
     TlFor<0, NB, 1>::run([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        T dFq[6], dFv[6];                 // tangent of the total force through the current joint (accumulated from the tip inwards)
-        T dtq[NB], dtv[NB];
-        // forward over the links at and below joint j
-        T dvq[NB][6], daq[NB][6], dvv[NB][6], dav[NB][6];
-        {
-            const T* v = st.v[j];
-            // d(X_j v_p)/dq_j = -e_z x (X_j v_p) = -e_z x v_j (e_z x e_z = 0):  -(e_z x w) = (w_y, -w_x, 0)
-            dvq[j][0] = v[1]; dvq[j][1] = -v[0]; dvq[j][2] = T(0); dvq[j][3] = v[4]; dvq[j][4] = -v[3]; dvq[j][5] = T(0);
-            // X_j a_p = a_j - e_z qdd_j - v_j x (e_z qd_j)
-            const T xa[6] = {a[j][0] - qd[j] * v[1], a[j][1] + qd[j] * v[0], a[j][2] - qdd[j], a[j][3] - qd[j] * v[4], a[j][4] + qd[j] * v[3], a[j][5]};
-            daq[j][0] = xa[1] + qd[j] * dvq[j][1]; daq[j][1] = -xa[0] - qd[j] * dvq[j][0]; daq[j][2] = T(0);
-            daq[j][3] = xa[4] + qd[j] * dvq[j][4]; daq[j][4] = -xa[3] - qd[j] * dvq[j][3]; daq[j][5] = T(0);
-            // d/dqd_j: dv_j = e_z, da_j = v_j x e_z  (the e_z x e_z qd term vanishes)
-            dvv[j][0] = T(0); dvv[j][1] = T(0); dvv[j][2] = T(1); dvv[j][3] = T(0); dvv[j][4] = T(0); dvv[j][5] = T(0);
-            dav[j][0] = v[1]; dav[j][1] = -v[0]; dav[j][2] = T(0); dav[j][3] = v[4]; dav[j][4] = -v[3]; dav[j][5] = T(0);
-        }
-        TlFor<j + 1, NB, 1>::run([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int K = arm_tl_kind(i);
-            tl_motion_to_child<K>(dvq[i], dvq[i - 1], md.r[i], st.c[i], st.s[i]);
-            tl_motion_to_child<K>(daq[i], daq[i - 1], md.r[i], st.c[i], st.s[i]);
-            daq[i][0] += qd[i] * dvq[i][1]; daq[i][1] -= qd[i] * dvq[i][0]; daq[i][3] += qd[i] * dvq[i][4]; daq[i][4] -= qd[i] * dvq[i][3];
-            tl_motion_to_child<K>(dvv[i], dvv[i - 1], md.r[i], st.c[i], st.s[i]);
-            tl_motion_to_child<K>(dav[i], dav[i - 1], md.r[i], st.c[i], st.s[i]);
-            dav[i][0] += qd[i] * dvv[i][1]; dav[i][1] -= qd[i] * dvv[i][0]; dav[i][3] += qd[i] * dvv[i][4]; dav[i][4] -= qd[i] * dvv[i][3];
-        });
-        // backward: df_i = I da_i + dv_i x* (I v_i) + v_i x* (I dv_i), accumulated towards the base; joint j adds e_z x* F_j to the q tangent
-        TlFor<NB - 1, -1, -1>::run([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int K = arm_tl_kind(i);
-            if (i >= j) {
-                T dfq[6], dfv[6], t6[6];
-                tl_inertia_mul(dfq, md.m[i], md.h[i], md.I[i], daq[i]);
-                tl_crf_add(dfq, dvq[i], Iv[i]);
-                tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvq[i]);
-                tl_crf_add(dfq, st.v[i], t6);
-                tl_inertia_mul(dfv, md.m[i], md.h[i], md.I[i], dav[i]);
-                tl_crf_add(dfv, dvv[i], Iv[i]);
-                tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvv[i]);
-                tl_crf_add(dfv, st.v[i], t6);
-                if (i == NB - 1) {
-#pragma unroll
-                    for (int e = 0; e < 6; e++) { dFq[e] = dfq[e]; dFv[e] = dfv[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 6; e++) { dFq[e] += dfq[e]; dFv[e] += dfv[e]; }
-                }
-            }
-            dtq[i] = dFq[2]; dtv[i] = dFv[2];
-            if (i > 0) {
-                if (i == j) {                          // d(X_j' F_j)/dq_j = X_j' (e_z x* F_j + dF_j):  e_z x (n; f) = (-n_y, n_x, 0; -f_y, f_x, 0)
-                    dFq[0] -= Ft[j][1]; dFq[1] += Ft[j][0]; dFq[3] -= Ft[j][4]; dFq[4] += Ft[j][3];
-                }
-                T fp[6];
-                tl_force_to_parent<K>(fp, dFq, md.r[i], st.c[i], st.s[i]);
-#pragma unroll
-                for (int e = 0; e < 6; e++) dFq[e] = fp[e];
-                tl_force_to_parent<K>(fp, dFv, md.r[i], st.c[i], st.s[i]);
-#pragma unroll
-                for (int e = 0; e < 6; e++) dFv[e] = fp[e];
-            }
-        });
-        dtv[j] += T(0.5);                              // d(0.5 qd)/dqd_j
-        // dqdd/dq_j = -M^-1 dtau/dq_j
-#pragma unroll
-        for (int i = 0; i < NB; i++) { dtq[i] = -dtq[i]; dtv[i] = -dtv[i]; }
-        tl_ldl_solve(st, dtq);
-        tl_ldl_solve(st, dtv);
-#pragma unroll
-        for (int i = 0; i < NB; i++) { emit(j, i, dtq[i]); emit(NB + j, i, dtv[i]); }
+        arm_tl_grad_joint<j, T>(md, st, qd, qdd, nm, emit);
         if (j == 3) mark(0);
         if (j == NB - 1) mark(1);
     });
-    // ---- dqdd/du = M^-1
-    TlFor<0, NB, 1>::run([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        T e[NB];
-#pragma unroll
-        for (int i = 0; i < NB; i++) e[i] = (i == j) ? T(1) : T(0);
-        tl_ldl_solve(st, e);
-#pragma unroll
-        for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
-    });
+    TlFor<0, NB, 1>::run([&](auto jc) { arm_tl_grad_control<decltype(jc)::value, T>(st, emit); });
     mark(2);
 }
 template <typename T, typename Emit>

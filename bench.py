@@ -31,6 +31,7 @@ import pyddp  # noqa: E402
 from pyddp import shard  # noqa: E402
 
 BENCH_BATCH = 16384       # independent problems per GPU of the headline line (tests/test_fp32_bar.py runs its what-the-bench-runs cases at this size)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix-core peak of MI355X (256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 PHASES = ("bp", "fp", "ls", "nis")                      # the four phases of a sweep, in launch order (per-phase figures of the latency block)
 # reference phase whose algorithmic bytes a kernel covers, by kernel-name prefix
@@ -160,6 +161,17 @@ def main():
             # re-reads of the gains / sweep operands included -- the forward kernels read them once for all alphas, so their figure can exceed the HBM peak)
             "per_kernel": {nm: {"ms": round(ms, 5), "reference_equivalent_GBs": round(alg_of(nm) * B / (ms * 1e-3) / 1e9, 1)} for nm, ms in kern},
             "whole_sweep_reference_equivalent_GBs": round(sweep_bytes / (t_local / K) / 1e9, 2)}
+    if traffic:
+        roof["traffic_GBs"] = round(traffic / (dom_ms * 1e-3) / 1e9, 1)        # what the kernel really moves: it keeps only the dynamic half of [A B] and the block-boundary cost-to-go
+    if dom_name == "k_bp_mfma":
+        # the same kernel against the matrix-core roofline: 34 v_mfma_f32_16x16x4_f32 per knot as issued (2048 flop each) and the dense products the reference's
+        # backward pass needs per knot (n = 14, m = 7: W = P'[A B], H = [A B]'W, K, T1, P+, A - BK ~ 16.3 k multiply-adds)
+        knots = B * (N - M)                                                    # every block walks N/M - 1 knots
+        issued, useful = 34 * 2048.0 * knots, 2.0 * 16300.0 * knots
+        roof["mfma"] = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": round(issued / (dom_ms * 1e-3) / 1e12, 2),
+                        "issued_frac": round(issued / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                        "algorithmic_TFLOPs": round(useful / (dom_ms * 1e-3) / 1e12, 2),
+                        "limiter": "serial chain per knot (matrix-core phases + the 7x7 inversion on the vector ALU) at 5 waves per SIMD: neither HBM nor the matrix pipe saturates"}
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),

@@ -475,7 +475,7 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpyAsync(d_shift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
         if (cfg.ee_cost && cfg.ee_cost_shift) HIPCHK(hipMemcpyAsync(b.tshift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
         else HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
-        hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+        hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
         const int saved_max_iter = sp.max_iter;
         sp.max_iter = max_iter;                                  // acceptRejectTrajGPU(..., max_iter)
         const int ee = cfg.ee_cost ? 1 : 0;

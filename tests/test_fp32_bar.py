@@ -373,3 +373,35 @@ def test_bench_batch_whole_solves_equal_single_problem_solves():
     print("J: err(kernel32, oracle64) median %.2e max %.2e; err(oracle32, oracle64) median %.2e max %.2e" % (np.median(ek), ek.max(), np.median(eo), eo.max()))
     assert min(agree) >= 3 and np.median(agree) >= 6, agree
     assert np.median(ek) <= max(1e-4, 1.5 * np.median(eo)) and ek.max() <= max(1e-4, 1.5 * eo.max()) and np.mean(ek <= np.maximum(1e-4, 3 * eo)) >= 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,env", [pytest.param(100, {}, id="100-problems-few-problem-kernels"),
+                                   pytest.param(512, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "wg"}, id="512-problems-thread-lanes-with-staged-sweep"),
+                                   pytest.param(600, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "st"}, id="600-problems-large-batch-kernels")])
+def test_batches_between_one_and_the_bench_equal_single_problem_solves(B, env):
+    """The kernel selection changes with the number of problems in flight (one problem ... 128: k_sweep_wg + k_fp_tl2 + k_nis_tl7; up to 512: the staged sweep
+    with the thread-lane kernels; above: the large-batch set).  At each of these sizes a batch -- more than one workgroup of every kernel, ragged last
+    workgroups -- must give, bit for bit, what single-problem handles on the SAME kernels give (`env` = the selection the library made for the batch, forced
+    for the single problem); the per-iteration bar of those kernels is test_kuka_headline_config_float32_bar_every_iteration's."""
+    kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=8)
+    rng = np.random.default_rng(77 + B)
+    xs, us = [], []
+    for b_ in range(B):
+        x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
+        xs.append(x0); us.append(u0)
+    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
+    out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
+    assert (out["iters"] == 8).all()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for b_ in list(rng.choice(B, 6, replace=False)) + [0, B - 1]:
+        o1 = s1.solve(xs[b_], us[b_], xg)
+        for key in ("Jout", "alphaOut", "x", "u", "KT"):
+            assert np.array_equal(o1[key][0], out[key][b_]), (int(b_), key)
+        assert (out["alphaOut"][b_][1:9] >= 0).any()

@@ -61,6 +61,9 @@ typedef struct pddp_config {
     int ee_initial_cost_fix; /* 0 (default) = the reference: an MPC solve with the EE cost reads its initial cost from d_JT[alphaIndex]
                               * (nisInitHelpers.cuh:392), i.e. the cost of ONE knot whenever the previous solve ended on a shortened step, and
                               * then rejects every iteration; 1 = always the whole trajectory's cost (d_JT[0]).  Not a reference behaviour. */
+    int use_finite_diff;  /* USE_FINITE_DIFF (config.cuh:68): [A B] of the Euler step by central differences of the plant's `dynamics`, column by column
+                           * (finiteDiffInner, DDPHelpers/nisInitHelpers.cuh:138-183) instead of the analytic gradient.  Euler only, joint-space cost. */
+    double finite_diff_epsilon; /* FINITE_DIFF_EPSILON (config.cuh:69-71), default 0.00001 */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */

@@ -23,6 +23,9 @@ extern "C" {
 typedef struct pddp_cpu_buffers {
     void *x, *xp, *xp2, *u, *up, *P, *p, *Pp, *pp, *AB, *H, *g, *KT, *du, *d, *dp, *ApBK, *Bdu, *alpha, *JT, *dJexp;
     int* err;
+    /* allocateMemory_CPU2 (nisInitHelpers.cuh:927-948) only: one trajectory slot and one cost-partial-sum array per line-search candidate -- arrays of A pointers
+     * (xs[a]: N*n, us[a]: N*m, ds[a]: N*n, JTs[a]: max(COST_THREADS, FSIM_THREADS) elements); NULL for runiLQR_CPU */
+    void **xs, **us, **ds, **JTs;
 } pddp_cpu_buffers;
 
 /* thread counts the reference derives from CPU_CORES (config.cuh:155-161); cores <= 0: std::thread::hardware_concurrency() */
@@ -36,6 +39,14 @@ int pddp_cpu_run_ilqr(const pddp_config* cfg, const pddp_cpu_buffers* buf, void*
                       const void* d0, const void* xGoal, void* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag,
                       int ignoreFirstDefectFlag, double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime,
                       double* initTime, int cores, int* iters_out);
+
+/* runiLQR_CPU2<T> (DDPWrappers.cuh:252-363): the same solve with the PARALLEL line search -- chunks of FSIM_ALPHA_THREADS = max(cores / M, 1) step sizes are
+ * swept, rolled out and costed concurrently in their own slots (buf->xs, us, ds, JTs), the best acceptable one of a chunk wins; no cost-tolerance exit
+ * (nisInitHelpers.cuh:586), as in the reference.  Same arguments as pddp_cpu_run_ilqr. */
+int pddp_cpu_run_ilqr2(const pddp_config* cfg, const pddp_cpu_buffers* buf, void* x0, void* u0, const void* KT0, const void* P0, const void* p0,
+                       const void* d0, const void* xGoal, void* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag,
+                       int ignoreFirstDefectFlag, double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime,
+                       double* initTime, int cores, int* iters_out);
 
 const char* pddp_cpu_last_error(void);
 

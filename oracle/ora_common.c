@@ -28,4 +28,5 @@ void ora_default_cfg(ora_cfg *c, int plant) {
     c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
     c->ee_on_link_z = 0.0635;
     c->ee_type = 1;
+    c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;
 }

@@ -65,6 +65,8 @@ typedef struct ora_cfg {
     double xTarget[14];                 /* nominal-state target (d_xTarget); zeros = the reference's xTarget == nullptr case */
     int ee_type;                        /* EE_TYPE 0 none / 1 flange (default) / 2 flange + peg: link-7 INERTIA_MODIFIER, WEIGHT_MODIFIER
                                            (default-URDF branch only)                              dynamics_arm.cuh:48-65,338-347 */
+    int use_finite_diff;                /* USE_FINITE_DIFF: [A B] of the Euler step by central differences of `dynamics` (nisInitHelpers.cuh:138-166)  config.cuh:68 */
+    double finite_diff_epsilon;         /* FINITE_DIFF_EPSILON                                                                                         config.cuh:69-71 */
 } ora_cfg;
 
 /* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */
@@ -103,6 +105,9 @@ typedef struct ora_result {
                                    REAL prevJ, int *ignore_defect, int *alphaIndex, REAL *dJ, REAL *z);       \
     /* solver-level (G3/G4): x0 [n*N], u0 [m*N] in/out; KT_out [n*m*N] optional */                            \
     int ora_run_ilqr_cpu_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,           \
+                               int *alphaOut, int rollout, int ignoreFirstDefect, REAL *KT_out,               \
+                               ora_result *res);                                                              \
+    int ora_run_ilqr_cpu2_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,           \
                                int *alphaOut, int rollout, int ignoreFirstDefect, REAL *KT_out,               \
                                ora_result *res);                                                              \
     int ora_run_ilqr_gpusem_##SUF(const ora_cfg *c, REAL *x0, REAL *u0, const REAL *xGoal, REAL *Jout,        \

@@ -30,6 +30,32 @@ PDDP_HD T dxd(const T* dqdd, int r, int c) {
     return r < NPOS ? T(r + NPOS == c ? 1 : 0) : dqdd[c * NPOS + (r - NPOS)];
 }
 
+// USE_FINITE_DIFF (config.cuh:68; finiteDiffInner, DDPHelpers/nisInitHelpers.cuh:138-166): [A B] of the EULER step column by column from two evaluations of
+// the plant's dynamics at x, u -+ eps e_col -- position rows are the exact constants of dqddk2dxd (utils/integrators.cuh:21), velocity rows
+// (col == row) + dt (qdd+ - qdd-) / (2 eps) with the quotient taken in double like the reference's `delta / (2.0*FINITE_DIFF_EPSILON)`.
+template <typename P, typename T>
+struct FdScratch { T xp[P::NX], xm[P::NX], up[P::NU], um[P::NU], qp[P::NPOS], qm[P::NPOS]; };
+template <typename P, typename T>
+PDDP_HD void integrator_gradient_fd(const Wave& w, typename P::Scratch& ps, FdScratch<P, T>& f, T* AB, const T* x, const T* u, T dt, double eps) {
+    constexpr int NP = P::NPOS, NX = P::NX, NU = P::NU, NM = NX + NU;
+    for (int col = 0; col < NM; col++) {
+        PDDP_FOR(i, NX) { const T adj = T(col == i ? eps : 0.0); f.xp[i] = x[i] + adj; f.xm[i] = x[i] - adj; }
+        PDDP_FOR(i, NU) { const T adj = T(col == i + NX ? eps : 0.0); f.up[i] = u[i] + adj; f.um[i] = u[i] - adj; }
+        wsync(w);
+        P::dynamics(w, ps, f.qp, f.xp, f.up);
+        wsync(w);
+        P::dynamics(w, ps, f.qm, f.xm, f.um);
+        wsync(w);
+        PDDP_FOR(i, NX) {
+            const T delta = i < NP ? (f.xp[i + NP] - f.xm[i + NP]) : (f.qp[i - NP] - f.qm[i - NP]);
+            const T dxdd = T(double(delta) / (2.0 * eps));
+            const T v = i < NP ? T(i + NP == col ? 1 : 0) : dxdd;
+            AB[col * NX + i] = T((i == col ? 1.0 : 0.0) + double(dt * v));
+        }
+        wsync(w);
+    }
+}
+
 // xkp1, x, u in LDS (or host memory).  xkp1 must not alias x.
 template <typename P, int INTEG, typename T>
 PDDP_HD void integrator_step(const Wave& w, typename P::Scratch& ps, IntegScratch<P, T>& s, T* xkp1, const T* x, const T* u, T dt) {

@@ -19,6 +19,7 @@ struct NisScratch {
     T x[P::NX], u[P::NU];
     EeScratch<T> ee;
     T qdd[P::NPOS];
+    FdScratch<P, T> fd;
 };
 
 // xk/uk: the knot's state and control (global).  Writes ABk (k < N-1), Hk, gk (global).
@@ -43,7 +44,10 @@ PDDP_HD void nis_knot(const Wave& w, NisScratch<P, INTEG, T>& s, const Dims& dm,
     }
     PDDP_FOR(e, NM * NM) { const int i = e / NM, j = e % NM; Hk[e] = (i == j) ? P::weight(cw, i, k, dm.N) : T(0); }
     PDDP_FOR(i, NM) gk[i] = P::weight(cw, i, k, dm.N) * (i < NX ? (s.x[i] - xg[i]) : s.u[i - NX]);
-    if (k < dm.N - 1) integrator_gradient<P, INTEG>(w, s.plant, s.pgrad, s.integ, ABk, s.x, s.u, dt);
+    if (k < dm.N - 1) {
+        if (INTEG == 1 && cw.fd_eps > 0.0) integrator_gradient_fd<P, T>(w, s.plant, s.fd, ABk, s.x, s.u, dt, cw.fd_eps);   // USE_FINITE_DIFF
+        else integrator_gradient<P, INTEG>(w, s.plant, s.pgrad, s.integ, ABk, s.x, s.u, dt);
+    }
 }
 
 }  // namespace pddp

@@ -51,6 +51,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
     c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
     c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
+    c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;   // config.cuh:68-71
     return 0;
 }
 
@@ -129,12 +130,14 @@ struct Solver : SolverBase {
         if (arm_tl_model_from_tables(m, hm))
             for (int v = 0; v < 2; v++) if (arm_tl_models_equal(m, arm_tl_builtin<T>(v))) tl_variant = v;
         tl_grav = hm.grav;
-        fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0, cfg.batch);
+        // USE_FINITE_DIFF: the setup runs on the wave-cooperative kernel (k_nis: any plant's `dynamics`), which adopts the winner from the candidate-major
+        // xs / us / ds -- so the rollouts stay on lane groups (they write those), not on the thread-lane kernels
+        fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0 && !cfg.use_finite_diff, cfg.batch);
         fp_coop = (fp_path == kFpCoop);
         // few problems in flight, joint-space cost, float, built-in robot model: the rollouts run on k_fp_tl2 (every step split over two wavefronts);
         // sweep, line search and setup stay on the lane-group kernels.  PDDP_FP=lg keeps the lane-group rollouts (bit-identity tests), PDDP_FP=tl2 asks for the split.
         const char* fpenv = std::getenv("PDDP_FP");
-        fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.ee_cost && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
+        fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.ee_cost && !cfg.use_finite_diff && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
     }
     void derive_tl_model(const EmptyModel&) {}
     // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
@@ -205,6 +208,7 @@ struct Solver : SolverBase {
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
         cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
+        cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;
         dt = (T)(c.total_time / (c.N - 1));                       // TIME_STEP, config.cuh:136
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
         int rc = 0;
@@ -350,7 +354,7 @@ struct Solver : SolverBase {
                 if (part != 0) launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);   // mode 0: adopts the accepted candidate first (arm_tl_adopt_knot)
                 return;
             }
-            if (!fp_coop) {
+            if (!fp_coop && !cfg.use_finite_diff) {
                 if (part == 0) return;
                 if constexpr (sizeof(T) == 4) { if (fp_split && cfg.batch <= kNisTl7MaxBatch) { launch_nis_tl7(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B); return; } }
                 if (cfg.ee_cost) hipLaunchKernelGGL((k_nis_lg<T, true>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
@@ -704,6 +708,8 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     if (c.ee_cost && c.plant != 4) return fail(PDDP_EINVAL, "ee_cost: the end-effector cost family belongs to the KUKA arm (plant 4)");
+    if (c.use_finite_diff && (c.integrator != 1 || c.ee_cost || !(c.finite_diff_epsilon > 0.0)))
+        return fail(PDDP_EINVAL, "use_finite_diff: the finite-difference [A B] is the Euler rule's (finiteDiffInner, nisInitHelpers.cuh:138-166), with the joint-space cost and a positive finite_diff_epsilon");
     if (c.plant == 4 && ((c.A > 8 && c.A % 8 == 0) ? 8 : c.A) * c.M > 128)
         return fail(PDDP_EINVAL, "KUKA arm: (candidates per workgroup) * M must not exceed 128 -- a workgroup rolls out 8 candidates when A is a multiple of 8, otherwise all A");
     if (c.plant == 4 && (double)c.batch * c.N * (c.A * 14 > 441 ? c.A * 14 : 441) >= 4294967296.0)

@@ -126,27 +126,37 @@ static void testGPU(int solves, unsigned seed) {
                       d_dT, d, d_ApBK, d_Bdu, d_JT, J, d_dJexp, dJexp, alpha, d_alpha, alphaIndex, d_err, err, streams, d_I, d_Tbody);
 }
 
-// testCPU of the reference example, serial-alpha branch (examples/WAFR_iLQR_examples.cu:231-299 with 'CS'): the same call sequence against
-// allocateMemory_CPU / runiLQR_CPU / freeMemory_CPU
+// testCPU of the reference example (examples/WAFR_iLQR_examples.cu:231-299): serialAlphas = 1 ('CS') runs allocateMemory_CPU / runiLQR_CPU / freeMemory_CPU,
+// serialAlphas = 0 ('C', the reference's default for the CPU) the parallel line search allocateMemory_CPU2 / runiLQR_CPU2 / freeMemory_CPU2 -- the same call
+// sequences as upstream.
 template <typename T>
-static void testCPU(int solves, unsigned seed) {
+static void testCPU(int serialAlphas, int solves, unsigned seed) {
     int ld_x, ld_u, ld_P, ld_p, ld_AB, ld_H, ld_g, ld_KT, ld_du, ld_d, ld_A;
-    T *alpha, *P, *p, *Pp, *pp, *AB, *H, *g, *KT, *du, *x, *u, *xp, *xp2, *up, *JT, *d, *dp, *ApBK, *Bdu, *dJexp, *xGoal, *I, *Tbody;
+    T *alpha, *P, *p, *Pp, *pp, *AB, *H, *g, *KT, *du, *x, *u, *xp, *xp2, *up, *JT = nullptr, *d, *dp, *ApBK, *Bdu, *dJexp, *xGoal, *I, *Tbody;
+    T **xs = nullptr, **us = nullptr, **ds = nullptr, **JTs = nullptr;
     int* err;
-    allocateMemory_CPU<T>(&x, &xp, &xp2, &u, &up, &xGoal, &P, &Pp, &p, &pp, &AB, &H, &g, &KT, &du, &d, &dp, &ApBK, &Bdu, &JT, &dJexp, &alpha, &err, &ld_x, &ld_u,
-                          &ld_P, &ld_p, &ld_AB, &ld_H, &ld_g, &ld_KT, &ld_du, &ld_d, &ld_A, &I, &Tbody);
+    if (serialAlphas) allocateMemory_CPU<T>(&x, &xp, &xp2, &u, &up, &xGoal, &P, &Pp, &p, &pp, &AB, &H, &g, &KT, &du, &d, &dp, &ApBK, &Bdu, &JT, &dJexp, &alpha, &err, &ld_x,
+                                            &ld_u, &ld_P, &ld_p, &ld_AB, &ld_H, &ld_g, &ld_KT, &ld_du, &ld_d, &ld_A, &I, &Tbody);
+    else allocateMemory_CPU2<T>(&xs, &x, &xp, &xp2, &us, &u, &up, &xGoal, &P, &Pp, &p, &pp, &AB, &H, &g, &KT, &du, &ds, &d, &dp, &ApBK, &Bdu, &JTs, &dJexp, &alpha, &err,
+                                &ld_x, &ld_u, &ld_P, &ld_p, &ld_AB, &ld_H, &ld_g, &ld_KT, &ld_du, &ld_d, &ld_A, &I, &Tbody);
     std::vector<T> x0(ld_x * NUM_TIME_STEPS), u0(ld_u * NUM_TIME_STEPS);
     std::vector<T> Jout((size_t)solves * (MAX_ITER + 1)); std::vector<int> alphaOut((size_t)solves * (MAX_ITER + 1), -2);
     std::vector<double> tTime(solves), initTime(solves), fsim((size_t)solves * MAX_ITER), fsweep((size_t)solves * MAX_ITER), bp((size_t)solves * MAX_ITER),
         nis((size_t)solves * MAX_ITER);
     std::mt19937 rng(seed);
     for (int i = 0; i < solves; i++) {
-        std::printf("<<<TESTING CPU %d/%d>>>\n", i + 1, solves);
+        std::printf(serialAlphas ? "<<<TESTING CPU %d/%d>>>\n" : "<<<TESTING CPU-P %d/%d>>>\n", i + 1, solves);
         loadXU<T>(x0.data(), u0.data(), xGoal, ld_x, ld_u, rng);
-        runiLQR_CPU<T>(x0.data(), u0.data(), nullptr, nullptr, nullptr, nullptr, xGoal, &Jout[(size_t)i * (MAX_ITER + 1)], &alphaOut[(size_t)i * (MAX_ITER + 1)],
-                       ROLLOUT_FLAG, 1, 1, &tTime[i], &fsim[(size_t)i * MAX_ITER], &fsweep[(size_t)i * MAX_ITER], &bp[(size_t)i * MAX_ITER], &nis[(size_t)i * MAX_ITER],
-                       &initTime[i], x, xp, xp2, u, up, P, p, Pp, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, alpha, JT, dJexp, err, ld_x, ld_u, ld_P, ld_p, ld_AB, ld_H,
-                       ld_g, ld_KT, ld_du, ld_d, ld_A, I, Tbody);
+        if (serialAlphas)
+            runiLQR_CPU<T>(x0.data(), u0.data(), nullptr, nullptr, nullptr, nullptr, xGoal, &Jout[(size_t)i * (MAX_ITER + 1)], &alphaOut[(size_t)i * (MAX_ITER + 1)],
+                           ROLLOUT_FLAG, 1, 1, &tTime[i], &fsim[(size_t)i * MAX_ITER], &fsweep[(size_t)i * MAX_ITER], &bp[(size_t)i * MAX_ITER], &nis[(size_t)i * MAX_ITER],
+                           &initTime[i], x, xp, xp2, u, up, P, p, Pp, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, alpha, JT, dJexp, err, ld_x, ld_u, ld_P, ld_p, ld_AB, ld_H,
+                           ld_g, ld_KT, ld_du, ld_d, ld_A, I, Tbody);
+        else
+            runiLQR_CPU2<T>(x0.data(), u0.data(), nullptr, nullptr, nullptr, nullptr, xGoal, &Jout[(size_t)i * (MAX_ITER + 1)], &alphaOut[(size_t)i * (MAX_ITER + 1)],
+                            ROLLOUT_FLAG, 1, 1, &tTime[i], &fsim[(size_t)i * MAX_ITER], &fsweep[(size_t)i * MAX_ITER], &bp[(size_t)i * MAX_ITER], &nis[(size_t)i * MAX_ITER],
+                            &initTime[i], xs, x, xp, xp2, us, u, up, P, p, Pp, pp, AB, H, g, KT, du, ds, d, dp, ApBK, Bdu, alpha, JTs, dJexp, err, ld_x, ld_u, ld_P, ld_p,
+                            ld_AB, ld_H, ld_g, ld_KT, ld_du, ld_d, ld_A, I, Tbody);
     }
     std::printf("Final state:\n");
     for (int i = 0; i < STATE_SIZE; i++) std::printf("%15.5f ", (double)x0[(NUM_TIME_STEPS - 2) * ld_x + i]);
@@ -157,10 +167,11 @@ static void testCPU(int solves, unsigned seed) {
     while (its < MAX_ITER && alphaOut[its + 1] != -2) its++;
     std::printf("CPU median total %.3f ms, init %.3f ms, loop %.3f ms; solve 0: %d iterations, J %.6f -> %.6f\n", median(tTime), median(initTime), median(loop), its,
                 (double)Jout[0], (double)Jout[its]);
-    freeMemory_CPU<T>(x, xp, xp2, u, up, P, Pp, p, pp, AB, H, g, KT, du, d, dp, Bdu, ApBK, dJexp, err, alpha, JT, xGoal, I, Tbody);
+    if (serialAlphas) freeMemory_CPU<T>(x, xp, xp2, u, up, P, Pp, p, pp, AB, H, g, KT, du, d, dp, Bdu, ApBK, dJexp, err, alpha, JT, xGoal, I, Tbody);
+    else freeMemory_CPU2<T>(xs, x, xp, xp2, us, u, up, P, Pp, p, pp, AB, H, g, KT, du, ds, d, dp, Bdu, ApBK, dJexp, err, alpha, JTs, xGoal, I, Tbody);
 }
 
-// usage: iLQR_examples [G|C] [solves] [seed]   (the reference's main takes 'G', 'CS', 'CP', 'S'; WAFR_iLQR_examples.cu:425-438).  A leading number keeps
+// usage: iLQR_examples [G|C|CS] [solves] [seed]   (the reference's main: 'G' GPU, 'C' CPU with the parallel line search, 'CS' CPU serial, 'S' SLQ -- WAFR_iLQR_examples.cu:425-438).  A leading number keeps
 // the old form "iLQR_examples solves seed" = GPU.
 int main(int argc, char** argv) {
     int a = 1;
@@ -168,6 +179,6 @@ int main(int argc, char** argv) {
     if (argc > 1 && (argv[1][0] == 'G' || argv[1][0] == 'C')) { hardware = argv[1][0]; a = 2; }
     const int solves = argc > a ? std::atoi(argv[a]) : 10;
     const unsigned seed = argc > a + 1 ? (unsigned)std::atoi(argv[a + 1]) : 1u;
-    if (hardware == 'C') testCPU<algType>(solves, seed); else testGPU<algType>(solves, seed);
+    if (hardware == 'C') testCPU<algType>((int)(argv[1][1] == 'S'), solves, seed); else testGPU<algType>(solves, seed);
     return 0;
 }

@@ -109,6 +109,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     c.ee_cost = EE_COST; c.Q_EE1 = _Q_EE1; c.Q_EE2 = _Q_EE2; c.QF_EE1 = _QF_EE1; c.QF_EE2 = _QF_EE2; c.R_EE = _R_EE;
     c.Q_xEE = _Q_xEE; c.QF_xEE = _QF_xEE; c.Q_xdEE = _Q_xdEE; c.QF_xdEE = _QF_xdEE; c.ee_on_link_z = EE_ON_LINK_Z;
     c.ee_initial_cost_fix = PDDP_EE_INITIAL_COST_FIX;
+    c.use_finite_diff = USE_FINITE_DIFF; c.finite_diff_epsilon = FINITE_DIFF_EPSILON;   // config.cuh:68-71
     Context* ctx = new Context();
     check(pddp_create(&c, &ctx->h), "allocateMemory_GPU");
     pddp_handle h = ctx->h;
@@ -221,8 +222,8 @@ void freeMemory_GPU(T** d_x, T** h_d_x, T* d_xp, T* d_xp2, T** d_u, T** h_d_u, T
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // The reference's CPU twins (DDPHelpers/nisInitHelpers.cuh:886-925 allocateMemory_CPU, :950-958 freeMemory_CPU; DDPHelpers/DDPWrappers.cuh:142-248
 // runiLQR_CPU), same names and argument order, over libpddp_cpu.so (include/pddp_cpu.h): the caller owns plain host buffers, exactly as upstream.
-// Compiled in when the translation unit defines PDDP_WITH_CPU_PATH (link with -lpddp_cpu); examples/WAFR_iLQR_examples.cu:231-299 (`testCPU`, the
-// serial-alpha branch) then recompiles unchanged.  runiLQR_GPU never routes here, and this path never touches the GPU library.
+// Compiled in when the translation unit defines PDDP_WITH_CPU_PATH (link with -lpddp_cpu); examples/WAFR_iLQR_examples.cu:231-299 (`testCPU`, both
+// its serial and its parallel line-search branch) then recompiles unchanged.  runiLQR_GPU never routes here, and this path never touches the GPU library.
 #ifdef PDDP_WITH_CPU_PATH
 #include "../../include/pddp_cpu.h"
 #include <cmath>
@@ -254,6 +255,19 @@ void allocateMemory_CPU(T** x, T** xp, T** xp2, T** u, T** up, T** xGoal, T** P,
 }
 
 template <typename T>
+inline pddp_config pddp_cpu_config_from_macros(T Q1, T Q2, T R, T QF1, T QF2) {
+    pddp_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.plant = PLANT; c.dtype = std::is_same<T, double>::value ? 1 : 0;
+    c.N = NUM_TIME_STEPS; c.M = M_BLOCKS; c.A = NUM_ALPHA; c.integrator = INTEGRATOR; c.batch = 1; c.max_iter = MAX_ITER;
+    c.wafr_urdf = USE_WAFR_URDF; c.mpc_mode = MPC_MODE; c.ignore_max_rho_exit = IGNORE_MAX_ROX_EXIT;
+    c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
+    c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX; c.Q1 = Q1; c.Q2 = Q2; c.R = R; c.QF1 = QF1; c.QF2 = QF2; c.ee_cost = EE_COST;
+    c.use_finite_diff = USE_FINITE_DIFF; c.finite_diff_epsilon = FINITE_DIFF_EPSILON;
+    return c;
+}
+
+template <typename T>
 void runiLQR_CPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag, int ignoreFirstDefectFlag,
                  double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime, double* initTime, T* x, T* xp, T* xp2, T* u, T* up, T* P,
                  T* p, T* Pp, T* pp, T* AB, T* H, T* g, T* KT, T* du, T* d, T* dp, T* ApBK, T* Bdu, T* alpha, T* JT, T* dJexp, int* err, int ld_x, int ld_u,
@@ -264,18 +278,55 @@ void runiLQR_CPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, i
     (void)ld_x; (void)ld_u; (void)ld_P; (void)ld_p; (void)ld_AB; (void)ld_H; (void)ld_g; (void)ld_KT; (void)ld_du; (void)ld_d; (void)ld_A; (void)I; (void)Tbody;
     (void)Q_EE1; (void)Q_EE2; (void)QF_EE1; (void)QF_EE2; (void)Q_EEV1; (void)Q_EEV2; (void)QF_EEV1; (void)QF_EEV2; (void)R_EE; (void)Q_xdEE; (void)QF_xdEE;
     (void)Q_xEE; (void)QF_xEE;
-    pddp_config c;
-    std::memset(&c, 0, sizeof(c));
-    c.plant = PLANT; c.dtype = std::is_same<T, double>::value ? 1 : 0;
-    c.N = NUM_TIME_STEPS; c.M = M_BLOCKS; c.A = NUM_ALPHA; c.integrator = INTEGRATOR; c.batch = 1; c.max_iter = MAX_ITER;
-    c.wafr_urdf = USE_WAFR_URDF; c.mpc_mode = MPC_MODE; c.ignore_max_rho_exit = IGNORE_MAX_ROX_EXIT;
-    c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
-    c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX; c.Q1 = Q1; c.Q2 = Q2; c.R = R; c.QF1 = QF1; c.QF2 = QF2; c.ee_cost = EE_COST;
-    pddp_cpu_buffers b = {x, xp, xp2, u, up, P, p, Pp, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, alpha, JT, dJexp, err};
+    pddp_config c = pddp_cpu_config_from_macros<T>(Q1, Q2, R, QF1, QF2);
+    pddp_cpu_buffers b = {x, xp, xp2, u, up, P, p, Pp, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, alpha, JT, dJexp, err, nullptr, nullptr, nullptr, nullptr};
     int iter = 0;
     const int rc = pddp_cpu_run_ilqr(&c, &b, x0, u0, KT0, P0, p0, d0, xGoal, Jout, alphaOut, forwardRolloutFlag, clearVarsFlag, ignoreFirstDefectFlag, tTime,
                                      simTime, sweepTime, bpTime, nisTime, initTime, 0, &iter);
     if (rc) { std::fprintf(stderr, "runiLQR_CPU: %s (code %d)\n", pddp_cpu_last_error(), rc); std::exit(rc < 0 ? -rc : rc); }
+    std::printf("CPU Parallel blocks:[%d] t:[%f] with FP[%f], FS[%f], BP[%f], NIU[%f] Xf:[%.4f, %.4f] iters:[%d] cost:[%f] max_d[%f]\n", M_BLOCKS_B, *tTime,
+                *simTime, *sweepTime, *bpTime, *nisTime, (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1)], (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1) + 1], iter,
+                (double)Jout[iter], 0.0);
+}
+
+// The parallel-line-search variants (nisInitHelpers.cuh:927-948 allocateMemory_CPU2, :959-966 freeMemory_CPU2; DDPWrappers.cuh:252-363 runiLQR_CPU2): one
+// trajectory slot (xs, us, ds) and one partial-sum array (JTs) per step size; `testCPU(0)` of examples/WAFR_iLQR_examples.cu:231-299 runs this path.
+template <typename T>
+void allocateMemory_CPU2(T*** xs, T** x, T** xp, T** xp2, T*** us, T** u, T** up, T** xGoal, T** P, T** Pp, T** p, T** pp, T** AB, T** H, T** g, T** KT, T** du,
+                         T*** ds, T** d, T** dp, T** ApBK, T** Bdu, T*** JTs, T** dJexp, T** alpha, int** err, int* ld_x, int* ld_u, int* ld_P, int* ld_p,
+                         int* ld_AB, int* ld_H, int* ld_g, int* ld_KT, int* ld_du, int* ld_d, int* ld_A, T** I = nullptr, T** Tbody = nullptr) {
+    *xs = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*))); *us = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*)));
+    *ds = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*))); *JTs = static_cast<T**>(std::malloc(NUM_ALPHA * sizeof(T*)));
+    allocateMemory_CPU<T>(x, xp, xp2, u, up, xGoal, P, Pp, p, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, &((*JTs)[0]), dJexp, alpha, err, ld_x, ld_u, ld_P, ld_p, ld_AB,
+                          ld_H, ld_g, ld_KT, ld_du, ld_d, ld_A, I, Tbody);
+    int bp_t = 1, fsim_t = 1, cost_t = 1, integ_t = 1;
+    pddp_cpu_thread_counts(M_BLOCKS_B, 0, &bp_t, &fsim_t, &cost_t, &integ_t);
+    const size_t N = NUM_TIME_STEPS, nj = fsim_t > cost_t ? fsim_t : cost_t;
+    for (int i = 0; i < NUM_ALPHA; i++) {
+        (*xs)[i] = static_cast<T*>(std::calloc(DIM_x_r * N, sizeof(T))); (*us)[i] = static_cast<T*>(std::calloc(DIM_u_r * N, sizeof(T)));
+        (*ds)[i] = static_cast<T*>(std::calloc(DIM_d_r * N, sizeof(T)));
+        if (i > 0) (*JTs)[i] = static_cast<T*>(std::calloc(nj, sizeof(T)));      // slot 0 is allocateMemory_CPU's JT (upstream allocates it twice and leaks the first)
+    }
+}
+
+template <typename T>
+void runiLQR_CPU2(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag, int ignoreFirstDefectFlag,
+                  double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime, double* initTime, T** xs, T* x, T* xp, T* xp2, T** us, T* u,
+                  T* up, T* P, T* p, T* Pp, T* pp, T* AB, T* H, T* g, T* KT, T* du, T** ds, T* d, T* dp, T* ApBK, T* Bdu, T* alphas, T** JTs, T* dJexp, int* err,
+                  int ld_x, int ld_u, int ld_P, int ld_p, int ld_AB, int ld_H, int ld_g, int ld_KT, int ld_du, int ld_d, int ld_A, T* I = nullptr, T* Tbody = nullptr,
+                  T Q_EE1 = _Q_EE1, T Q_EE2 = _Q_EE2, T QF_EE1 = _QF_EE1, T QF_EE2 = _QF_EE2, T Q_EEV1 = _Q_EEV1, T Q_EEV2 = _Q_EEV2, T QF_EEV1 = _QF_EEV1,
+                  T QF_EEV2 = _QF_EEV2, T R_EE = _R_EE, T Q_xdEE = _Q_xdEE, T QF_xdEE = _QF_xdEE, T Q_xEE = _Q_xEE, T QF_xEE = _QF_xEE, T Q1 = _Q1, T Q2 = _Q2,
+                  T R = _R, T QF1 = _QF1, T QF2 = _QF2) {
+    (void)ld_x; (void)ld_u; (void)ld_P; (void)ld_p; (void)ld_AB; (void)ld_H; (void)ld_g; (void)ld_KT; (void)ld_du; (void)ld_d; (void)ld_A; (void)I; (void)Tbody;
+    (void)Q_EE1; (void)Q_EE2; (void)QF_EE1; (void)QF_EE2; (void)Q_EEV1; (void)Q_EEV2; (void)QF_EEV1; (void)QF_EEV2; (void)R_EE; (void)Q_xdEE; (void)QF_xdEE;
+    (void)Q_xEE; (void)QF_xEE;
+    pddp_config c = pddp_cpu_config_from_macros<T>(Q1, Q2, R, QF1, QF2);
+    pddp_cpu_buffers b = {x, xp, xp2, u, up, P, p, Pp, pp, AB, H, g, KT, du, d, dp, ApBK, Bdu, alphas, JTs[0], dJexp, err,
+                          reinterpret_cast<void**>(xs), reinterpret_cast<void**>(us), reinterpret_cast<void**>(ds), reinterpret_cast<void**>(JTs)};
+    int iter = 0;
+    const int rc = pddp_cpu_run_ilqr2(&c, &b, x0, u0, KT0, P0, p0, d0, xGoal, Jout, alphaOut, forwardRolloutFlag, clearVarsFlag, ignoreFirstDefectFlag, tTime,
+                                      simTime, sweepTime, bpTime, nisTime, initTime, 0, &iter);
+    if (rc) { std::fprintf(stderr, "runiLQR_CPU2: %s (code %d)\n", pddp_cpu_last_error(), rc); std::exit(rc < 0 ? -rc : rc); }
     std::printf("CPU Parallel blocks:[%d] t:[%f] with FP[%f], FS[%f], BP[%f], NIU[%f] Xf:[%.4f, %.4f] iters:[%d] cost:[%f] max_d[%f]\n", M_BLOCKS_B, *tTime,
                 *simTime, *sweepTime, *bpTime, *nisTime, (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1)], (double)x0[DIM_x_r * (NUM_TIME_STEPS - 1) + 1], iter,
                 (double)Jout[iter], 0.0);
@@ -287,6 +338,13 @@ void freeMemory_CPU(T* x, T* xp, T* xp2, T* u, T* up, T* P, T* Pp, T* p, T* pp, 
     std::free(x); std::free(xp); std::free(xp2); std::free(u); std::free(up); std::free(P); std::free(Pp); std::free(p); std::free(pp); std::free(AB); std::free(H);
     std::free(g); std::free(KT); std::free(du); std::free(d); std::free(dp); std::free(Bdu); std::free(ApBK); std::free(dJexp); std::free(err); std::free(alpha);
     std::free(JT); std::free(xGoal); if (I) std::free(I); if (Tbody) std::free(Tbody);
+}
+template <typename T>
+void freeMemory_CPU2(T** xs, T* x, T* xp, T* xp2, T** us, T* u, T* up, T* P, T* Pp, T* p, T* pp, T* AB, T* H, T* g, T* KT, T* du, T** ds, T* d, T* dp, T* Bdu, T* ApBK,
+                     T* dJexp, int* err, T* alpha, T** JTs, T* xGoal, T* I = nullptr, T* Tbody = nullptr) {
+    freeMemory_CPU<T>(x, xp, xp2, u, up, P, Pp, p, pp, AB, H, g, KT, du, d, dp, Bdu, ApBK, dJexp, err, alpha, JTs[0], xGoal, I, Tbody);
+    for (int i = 0; i < NUM_ALPHA; i++) { std::free(xs[i]); std::free(us[i]); std::free(ds[i]); if (i > 0) std::free(JTs[i]); }
+    std::free(xs); std::free(us); std::free(ds); std::free(JTs);
 }
 #endif   // PDDP_WITH_CPU_PATH
 

@@ -121,6 +121,12 @@ typedef float algType;                //                                        
 #ifndef EXP_RED_MAX
 #define EXP_RED_MAX 1.25              //                                                          config.cuh:120-122
 #endif
+#ifndef USE_FINITE_DIFF
+#define USE_FINITE_DIFF 0               // 1: [A B] by central differences of the dynamics (Euler)      config.cuh:68
+#endif
+#ifndef FINITE_DIFF_EPSILON
+#define FINITE_DIFF_EPSILON 0.00001     //                                                          config.cuh:69-71
+#endif
 #ifndef MAX_DEFECT_SIZE
 #define MAX_DEFECT_SIZE 1.0           //                                                          config.cuh:124-126
 #endif

@@ -25,6 +25,7 @@ class PddpConfig(C.Structure):
         ("Q_EE1", C.c_double), ("Q_EE2", C.c_double), ("QF_EE1", C.c_double), ("QF_EE2", C.c_double), ("R_EE", C.c_double),
         ("Q_xEE", C.c_double), ("QF_xEE", C.c_double), ("Q_xdEE", C.c_double), ("QF_xdEE", C.c_double), ("ee_on_link_z", C.c_double),
         ("ee_initial_cost_fix", C.c_int),
+        ("use_finite_diff", C.c_int), ("finite_diff_epsilon", C.c_double),
     ]
 
 

@@ -44,6 +44,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->Q1 = 0.1; c->Q2 = 0.001; c->R = 0.0001; c->QF1 = 1000.0; c->QF2 = 1000.0;
     c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
     c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
+    c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;
     return 0;
 }
 
@@ -94,6 +95,7 @@ struct Sim : Base {
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
         cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
+        cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;
         dt = (T)(c.total_time / (c.N - 1));
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
 #define AL(name, count) al(#name, &b.name, (count))
@@ -119,7 +121,7 @@ struct Sim : Base {
     ArmTlModel<T> tl_model{}; bool tl_ok = false;
     void derive_tl(const ArmModel<T>& m) { tl_ok = arm_tl_model_from_tables(tl_model, m); }
     void derive_tl(const EmptyModel&) {}
-    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok, cfg.batch) == kFpTl; }
+    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok && !cfg.use_finite_diff, cfg.batch) == kFpTl; }
     void phase(int ph) {
         const int B = cfg.batch; const Wave w = this_wave();
         if (ph == PDDP_PHASE_BP) {
@@ -179,7 +181,7 @@ struct Sim : Base {
                 }
                 return;
             }
-            if constexpr (P::PLANT == 4) if (!fp_coop()) {   // the arm's next-iteration setup runs on lane groups (nis_lg.hpp)
+            if constexpr (P::PLANT == 4) if (!fp_coop() && !cfg.use_finite_diff) {   // the arm's next-iteration setup runs on lane groups (nis_lg.hpp); USE_FINITE_DIFF: the cooperative body
                 using L = LgHost<T>;
                 ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                 for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) {

@@ -65,13 +65,15 @@ def test_facade_compiles_with_plain_gxx_and_fails_loudly_without_gpu():
     assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
-def test_reference_example_cpu_branch_through_the_facade():
-    """testCPU of examples/WAFR_iLQR_examples.cu:231-299 (serial-alpha branch) against hostapi/: allocateMemory_CPU / runiLQR_CPU / freeMemory_CPU over
-    libpddp_cpu.so, Kuka N=128, A=8, M=4, TOL_COST 0, 1 solve.  Runs without a GPU (it is the reference's CPU path, not a fallback of the GPU one)."""
+@pytest.mark.parametrize("arg,banner", [("CS", "<<<TESTING CPU 1/1>>>"), ("C", "<<<TESTING CPU-P 1/1>>>")])
+def test_reference_example_cpu_branches_through_the_facade(arg, banner):
+    """testCPU of examples/WAFR_iLQR_examples.cu:231-299 against hostapi/, both branches of its `serialAlphas` switch as the reference's main selects them
+    (:434: 'CS' serial line search = allocateMemory_CPU / runiLQR_CPU / freeMemory_CPU, 'C' parallel = the ..._CPU2 entry points) over libpddp_cpu.so,
+    Kuka N=128, A=8, M=4, TOL_COST 0, 1 solve.  Runs without a GPU (it is the reference's CPU path, not a fallback of the GPU one)."""
     exe = build_examples()
-    r = subprocess.run([exe, "C", "1", "1"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, arg, "1", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.count("CPU Parallel blocks:[4]") == 1 and "<<<TESTING CPU 1/1>>>" in r.stdout
+    assert r.stdout.count("CPU Parallel blocks:[4]") == 1 and banner in r.stdout
     m = re.search(r"solve 0: (\d+) iterations, J ([0-9.]+) -> ([0-9.]+)", r.stdout)
     assert m and int(m.group(1)) == 100 and float(m.group(3)) < 0.5 * float(m.group(2))      # the first-acceptable line search stalls around 600-750 on this problem (SURVEY.md 8c, G3 trace)
 

@@ -16,10 +16,11 @@ LIB = os.path.join(ROOT, "parallel-ddp_amd", "lib", "libpddp_cpu.so")
 
 
 class CpuBuffers(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("x", "xp", "xp2", "u", "up", "P", "p", "Pp", "pp", "AB", "H", "g", "KT", "du", "d", "dp", "ApBK", "Bdu", "alpha", "JT", "dJexp")] + [("err", C.c_void_p)]
+    _fields_ = [(k, C.c_void_p) for k in ("x", "xp", "xp2", "u", "up", "P", "p", "Pp", "pp", "AB", "H", "g", "KT", "du", "d", "dp", "ApBK", "Bdu", "alpha", "JT", "dJexp")] + [("err", C.c_void_p)] \
+               + [(k, C.c_void_p) for k in ("xs", "us", "ds", "JTs")]
 
 
-def run_cpu_twin(plant, dtype, x0, u0, xg, cores=8, rollout=0, **kw):
+def run_cpu_twin(plant, dtype, x0, u0, xg, cores=8, rollout=0, parallel=False, **kw):
     lib = C.CDLL(LIB)
     lib.pddp_cpu_last_error.restype = C.c_char_p
     cfg = pyddp.default_config(plant, dtype=0 if dtype == np.float32 else 1, **kw)
@@ -31,13 +32,20 @@ def run_cpu_twin(plant, dtype, x0, u0, xg, cores=8, rollout=0, **kw):
     arrs = {k: np.zeros(v, dtype) for k, v in sizes.items()}
     arrs["alpha"][:] = [cfg.alpha_base ** i for i in range(A)]           # allocateMemory_CPU, nisInitHelpers.cuh:920
     err = np.zeros(max(M, cores), np.int32)
-    buf = CpuBuffers(**{k: v.ctypes.data for k, v in arrs.items()}, err=err.ctypes.data)
+    extra, keep = {}, []
+    if parallel:                                                          # allocateMemory_CPU2: one slot per candidate
+        for name, size in (("xs", n * N), ("us", m * N), ("ds", n * N), ("JTs", max(M, cores))):
+            slots = [np.zeros(size, dtype) for _ in range(A)]
+            ptrs = (C.c_void_p * A)(*[sl.ctypes.data for sl in slots])
+            keep += [slots, ptrs]
+            extra[name] = C.cast(ptrs, C.c_void_p)
+    buf = CpuBuffers(**{k: v.ctypes.data for k, v in arrs.items()}, err=err.ctypes.data, **extra)
     x, u, g_ = np.ascontiguousarray(x0, dtype).copy(), np.ascontiguousarray(u0, dtype).copy(), np.ascontiguousarray(xg, dtype)
     Jout, aout = np.zeros(mi + 2, dtype), np.full(mi + 2, -99, np.int32)
     tt = [np.zeros(1), np.zeros(mi + 1), np.zeros(mi + 1), np.zeros(mi + 1), np.zeros(mi + 1), np.zeros(1)]
     iters = C.c_int(0)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = lib.pddp_cpu_run_ilqr(C.byref(cfg), C.byref(buf), p(x), p(u), None, None, None, None, p(g_), p(Jout), p(aout), int(rollout), 1, 1,
+    rc = (lib.pddp_cpu_run_ilqr2 if parallel else lib.pddp_cpu_run_ilqr)(C.byref(cfg), C.byref(buf), p(x), p(u), None, None, None, None, p(g_), p(Jout), p(aout), int(rollout), 1, 1,
                                p(tt[0]), p(tt[1]), p(tt[2]), p(tt[3]), p(tt[4]), p(tt[5]), int(cores), C.byref(iters))
     assert rc == 0, lib.pddp_cpu_last_error()
     return dict(x=x, u=u, KT=arrs["KT"], Jout=Jout, alphaOut=aout, iters=iters.value, t_total_ms=float(tt[0][0]), t_init_ms=float(tt[5][0]), bpTime=tt[3])
@@ -96,3 +104,26 @@ def test_cpu_library_exports_every_declared_symbol_and_the_header_is_c99():
     src = os.path.join(ROOT, "tests", "cabi", "cpu_hdr.c")
     open(src, "w").write('#include "pddp_cpu.h"\nint main(void) { return pddp_cpu_last_error() == 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", os.devnull])
+
+
+@pytest.mark.parametrize("plant,kw,cores", [
+    pytest.param(4, dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=10), 8, id="kuka-chunks-of-2"),
+    pytest.param(4, dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=10), 32, id="kuka-one-chunk-of-8"),
+    pytest.param(4, dict(N=64, M=1, A=6, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=8), 4, id="kuka-M1-ragged-last-chunk"),
+    pytest.param(2, dict(N=64, M=4, A=8, integrator=3, total_time=2.0, tol_cost=0.0, max_iter=10), 8, id="cart-rk3"),
+])
+def test_cpu_parallel_line_search_follows_the_oracle(plant, kw, cores):
+    """runiLQR_CPU2 (DDPWrappers.cuh:252-363): the product's parallel-line-search CPU path against the oracle's restatement -- float64, identical step-size
+    indices (the best acceptable candidate of each chunk of max(cores / M, 1)), J / x / u to 1e-8; and it is a different algorithm from the serial search
+    (which takes the FIRST acceptable step size)."""
+    o = Oracle(default_cfg(plant, cores=cores, spawn_threads=0, **kw), np.float64)
+    x0, u0, xg = example_inputs(plant, kw["N"], np.float64, noise=np.random.default_rng(19).normal(0, 0.001, (kw["N"], o.n)))
+    ref = o.run_ilqr_cpu2(x0, u0, xg)
+    got = run_cpu_twin(plant, np.float64, x0, u0, xg, cores=cores, parallel=True, **kw)
+    it = ref["iters"]
+    assert got["iters"] == it == kw["max_iter"]                       # no cost-tolerance exit on this path (nisInitHelpers.cuh:586)
+    assert list(got["alphaOut"][: it + 1]) == list(ref["alphaOut"][: it + 1])
+    np.testing.assert_allclose(got["Jout"][: it + 1], ref["Jout"][: it + 1], rtol=1e-8)
+    np.testing.assert_allclose(got["x"], ref["x"], rtol=0, atol=1e-8 * max(np.abs(ref["x"]).max(), 1))
+    np.testing.assert_allclose(got["u"], ref["u"], rtol=0, atol=1e-7 * max(np.abs(ref["u"]).max(), 1))
+    assert (np.asarray(ref["alphaOut"][1: it + 1]) >= 0).any()

@@ -170,7 +170,22 @@ __global__ __launch_bounds__(64) void k_reduce_parts(Buffers<T> b, Dims dm, int 
 // (fpHelpers.cuh:395-408, nisInitHelpers.cuh:489-518).
 template <typename T>
 __global__ __launch_bounds__(64) void k_ls(Buffers<T> b, Dims dm, SolverParams sp, int freeze_exit) {
-    if (threadIdx.x == 0) ls_body<T>(b, dm, sp, blockIdx.x, freeze_exit);
+    const int pb = blockIdx.x;
+    // thread-lane forward pass: lane a adds candidate a's per-segment partial sums (tl_reduce_parts, the same order) -- the loads of the A x M parts are in
+    // flight together instead of one after the other on the deciding lane
+    if (b.parts_fresh && b.parts_fresh[pb]) {
+        const int a = threadIdx.x;
+        if (a < dm.A) {
+            const size_t slot = (size_t)pb * dm.A + a;
+            T J = T(0), mx = T(0);
+            for (int s = 0; s < dm.M; s++) { J += b.Jpart[slot * dm.M + s]; mx = tmax(mx, b.dpart[slot * dm.M + s]); }
+            b.J[slot] = J; b.dmax[slot] = mx;
+        }
+        __syncthreads();                                    // (A <= 64: one wave) the sums are visible to lane 0
+        if (threadIdx.x == 0) b.parts_fresh[pb] = 0;
+        __threadfence_block();
+    }
+    if (threadIdx.x == 0) ls_body<T>(b, dm, sp, pb, freeze_exit);
 }
 
 // next-iteration setup: grid (N, B), block 64 (see nis_body).

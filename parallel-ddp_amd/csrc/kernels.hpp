@@ -209,11 +209,11 @@ __global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
 }
 
 // MPC warm start / fall-back (mpc.hpp): grid (B), block 256 -- four waves share the shifting of the previous solution, wave 0 rolls out.
-template <typename P, int INTEG, typename T>
+template <typename P, int INTEG, typename T, int V = -1>
 __global__ __launch_bounds__(256) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout) {
     __shared__ MpcScratch<P, T> s;
-    mpc_load_body<P, INTEG, T>(this_wave(), s, b, mb, dm, dt, blockIdx.x, xActual + (size_t)blockIdx.x * P::NX, shift[blockIdx.x], clear_vars, full_rollout,
-                               (int)threadIdx.x >> 6, 4);
+    mpc_load_body<P, INTEG, T, V>(this_wave(), s, b, mb, dm, dt, blockIdx.x, xActual + (size_t)blockIdx.x * P::NX, shift[blockIdx.x], clear_vars, full_rollout,
+                                  (int)threadIdx.x >> 6, 4);
 }
 template <typename P, typename T>
 __global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm) {

@@ -65,9 +65,10 @@ struct MpcScratch {
     typename P::Scratch plant;
     IntegScratch<P, T> integ;
     T x[P::NX], xn[P::NX], u[P::NU], dx[P::NX];
+    T tau[8];                 // split warm-start rollout (two waves): joint torques minus bias from wave 0 to wave 1
 };
 
-template <typename P, int INTEG, typename T>
+template <typename P, int INTEG, typename T, int V = -1>
 PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>& b, const MpcBuffers<T>& mb, const Dims& dm, T dt, int pb,
                            const T* xActual, int shift, int clear_vars, int full_rollout, int wave_id = 0, int nwaves = 1) {
     // wave_id / nwaves: the workgroup's waves share the shifting and the fall-back copies (task t runs on wave t % nwaves); the rollout is wave 0's
@@ -110,6 +111,61 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
         const int e0 = part == 1 ? half : 0, e1 = part == 0 ? half : N * NX * NU;
         for (int e = e0 + w.lane; e < e1; e += w.nlanes) KT_old[e] = KT[e];
     }
+    bool split_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) {
+        // The arm in float with a built-in robot model: the serial open-loop rollout (64 steps: the longest single item of a control cycle) runs like k_fp_tl2 --
+        // every step split over waves 0 and 1 (Newton-Euler bias | composite bodies, mass matrix, L D L'; then solve + Euler step), one lane each.
+        if (nwaves >= 2) {
+            if (wave_id > 1) return;
+            constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+            const T grav = reinterpret_cast<const ArmModel<T>*>(b.model)->grav;
+            const int n_roll = full_rollout ? N : dm.NB;
+            T xx[NX];
+#pragma unroll
+            for (int i = 0; i < NX; i++) xx[i] = xActual[i];
+            if (wave_id == 1 && w.lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; i++) x0[i] = xx[i];
+            }
+            for (int k = 0; k < n_roll - 1; k++) {
+                ArmTlState<T> st;
+                if (wave_id == 0) {
+                    if (w.lane == 0) {
+                        T bias[NU];
+                        arm_tl_trig<T>(st, xx);
+                        arm_tl_bias<T>(md, grav, st, xx + 7, bias);
+#pragma unroll
+                        for (int i = 0; i < NU; i++) s.tau[i] = u[NU * k + i] - bias[i];
+                    }
+                    __syncthreads();
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < NX; i++) xx[i] = s.xn[i];
+                } else {
+                    if (w.lane == 0) { arm_tl_trig<T>(st, xx); arm_tl_factor<T>(md, st); }
+                    __syncthreads();
+                    if (w.lane == 0) {
+                        T qdd[NU];
+#pragma unroll
+                        for (int i = 0; i < NU; i++) qdd[i] = s.tau[i];
+                        tl_ldl_solve(st, qdd);
+#pragma unroll
+                        for (int i = 0; i < 7; i++) { const T qn = xx[i] + dt * xx[7 + i], vn = xx[7 + i] + dt * qdd[i]; s.xn[i] = qn; s.xn[7 + i] = vn; }
+#pragma unroll
+                        for (int i = 0; i < NX; i++) x0[NX * (k + 1) + i] = s.xn[i];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < NX; i++) xx[i] = s.xn[i];
+                }
+            }
+            if (wave_id == 1) return;
+            __threadfence_block();
+            split_done = true;
+        }
+    }
+#endif
     if (wave_id != 0) return;
     wsync();
     // ---- open-loop rollout from the measured state (rolloutMPC)
@@ -117,9 +173,9 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
     PDDP_FOR(i, NX) { const T v = xActual[i]; s.x[i] = v; x0[i] = v; }
     wsync();
     const int n_roll = full_rollout ? N : dm.NB;
-    bool rolled = false;
+    bool rolled = split_done;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (P::PLANT == 4 && INTEG == 1) {
+    if constexpr (P::PLANT == 4 && INTEG == 1) if (!rolled) {
         // the arm: this serial rollout is a third of an MPC control cycle; one lane group runs it with the register-resident dynamics of the forward
         // pass (plant_arm_lg.hpp: the same numbers as P::dynamics, bit for bit), about half the time per step of the wave-cooperative evaluation
         if (w.lane < 7) {                       // lane 7 and the rest of the wave stay out of the lane-group code (lanegroup.hpp)

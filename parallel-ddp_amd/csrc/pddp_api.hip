@@ -479,7 +479,16 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpyAsync(d_shift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
         if (cfg.ee_cost && cfg.ee_cost_shift) HIPCHK(hipMemcpyAsync(b.tshift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
         else HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
-        hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+        bool split_roll = false;
+        if constexpr (P::PLANT == 4 && INTEG == 1 && sizeof(T) == 4) {                // float arm with a built-in robot model: the warm-start rollout split over two waves
+            const char* fpenv = std::getenv("PDDP_FP");
+            if (tl_variant >= 0 && !(fpenv && (std::string(fpenv) == "lg" || std::string(fpenv) == "coop"))) {
+                split_roll = true;
+                if (tl_variant == 0) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 0>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+                else hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 1>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+            }
+        }
+        if (!split_roll) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
         const int saved_max_iter = sp.max_iter;
         sp.max_iter = max_iter;                                  // acceptRejectTrajGPU(..., max_iter)
         const int ee = cfg.ee_cost ? 1 : 0;

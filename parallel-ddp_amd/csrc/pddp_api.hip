@@ -198,8 +198,9 @@ struct Solver : SolverBase {
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
-            sweep_kind = c.batch <= 512 ? 2 : 1;
+            sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
+            if (sweep_kind == 2 && c.N / c.M > 96) sweep_kind = 1;
         }
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }

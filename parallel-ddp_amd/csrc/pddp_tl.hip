@@ -298,13 +298,17 @@ void launch_sweep_st(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
 }
 
 // k_sweep_wg: grid B, block 256, dynamic LDS.  The same two-sequence linear sweep as k_sweep_st for handles with FEW problems in flight, where the
-// length of the serial chain is all that counts: the whole workgroup first copies the chain's operands (A - B K and B du of up to 96 knots: 80 KB)
-// into LDS with 16-byte accesses -- one memory latency for the whole sweep instead of one per step --, then wave 0 walks the chain alone on the
-// MATRIX CORE: E = [s | t] is a 16x16 tile in accumulator layout (lane (g, c) holds rows 4g..4g+3 of column c; column 0 = s, column 1 = t), and one
-// step E <- F_k E + [B du_k | d_k] is four chained v_mfma_f32_16x16x4_f32 with F_k' as the first operand (read from LDS one step ahead: lane (g, c)
-// needs F_k(c, 4g + r), four strided words), the inhomogeneous term as the accumulator's initial value, and the result already in the layout the
-// next step consumes -- no cross-lane traffic, no vector arithmetic in the chain at all.
-// One problem (Kuka N=128, M=4): 66 us (k_sweep_lg, one 8-lane group per alpha) -> see profiles/.  float handles only, like k_sweep_st.
+// length of the serial chain is all that counts.  Two things shorten it:
+//   * the whole workgroup first copies the chain's operands (A - B K and B du of up to 96 knots: 80 KB) into LDS with 16-byte accesses -- one memory latency for
+//     the sweep instead of one per step;
+//   * only the states at the M - 1 segment boundaries are wanted, and a segment's effect on (s, t) is an AFFINE MAP  e_end = Phi e_start + gamma.  So every
+//     segment is walked by its OWN wavefront, all at once, carrying the 16x16 tile E = [Phi | gamma_s | gamma_t] (14 columns of the composed matrix, column 14
+//     the s-part, column 15 the t-part) on the MATRIX CORE: one step E <- F_k E + [0 | B du_k | d_k] is four chained v_mfma_f32_16x16x4_f32 with F_k' as the
+//     first operand (lane (g, c) needs F_k(c, 4g + r): four strided LDS words), the inhomogeneous term as the accumulator's initial value, and the result
+//     already in the layout the next step consumes -- the extra columns ride for free in the instruction.  The chain is N / M steps long instead of
+//     (M - 1) N / M; wave 0 then composes the M - 1 maps (two 14x14 matrix-vector products per boundary) and writes every candidate's segment start state.
+// One problem (Kuka N=128, M=4): 66 us (k_sweep_lg, one 8-lane group per alpha) -> 37 us (one chain of 96 steps) -> see profiles/.  float handles only, like
+// k_sweep_st; segments longer than the 96-knot staging area use k_sweep_st (launch_sweep_wg).
 constexpr int kSweepWgChunk = 96;
 typedef float sw4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int sw_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -313,69 +317,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     constexpr int NX = 14, SZ = NX * NX;
     const int pb = blockIdx.x;
     if (!fp_active<float>(b, dm, pb)) return;                          // uniform over the workgroup
-    const int total = (dm.M - 1) * dm.NB, N = dm.N;                    // steps k = 0 .. total - 1, the last one is the last defect boundary
-    if (total <= 0) return;
-    const int chunk = total < kSweepWgChunk ? total : kSweepWgChunk;
-    float* F = sweep_lds; float* cB = sweep_lds + (size_t)chunk * SZ;   // cB: [chunk][16]: B du_k in 0..13, zeros in 14, 15
+    const int NBk = dm.NB, nseg = dm.M - 1, N = dm.N;                  // segments 0 .. M - 2 end on a defect boundary
+    if (nseg <= 0) return;
+    const int seg_per_chunk = kSweepWgChunk / NBk, chunk = seg_per_chunk * NBk;        // whole segments per staging pass (NB <= 96: launch_sweep_wg)
+    float* F = sweep_lds; float* cB = F + (size_t)chunk * SZ; float* Et = cB + (size_t)chunk * 16 + 16;   // Et: [M - 1][16][16] composed maps, row-major
     const float* gF = b.ApBK + (size_t)pb * N * SZ; const float* gB = b.Bdu + (size_t)pb * N * NX;
     const float* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX; const float* dcur = b.dcur + (size_t)pb * N * NX;
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g;
-    const bool chain_wave = sw_uniform((int)threadIdx.x >> 6) == 0;
+    const int wave = sw_uniform((int)threadIdx.x >> 6);
     // this lane's four words of F_k' (F_k(c, 4g + r) = F[c + 14 (4g + r)]).  Rows 14, 15 of the contraction read finite neighbours and meet the zero rows 14, 15
     // of E; lanes c >= 14 would produce rows 14, 15 of the result, which are cleared after every step instead of masking the operand.
     const float* pF = F + (c < NX ? c : NX - 1) + NX * row0;
-    const float* pC = cB + row0;                                        // lanes of column 0: rows 4g..4g+3 of B du_k as one 16-byte read
-    sw4 E = {0.f, 0.f, 0.f, 0.f};
-    int to_bnd = dm.NB;                                                 // steps until the next defect boundary (step k is one when (k + 1) % NB == 0)
-    for (int k0 = 0; k0 < total; k0 += chunk) {
-        const int cnt = total - k0 < chunk ? total - k0 : chunk;
-        __syncthreads();                                               // the previous chunk has been consumed
+    const float* pC = cB + row0;                                        // rows 4g..4g+3 of B du_k as one 16-byte read (lanes of column 14)
+    for (int s0 = 0; s0 < nseg; s0 += seg_per_chunk) {
+        const int segs = nseg - s0 < seg_per_chunk ? nseg - s0 : seg_per_chunk, k0 = s0 * NBk, cnt = segs * NBk;
+        __syncthreads();                                               // the previous staging pass has been consumed
         {
             const float4* src = reinterpret_cast<const float4*>(gF + (size_t)k0 * SZ); float4* dst = reinterpret_cast<float4*>(F);
             for (int i = threadIdx.x; i < cnt * (SZ / 4); i += 256) dst[i] = src[i];
             for (int i = threadIdx.x; i < cnt * 16; i += 256) { const int kk = i >> 4, e = i & 15; cB[i] = e < NX ? gB[((size_t)k0 + kk) * NX + e] : 0.f; }
         }
         __syncthreads();
-        if (!chain_wave) continue;
-        for (int kk = 0; kk < cnt; kk++) {
-            const int k = k0 + kk;
-            to_bnd = sw_uniform(to_bnd - 1);
-            const bool bnd = to_bnd == 0;
-            sw4 X;                                                      // (reading a step ahead buys nothing: measured, the chain waits on the matrix instructions)
+        for (int sl = wave; sl < segs; sl += 4) {                       // this wave's segments of the pass, one after the other
+            const int kbase = sl * NBk;
+            sw4 E;                                                      // [Phi | gamma_s | gamma_t], starts as [I | 0 | 0]
 #pragma unroll
-            for (int r = 0; r < 4; r++) X[r] = pF[kk * SZ + NX * r];
-            const sw4 cv = *reinterpret_cast<const sw4*>(pC + kk * 16);
-            sw4 acc;
+            for (int r = 0; r < 4; r++) E[r] = (row0 + r == c && c < NX) ? 1.f : 0.f;
+            for (int j = 0; j < NBk; j++) {
+                const int kk = kbase + j;
+                sw4 X;
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = c == 0 ? cv[r] : 0.f;
-            if (bnd) {                                                  // column 1 (t) takes the defect of this boundary
-                to_bnd = dm.NB;
+                for (int r = 0; r < 4; r++) X[r] = pF[kk * SZ + NX * r];
+                const sw4 cv = *reinterpret_cast<const sw4*>(pC + kk * 16);
+                sw4 acc;
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (c == 1 && row0 + r < NX) acc[r] = dcur[(size_t)k * NX + row0 + r];
-            }
+                for (int r = 0; r < 4; r++) acc[r] = c == 14 ? cv[r] : 0.f;
+                if (j == NBk - 1) {                                     // the segment's last step is its defect boundary: column 15 (t) takes the defect
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[r], E[r], acc, 0, 0, 0);
-            E[0] = acc[0]; E[1] = acc[1]; E[2] = g == 3 ? 0.f : acc[2]; E[3] = g == 3 ? 0.f : acc[3];
-            if (bnd) {                                                  // segment start states of every candidate: x = xcur + (t - alpha s)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float tt = __shfl(E[r], lane + 1);           // column 1 of the same rows
-                    if (c == 0 && row0 + r < NX) {
-                        const float base = xcur[(size_t)(k + 1) * NX + row0 + r];
-                        for (int a = 0; a < dm.A; a++) b.xs[(((size_t)pb * dm.A + a) * N + k + 1) * NX + row0 + r] = base + (tt - b.alpha[a] * E[r]);
-                    }
+                    for (int r = 0; r < 4; r++) if (c == 15 && row0 + r < NX) acc[r] = dcur[(size_t)(k0 + kk) * NX + row0 + r];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[r], E[r], acc, 0, 0, 0);
+                E[0] = acc[0]; E[1] = acc[1]; E[2] = g == 3 ? 0.f : acc[2]; E[3] = g == 3 ? 0.f : acc[3];
             }
+            float* o = Et + (size_t)(s0 + sl) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[(row0 + r) * 16 + c] = E[r];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // compose: e <- Phi_s e + gamma_s over the segments, lane l < 14 owns entry l of the s- and of the t-sequence; at every boundary the start states of all candidates
+    const int l = lane < NX ? lane : NX - 1;
+    float es = 0.f, et = 0.f;
+    for (int sgm = 0; sgm < nseg; sgm++) {
+        const float* o = Et + (size_t)sgm * 256 + l * 16;
+        float ns = o[14], nt = o[15];
+#pragma unroll
+        for (int cc = 0; cc < NX; cc++) {
+            const float ph = o[cc];
+            ns = __builtin_fmaf(ph, __shfl(es, cc), ns); nt = __builtin_fmaf(ph, __shfl(et, cc), nt);
+        }
+        es = ns; et = nt;
+        if (lane < NX) {
+            const int k = (sgm + 1) * NBk - 1;
+            const float base = xcur[(size_t)(k + 1) * NX + lane];
+            for (int a = 0; a < dm.A; a++) b.xs[(((size_t)pb * dm.A + a) * N + k + 1) * NX + lane] = base + (et - b.alpha[a] * es);
         }
     }
 }
 static size_t sweep_wg_lds(const Dims& dm) {
-    const int total = (dm.M - 1) * dm.NB, chunk = total < kSweepWgChunk ? total : kSweepWgChunk;
-    return (size_t)(chunk > 0 ? chunk : 1) * (14 * 14 + 16) * sizeof(float) + 64;      // + slack: the last knot's rows 14, 15 of the contraction read past its block
+    const int chunk = (kSweepWgChunk / dm.NB) * dm.NB;
+    return ((size_t)chunk * (14 * 14 + 16) + 16 + (size_t)(dm.M > 1 ? dm.M - 1 : 1) * 256) * sizeof(float);      // operands + slack (rows 14, 15 of the last knot's contraction read past its block) + composed maps
 }
 void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch) {
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_wg), hipFuncAttributeMaxDynamicSharedMemorySize, kSweepWgChunk * (14 * 14 + 16) * (int)sizeof(float) + 64); attr_set = true; }
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_wg), hipFuncAttributeMaxDynamicSharedMemorySize, (kSweepWgChunk * (14 * 14 + 16) + 16 + 15 * 256) * (int)sizeof(float)); attr_set = true; }
     hipLaunchKernelGGL(k_sweep_wg, dim3((unsigned)batch), dim3(256), sweep_wg_lds(dm), s, b, dm);
 }
 

@@ -186,8 +186,15 @@ __device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<FS, DIAGH>& k, con
 // written -- the one in front of the block's first knot, which the neighbouring block's next pass starts from (the reference's d_Pp / d_pp boundary slots); the
 // per-knot P, p of the interior are by-products nobody reads (not an output of runiLQR_GPU).  The phase hook and MPC handles (whose warm start shifts the
 // whole array, MPCHelpers.cuh:602-655) pass keepP = 1.
-template <bool FS, bool DIAGH, bool CAB>
-__device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims& dm, int pb, int blk, float hq1, float hq2, float hr, float dt, int keepP) {
+// flags bit 1 (kMxFuseSweep): the block also composes its shooting segment's effect on the forward sweep's two sequences -- with G_k = [A - B K, B du; 0, 1] (15 x 15)
+// the segment's map is Psi = G_last ... G_first, and Psi' <- G_k' Psi' is one more mfma4 per knot on tiles this pass holds anyway (Psi' again in accumulator layout) --
+// and leaves Psi' in b.segmap[problem][block] (1 KB) INSTEAD of writing A - B K and B du of every knot (107 KB per problem, and the linear sweep kernel that would
+// read them back): k_sweep_maps composes the M - 1 maps.  Same mathematics as k_sweep_wg's per-segment tiles (pddp_tl.hip).
+constexpr int kMxKeepP = 1, kMxFuseSweep = 2;
+template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+__device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims& dm, int pb, int blk, float hq1, float hq2, float hr, float dt, int flags) {
+    const int keepP = flags & kMxKeepP;
+    const bool fuse = FUSE && blk < dm.M - 1;                          // (the last block's segment has no boundary after it)
     constexpr int NX = 14, NU = 7, NM = 21, SZP = NX * NX, SZAB = NX * NM, SZH = NM * NM;
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g, u0 = 2 * g;
     const int ub = ((c & 3) < 2) ? 2 * (c >> 2) + (c & 3) : 8;       // the control whose column this lane holds in control-column tiles (8: none)
@@ -238,6 +245,11 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     float* ldsI = lds + 16;                                           // Huu^-1, entry (a, b) at [a * 8 + b]
     lds[16 + lane] = 0.f;                                             // slot b = 7 of every row stays 0
     wsync();
+    mx4 PsiT = zero;                                                  // Psi'(m, i) = Psi(i, m): starts as the identity of the 15 x 15 augmented map
+    if (FUSE) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) PsiT[r] = (row0 + r == c && c <= NX) ? 1.f : 0.f;
+    }
     MxKnotIn<FS, DIAGH> in;
     const float* ABk = AB + (size_t)ks * SZAB; const float* Hk = H + (size_t)ks * SZH; const float* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
     float* KTk = KT + (size_t)ks * (NX * NU); float* duk = du + (size_t)ks * NU; float* Fk = ApBK + (size_t)ks * SZP; float* Bduk = Bdu + (size_t)ks * NX;
@@ -334,7 +346,12 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         if (FS) {                                                     // A - B K | B du  (computeFSVars :281-312)
             const mx4 BT = {k.BT0, k.BT1, 0.f, 0.f};                                              // [b][kx = c] = B(kx, b)
             const mx4 BK = mx_mfma2(BT, Kp, zero);
-            mx_store_rows4(cx ? Fk + c * NX + row0 : Bduk + row0, row0, NX, cx || c14, c14 ? BK : k.A0 - BK);
+            mx4 Gt = c14 ? BK : k.A0 - BK;                                                        // [A - B K | B du], rows 14, 15 are zero
+            if (!FUSE) mx_store_rows4(cx ? Fk + c * NX + row0 : Bduk + row0, row0, NX, cx || c14, Gt);
+            if (FUSE && fuse) {
+                if (c14 && g == 3) Gt[2] = 1.f;                                                   // G(14, 14) = 1: the homogeneous coordinate
+                PsiT = mx_mfma4(Gt, PsiT, zero);
+            }
         }
         if (do_ctg) {                                                 // new cost-to-go (computeCTG :225-276): P(kx, ky) | p(kx)
             mx4 val = mx_mfma2(T1t, Kp, zero);
@@ -345,6 +362,11 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
             Pa = Pn;
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;
+    }
+    if (FUSE && fuse) {                                               // Psi' of this segment, row-major [16][16]
+        float* o = b.segmap + ((size_t)pb * dm.M + blk) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[(row0 + r) * 16 + c] = PsiT[r];
     }
     // dJexp[2 blk], [2 blk + 1]: the 7 per-control partial sums in order (column-14 lanes 14, 30, 46, 62 hold controls 2g, 2g + 1)
     {

@@ -11,6 +11,8 @@ namespace pddp {
 // the kernel takes the three numbers from here and does not read H in its loop (the final knot's block is always read)
 // b.ABc non-null (and diag_h): [A B] is read from the compact array (ab_compact.hpp), dt rebuilds its constant rows.  keep_P: write every knot's cost-to-go
 // (phase hook, MPC handles); otherwise only the block-boundary slots the next pass reads.
-void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr, float dt, bool keep_P);
+void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr, float dt, bool keep_P, bool fuse_sweep);
+// fuse_sweep (and b.segmap): the pass composes every shooting segment's sweep map instead of writing A - B K / B du; launch_sweep_maps then replaces the sweep kernel
+void launch_sweep_maps(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch);
 
 }  // namespace pddp

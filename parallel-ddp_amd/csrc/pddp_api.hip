@@ -162,6 +162,7 @@ struct Solver : SolverBase {
         return 0;
     }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
+    bool sweep_fused = false;      // production sweeps: forward-sweep maps composed inside k_bp_mfma + k_sweep_maps (no A - B K / B du traffic)
     int sweep_kind = 0;            // the arm's linear sweep: 0 one lane group per candidate (k_sweep_lg), 1 two sequences on lane groups (k_sweep_st), 2 two sequences, workgroup per problem (k_sweep_wg); PDDP_SWEEP=alpha|st|wg
     bool mpc_used = false;         // pddp_mpc_solve ran on this handle: its warm start shifts every cost-to-go slot, so the backward pass keeps writing all of them
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
@@ -201,9 +202,12 @@ struct Solver : SolverBase {
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
             if (sweep_kind == 2 && c.N / c.M > 96) sweep_kind = 1;
+            // default with the matrix-core backward pass: that pass composes the segments' sweep maps itself (bp_mfma.hpp kMxFuseSweep) and k_sweep_maps finishes;
+            // sweep_kind stays the kernel of the phase hook, whose teacher-forced A - B K / B du must be what the sweep reads.  PDDP_SWEEP=alpha|st|wg: no fusion.
         }
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
         if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }
+        sweep_fused = bp_mfma && c.M > 1 && !std::getenv("PDDP_SWEEP");
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
@@ -239,6 +243,7 @@ struct Solver : SolverBase {
         register_model(dmodel, hm);
         derive_tl_model(hm);
         if constexpr (P::PLANT == 4) { if (fp_path == kFpTl && !std::getenv("PDDP_NO_XW")) { if ((rc = alloc("xw", &b.xw, B * N * A * NX))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
+        if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
         if constexpr (P::PLANT == 4 && sizeof(T) == 4) {
             const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
             if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) { if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc; }
@@ -325,7 +330,8 @@ struct Solver : SolverBase {
             if (!init_rollout && cfg.M > 1 && part != 1) {
                 bool st = false;
                 if constexpr (sizeof(T) == 4) {
-                    if (sweep_kind == 2) { launch_sweep_wg(s, b, dm, (int)B); st = true; }
+                    if (sweep_fused && !store_candidates) { launch_sweep_maps(s, b, dm, (int)B); st = true; }
+                    else if (sweep_kind == 2) { launch_sweep_wg(s, b, dm, (int)B); st = true; }
                     else if (sweep_kind == 1) { launch_sweep_st(s, b, dm, (int)B); st = true; }
                 }
                 if (!st) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
@@ -371,7 +377,7 @@ struct Solver : SolverBase {
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
             if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups || bp_mfma;
-            if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (bp_mfma) launch_bp_mfma(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, (float)cw.Q1, (float)cw.Q2, (float)cw.R, (float)dt, store_candidates || cfg.mpc_mode || mpc_used); }
+            if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (bp_mfma) launch_bp_mfma(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, (float)cw.Q1, (float)cw.Q2, (float)cw.R, (float)dt, store_candidates || cfg.mpc_mode || mpc_used, sweep_fused && !store_candidates); }
             if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
                 if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
@@ -388,7 +394,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

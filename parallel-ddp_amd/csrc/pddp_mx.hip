@@ -7,29 +7,66 @@
 namespace pddp {
 
 // k_bp_mfma: grid B*M, block 64 -- one wavefront per (problem, block of knots); <= 102 registers so that five waves share a SIMD.  Replaces backPassKern<<<M, (8,7)>>> (bpHelpers.cuh:339-420).
-template <bool FS, bool DIAGH, bool CAB>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bp_mfma(Buffers<float> b, Dims dm, int batch, float hq1, float hq2, float hr, float dt, int keepP) {
+template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bp_mfma(Buffers<float> b, Dims dm, int batch, float hq1, float hq2, float hr, float dt, int flags) {
     __shared__ __attribute__((aligned(16))) float lds[96];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
-    arm_mx_bp_block<FS, DIAGH, CAB>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, keepP);
+    arm_mx_bp_block<FS, DIAGH, CAB, FUSE>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
 }
 
-void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr, float dt, bool keep_P) {
+void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr, float dt, bool keep_P, bool fuse_sweep) {
     const unsigned n = (unsigned)batch * dm.M;
-    const int kp = keep_P ? 1 : 0;
+    const int kp = (keep_P ? kMxKeepP : 0) | ((fuse_sweep && b.segmap) ? kMxFuseSweep : 0);
     const bool cab = b.ABc != nullptr && diag_h;
-#define PDDP_MX_LAUNCH(FS, DH, CB) hipLaunchKernelGGL((k_bp_mfma<FS, DH, CB>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp)
+#define PDDP_MX_LAUNCH(FS, DH, CB, FU) hipLaunchKernelGGL((k_bp_mfma<FS, DH, CB, FU>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp)
+    const bool fu = (kp & kMxFuseSweep) != 0;
     if (dm.M > 1) {
-        if (cab) PDDP_MX_LAUNCH(true, true, true);
-        else if (diag_h) PDDP_MX_LAUNCH(true, true, false);
-        else PDDP_MX_LAUNCH(true, false, false);
+        if (cab) { if (fu) PDDP_MX_LAUNCH(true, true, true, true); else PDDP_MX_LAUNCH(true, true, true, false); }
+        else if (diag_h) { if (fu) PDDP_MX_LAUNCH(true, true, false, true); else PDDP_MX_LAUNCH(true, true, false, false); }
+        else { if (fu) PDDP_MX_LAUNCH(true, false, false, true); else PDDP_MX_LAUNCH(true, false, false, false); }
     } else {
-        if (cab) PDDP_MX_LAUNCH(false, true, true);
-        else if (diag_h) PDDP_MX_LAUNCH(false, true, false);
-        else PDDP_MX_LAUNCH(false, false, false);
+        if (cab) PDDP_MX_LAUNCH(false, true, true, false);
+        else if (diag_h) PDDP_MX_LAUNCH(false, true, false, false);
+        else PDDP_MX_LAUNCH(false, false, false, false);
     }
 #undef PDDP_MX_LAUNCH
 }
 
+}  // namespace pddp
+
+namespace pddp {
+// k_sweep_maps: grid B, block 64.  The forward sweep from the per-segment maps the backward pass composed (bp_mfma.hpp kMxFuseSweep): e <- Phi_s e + gamma_s over the
+// segments for the s-sequence (gamma = the map's column 14) and the t-sequence (gamma = the defect of the segment's boundary knot: it enters at the segment's last
+// step), lane l < 14 owns entry l; at every boundary the segment start state of every candidate, x = xcur + (t - alpha s), goes to xs.  Replaces forwardSweepKern x A
+// (fpHelpers.cuh:19-63) together with the A - B K / B du traffic between the two passes.
+__global__ __launch_bounds__(64) void k_sweep_maps(Buffers<float> b, Dims dm, int batch) {
+    constexpr int NX = 14;
+    const int pb = blockIdx.x, lane = threadIdx.x;
+    if (pb >= batch) return;
+    const SolverState<float>& st = b.state[pb];
+    if (st.done) return;
+    for (int i = 0; i < dm.M; i++) if (b.err[(size_t)pb * dm.M + i]) return;      // failed backward pass: no forward pass this sweep (fp_active)
+    const int N = dm.N, NBk = dm.NB, l = lane < NX ? lane : NX - 1;
+    const float* xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const float* dcur = b.dcur + (size_t)pb * N * NX;
+    float es = 0.f, et = 0.f;
+    for (int sgm = 0; sgm < dm.M - 1; sgm++) {
+        const float* o = b.segmap + ((size_t)pb * dm.M + sgm) * 256;               // Psi'(c, l) at [c * 16 + l]
+        const int k = (sgm + 1) * NBk - 1;
+        float ns = o[14 * 16 + l], nt = dcur[(size_t)k * NX + l];
+#pragma unroll
+        for (int cc = 0; cc < NX; cc++) {
+            const float ph = o[cc * 16 + l];
+            ns = __builtin_fmaf(ph, __shfl(es, cc), ns); nt = __builtin_fmaf(ph, __shfl(et, cc), nt);
+        }
+        es = ns; et = nt;
+        if (lane < NX) {
+            const float base = xcur[(size_t)(k + 1) * NX + lane];
+            for (int a = 0; a < dm.A; a++) b.xs[(((size_t)pb * dm.A + a) * N + k + 1) * NX + lane] = base + (et - b.alpha[a] * es);
+        }
+    }
+}
+void launch_sweep_maps(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch) {
+    hipLaunchKernelGGL(k_sweep_maps, dim3((unsigned)batch), dim3(64), 0, s, b, dm, batch);
+}
 }  // namespace pddp

@@ -60,6 +60,7 @@ struct Buffers {
     T *costk;            // [B][N] per-knot cost of the loaded trajectory (end-effector cost: written by the setup kernel, d_JT[k] of initAlgGPU)
     int *tshift;         // [B] finalCostShift of the end-effector cost (0 unless the MPC call shifts it)
     T *xw;               // [B][N][A][n] candidate states knot-major (thread-lane rollouts -> setup kernel, fp_tl.hpp); null otherwise
+    T *segmap;           // [B][M][16*16] per-segment affine maps of the forward sweep composed by the matrix-core backward pass (bp_mfma.hpp kMxFuseSweep); null otherwise
     T *ABc;              // compact [A B] of the arm's Euler step (ab_compact.hpp) when the handle runs the thread-lane setup + matrix-core backward pass; null otherwise
     T *Jpart, *dpart;    // [B][A][M] per-segment partial cost / defect norm of the thread-lane forward pass (fp_tl.hpp); null otherwise
     int *parts_fresh;    // [B] set by that forward pass, consumed by the line-search kernel (which then adds the partial sums into J / dmax)

@@ -345,8 +345,8 @@ def test_bench_batch_whole_solves_equal_single_problem_solves():
     assert (out["iters"] == 10).all()
     o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)
     o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
-    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP", "PDDP_SWEEP")}
-    os.environ.update({"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "st"})
+    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP")}
+    os.environ.update({"PDDP_BP": "mx", "PDDP_FP": "tl"})
     try:
         s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw)
     finally:
@@ -377,31 +377,66 @@ def test_bench_batch_whole_solves_equal_single_problem_solves():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,env", [pytest.param(100, {}, id="100-problems-few-problem-kernels"),
-                                   pytest.param(512, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "wg"}, id="512-problems-thread-lanes-with-staged-sweep"),
-                                   pytest.param(600, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "st"}, id="600-problems-large-batch-kernels")])
+                                   pytest.param(512, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, id="512-problems-thread-lanes"),
+                                   pytest.param(600, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, id="600-problems-large-batch-kernels"),
+                                   pytest.param(100, {"PDDP_SWEEP": "wg"}, id="100-problems-separate-sweep-kernel-wg"),
+                                   pytest.param(512, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "wg"}, id="512-problems-separate-sweep-kernel-wg"),
+                                   pytest.param(600, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "st"}, id="600-problems-separate-sweep-kernel-st")])
 def test_batches_between_one_and_the_bench_equal_single_problem_solves(B, env):
-    """The kernel selection changes with the number of problems in flight (one problem ... 128: k_sweep_wg + k_fp_tl2 + k_nis_tl7; up to 512: the staged sweep
-    with the thread-lane kernels; above: the large-batch set).  At each of these sizes a batch -- more than one workgroup of every kernel, ragged last
-    workgroups -- must give, bit for bit, what single-problem handles on the SAME kernels give (`env` = the selection the library made for the batch, forced
-    for the single problem); the per-iteration bar of those kernels is test_kuka_headline_config_float32_bar_every_iteration's."""
+    """The kernel selection changes with the number of problems in flight (one problem ... 128: k_fp_tl2 + k_nis_tl7; from 512: the thread-lane kernels;
+    the forward sweep by default fused into the matrix-core backward pass + k_sweep_maps, or -- PDDP_SWEEP -- a kernel of its own reading A - B K / B du).
+    At each of these sizes a batch -- more than one workgroup of every kernel, ragged last workgroups -- must give, bit for bit, what single-problem
+    handles on the SAME kernels give (`env` = the selection, in force for both handles); the per-iteration bar of those kernels is
+    test_kuka_headline_config_float32_bar_every_iteration's and test_fused_sweep_matches_the_sweep_kernels'."""
     kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=8)
     rng = np.random.default_rng(77 + B)
     xs, us = [], []
     for b_ in range(B):
         x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
         xs.append(x0); us.append(u0)
-    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
-    out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
-    assert (out["iters"] == 8).all()
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
+        s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
         s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw)
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
+    assert (out["iters"] == 8).all()
     for b_ in list(rng.choice(B, 6, replace=False)) + [0, B - 1]:
         o1 = s1.solve(xs[b_], us[b_], xg)
         for key in ("Jout", "alphaOut", "x", "u", "KT"):
             assert np.array_equal(o1[key][0], out[key][b_]), (int(b_), key)
         assert (out["alphaOut"][b_][1:9] >= 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,env", [pytest.param(1, {}, id="one-problem"), pytest.param(1024, {}, id="1024-problems")])
+def test_fused_sweep_matches_the_sweep_kernels(B, env):
+    """Production sweeps compose every shooting segment's sweep map inside the matrix-core backward pass (Psi = G_last ... G_first, G_k = [A - B K, B du; 0, 1]) and
+    k_sweep_maps chains the maps -- A - B K / B du never reach HBM.  Phase by phase this path has no teacher-forcing hook (the hook's sweep reads the arrays the test
+    hands in), so it is pinned here: whole solves with the fused sweep against the same solves with the separate sweep kernel (PDDP_SWEEP=st: sequential
+    matrix-vector steps over A - B K in memory).  The two are different float32 evaluations of the same linear recurrence -- identical step-size indices over the
+    leading iterations, and the costs of the first iterations (before rounding differences have been amplified by the solve) within 2e-5."""
+    kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=6)
+    rng = np.random.default_rng(5 + B)
+    xs, us = [], []
+    for b_ in range(B):
+        x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
+        xs.append(x0); us.append(u0)
+    outs = {}
+    for name, e in (("fused", {}), ("kernel", {"PDDP_SWEEP": "st"})):
+        old = {k: os.environ.get(k) for k in e}
+        os.environ.update(e)
+        try:
+            s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        outs[name] = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
+    a, k = outs["fused"], outs["kernel"]
+    same = [next((i for i in range(7) if a["alphaOut"][b_][i] != k["alphaOut"][b_][i]), 7) for b_ in range(B)]
+    assert np.median(same) >= 5 and min(same) >= 2, (np.median(same), min(same))
+    rel = np.abs(a["Jout"][:, :3] - k["Jout"][:, :3]) / k["Jout"][:, :3]
+    assert rel.max() <= 2e-5, rel.max()

@@ -238,18 +238,10 @@ PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int p
         for (int i = 0; i < NU; i++) duv[i] = b.du[knot * NU + i];
         const T* Kg = b.KT + knot * (NX * NU);
         const T alpha = b.alpha[st.alphaIndex];
-        T dx[NX];
+        T Kk[NX * NU];                                                    // the whole gain first: 49 loads in flight together (row by row costs a memory latency per row)
 #pragma unroll
-        for (int i = 0; i < NX; i++) dx[i] = x[i] - xr[i];
-#pragma unroll
-        for (int rr = 0; rr < NU; rr++) {                                 // tl_control_law, one gain row in registers at a time
-            T Kr[NX];
-            tl_load14(Kr, Kg + rr * NX);
-            T acc = alpha * duv[rr];
-#pragma unroll
-            for (int c = 0; c < NX; c++) acc = tl_fma(Kr[c], dx[c], acc);
-            u[rr] = ucv[rr] - acc;
-        }
+        for (int rr = 0; rr < NU; rr++) tl_load14(Kk + rr * NX, Kg + rr * NX);
+        tl_control_law<T>(u, alpha, duv, Kk, x, xr, ucv);
 #pragma unroll
         for (int i = 0; i < NU; i++) uc[i] = u[i];
     } else {                                                              // the terminal knot carries its nominal control along unchanged (tl_rollout_end)

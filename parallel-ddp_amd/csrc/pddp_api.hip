@@ -119,7 +119,7 @@ struct Solver : SolverBase {
     // full; the wave-cooperative kernel has the shorter critical path for a handful of problems.  PDDP_BP=lg|coop overrides.
     bool bp_lane_groups = false;
     bool fp_coop = false;          // PDDP_FP=coop
-    static constexpr int kNisTl7MaxBatch = 128;   // measured crossover against k_nis_lg (profiles/)
+    static constexpr int kNisTl7MaxBatch = 511;   // measured crossover against k_nis_lg (profiles/)
     bool fp_split = false;         // rollouts of a lane-group handle on the split thread-lane kernel (k_fp_tl2)
     FpPath fp_path = kFpLg;        // the arm's forward pass / next-iteration setup (fp_tl.hpp select_fp_path)
     int tl_variant = -1;           // which built-in robot model the handle's tables equal (the thread-lane kernels fold it into literals); -1: neither

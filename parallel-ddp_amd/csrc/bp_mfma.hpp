@@ -341,8 +341,12 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         // T1(kx, b) = sum_a K(a,kx) Huu(a,b) - Hxu(kx,b) as [b][kx]; its column 14 is Huu' du
         const mx4 T1t = mx_mfma2(Huu, Kp, zero) - HxuT;
         // ---- expected reduction (computeExpRed :317-334): du . g_u and du . Huu du, per control
-        dJ00 += Kp[0] * Hux[0]; dJ01 += Kp[1] * Hux[1];
-        dJ10 += Kp[0] * T1t[0]; dJ11 += Kp[1] * T1t[1];
+        if (FUSE) {                                                   // (two accumulators instead of four: the fused variant is at its register limit)
+            dJ00 += Kp[0] * Hux[0] + Kp[1] * Hux[1]; dJ10 += Kp[0] * T1t[0] + Kp[1] * T1t[1];
+        } else {
+            dJ00 += Kp[0] * Hux[0]; dJ01 += Kp[1] * Hux[1];
+            dJ10 += Kp[0] * T1t[0]; dJ11 += Kp[1] * T1t[1];
+        }
         if (FS) {                                                     // A - B K | B du  (computeFSVars :281-312)
             const mx4 BT = {k.BT0, k.BT1, 0.f, 0.f};                                              // [b][kx = c] = B(kx, b)
             const mx4 BK = mx_mfma2(BT, Kp, zero);

@@ -109,6 +109,7 @@ struct Solver : SolverBase {
     Buffers<T> b{};
     MpcBuffers<T> mb{};
     T* d_xActual = nullptr; int* d_shift = nullptr;
+    unsigned char* h_stage = nullptr; size_t h_stage_bytes = 0;     // pinned host staging of the MPC call (inputs, then outputs): its transfers are asynchronous, one sync per control cycle
     Dims dm{};
     SolverParams sp{};
     CostWeights<T> cw{};
@@ -173,6 +174,7 @@ struct Solver : SolverBase {
     ~Solver() override {
         if (graph) hipGraphExecDestroy(graph);
         for (void* p : allocs) hipFree(p);
+        if (h_stage) hipHostFree(h_stage);
         if (stream) hipStreamDestroy(stream);
     }
     void register_model(void* dmodel, const ArmModel<T>&) {
@@ -481,11 +483,26 @@ struct Solver : SolverBase {
         if (!mpc_used) { mpc_used = true; drop_graph(); }
         for (size_t i = 0; i < B; i++) if (shift[i] < 0 || shift[i] >= (int)N - 1) return fail(PDDP_EINVAL, "mpc_solve: shift must be in [0, N-2]");
         const double t0 = now_ms();
-        HIPCHK(hipMemcpyAsync(d_xActual, xActual, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(b.xGoal, xGoal, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(d_shift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
-        if (cfg.ee_cost && cfg.ee_cost_shift) HIPCHK(hipMemcpyAsync(b.tshift, shift, B * sizeof(int), hipMemcpyHostToDevice, stream));
-        else HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
+        // one pinned staging area: pageable host memory would make every small transfer of the cycle a synchronous staging copy of its own
+        const size_t out_stride = (size_t)cfg.max_iter + 2;
+        const size_t o_state = 0, o_xb = o_state + B * sizeof(SolverState<T>), o_u = o_xb + B * 2 * N * NX * sizeof(T), o_KT = o_u + B * N * NU * sizeof(T),
+                     o_J = o_KT + B * N * NX * NU * sizeof(T), o_a = o_J + B * out_stride * sizeof(T), need_bytes = o_a + B * out_stride * sizeof(int);
+        if (h_stage_bytes < need_bytes) {
+            if (h_stage) hipHostFree(h_stage);
+            h_stage = nullptr; h_stage_bytes = 0;
+            HIPCHK(hipHostMalloc((void**)&h_stage, need_bytes, hipHostMallocDefault));
+            h_stage_bytes = need_bytes;
+        }
+        {
+            unsigned char* hi = h_stage;                            // inputs first (the outputs overwrite them after the solve)
+            T* hx = (T*)hi; T* hg = hx + B * NX; int* hs = (int*)(hg + B * NX);
+            std::memcpy(hx, xActual, B * NX * sizeof(T)); std::memcpy(hg, xGoal, B * NX * sizeof(T)); std::memcpy(hs, shift, B * sizeof(int));
+            HIPCHK(hipMemcpyAsync(d_xActual, hx, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(b.xGoal, hg, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_shift, hs, B * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (cfg.ee_cost && cfg.ee_cost_shift) HIPCHK(hipMemcpyAsync(b.tshift, hs, B * sizeof(int), hipMemcpyHostToDevice, stream));
+            else HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
+        }
         bool split_roll = false;
         if constexpr (P::PLANT == 4 && INTEG == 1 && sizeof(T) == 4) {                // float arm with a built-in robot model: the warm-start rollout split over two waves
             const char* fpenv = std::getenv("PDDP_FP");
@@ -506,6 +523,31 @@ struct Solver : SolverBase {
         std::vector<int> done(B);
         int rc = 0;
         const int chunk = poll_every > 0 ? poll_every : 4;
+        if (budget_ms <= 0 && chunk >= max_iter) {
+            // no time budget and the whole iteration limit in one chunk: every problem is done after max_iter sweeps whatever happens (the limit forces the exit), so
+            // nothing has to be polled -- sweeps, fall-back kernel and ALL result transfers are enqueued back to back and the cycle synchronises once
+            if ((rc = iterate(max_iter))) { sp.max_iter = saved_max_iter; return rc; }
+            sp.max_iter = saved_max_iter;
+            hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_stage + o_state, b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
+            if (x) HIPCHK(hipMemcpyAsync(h_stage + o_xb, b.xb, B * 2 * N * NX * sizeof(T), hipMemcpyDeviceToHost, stream));
+            if (u) HIPCHK(hipMemcpyAsync(h_stage + o_u, b.ucur, B * N * NU * sizeof(T), hipMemcpyDeviceToHost, stream));
+            if (KT) HIPCHK(hipMemcpyAsync(h_stage + o_KT, b.KT, B * N * NX * NU * sizeof(T), hipMemcpyDeviceToHost, stream));
+            if (Jout) HIPCHK(hipMemcpyAsync(h_stage + o_J, b.Jout, B * out_stride * sizeof(T), hipMemcpyDeviceToHost, stream));
+            if (alphaOut) HIPCHK(hipMemcpyAsync(h_stage + o_a, b.alphaOut, B * out_stride * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hstate.resize(B);
+            std::memcpy(hstate.data(), h_stage + o_state, B * sizeof(SolverState<T>));
+            for (size_t pb = 0; pb < B; pb++)
+                if (x) std::memcpy((T*)x + pb * N * NX, (const T*)(h_stage + o_xb) + (pb * 2 + hstate[pb].cur) * N * NX, N * NX * sizeof(T));
+            if (u) std::memcpy(u, h_stage + o_u, B * N * NU * sizeof(T));
+            if (KT) std::memcpy(KT, h_stage + o_KT, B * N * NX * NU * sizeof(T));
+            if (Jout) std::memcpy(Jout, h_stage + o_J, B * out_stride * sizeof(T));
+            if (alphaOut) std::memcpy(alphaOut, h_stage + o_a, B * out_stride * sizeof(int));
+            for (size_t i = 0; i < B; i++) { if (success) success[i] = hstate[i].took_step; if (iters) iters[i] = hstate[i].iter; }
+            return 0;
+        }
         bool fresh = false;
         for (int guard = 0; guard < 100000; guard++) {
             if (budget_ms > 0 && now_ms() - t0 > budget_ms) break;   // time_budget (MPCHelpers.cuh:919,941,1001): checked between chunks of sweeps

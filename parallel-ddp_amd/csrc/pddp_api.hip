@@ -109,6 +109,7 @@ struct Solver : SolverBase {
     Buffers<T> b{};
     MpcBuffers<T> mb{};
     T* d_xActual = nullptr; int* d_shift = nullptr;
+    unsigned char* h_state = nullptr;                              // pinned copy target of the solver states (status polls)
     unsigned char* h_stage = nullptr; size_t h_stage_bytes = 0;     // pinned host staging of the MPC call (inputs, then outputs): its transfers are asynchronous, one sync per control cycle
     Dims dm{};
     SolverParams sp{};
@@ -175,6 +176,7 @@ struct Solver : SolverBase {
         if (graph) hipGraphExecDestroy(graph);
         for (void* p : allocs) hipFree(p);
         if (h_stage) hipHostFree(h_stage);
+        if (h_state) hipHostFree(h_state);
         if (stream) hipStreamDestroy(stream);
     }
     void register_model(void* dmodel, const ArmModel<T>&) {
@@ -489,6 +491,7 @@ struct Solver : SolverBase {
                      o_J = o_KT + B * N * NX * NU * sizeof(T), o_a = o_J + B * out_stride * sizeof(T), need_bytes = o_a + B * out_stride * sizeof(int);
         if (h_stage_bytes < need_bytes) {
             if (h_stage) hipHostFree(h_stage);
+        if (h_state) hipHostFree(h_state);
             h_stage = nullptr; h_stage_bytes = 0;
             HIPCHK(hipHostMalloc((void**)&h_stage, need_bytes, hipHostMallocDefault));
             h_stage_bytes = need_bytes;
@@ -570,8 +573,11 @@ struct Solver : SolverBase {
     std::vector<SolverState<T>> hstate;      // the solver states as last fetched by status()
     int status(int* done, int* iters) override {
         hstate.resize(cfg.batch);
-        HIPCHK(hipMemcpyAsync(hstate.data(), b.state, cfg.batch * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
+        const size_t bytes = cfg.batch * sizeof(SolverState<T>);
+        if (!h_state) HIPCHK(hipHostMalloc((void**)&h_state, bytes, hipHostMallocDefault));   // pinned: the poll is one asynchronous copy + one wait
+        HIPCHK(hipMemcpyAsync(h_state, b.state, bytes, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        std::memcpy(hstate.data(), h_state, bytes);
         for (int i = 0; i < cfg.batch; i++) { if (done) done[i] = hstate[i].done; if (iters) iters[i] = hstate[i].iter; }
         return 0;
     }

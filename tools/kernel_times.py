@@ -4,9 +4,10 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, ROOT)
 import numpy as np, pyddp, bench
+LIB = os.environ.get("PDDP_LIB")          # alternative build of libpddp (A/B measurements of build variants)
 for B in [int(v) for v in sys.argv[1:]] or [4096]:
-    cfg = pyddp.default_config(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, max_iter=200, use_graph=1)
-    s = pyddp.Solver(cfg)
+    cfg = pyddp.default_config(4, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, max_iter=200, use_graph=1, _lib_path=LIB)
+    s = pyddp.Solver(cfg, _lib_path=LIB)
     x0, u0, xg = bench.example_inputs(128, np.random.default_rng(1), B)
     s.load(x0, u0, xg); s.iterate(5); s.sync()
     k = s.time_kernels(30)

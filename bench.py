@@ -164,14 +164,24 @@ def main():
     if traffic:
         roof["traffic_GBs"] = round(traffic / (dom_ms * 1e-3) / 1e9, 1)        # what the kernel really moves: it keeps only the dynamic half of [A B] and the block-boundary cost-to-go
     if dom_name == "k_bp_mfma":
-        # the same kernel against the matrix-core roofline: 34 v_mfma_f32_16x16x4_f32 per knot as issued (2048 flop each) and the dense products the reference's
-        # backward pass needs per knot (n = 14, m = 7: W = P'[A B], H = [A B]'W, K, T1, P+, A - BK ~ 16.3 k multiply-adds)
+        # the same kernel against the matrix-core roofline: v_mfma_f32_16x16x4_f32 per knot as issued (34, + 4 in the M - 1 blocks that compose their segment's
+        # sweep map; 2048 flop each) and the dense products the reference's backward pass needs per knot (n = 14, m = 7: W = P'[A B], H = [A B]'W, K, T1, P+,
+        # A - BK ~ 16.3 k multiply-adds)
         knots = B * (N - M)                                                    # every block walks N/M - 1 knots
-        issued, useful = 34 * 2048.0 * knots, 2.0 * 16300.0 * knots
+        issued, useful = (34 + 4.0 * (M - 1) / M) * 2048.0 * knots, 2.0 * 16300.0 * knots
         roof["mfma"] = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": round(issued / (dom_ms * 1e-3) / 1e12, 2),
                         "issued_frac": round(issued / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                         "algorithmic_TFLOPs": round(useful / (dom_ms * 1e-3) / 1e12, 2),
-                        "limiter": "serial chain per knot (matrix-core phases + the 7x7 inversion on the vector ALU) at 5 waves per SIMD: neither HBM nor the matrix pipe saturates"}
+                        "limiter": "the SIMD's float32 lanes: a float32 matrix-core instruction and the vector instructions of the OTHER resident waves do not overlap "
+                                   "on gfx950 (tools/probes/mfma_valu_overlap.hip: a wave of v_mfma_f32_16x16x4_f32 beside a wave of v_fma_f32 takes the SUM of their times, "
+                                   "while the bf16 matrix instruction overlaps) -- the kernel's time is its matrix-core cycles PLUS its vector-ALU issue cycles"}
+        if counters and counters.get("SQ_INSTS_MFMA") and counters.get("SQ_INSTS_VALU"):
+            # shared-lane model: 32 cycles per 16x16x4 float32 matrix instruction + 4 per other vector instruction (SQ_INSTS_VALU counts both), over 1024 SIMDs at 2.4 GHz
+            n_mx, n_v = counters["SQ_INSTS_MFMA"], counters["SQ_INSTS_VALU"] - counters["SQ_INSTS_MFMA"]
+            cyc = (32.0 * n_mx + 4.0 * n_v) / 1024.0
+            roof["alu"] = {"model": "cycles per SIMD = 32 x matrix-core instructions + 4 x other vector instructions (they share the float32 lanes), 1024 SIMDs, 2.4 GHz",
+                           "matrix_core_ms": round(32.0 * n_mx / 1024.0 / 2.4e6, 4), "vector_ms": round(4.0 * n_v / 1024.0 / 2.4e6, 4),
+                           "model_ms": round(cyc / 2.4e6, 4), "frac_of_launch": round(cyc / 2.4e6 / dom_ms, 4)}
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),

@@ -309,15 +309,16 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         }
 #pragma unroll
         for (int pv = 0; pv < NU; pv++) {
-            const float rowp = R[pv];
-            const float inv = mx_recip(mx_readlane(rowp, mx_pi(pv)));
+            float col[NU];                                                        // the pivot column, wave-uniform (read before the reciprocal is needed)
+#pragma unroll
+            for (int a = 0; a < NU; a++) col[a] = mx_readlane(R[a], mx_pi(pv));
+            const float q = R[pv] * mx_recip(col[pv]);                            // the scaled pivot row; row a loses (its pivot-column entry) x q
 #pragma unroll
             for (int a = 0; a < NU; a++) {
                 if (a == pv) continue;
-                const float f = mx_readlane(R[a], mx_pi(pv)) * inv;
-                R[a] = __builtin_fmaf(-f, rowp, R[a]);
+                R[a] = __builtin_fmaf(-col[a], q, R[a]);
             }
-            R[pv] = rowp * inv;
+            R[pv] = q;
         }
         if (lane < 16 && (c & 3) >= 2) {
             const int e = 2 * (c >> 2) + (c & 3) - 2;

@@ -5,27 +5,34 @@
 // (DDPHelpers/bpHelpers.cuh:18-420: linearXfrmOrLoad, backprop, invHuu + invertMatrix, computeKTdu, computeCTG, computeFSVars,
 // computeExpRed) including the asymmetric placement of the regulariser (rho reaches Hxu and Huu, not the Hux block the gains are computed
 // from).  What differs is the arithmetic decomposition, so the float32 results agree with the oracle within the float32 bar
-// (tests/test_fp32_bar.py), not bit for bit: sums over the state index run in the matrix core's order (k = r, 4+r, 8+r, 12+r per
-// instruction, r = 0..3), rho B is added to AB'P instead of rho to P.
+// (tests/test_fp32_bar.py), not bit for bit: sums over the state index run in the matrix core's order (tile rows r, 4+r, 8+r, 12+r per
+// instruction, r = 0..3, in the state order mx_state() below), rho B is added to AB'P instead of rho to P.
 //
 // Layout.  "RB tile" of a matrix X with <= 16 rows and <= 16 columns: four registers t[0..3] per lane; lane (g = lane >> 4, c = lane & 15)
-// holds X[4 g + r][c] in t[r].  That is the accumulator layout of the 16x16x4 instruction, and -- with the k index of step r taken as
+// holds X[4 g + r][c] in t[r] -- tile indices; WHICH state a tile row / column index stands for is mx_state() (positions in registers 0, 1, velocities
+// in registers 2, 3, the vector column last), the same on rows and columns.  That is the accumulator layout of the 16x16x4 instruction, and -- with the k index of step r taken as
 // 4 g + r -- it is at the same time the A operand of X' (.) and the B operand of (.) X.  So for two RB tiles X, Y with a common row index
 //          mfma4(X, Y, C) = C + X' Y        (four instructions, result again an RB tile, rows = columns of X)
 // and the whole knot is written as products of that one form; no operand is ever transposed through LDS or shuffled between lanes:
-//   W_x, W_u = P' [A | B]                                    (= AB2', rows i)                      8 instructions
-//   Hxx' = A' W_x + Hxx_cost    Hux = B' W_x + Hux_cost      -Hxu' = (-W_u)' A - Hxu_cost'    Huu = B' W_u + Huu_cost      16
-//   K    = (Huu^-1')' Hux                                    (rows a)                              4
-//   T1'  = Huu' K - Hxu'                                     (rows b)                              4
-//   P+   = Hxx + T1'' K - K' Hux                             (rows kx: the next knot's P)          8
-//   A-BK = A + (-B')' K                                                                           4
+//   W_x, W_u = P' [A | B]                                    (= AB2', rows i)                      8 instructions   (6 with the Euler step's compact [A B])
+//   Hxx' = A' W_x + Hxx_cost    Hux = B' W_x + Hux_cost      -Hxu' = (-W_u)' A - Hxu_cost'    Huu = B' W_u + Huu_cost      16       (10)
+//   K    = (Huu^-1')' Hux                                    (rows a)                              2
+//   T1'  = Huu' K - Hxu'                                     (rows b)                              2
+//   P+   = Hxx + T1'' K - K' Hux                             (rows kx: the next knot's P)          4
+//   A-BK = A + (-B')' K                                                                           2
+//   Psi' <- G' Psi'   (sweep map of the segment, blocks 0..M-2)                                   4                 (2)
+// Euler step (compact [A B], CAB): the position rows of B are exact zeros and those of A are [I  dt I]; with the positions in registers 0, 1 of every lane a sum
+// over the state rows of B is instructions 2, 3 only, and the position rows' share of A'W and of G'Psi' is W's / Psi''s own registers 0, 1 and dt x them
+// (state 7 + s sits two registers above state s in the same lane): 28-30 matrix instructions per knot instead of 38.  The float32 matrix instruction executes on
+// the SIMD's float32 lanes -- it excludes the vector instructions of the other resident waves for its 32 cycles (tools/probes/mfma_valu_overlap.hip) -- so every
+// instruction removed, matrix or vector, is launch time removed.
 // The vectors ride along as column 14 of the tiles: p is column 14 of P, so g_x = A'p + g_cost, g_u = B'p + g_cost come out as column 14
 // of Hxx and Hux, du = Huu^-1 g_u as column 14 of K, Huu'du as column 14 of T1', the new p as column 14 of P+, and -B du as column 14 of
 // A - BK.  Only the 7x7 Gauss-Jordan inversion (unpivoted, never failing -- utils/cudaUtils.h:236-292) runs on the vector ALU: lane j keeps
 // column j of [Huu | I], pivot-column entries travel through v_readlane (the wave owns ONE problem, so they are wave-uniform scalars).
 //
-// Global memory: every per-knot block is read / written straight in RB order -- 16-byte pieces per lane (4 consecutive rows of a column of
-// the column-major blocks) or 56-byte runs across lanes; the bytes are the same as the lane-group kernel's (algorithmic bytes).
+// Global memory: every per-knot block is read / written straight in RB order -- two 8-byte pieces per lane (states 2g, 2g + 1 and 7 + 2g, 8 + 2g of a column
+// of the column-major blocks) or 56-byte runs across lanes; the bytes are the same as the lane-group kernel's (algorithmic bytes).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -51,33 +58,47 @@ __device__ __forceinline__ float mx_recip(float d) { const float x = __builtin_a
 __device__ __forceinline__ float mx_readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float mx_from_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
 
-// RB tile whose rows 4g..4g+3 are CONSECUTIVE in memory at p (a column of a column-major block): rows below `nrows` are read, the rest are 0
-__device__ __forceinline__ mx4 mx_load_rows4(const float* p, int row0, int nrows, bool lane_ok) {
+// State order inside the tiles.  Physical tile index q (row 4g + r, or column = lane & 15) keeps state mx_state(q): registers 0, 1 of lane group g the POSITION
+// states 2g, 2g + 1 (q = 13: padding), registers 2, 3 the VELOCITY states 7 + 2g, 8 + 2g (q = 15: index 14, the vector column / homogeneous row).  The same map
+// on rows and columns, so the product algebra above is unchanged; what it buys: the rows in which the Euler step's B is exactly zero (and A is {1, dt, 0}) fill
+// instructions 0 and 1 completely, so a sum over the state rows of B needs instructions 2 and 3 only (mx_mfma_hi) -- like the controls (mx_mfma2 below).
+__host__ __device__ constexpr int mx_state(int q) { return (q & 2) ? 7 + 2 * (q >> 2) + (q & 1) : (2 * (q >> 2) + (q & 1) < 7 ? 2 * (q >> 2) + (q & 1) : 15); }
+
+// tile column from a column of a column-major block (14 states consecutive at col): not for the hot loop (predicated)
+__device__ __forceinline__ mx4 mx_load_col(const float* col, int g, bool lane_ok) {
     mx4 t = {0.f, 0.f, 0.f, 0.f};
     if (lane_ok) {
-        const int left = nrows - row0;
-        if (left >= 4) t = *reinterpret_cast<const mx4u*>(p);
-        else if (left == 3) { const mx2u v = *reinterpret_cast<const mx2u*>(p); t[0] = v[0]; t[1] = v[1]; t[2] = p[2]; }
-        else if (left == 2) { const mx2u v = *reinterpret_cast<const mx2u*>(p); t[0] = v[0]; t[1] = v[1]; }
-        else if (left == 1) t[0] = p[0];
+        if (g < 3) {
+            const mx2u lo = *reinterpret_cast<const mx2u*>(col + 2 * g), hi = *reinterpret_cast<const mx2u*>(col + 7 + 2 * g);
+            t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
+        } else { t[0] = col[6]; t[2] = col[13]; }
     }
     return t;
 }
-__device__ __forceinline__ void mx_store_rows4(float* p, int row0, int nrows, bool lane_ok, const mx4& t) {
+__device__ __forceinline__ void mx_store_col(float* col, int g, bool lane_ok, const mx4& t) {
     if (lane_ok) {
-        const int left = nrows - row0;
-        if (left >= 4) *reinterpret_cast<mx4u*>(p) = t;
-        else if (left == 3) { mx2u v; v[0] = t[0]; v[1] = t[1]; *reinterpret_cast<mx2u*>(p) = v; p[2] = t[2]; }
-        else if (left == 2) { mx2u v; v[0] = t[0]; v[1] = t[1]; *reinterpret_cast<mx2u*>(p) = v; }
-        else if (left == 1) p[0] = t[0];
+        if (g < 3) {
+            mx2u lo, hi; lo[0] = t[0]; lo[1] = t[1]; hi[0] = t[2]; hi[1] = t[3];
+            *reinterpret_cast<mx2u*>(col + 2 * g) = lo; *reinterpret_cast<mx2u*>(col + 7 + 2 * g) = hi;
+        } else { col[6] = t[0]; col[13] = t[2]; }
     }
 }
-// RB tile whose row 4g+r lies at p + (4g+r)*ld, lanes c consecutive (a row of a column-major block read as a tile row)
-__device__ __forceinline__ mx4 mx_load_strided(const float* p, int ld, int row0, int nrows, bool lane_ok) {
-    mx4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; r++) if (lane_ok && row0 + r < nrows) t[r] = p[(row0 + r) * ld];
+// the same, unconditional (hot loop): both halves are read from clamped addresses, what the tile must not keep is zeroed by the caller's selects
+// (unsigned 32-bit BYTE offsets from a wave-uniform pointer: the loads take the scalar-base + vector-offset addressing mode instead of 64-bit vector adds)
+template <class T>
+__device__ __forceinline__ T mx_ld(const float* base, unsigned float_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + 4u * float_off);
+}
+__device__ __forceinline__ mx4 mx_load_col_raw(const float* col, int g) {
+    const unsigned o = 2u * (unsigned)g;
+    const mx2u lo = mx_ld<mx2u>(col, o), hi = mx_ld<mx2u>(col, o + 7u);
+    mx4 t; t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
     return t;
+}
+__device__ __forceinline__ mx4 mx_mfma_hi(const mx4& X, const mx4& Y, mx4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[2], Y[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[3], Y[3], acc, 0, 0, 0);
+    return acc;
 }
 
 // Control-indexed tiles.  A tile whose ROWS are a control index a = 0..6 comes out of the matrix core in accumulator rows = the lanes of the
@@ -110,71 +131,67 @@ struct MxKnotIn {
 template <bool FS, bool DIAGH>
 __device__ __forceinline__ void mx_load_knot(MxKnotIn<FS, DIAGH>& k, const float* ABk, const float* Hk, const float* gk, int g, int c, int ub) {
     constexpr int NX = 14, NU = 7, NM = 21;
-    const int row0 = 4 * g, u0 = 2 * g;
-    const bool cx = c < NX, cu = ub < NU, c14 = (c == NX);
-    const int cc = cx ? c : NX - 1, uc = cu ? ub : NU - 1;            // clamped column indices
-    const mx4 a0 = *reinterpret_cast<const mx4u*>(ABk + cc * NX + row0);
-    const mx4 b1 = *reinterpret_cast<const mx4u*>(ABk + (NX + uc) * NX + row0);
+    const int u0 = 2 * g, sc = mx_state(c);
+    const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX), g3 = g < 3;
+    const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1;           // clamped column indices
+    const mx4 a0 = mx_load_col_raw(ABk + cc * NX, g);
+    const mx4 b1 = mx_load_col_raw(ABk + (NX + uc) * NX, g);
 #pragma unroll
-    for (int r = 0; r < 4; r++) { k.A0[r] = (cx && row0 + r < NX) ? a0[r] : 0.f; k.B1[r] = (cu && row0 + r < NX) ? b1[r] : 0.f; }
+    for (int r = 0; r < 4; r++) { const bool ok = g3 || !(r & 1); k.A0[r] = (cx && ok) ? a0[r] : 0.f; k.B1[r] = (cu && ok) ? b1[r] : 0.f; }
     if (FS) {
         const float t0 = ABk[NX * NX + cc + NX * u0], t1 = ABk[NX * NX + cc + NX * (u0 + 1)];
         k.BT0 = cx ? t0 : 0.f; k.BT1 = (cx && u0 + 1 < NU) ? t1 : 0.f;
     }
     if (DIAGH) {
-        const mx4 gx = *reinterpret_cast<const mx4u*>(gk + row0);
+        const mx4 gx = mx_load_col_raw(gk, g);
         const float gu0 = gk[NX + u0], gu1 = gk[NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)];
 #pragma unroll
-        for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && row0 + r < NX) ? gx[r] : 0.f;
+        for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : 0.f;
         k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
         (void)Hk;                                                     // the diagonal comes from the cost weights (arm_mx_bp_block): no Hessian traffic at all
         k.hx = 0.f; k.hu = 0.f;
     } else {
-        const mx4 xx = *reinterpret_cast<const mx4u*>(c14 ? gk + row0 : Hk + cc * NM + row0);
+        const mx4 xx = mx_load_col_raw(c14 ? gk : Hk + cc * NM, g);
         const float* pu = c14 ? gk + NX + u0 : Hk + cc * NM + NX + u0;
         const float ux0 = pu[0], ux1 = pu[1];
         const float xu0 = Hk[(NX + u0) * NM + cc], xu1 = Hk[(NX + u0 + 1) * NM + cc];
         const float uu0 = Hk[(NX + uc) * NM + NX + u0], uu1 = Hk[(NX + uc) * NM + NX + u0 + 1];
         const bool v1 = u0 + 1 < NU;
 #pragma unroll
-        for (int r = 0; r < 4; r++) k.CXX[r] = ((cx || c14) && row0 + r < NX) ? xx[r] : 0.f;
+        for (int r = 0; r < 4; r++) k.CXX[r] = ((cx || c14) && (g3 || !(r & 1))) ? xx[r] : 0.f;
         k.CUX0 = (cx || c14) ? ux0 : 0.f; k.CUX1 = ((cx || c14) && v1) ? ux1 : 0.f;
         k.CXU0 = cx ? xu0 : 0.f; k.CXU1 = (cx && v1) ? xu1 : 0.f;
         k.CUU0 = cu ? uu0 : 0.f; k.CUU1 = (cu && v1) ? uu1 : 0.f;
     }
 }
 
-// The same operands from the COMPACT [A B] (ab_compact.hpp): only state rows 7..13 of a column are in memory, seven consecutive floats.  One 16-byte
-// load per tile and lane at an offset that depends on the lane's row group g -- g = 1: the column's first float (row 7, wanted in register 3), g = 2:
-// floats 1..4 (rows 8..11), g = 3: floats 5, 6 (rows 12, 13; the two floats read beyond the column are discarded), g = 0: nothing wanted -- and the
-// constant rows {1, dt, 0} of the Euler step come from compares.  pA / pB: this lane's column of the knot's share of its piece (wave-uniform knot part
-// already added), pT0 / pT1: B(row c, controls 2g, 2g + 1).
+// The same operands from the COMPACT [A B] (ab_compact.hpp): only the velocity rows 7..13 of a column are in memory, seven consecutive floats -- exactly the
+// rows registers 2, 3 keep: one 8-byte load per tile and lane at float 2g of the column (g = 3: the second float belongs to the next column and is
+// discarded); the constant rows {1, dt, 0} of the Euler step (registers 0, 1) come from compares and B's are zero (never multiplied: mx_mfma_hi).
+// chA + offA / chB + offB: this lane's column of the knot's share of its piece, + 2g (ch*: wave-uniform, off*: the lane's float offset); offT0 / offT1: B(state of
+// column c, controls 2g, 2g + 1).
 template <bool FS, bool DIAGH>
-__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<FS, DIAGH>& k, const float* pA, const float* pB, const float* pT0, const float* pT1, const float* gk,
-                                                     int g, int c, int ub, float dt) {
+__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<FS, DIAGH>& k, const float* chA, unsigned offA, const float* chB, unsigned offB, unsigned offT0,
+                                                     unsigned offT1, const float* gk, int g, int c, int ub, float dt) {
     constexpr int NX = 14, NU = 7;
-    const int row0 = 4 * g, u0 = 2 * g;
-    const bool cx = c < NX, cu = ub < NU, c14 = (c == NX);
-    const mx4 ta = *reinterpret_cast<const mx4u*>(pA);
-    const mx4 tb = *reinterpret_cast<const mx4u*>(pB);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = row0 + r;
-        const float ca = (c == row) ? 1.f : ((c == row + 7) ? dt : 0.f);              // rows < 7 of A; B has zeros there
-        const float da = (g == 1) ? ta[0] : ta[r], db = (g == 1) ? tb[0] : tb[r];     // the dynamic row this register holds, if any
-        const bool dyn = (row >= 7) && (row < NX);
-        k.A0[r] = cx ? (dyn ? da : (row < 7 ? ca : 0.f)) : 0.f;
-        k.B1[r] = (cu && dyn) ? db : 0.f;
-    }
+    const int u0 = 2 * g, sc = mx_state(c);
+    const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX), g3 = g < 3;
+    const mx2u ta = mx_ld<mx2u>(chA, offA);
+    const mx2u tb = mx_ld<mx2u>(chB, offB);
+    k.A0[0] = cx ? ((sc == u0) ? 1.f : ((sc == u0 + 7) ? dt : 0.f)) : 0.f;                // position rows 2g, 2g + 1 of A; B has zeros there
+    k.A0[1] = (cx && g3) ? ((sc == u0 + 1) ? 1.f : ((sc == u0 + 8) ? dt : 0.f)) : 0.f;
+    k.A0[2] = cx ? ta[0] : 0.f; k.A0[3] = (cx && g3) ? ta[1] : 0.f;                       // velocity rows 7 + 2g, 8 + 2g
+    k.B1[0] = 0.f; k.B1[1] = 0.f;
+    k.B1[2] = cu ? tb[0] : 0.f; k.B1[3] = (cu && g3) ? tb[1] : 0.f;
     if (FS) {
-        const float t0 = *pT0, t1 = *pT1;
-        k.BT0 = (cx && c >= 7) ? t0 : 0.f; k.BT1 = (cx && c >= 7 && u0 + 1 < NU) ? t1 : 0.f;
+        const float t0 = mx_ld<float>(chB, offT0), t1 = mx_ld<float>(chB, offT1);
+        k.BT0 = (cx && sc >= 7) ? t0 : 0.f; k.BT1 = (cx && sc >= 7 && u0 + 1 < NU) ? t1 : 0.f;
     }
     static_assert(DIAGH, "the compact [A B] is produced by the thread-lane setup kernel, whose cost Hessian is the joint-space diagonal");
-    const mx4 gx = *reinterpret_cast<const mx4u*>(gk + row0);
-    const float gu0 = gk[NX + u0], gu1 = gk[NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)];
+    const mx4 gx = mx_load_col_raw(gk, g);
+    const float gu0 = mx_ld<float>(gk, (unsigned)(NX + u0)), gu1 = mx_ld<float>(gk, (unsigned)(NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)));
 #pragma unroll
-    for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && row0 + r < NX) ? gx[r] : 0.f;
+    for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : 0.f;
     k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
     k.hx = 0.f; k.hu = 0.f;
 }
@@ -196,7 +213,7 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     const int keepP = flags & kMxKeepP;
     const bool fuse = FUSE && blk < dm.M - 1;                          // (the last block's segment has no boundary after it)
     constexpr int NX = 14, NU = 7, NM = 21, SZP = NX * NX, SZAB = NX * NM, SZH = NM * NM;
-    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g, u0 = 2 * g;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g, u0 = 2 * g, sc = mx_state(c);      // sc: the state (14: the vector) of this lane's column
     const int ub = ((c & 3) < 2) ? 2 * (c >> 2) + (c & 3) : 8;       // the control whose column this lane holds in control-column tiles (8: none)
     const SolverState<float>& st = b.state[pb];
     if (st.done) return;
@@ -211,19 +228,19 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     float* KT = b.KT + knot0 * (NX * NU); float* du = b.du + knot0 * NU; float* ApBK = b.ApBK + knot0 * SZP; float* Bdu = b.Bdu + knot0 * NX;
     const float* dcur = b.dcur + knot0 * NX;
     const float* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const float* xp2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
-    const bool cx = c < NX, cu = ub < NU, c14 = (c == NX);            // lane holds a state column / a control column / the vector column
+    const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX);          // lane holds a state column / a control column / the vector column (lane & 15 == 15)
 
     int ks = NBk * (blk + 1) - 1, iterCount;
     mx4 Pa;                                                           // [P | p]: P(4g+r, c) for c < 14, p(4g+r) in column 14
     if (ks == N - 1) {                                                // last block: the final cost (bpHelpers.cuh:362-367)
         const float* Hf = H + (size_t)ks * SZH; const float* gf = gg + (size_t)ks * NM;
-        Pa = mx_load_rows4(cx ? Hf + c * NM + row0 : gf + row0, row0, NX, cx || c14);
-        if (keepP) mx_store_rows4(cx ? Pw + (size_t)(ks - 1) * SZP + c * NX + row0 : pw + (size_t)(ks - 1) * NX + row0, row0, NX, cx || c14, Pa);
+        Pa = mx_load_col(cx ? Hf + sc * NM : gf, g, cx || c14);
+        if (keepP) mx_store_col(cx ? Pw + (size_t)(ks - 1) * SZP + sc * NX : pw + (size_t)(ks - 1) * NX, g, cx || c14, Pa);
         ks--; iterCount = NBk - 2;
     } else {                                                          // boundary cost-to-go of the previous iteration + linear transform (:18-34)
         iterCount = NBk - 1;
         const float* bP = Pr + (size_t)ks * SZP;
-        Pa = mx_load_rows4(bP + c * NX + row0, row0, NX, cx);
+        Pa = mx_load_col(bP + sc * NX, g, cx);
         if (lane < NX) {                                              // p = (Pp dx + pp) + Pp d: lane = row (the block's first knot is a defect boundary, :73)
             float dot = 0.f, val = 0.f;
             for (int j = 0; j < NX; j++) {
@@ -236,7 +253,7 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         wsync();
         if (c14) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) Pa[r] = (row0 + r < NX) ? lds[row0 + r] : 0.f;
+            for (int r = 0; r < 4; r++) { const int sr = mx_state(row0 + r); Pa[r] = (sr < NX) ? lds[sr] : 0.f; }
         }
         wsync();
     }
@@ -248,21 +265,21 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     mx4 PsiT = zero;                                                  // Psi'(m, i) = Psi(i, m): starts as the identity of the 15 x 15 augmented map
     if (FUSE) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) PsiT[r] = (row0 + r == c && c <= NX) ? 1.f : 0.f;
+        for (int r = 0; r < 4; r++) PsiT[r] = (row0 + r == c && sc <= NX) ? 1.f : 0.f;
     }
     MxKnotIn<FS, DIAGH> in;
     const float* ABk = AB + (size_t)ks * SZAB; const float* Hk = H + (size_t)ks * SZH; const float* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
     float* KTk = KT + (size_t)ks * (NX * NU); float* duk = du + (size_t)ks * NU; float* Fk = ApBK + (size_t)ks * SZP; float* Bduk = Bdu + (size_t)ks * NX;
     float* Pk = Pw + (size_t)(ks - 1) * SZP; float* pk = pw + (size_t)(ks - 1) * NX;
     // compact [A B]: per-lane float offsets of this lane's columns inside a knot's share of their pieces, and the per-knot strides of those pieces
-    int oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
+    unsigned oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
     if (CAB) {
-        const int cc = cx ? c : NX - 1, uc = cu ? ub : NU - 1, roff = g == 2 ? 1 : g == 3 ? 5 : 0;
+        const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1, roff = 2 * g;
         const int pa = abc_piece(cc);
         sA = abc_piece_cols(pa) * 7;
         oA = abc_piece_off(pa) + abc_col_in_piece(cc) * 7 + roff;
         oB = abc_piece_off(2) + uc * 7 + roff;
-        const int tr = cx && c >= 7 ? c - 7 : 0, u1 = u0 + 1 < NU ? u0 + 1 : NU - 1;
+        const int tr = cx && sc >= 7 ? sc - 7 : 0, u1 = u0 + 1 < NU ? u0 + 1 : NU - 1;
         oT0 = abc_piece_off(2) + u0 * 7 + tr; oT1 = abc_piece_off(2) + u1 * 7 + tr;
     }
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
@@ -271,8 +288,9 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         if constexpr (CAB) {
             const size_t G = knot0 + (size_t)ks;
             const float* ch = b.ABc + (G >> 6) * kAbcChunk;
-            const int kk = (int)(G & 63);
-            mx_load_knot_compact<FS, DIAGH>(in, ch + oA + kk * sA, ch + oB + kk * 49, ch + oT0 + kk * 49, ch + oT1 + kk * 49, gk, g, c, ub, dt);
+            const unsigned kk = (unsigned)(G & 63);
+            const float* chB = ch + kk * 49u;                        // (wave-uniform; the lane parts are unsigned 32-bit offsets)
+            mx_load_knot_compact<FS, DIAGH>(in, ch, oA + kk * sA, chB, oB, oT0, oT1, gk, g, c, ub, dt);
         } else mx_load_knot<FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
         const MxKnotIn<FS, DIAGH>& k = in;
         ABk -= SZAB; Hk -= SZH; gk -= NM;
@@ -280,21 +298,25 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         mx4 CXX = k.CXX, CUX = {k.CUX0, k.CUX1, 0.f, 0.f}, CXU = zero, CUU = zero;
         if (DIAGH) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) if (cx) CXX[r] = (row0 + r == c) ? (c < 7 ? hq1 : hq2) : 0.f;
+            for (int r = 0; r < 4; r++) if (cx) CXX[r] = (row0 + r == c) ? (sc < 7 ? hq1 : hq2) : 0.f;
             CUU[0] = (cu && u0 == ub) ? hr : 0.f; CUU[1] = (cu && u0 + 1 == ub) ? hr : 0.f;
         } else {
             CXU[0] = k.CXU0; CXU[1] = k.CXU1; CUU[0] = k.CUU0; CUU[1] = k.CUU1;
         }
         // ---- W = P' [A | B]  (AB2', rows i = column of P); the B columns take rho B (backprop, :39-64)
         const mx4 W0 = mx_mfma4(Pa, k.A0, zero);
-        mx4 W1 = mx_mfma4(Pa, k.B1, zero);
-        W1 = W1 + rho * k.B1;
-        const mx4 W0a = c14 ? Pa : W0;                                                            // column 14 := p
+        mx4 W1 = CAB ? mx_mfma_hi(Pa, k.B1, zero) : mx_mfma4(Pa, k.B1, zero);                    // (compact [A B] = Euler step: the position rows of B are exact zeros)
+        if (CAB) { W1[2] += rho * k.B1[2]; W1[3] += rho * k.B1[3]; } else W1 = W1 + rho * k.B1;
+        const mx4 W0a = c14 ? Pa : W0;                                                            // vector column := p
         // ---- H blocks (:66-93): products first, cost added after, like the reference
-        const mx4 Hxx = mx_mfma4(k.A0, W0a, zero) + CXX;                                          // Hxx(kx, ky) | g_x
-        const mx4 Hux = mx_mfma4(k.B1, W0a, zero) + CUX;                                          // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
+        // Hxx(kx, ky) | g_x.  Compact [A B]: the position rows of A are [I  dt I], so their share of A'W is W's position rows themselves (output position rows)
+        // and dt x the same registers (output velocity rows: state 7 + s sits two registers above state s in the same lane) -- what instructions 0, 1 would have
+        // produced, bit for bit (one nonzero term per element); instructions 2, 3 add the velocity rows
+        const mx4 HxxLow = {W0a[0], W0a[1], dt * W0a[0], dt * W0a[1]};
+        const mx4 Hxx = (CAB ? mx_mfma_hi(k.A0, W0a, HxxLow) : mx_mfma4(k.A0, W0a, zero)) + CXX;
+        const mx4 Hux = (CAB ? mx_mfma_hi(k.B1, W0a, zero) : mx_mfma4(k.B1, W0a, zero)) + CUX;                                          // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
         const mx4 HxuT = mx_mfma4(W1, k.A0, zero) + CXU;                                          // Hxu(kx, b) as [b][kx]   (with rho)
-        const mx4 Huu = mx_mfma4(k.B1, W1, zero) + CUU;                                           // Huu(a, b)               (with rho)
+        const mx4 Huu = (CAB ? mx_mfma_hi(k.B1, W1, zero) : mx_mfma4(k.B1, W1, zero)) + CUU;                                           // Huu(a, b)               (with rho)
         // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292): lane mx_pi(j) keeps column j of Huu,
         //      lane mx_pi(j) + 2 column j of the identity part; register a = row a
         float R[NU];
@@ -333,8 +355,8 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         wsync();
         // ---- gains (computeKTdu :208-220): K(a, kx) | du(a), rows a = 2g + r
         const mx4 Kp = mx_mfma2(InvT, Hux, zero);
-        if (c <= NX) {                                                // K row a = 2g + r: 14 consecutive floats of KT; du(a) from the lane of column 14
-            float* q0 = cx ? KTk + u0 * NX + c : duk + u0;
+        if (sc <= NX) {                                               // K row a = 2g + r: 14 floats of KT (lane -> state of its column); du(a) from the lane of the vector column
+            float* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
             q0[0] = Kp[0];
             if (u0 + 1 < NU) (cx ? q0 + NX : q0 + 1)[0] = Kp[1];
         }
@@ -351,19 +373,22 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         if (FS) {                                                     // A - B K | B du  (computeFSVars :281-312)
             const mx4 BT = {k.BT0, k.BT1, 0.f, 0.f};                                              // [b][kx = c] = B(kx, b)
             const mx4 BK = mx_mfma2(BT, Kp, zero);
-            mx4 Gt = c14 ? BK : k.A0 - BK;                                                        // [A - B K | B du], rows 14, 15 are zero
-            if (!FUSE) mx_store_rows4(cx ? Fk + c * NX + row0 : Bduk + row0, row0, NX, cx || c14, Gt);
+            mx4 Gt = c14 ? BK : k.A0 - BK;                                                        // [A - B K | B du]; tile rows 13, 15 are zero
+            if (!FUSE) mx_store_col(cx ? Fk + sc * NX : Bduk, g, cx || c14, Gt);
             if (FUSE && fuse) {
-                if (c14 && g == 3) Gt[2] = 1.f;                                                   // G(14, 14) = 1: the homogeneous coordinate
-                PsiT = mx_mfma4(Gt, PsiT, zero);
+                if (c14 && g == 3) Gt[3] = 1.f;                                                   // G(14, 14) = 1: the homogeneous coordinate (tile index 15)
+                if (CAB) {                                                                        // position rows of G are [I  dt I | 0] (B is zero there): as for Hxx
+                    const mx4 low = {PsiT[0], PsiT[1], dt * PsiT[0], dt * PsiT[1]};
+                    PsiT = mx_mfma_hi(Gt, PsiT, low);
+                } else PsiT = mx_mfma4(Gt, PsiT, zero);
             }
         }
         if (do_ctg) {                                                 // new cost-to-go (computeCTG :225-276): P(kx, ky) | p(kx)
             mx4 val = mx_mfma2(T1t, Kp, zero);
             val = mx_mfma2(-Kp, Hux, val);
             mx4 Pn = Hxx + val;
-            if (g == 3) { Pn[2] = 0.f; Pn[3] = 0.f; }                 // rows 14, 15 carry by-products of column 14: keep the padding clean
-            if (keepP || iter == 0) mx_store_rows4(cx ? Pk + c * NX + row0 : pk + row0, row0, NX, cx || c14, Pn);
+            if (g == 3) { Pn[1] = 0.f; Pn[3] = 0.f; }                 // tile rows 13, 15 (padding, vector) carry by-products of the vector column: keep them clean
+            if (keepP || iter == 0) mx_store_col(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
             Pa = Pn;
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;
@@ -371,16 +396,16 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     if (FUSE && fuse) {                                               // Psi' of this segment, row-major [16][16]
         float* o = b.segmap + ((size_t)pb * dm.M + blk) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[(row0 + r) * 16 + c] = PsiT[r];
+        for (int r = 0; r < 4; r++) o[mx_state(row0 + r) * 16 + sc] = PsiT[r];        // in state order (the padding index lands in row / column 15)
     }
-    // dJexp[2 blk], [2 blk + 1]: the 7 per-control partial sums in order (column-14 lanes 14, 30, 46, 62 hold controls 2g, 2g + 1)
+    // dJexp[2 blk], [2 blk + 1]: the 7 per-control partial sums in order (vector-column lanes 15, 31, 47, 63 hold controls 2g, 2g + 1)
     {
         float a0 = dJ00, a1 = dJ10;
-        a0 = a0 + mx_readlane(dJ01, 14); a1 = a1 + mx_readlane(dJ11, 14);
-        a0 = (a0 + mx_readlane(dJ00, 30)) + mx_readlane(dJ01, 30); a1 = (a1 + mx_readlane(dJ10, 30)) + mx_readlane(dJ11, 30);
-        a0 = (a0 + mx_readlane(dJ00, 46)) + mx_readlane(dJ01, 46); a1 = (a1 + mx_readlane(dJ10, 46)) + mx_readlane(dJ11, 46);
-        a0 = a0 + mx_readlane(dJ00, 62); a1 = a1 + mx_readlane(dJ10, 62);
-        if (lane == NX) {
+        a0 = a0 + mx_readlane(dJ01, 15); a1 = a1 + mx_readlane(dJ11, 15);
+        a0 = (a0 + mx_readlane(dJ00, 31)) + mx_readlane(dJ01, 31); a1 = (a1 + mx_readlane(dJ10, 31)) + mx_readlane(dJ11, 31);
+        a0 = (a0 + mx_readlane(dJ00, 47)) + mx_readlane(dJ01, 47); a1 = (a1 + mx_readlane(dJ10, 47)) + mx_readlane(dJ11, 47);
+        a0 = a0 + mx_readlane(dJ00, 63); a1 = a1 + mx_readlane(dJ10, 63);
+        if (lane == 15) {
             float* dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
             dJexp[2 * blk] = a0; dJexp[2 * blk + 1] = a1;
             b.err[(size_t)pb * dm.M + blk] = 0;                       // the generic 7x7 inversion never reports failure (utils/cudaUtils.h:291)

@@ -164,12 +164,15 @@ def main():
     if traffic:
         roof["traffic_GBs"] = round(traffic / (dom_ms * 1e-3) / 1e9, 1)        # what the kernel really moves: it keeps only the dynamic half of [A B] and the block-boundary cost-to-go
     if dom_name == "k_bp_mfma":
-        # the same kernel against the matrix-core roofline: v_mfma_f32_16x16x4_f32 per knot as issued (34, + 4 in the M - 1 blocks that compose their segment's
-        # sweep map; 2048 flop each) and the dense products the reference's backward pass needs per knot (n = 14, m = 7: W = P'[A B], H = [A B]'W, K, T1, P+,
-        # A - BK ~ 16.3 k multiply-adds)
+        # the same kernel against the matrix-core roofline: v_mfma_f32_16x16x4_f32 per knot as issued (26 with the Euler step's compact [A B], + 2 in the M - 1
+        # blocks that compose their segment's sweep map; 2048 flop each -- the committed counter pass has the exact number) and the dense products the reference's
+        # backward pass needs per knot (n = 14, m = 7: W = P'[A B], H = [A B]'W, K, T1, P+, A - BK ~ 16.3 k multiply-adds)
         knots = B * (N - M)                                                    # every block walks N/M - 1 knots
-        issued, useful = (34 + 4.0 * (M - 1) / M) * 2048.0 * knots, 2.0 * 16300.0 * knots
-        roof["mfma"] = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": round(issued / (dom_ms * 1e-3) / 1e12, 2),
+        per_knot = (26 + 2.0 * (M - 1) / M) if not os.environ.get("PDDP_AB") else (34 + 4.0 * (M - 1) / M)
+        if counters and counters.get("SQ_INSTS_MFMA"):
+            per_knot = counters["SQ_INSTS_MFMA"] / knots
+        issued, useful = per_knot * 2048.0 * knots, 2.0 * 16300.0 * knots
+        roof["mfma"] = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "instructions_per_knot": round(per_knot, 2), "issued_TFLOPs": round(issued / (dom_ms * 1e-3) / 1e12, 2),
                         "issued_frac": round(issued / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                         "algorithmic_TFLOPs": round(useful / (dom_ms * 1e-3) / 1e12, 2),
                         "limiter": "the SIMD's float32 lanes: a float32 matrix-core instruction and the vector instructions of the OTHER resident waves do not overlap "

@@ -89,6 +89,8 @@ template <class T>
 __device__ __forceinline__ T mx_ld(const float* base, unsigned float_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + 4u * float_off);
 }
+// (a loop-invariant lane offset is hoisted with its 64-bit extension and costs one 64-bit vector add per access; forcing it to stay 32-bit inside the loop
+// with an empty asm costs a register copy + shift per access instead -- measured in instructions, no gain)
 __device__ __forceinline__ mx4 mx_load_col_raw(const float* col, int g) {
     const unsigned o = 2u * (unsigned)g;
     const mx2u lo = mx_ld<mx2u>(col, o), hi = mx_ld<mx2u>(col, o + 7u);
@@ -317,36 +319,35 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         const mx4 Hux = (CAB ? mx_mfma_hi(k.B1, W0a, zero) : mx_mfma4(k.B1, W0a, zero)) + CUX;                                          // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
         const mx4 HxuT = mx_mfma4(W1, k.A0, zero) + CXU;                                          // Hxu(kx, b) as [b][kx]   (with rho)
         const mx4 Huu = (CAB ? mx_mfma_hi(k.B1, W1, zero) : mx_mfma4(k.B1, W1, zero)) + CUU;                                           // Huu(a, b)               (with rho)
-        // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292): lane mx_pi(j) keeps column j of Huu,
-        //      lane mx_pi(j) + 2 column j of the identity part; register a = row a
-        float R[NU];
+        // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292).  The rows stay where the matrix core left them:
+        //      lane group g owns rows 2g, 2g + 1 (R0, R1); lane mx_pi(j) of a group keeps column j of Huu, lane mx_pi(j) + 2 column j of the identity part.  Per pivot
+        //      the pivot row and a group's own two pivot-column entries travel through ds_bpermute (LDS crossbar: not the float32 lanes the matrix instructions
+        //      need), the pivot itself through v_readlane; every group then updates its two rows -- 8 vector instructions per pivot instead of 18 with all seven
+        //      rows replicated in every lane.  Same operations per element as before: R[a] -= R[a][pv] * (R[pv] / R[pv][pv]).
+        float R0, R1;
         {
             const int e = 2 * (c >> 2) + (c & 3) - 2;                 // identity column of this lane ((c & 3) >= 2)
             const bool left = (c & 3) < 2;
-            const float h2 = mx_from_lane(Huu[0], c + 16), h3 = mx_from_lane(Huu[1], c + 16), h4 = mx_from_lane(Huu[0], c + 32), h5 = mx_from_lane(Huu[1], c + 32),
-                        h6 = mx_from_lane(Huu[0], c + 48);
-            R[0] = left ? Huu[0] : (e == 0 ? 1.f : 0.f); R[1] = left ? Huu[1] : (e == 1 ? 1.f : 0.f);
-            R[2] = left ? h2 : (e == 2 ? 1.f : 0.f); R[3] = left ? h3 : (e == 3 ? 1.f : 0.f);
-            R[4] = left ? h4 : (e == 4 ? 1.f : 0.f); R[5] = left ? h5 : (e == 5 ? 1.f : 0.f); R[6] = left ? h6 : (e == 6 ? 1.f : 0.f);
+            R0 = left ? Huu[0] : (e == u0 ? 1.f : 0.f);
+            R1 = left ? Huu[1] : ((e == u0 + 1 && u0 + 1 < NU) ? 1.f : 0.f);
         }
 #pragma unroll
         for (int pv = 0; pv < NU; pv++) {
-            float col[NU];                                                        // the pivot column, wave-uniform (read before the reciprocal is needed)
-#pragma unroll
-            for (int a = 0; a < NU; a++) col[a] = mx_readlane(R[a], mx_pi(pv));
-            const float q = R[pv] * mx_recip(col[pv]);                            // the scaled pivot row; row a loses (its pivot-column entry) x q
-#pragma unroll
-            for (int a = 0; a < NU; a++) {
-                if (a == pv) continue;
-                R[a] = __builtin_fmaf(-col[a], q, R[a]);
-            }
-            R[pv] = q;
+            const int go = pv >> 1;                                                // owner group of the pivot row; its register is pv & 1
+            const float src = (pv & 1) ? R1 : R0;
+            const float piv = mx_readlane(src, 16 * go + mx_pi(pv));
+            const float prow = mx_from_lane(src, 16 * go + c);
+            const float col0 = mx_from_lane(R0, 16 * g + mx_pi(pv)), col1 = mx_from_lane(R1, 16 * g + mx_pi(pv));
+            const float q = prow * mx_recip(piv);                                 // the scaled pivot row; row a loses (its pivot-column entry) x q
+            const float n0 = __builtin_fmaf(-col0, q, R0), n1 = __builtin_fmaf(-col1, q, R1);
+            R0 = (g == go && !(pv & 1)) ? q : n0;
+            R1 = (g == go && (pv & 1)) ? q : n1;
         }
-        if (lane < 16 && (c & 3) >= 2) {
+        if ((c & 3) >= 2) {
             const int e = 2 * (c >> 2) + (c & 3) - 2;
             if (e < NU) {
-#pragma unroll
-                for (int a = 0; a < NU; a++) ldsI[a * 8 + e] = R[a];
+                ldsI[u0 * 8 + e] = R0;
+                if (u0 + 1 < NU) ldsI[(u0 + 1) * 8 + e] = R1;
             }
         }
         wsync();

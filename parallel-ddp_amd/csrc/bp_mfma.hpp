@@ -28,8 +28,8 @@
 // instruction removed, matrix or vector, is launch time removed.
 // The vectors ride along as column 14 of the tiles: p is column 14 of P, so g_x = A'p + g_cost, g_u = B'p + g_cost come out as column 14
 // of Hxx and Hux, du = Huu^-1 g_u as column 14 of K, Huu'du as column 14 of T1', the new p as column 14 of P+, and -B du as column 14 of
-// A - BK.  Only the 7x7 Gauss-Jordan inversion (unpivoted, never failing -- utils/cudaUtils.h:236-292) runs on the vector ALU: lane j keeps
-// column j of [Huu | I], pivot-column entries travel through v_readlane (the wave owns ONE problem, so they are wave-uniform scalars).
+// A - BK.  Only the 7x7 Gauss-Jordan inversion (unpivoted, never failing -- utils/cudaUtils.h:236-292) runs on the vector ALU: lane group g keeps
+// rows 2g, 2g + 1 of [Huu | I] as the matrix core delivered them, the pivot row and the pivot-column entries travel through ds_bpermute.
 //
 // Global memory: every per-knot block is read / written straight in RB order -- two 8-byte pieces per lane (states 2g, 2g + 1 and 7 + 2g, 8 + 2g of a column
 // of the column-major blocks) or 56-byte runs across lanes; the bytes are the same as the lane-group kernel's (algorithmic bytes).

@@ -304,6 +304,21 @@ def test_kuka_headline_config_float32_bar_every_iteration(backend, env, ensemble
     assert_inside(rows, fails, ens)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,env,full_h", [
+    pytest.param(KUKA, {"PDDP_BP": "mx", "PDDP_FP": "lg"}, True, id="reference-layout-full-hessian"),
+    pytest.param(KUKA, {"PDDP_BP": "mx", "PDDP_FP": "lg"}, False, id="reference-layout-diagonal-hessian"),
+    pytest.param({**KUKA, "M": 1}, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, False, id="single-shooting-compact"),
+    pytest.param({**KUKA, "M": 2}, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, True, id="two-segments-full-hessian")])
+def test_matrix_core_backward_pass_other_instantiations(kw, env, full_h):
+    """k_bp_mfma's other template instantiations -- [A B] in the reference layout (lane-group setup kernel; every handle whose cost Hessian was overridden or
+    is the end-effector cost's), the full cost Hessian, single shooting (no sweep operands) -- share the tile state order (bp_mfma.hpp mx_state) with the
+    compact-[A B] instantiation the bench runs, but not its shortened products: the same float32 bar, every phase, teacher-forced from oracle64."""
+    rows, fails, ints_ok = run_bar("hip", 4, kw, env, 5, 12, full_h=full_h, ensemble=True)
+    assert ints_ok, "err flags / step-size index / accept-reject / ignore_defect / rho schedule must be identical"
+    assert_inside(rows, fails, True)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_cartpole_config_float32_bar_every_iteration(backend):
     """BASELINE configs[1]: cart-pole N=128, A=8, M=4, RK3, float32 (Huu is 1x1: computeKTdu_dim1)."""

@@ -185,6 +185,13 @@ def main():
             roof["alu"] = {"model": "cycles per SIMD = 32 x matrix-core instructions + 4 x other vector instructions (they share the float32 lanes), 1024 SIMDs, 2.4 GHz",
                            "matrix_core_ms": round(32.0 * n_mx / 1024.0 / 2.4e6, 4), "vector_ms": round(4.0 * n_v / 1024.0 / 2.4e6, 4),
                            "model_ms": round(cyc / 2.4e6, 4), "frac_of_launch": round(cyc / 2.4e6 / dom_ms, 4)}
+        # Which resource binds: per launch the kernel needs ~66 GFLOP of dense products and really moves ~2.5 GB through HBM (`traffic`) -- 26 flop per byte, above
+        # the ridge of the float32 matrix peak over the HBM peak (157.3 TFLOP/s / 8 TB/s = 19.7).  The record's top level stays what the bench contract defines
+        # (ALGORITHMIC bytes of SURVEY 8(d) / launch time against the HBM peak: the rate at which the reference's byte accounting is got through -- it can pass 1,
+        # because most of those bytes are no longer moved); `mfma` is the same launch against the matrix-core roofline and `alu` the lanes it actually waits for.
+        roof["mfma"]["algorithmic_frac"] = round(roof["mfma"]["algorithmic_TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
+        roof["note"] = ("frac is in the reference's byte accounting (654.6 KB per problem and backward pass, of which this kernel moves 153 KB); the binding resource is the "
+                        "SIMD's float32 lanes: see `alu` (share of the launch explained by matrix + vector instruction cycles) and `mfma` (algorithmic_frac, issued_frac)")
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),

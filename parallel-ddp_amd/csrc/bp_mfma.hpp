@@ -26,7 +26,7 @@
 // (state 7 + s sits two registers above state s in the same lane): 28-30 matrix instructions per knot instead of 38.  The float32 matrix instruction executes on
 // the SIMD's float32 lanes -- it excludes the vector instructions of the other resident waves for its 32 cycles (tools/probes/mfma_valu_overlap.hip) -- so every
 // instruction removed, matrix or vector, is launch time removed.
-// The vectors ride along as column 14 of the tiles: p is column 14 of P, so g_x = A'p + g_cost, g_u = B'p + g_cost come out as column 14
+// The vectors ride along as state index 14 ("column 14" below; tile column 15, mx_state) of the tiles: p is column 14 of P, so g_x = A'p + g_cost, g_u = B'p + g_cost come out as column 14
 // of Hxx and Hux, du = Huu^-1 g_u as column 14 of K, Huu'du as column 14 of T1', the new p as column 14 of P+, and -B du as column 14 of
 // A - BK.  Only the 7x7 Gauss-Jordan inversion (unpivoted, never failing -- utils/cudaUtils.h:236-292) runs on the vector ALU: lane group g keeps
 // rows 2g, 2g + 1 of [Huu | I] as the matrix core delivered them, the pivot row and the pivot-column entries travel through ds_bpermute.
@@ -233,7 +233,7 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
     const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX);          // lane holds a state column / a control column / the vector column (lane & 15 == 15)
 
     int ks = NBk * (blk + 1) - 1, iterCount;
-    mx4 Pa;                                                           // [P | p]: P(4g+r, c) for c < 14, p(4g+r) in column 14
+    mx4 Pa;                                                           // [P | p] in tile order: P(mx_state(4g+r), mx_state(c)), p in the vector column
     if (ks == N - 1) {                                                // last block: the final cost (bpHelpers.cuh:362-367)
         const float* Hf = H + (size_t)ks * SZH; const float* gf = gg + (size_t)ks * NM;
         Pa = mx_load_col(cx ? Hf + sc * NM : gf, g, cx || c14);
@@ -259,7 +259,7 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         }
         wsync();
     }
-    float dJ00 = 0.f, dJ01 = 0.f, dJ10 = 0.f, dJ11 = 0.f;            // per-control partial sums of the expected reduction (lanes of column 14: controls 2g, 2g+1)
+    float dJ00 = 0.f, dJ01 = 0.f, dJ10 = 0.f, dJ11 = 0.f;            // per-control partial sums of the expected reduction (lanes of the vector column: controls 2g, 2g+1)
     const mx4 zero = {0.f, 0.f, 0.f, 0.f};
     float* ldsI = lds + 16;                                           // Huu^-1, entry (a, b) at [a * 8 + b]
     lds[16 + lane] = 0.f;                                             // slot b = 7 of every row stays 0

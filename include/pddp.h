@@ -64,6 +64,11 @@ typedef struct pddp_config {
     int use_finite_diff;  /* USE_FINITE_DIFF (config.cuh:68): [A B] of the Euler step by central differences of the plant's `dynamics`, column by column
                            * (finiteDiffInner, DDPHelpers/nisInitHelpers.cuh:138-183) instead of the analytic gradient.  Euler only, joint-space cost. */
     double finite_diff_epsilon; /* FINITE_DIFF_EPSILON (config.cuh:69-71), default 0.00001 */
+    int boundary_cost_to_go_only; /* 0 (default) = the reference: every backward pass leaves the cost-to-go P, p of EVERY knot in the device arrays (d_P, d_p;
+                           * the MPC warm start shifts the whole arrays, MPCHelpers.cuh:602-655).  1 = throughput option of the matrix-core backward pass: only the
+                           * slot in front of every block's first knot is written -- the only ones a later pass reads (the reference's d_Pp / d_pp boundary slots);
+                           * the interior cost-to-go is not an output of runiLQR_GPU.  A handle that iterated with 1 refuses a warm-started pddp_mpc_solve
+                           * (clear_vars = 0) until a solve has run with every slot kept. */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */
@@ -218,6 +223,9 @@ int pddp_set_state(pddp_handle h, const pddp_state* in /* [batch] */);
 #define PDDP_PHASE_INIT_COST 5   /* cost part of initAlgGPU        nisInitHelpers.cuh:385-395       */
 #define PDDP_PHASE_BP_COOP   6   /* the wave-cooperative backward pass (all plants); for the KUKA arm PDDP_PHASE_BP is the lane-group
                                     kernel and this one exists so that tests can require the two to agree bit for bit */
+#define PDDP_PHASE_BP_FUSED  7   /* handles whose production sweep composes the forward sweep's per-segment maps inside the matrix-core backward pass
+                                    (KUKA arm, M > 1): that backward pass -- every output of PDDP_PHASE_BP except A - B K / B du, plus the maps */
+#define PDDP_PHASE_SWEEP_FUSED 8 /* ... and the kernel that finishes forwardSweepKern from those maps: every candidate's segment start states -> xs */
 int pddp_run_phase(pddp_handle h, int phase);
 
 /* Plant plug-in evaluations on the device, `count` independent (x,u) pairs:

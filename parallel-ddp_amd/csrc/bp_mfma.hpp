@@ -1,5 +1,7 @@
-// Backward (Riccati-like) pass of the KUKA-sized problem (n = 14, m = 7, float) on the MATRIX CORES: one wavefront walks one of the M
-// blocks of knots of one problem backwards and every dense product of a knot is a chain of v_mfma_f32_16x16x4_f32.
+// Backward (Riccati-like) pass of the KUKA-sized problem (n = 14, m = 7) on the MATRIX CORES: one wavefront walks one of the M
+// blocks of knots of one problem backwards and every dense product of a knot is a chain of v_mfma_f32_16x16x4_f32 (float handles: the production
+// path) or v_mfma_f64_16x16x4_f64 (double handles, PDDP_BP=mx: the SAME tile algebra at a precision at which it can be held against the oracle
+// decision for decision -- tests/test_f64_benched_family.py; the two instructions differ only in which accumulator row a register holds, Mx<T> below).
 //
 // Same function as bp_block() (bp.hpp) / arm_lg_bp_block() (bp_lg.hpp), which restate backPassKern and its inner routines
 // (DDPHelpers/bpHelpers.cuh:18-420: linearXfrmOrLoad, backprop, invHuu + invertMatrix, computeKTdu, computeCTG, computeFSVars,
@@ -42,211 +44,259 @@
 
 namespace pddp {
 
-typedef float mx4 __attribute__((ext_vector_type(4)));
-typedef float mx4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float mx2u __attribute__((ext_vector_type(2), aligned(4)));
+// Element-type traits of the tile algebra.  Both 16x16x4 instructions take one A / B element per lane -- lane (g = lane >> 4, c = lane & 15) supplies
+// A[i = c][k = g], B[k = g][j = c] -- and return four accumulator elements per lane in column c; what differs is the ROW of register r:
+//     float  (v_mfma_f32_16x16x4_f32):  row 4 g + r          double (v_mfma_f64_16x16x4_f64):  row g + 4 r
+// Everything below is written in terms of (lane group g, register r): tile index q = Mx<T>::q_of(g, r), and a column index c is decomposed the same
+// way (g_of(c), r_of(c)), so that rows and columns keep ONE state order and the product algebra is the same for both element types.
+template <typename T> struct Mx;
+template <> struct Mx<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
+    static __host__ __device__ constexpr int q_of(int g, int r) { return 4 * g + r; }
+    static __host__ __device__ constexpr int g_of(int q) { return q >> 2; }
+    static __host__ __device__ constexpr int r_of(int q) { return q & 3; }
+    static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // 1 / d to within one unit in the last place: hardware reciprocal + one Newton step (the reference divides, cudaUtils.h:262)
+    static __device__ __forceinline__ float recip(float d) { const float x = __builtin_amdgcn_rcpf(d); return __builtin_fmaf(__builtin_fmaf(-d, x, 1.f), x, x); }
+    static __device__ __forceinline__ float readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+    static __device__ __forceinline__ float from_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+};
+template <> struct Mx<double> {
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
+    static __host__ __device__ constexpr int q_of(int g, int r) { return g + 4 * r; }
+    static __host__ __device__ constexpr int g_of(int q) { return q & 3; }
+    static __host__ __device__ constexpr int r_of(int q) { return q >> 2; }
+    static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ double recip(double d) { return 1.0 / d; }
+    static __device__ __forceinline__ double readlane(double v, int lane) {
+        const long long w = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), lane);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    static __device__ __forceinline__ double from_lane(double v, int src_lane) {
+        const long long w = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)w), hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)(w >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+};
+template <typename T> using mx4t = typename Mx<T>::v4;
 
-__device__ __forceinline__ mx4 mx_mfma4(const mx4& X, const mx4& Y, mx4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[2], Y[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[3], Y[3], acc, 0, 0, 0);
+template <typename T>
+__device__ __forceinline__ mx4t<T> mx_mfma4(const mx4t<T>& X, const mx4t<T>& Y, mx4t<T> acc) {
+    acc = Mx<T>::mfma(X[0], Y[0], acc);
+    acc = Mx<T>::mfma(X[1], Y[1], acc);
+    acc = Mx<T>::mfma(X[2], Y[2], acc);
+    acc = Mx<T>::mfma(X[3], Y[3], acc);
     return acc;
 }
-// 1 / d to within one unit in the last place: hardware reciprocal + one Newton step (the reference divides, nisInitHelpers / cudaUtils.h:262)
-__device__ __forceinline__ float mx_recip(float d) { const float x = __builtin_amdgcn_rcpf(d); return __builtin_fmaf(__builtin_fmaf(-d, x, 1.f), x, x); }
-__device__ __forceinline__ float mx_readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-__device__ __forceinline__ float mx_from_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
 
-// State order inside the tiles.  Physical tile index q (row 4g + r, or column = lane & 15) keeps state mx_state(q): registers 0, 1 of lane group g the POSITION
-// states 2g, 2g + 1 (q = 13: padding), registers 2, 3 the VELOCITY states 7 + 2g, 8 + 2g (q = 15: index 14, the vector column / homogeneous row).  The same map
-// on rows and columns, so the product algebra above is unchanged; what it buys: the rows in which the Euler step's B is exactly zero (and A is {1, dt, 0}) fill
-// instructions 0 and 1 completely, so a sum over the state rows of B needs instructions 2 and 3 only (mx_mfma_hi) -- like the controls (mx_mfma2 below).
-__host__ __device__ constexpr int mx_state(int q) { return (q & 2) ? 7 + 2 * (q >> 2) + (q & 1) : (2 * (q >> 2) + (q & 1) < 7 ? 2 * (q >> 2) + (q & 1) : 15); }
+// State order inside the tiles.  Register r of lane group g (tile index q_of(g, r), as a row; the same decomposition of lane & 15 as a column) keeps state
+// mx_state_gr(g, r): registers 0, 1 the POSITION states 2g, 2g + 1 (g = 3, r = 1: padding, 15), registers 2, 3 the VELOCITY states 7 + 2g, 8 + 2g (g = 3, r = 3:
+// index 14, the vector column / homogeneous row).  The same map on rows and columns, so the product algebra above is unchanged; what it buys: the rows in which
+// the Euler step's B is exactly zero (and A is {1, dt, 0}) fill instructions 0 and 1 completely, so a sum over the state rows of B needs instructions 2 and 3
+// only (mx_mfma_hi) -- like the controls (mx_mfma2 below).
+__host__ __device__ constexpr int mx_state_gr(int g, int r) { return (r & 2) ? 7 + 2 * g + (r & 1) : (2 * g + r < 7 ? 2 * g + r : 15); }
+template <typename T> __host__ __device__ constexpr int mx_state(int q) { return mx_state_gr(Mx<T>::g_of(q), Mx<T>::r_of(q)); }
 
 // tile column from a column of a column-major block (14 states consecutive at col): not for the hot loop (predicated)
-__device__ __forceinline__ mx4 mx_load_col(const float* col, int g, bool lane_ok) {
-    mx4 t = {0.f, 0.f, 0.f, 0.f};
+template <typename T>
+__device__ __forceinline__ mx4t<T> mx_load_col(const T* col, int g, bool lane_ok) {
+    mx4t<T> t = {T(0), T(0), T(0), T(0)};
     if (lane_ok) {
         if (g < 3) {
-            const mx2u lo = *reinterpret_cast<const mx2u*>(col + 2 * g), hi = *reinterpret_cast<const mx2u*>(col + 7 + 2 * g);
+            const typename Mx<T>::v2u lo = *reinterpret_cast<const typename Mx<T>::v2u*>(col + 2 * g), hi = *reinterpret_cast<const typename Mx<T>::v2u*>(col + 7 + 2 * g);
             t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
         } else { t[0] = col[6]; t[2] = col[13]; }
     }
     return t;
 }
-__device__ __forceinline__ void mx_store_col(float* col, int g, bool lane_ok, const mx4& t) {
+template <typename T>
+__device__ __forceinline__ void mx_store_col(T* col, int g, bool lane_ok, const mx4t<T>& t) {
     if (lane_ok) {
         if (g < 3) {
-            mx2u lo, hi; lo[0] = t[0]; lo[1] = t[1]; hi[0] = t[2]; hi[1] = t[3];
-            *reinterpret_cast<mx2u*>(col + 2 * g) = lo; *reinterpret_cast<mx2u*>(col + 7 + 2 * g) = hi;
+            typename Mx<T>::v2u lo, hi; lo[0] = t[0]; lo[1] = t[1]; hi[0] = t[2]; hi[1] = t[3];
+            *reinterpret_cast<typename Mx<T>::v2u*>(col + 2 * g) = lo; *reinterpret_cast<typename Mx<T>::v2u*>(col + 7 + 2 * g) = hi;
         } else { col[6] = t[0]; col[13] = t[2]; }
     }
 }
 // the same, unconditional (hot loop): both halves are read from clamped addresses, what the tile must not keep is zeroed by the caller's selects
 // (unsigned 32-bit BYTE offsets from a wave-uniform pointer: the loads take the scalar-base + vector-offset addressing mode instead of 64-bit vector adds)
-template <class T>
-__device__ __forceinline__ T mx_ld(const float* base, unsigned float_off) {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + 4u * float_off);
+template <class V, typename T>
+__device__ __forceinline__ V mx_ld(const T* base, unsigned elem_off) {
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (unsigned)sizeof(T) * elem_off);
 }
 // (a loop-invariant lane offset is hoisted with its 64-bit extension and costs one 64-bit vector add per access; forcing it to stay 32-bit inside the loop
 // with an empty asm costs a register copy + shift per access instead -- measured in instructions, no gain)
-__device__ __forceinline__ mx4 mx_load_col_raw(const float* col, int g) {
+template <typename T>
+__device__ __forceinline__ mx4t<T> mx_load_col_raw(const T* col, int g) {
     const unsigned o = 2u * (unsigned)g;
-    const mx2u lo = mx_ld<mx2u>(col, o), hi = mx_ld<mx2u>(col, o + 7u);
-    mx4 t; t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
+    const typename Mx<T>::v2u lo = mx_ld<typename Mx<T>::v2u, T>(col, o), hi = mx_ld<typename Mx<T>::v2u, T>(col, o + 7u);
+    mx4t<T> t; t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
     return t;
 }
-__device__ __forceinline__ mx4 mx_mfma_hi(const mx4& X, const mx4& Y, mx4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[2], Y[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[3], Y[3], acc, 0, 0, 0);
+template <typename T>
+__device__ __forceinline__ mx4t<T> mx_mfma_hi(const mx4t<T>& X, const mx4t<T>& Y, mx4t<T> acc) {
+    acc = Mx<T>::mfma(X[2], Y[2], acc);
+    acc = Mx<T>::mfma(X[3], Y[3], acc);
     return acc;
 }
 
 // Control-indexed tiles.  A tile whose ROWS are a control index a = 0..6 comes out of the matrix core in accumulator rows = the lanes of the
-// X operand's columns.  Control column b is therefore kept in lane mx_pi(b) = 4 (b >> 1) + (b & 1) of every tile that has controls in its
+// X operand's columns.  Control column b is therefore kept in lane mx_pi(b) = q_of(b >> 1, b & 1) of every tile that has controls in its
 // columns (B, W_u, Huu, Huu^-1'), which puts control row b into register b & 1 of lane group b >> 1: a product that sums over the controls
 // then needs instructions r = 0, 1 only (mx_mfma2) instead of four half-empty ones.
-__device__ __forceinline__ mx4 mx_mfma2(const mx4& X, const mx4& Y, mx4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], acc, 0, 0, 0);
+template <typename T>
+__device__ __forceinline__ mx4t<T> mx_mfma2(const mx4t<T>& X, const mx4t<T>& Y, mx4t<T> acc) {
+    acc = Mx<T>::mfma(X[0], Y[0], acc);
+    acc = Mx<T>::mfma(X[1], Y[1], acc);
     return acc;
 }
-__host__ __device__ constexpr int mx_pi(int b) { return 4 * (b >> 1) + (b & 1); }
+template <typename T> __host__ __device__ constexpr int mx_pi(int b) { return Mx<T>::q_of(b >> 1, b & 1); }
 
 // the read-only operands of one knot as they come from memory
-template <bool FS, bool DIAGH>
+template <typename T, bool FS, bool DIAGH>
 struct MxKnotIn {
-    mx4 A0, B1;            // A(i, kx = c), B(i, control of this lane)
-    float BT0, BT1;        // FS: B(kx = c, b = 2g + r)
-    mx4 CXX;               // full H: Hcost(kx, ky = c) | g_x in column 14;   diagonal H: g_x only (lane of column 14)
-    float CUX0, CUX1;      // full H: Hcost(14 + b, kx = c) | g_u;             diagonal H: g_u only
-    float CXU0, CXU1;      // full H: Hcost(kx = c, 14 + b)
-    float CUU0, CUU1;      // full H: Hcost(14 + a, 14 + control of this lane)
-    float hx, hu;          // unused
+    mx4t<T> A0, B1;        // A(i, kx = c), B(i, control of this lane)
+    T BT0, BT1;            // FS: B(kx = c, b = 2g + r)
+    mx4t<T> CXX;           // full H: Hcost(kx, ky = c) | g_x in column 14;   diagonal H: g_x only (lane of column 14)
+    T CUX0, CUX1;          // full H: Hcost(14 + b, kx = c) | g_u;             diagonal H: g_u only
+    T CXU0, CXU1;          // full H: Hcost(kx = c, 14 + b)
+    T CUU0, CUU1;          // full H: Hcost(14 + a, 14 + control of this lane)
+    T hx, hu;              // unused
 };
 
 // Every lane reads UNCONDITIONALLY from an address clamped into the arrays (no divergent control flow around the loads: the compiler would turn
 // every predicated load into its own exec-masked branch region) and what a lane must not use is replaced by 0 afterwards.  The clamped
 // addresses stay inside the allocation because the loop never touches the last knot's blocks (ks <= N - 2): an over-read of up to one row / two
-// floats past a knot's block lands in the next knot's block.
-template <bool FS, bool DIAGH>
-__device__ __forceinline__ void mx_load_knot(MxKnotIn<FS, DIAGH>& k, const float* ABk, const float* Hk, const float* gk, int g, int c, int ub) {
+// elements past a knot's block lands in the next knot's block.
+template <typename T, bool FS, bool DIAGH>
+__device__ __forceinline__ void mx_load_knot(MxKnotIn<T, FS, DIAGH>& k, const T* ABk, const T* Hk, const T* gk, int g, int c, int ub) {
     constexpr int NX = 14, NU = 7, NM = 21;
-    const int u0 = 2 * g, sc = mx_state(c);
+    const int u0 = 2 * g, sc = mx_state<T>(c);
     const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX), g3 = g < 3;
     const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1;           // clamped column indices
-    const mx4 a0 = mx_load_col_raw(ABk + cc * NX, g);
-    const mx4 b1 = mx_load_col_raw(ABk + (NX + uc) * NX, g);
+    const mx4t<T> a0 = mx_load_col_raw<T>(ABk + cc * NX, g);
+    const mx4t<T> b1 = mx_load_col_raw<T>(ABk + (NX + uc) * NX, g);
 #pragma unroll
-    for (int r = 0; r < 4; r++) { const bool ok = g3 || !(r & 1); k.A0[r] = (cx && ok) ? a0[r] : 0.f; k.B1[r] = (cu && ok) ? b1[r] : 0.f; }
+    for (int r = 0; r < 4; r++) { const bool ok = g3 || !(r & 1); k.A0[r] = (cx && ok) ? a0[r] : T(0); k.B1[r] = (cu && ok) ? b1[r] : T(0); }
     if (FS) {
-        const float t0 = ABk[NX * NX + cc + NX * u0], t1 = ABk[NX * NX + cc + NX * (u0 + 1)];
-        k.BT0 = cx ? t0 : 0.f; k.BT1 = (cx && u0 + 1 < NU) ? t1 : 0.f;
+        const T t0 = ABk[NX * NX + cc + NX * u0], t1 = ABk[NX * NX + cc + NX * (u0 + 1)];
+        k.BT0 = cx ? t0 : T(0); k.BT1 = (cx && u0 + 1 < NU) ? t1 : T(0);
     }
     if (DIAGH) {
-        const mx4 gx = mx_load_col_raw(gk, g);
-        const float gu0 = gk[NX + u0], gu1 = gk[NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)];
+        const mx4t<T> gx = mx_load_col_raw<T>(gk, g);
+        const T gu0 = gk[NX + u0], gu1 = gk[NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)];
 #pragma unroll
-        for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : 0.f;
-        k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
+        for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : T(0);
+        k.CUX0 = c14 ? gu0 : T(0); k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : T(0);
         (void)Hk;                                                     // the diagonal comes from the cost weights (arm_mx_bp_block): no Hessian traffic at all
-        k.hx = 0.f; k.hu = 0.f;
+        k.hx = T(0); k.hu = T(0);
     } else {
-        const mx4 xx = mx_load_col_raw(c14 ? gk : Hk + cc * NM, g);
-        const float* pu = c14 ? gk + NX + u0 : Hk + cc * NM + NX + u0;
-        const float ux0 = pu[0], ux1 = pu[1];
-        const float xu0 = Hk[(NX + u0) * NM + cc], xu1 = Hk[(NX + u0 + 1) * NM + cc];
-        const float uu0 = Hk[(NX + uc) * NM + NX + u0], uu1 = Hk[(NX + uc) * NM + NX + u0 + 1];
+        const mx4t<T> xx = mx_load_col_raw<T>(c14 ? gk : Hk + cc * NM, g);
+        const T* pu = c14 ? gk + NX + u0 : Hk + cc * NM + NX + u0;
+        const T ux0 = pu[0], ux1 = pu[1];
+        const T xu0 = Hk[(NX + u0) * NM + cc], xu1 = Hk[(NX + u0 + 1) * NM + cc];
+        const T uu0 = Hk[(NX + uc) * NM + NX + u0], uu1 = Hk[(NX + uc) * NM + NX + u0 + 1];
         const bool v1 = u0 + 1 < NU;
 #pragma unroll
-        for (int r = 0; r < 4; r++) k.CXX[r] = ((cx || c14) && (g3 || !(r & 1))) ? xx[r] : 0.f;
-        k.CUX0 = (cx || c14) ? ux0 : 0.f; k.CUX1 = ((cx || c14) && v1) ? ux1 : 0.f;
-        k.CXU0 = cx ? xu0 : 0.f; k.CXU1 = (cx && v1) ? xu1 : 0.f;
-        k.CUU0 = cu ? uu0 : 0.f; k.CUU1 = (cu && v1) ? uu1 : 0.f;
+        for (int r = 0; r < 4; r++) k.CXX[r] = ((cx || c14) && (g3 || !(r & 1))) ? xx[r] : T(0);
+        k.CUX0 = (cx || c14) ? ux0 : T(0); k.CUX1 = ((cx || c14) && v1) ? ux1 : T(0);
+        k.CXU0 = cx ? xu0 : T(0); k.CXU1 = (cx && v1) ? xu1 : T(0);
+        k.CUU0 = cu ? uu0 : T(0); k.CUU1 = (cu && v1) ? uu1 : T(0);
     }
 }
 
-// The same operands from the COMPACT [A B] (ab_compact.hpp): only the velocity rows 7..13 of a column are in memory, seven consecutive floats -- exactly the
-// rows registers 2, 3 keep: one 8-byte load per tile and lane at float 2g of the column (g = 3: the second float belongs to the next column and is
+// The same operands from the COMPACT [A B] (ab_compact.hpp): only the velocity rows 7..13 of a column are in memory, seven consecutive elements -- exactly the
+// rows registers 2, 3 keep: one two-element load per tile and lane at element 2g of the column (g = 3: the second element belongs to the next column and is
 // discarded); the constant rows {1, dt, 0} of the Euler step (registers 0, 1) come from compares and B's are zero (never multiplied: mx_mfma_hi).
-// chA + offA / chB + offB: this lane's column of the knot's share of its piece, + 2g (ch*: wave-uniform, off*: the lane's float offset); offT0 / offT1: B(state of
+// chA + offA / chB + offB: this lane's column of the knot's share of its piece, + 2g (ch*: wave-uniform, off*: the lane's element offset); offT0 / offT1: B(state of
 // column c, controls 2g, 2g + 1).
-template <bool FS, bool DIAGH>
-__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<FS, DIAGH>& k, const float* chA, unsigned offA, const float* chB, unsigned offB, unsigned offT0,
-                                                     unsigned offT1, const float* gk, int g, int c, int ub, float dt) {
+template <typename T, bool FS, bool DIAGH>
+__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, const T* chA, unsigned offA, const T* chB, unsigned offB, unsigned offT0,
+                                                     unsigned offT1, const T* gk, int g, int c, int ub, T dt) {
     constexpr int NX = 14, NU = 7;
-    const int u0 = 2 * g, sc = mx_state(c);
+    using V2 = typename Mx<T>::v2u;
+    const int u0 = 2 * g, sc = mx_state<T>(c);
     const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX), g3 = g < 3;
-    const mx2u ta = mx_ld<mx2u>(chA, offA);
-    const mx2u tb = mx_ld<mx2u>(chB, offB);
-    k.A0[0] = cx ? ((sc == u0) ? 1.f : ((sc == u0 + 7) ? dt : 0.f)) : 0.f;                // position rows 2g, 2g + 1 of A; B has zeros there
-    k.A0[1] = (cx && g3) ? ((sc == u0 + 1) ? 1.f : ((sc == u0 + 8) ? dt : 0.f)) : 0.f;
-    k.A0[2] = cx ? ta[0] : 0.f; k.A0[3] = (cx && g3) ? ta[1] : 0.f;                       // velocity rows 7 + 2g, 8 + 2g
-    k.B1[0] = 0.f; k.B1[1] = 0.f;
-    k.B1[2] = cu ? tb[0] : 0.f; k.B1[3] = (cu && g3) ? tb[1] : 0.f;
+    const V2 ta = mx_ld<V2, T>(chA, offA);
+    const V2 tb = mx_ld<V2, T>(chB, offB);
+    k.A0[0] = cx ? ((sc == u0) ? T(1) : ((sc == u0 + 7) ? dt : T(0))) : T(0);                // position rows 2g, 2g + 1 of A; B has zeros there
+    k.A0[1] = (cx && g3) ? ((sc == u0 + 1) ? T(1) : ((sc == u0 + 8) ? dt : T(0))) : T(0);
+    k.A0[2] = cx ? ta[0] : T(0); k.A0[3] = (cx && g3) ? ta[1] : T(0);                       // velocity rows 7 + 2g, 8 + 2g
+    k.B1[0] = T(0); k.B1[1] = T(0);
+    k.B1[2] = cu ? tb[0] : T(0); k.B1[3] = (cu && g3) ? tb[1] : T(0);
     if (FS) {
-        const float t0 = mx_ld<float>(chB, offT0), t1 = mx_ld<float>(chB, offT1);
-        k.BT0 = (cx && sc >= 7) ? t0 : 0.f; k.BT1 = (cx && sc >= 7 && u0 + 1 < NU) ? t1 : 0.f;
+        const T t0 = mx_ld<T, T>(chB, offT0), t1 = mx_ld<T, T>(chB, offT1);
+        k.BT0 = (cx && sc >= 7) ? t0 : T(0); k.BT1 = (cx && sc >= 7 && u0 + 1 < NU) ? t1 : T(0);
     }
     static_assert(DIAGH, "the compact [A B] is produced by the thread-lane setup kernel, whose cost Hessian is the joint-space diagonal");
-    const mx4 gx = mx_load_col_raw(gk, g);
-    const float gu0 = mx_ld<float>(gk, (unsigned)(NX + u0)), gu1 = mx_ld<float>(gk, (unsigned)(NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)));
+    const mx4t<T> gx = mx_load_col_raw<T>(gk, g);
+    const T gu0 = mx_ld<T, T>(gk, (unsigned)(NX + u0)), gu1 = mx_ld<T, T>(gk, (unsigned)(NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)));
 #pragma unroll
-    for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : 0.f;
-    k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
-    k.hx = 0.f; k.hu = 0.f;
+    for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : T(0);
+    k.CUX0 = c14 ? gu0 : T(0); k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : T(0);
+    k.hx = T(0); k.hu = T(0);
 }
 
-// One (problem, block of knots).  lds: 96 floats of this wave.  FS: M > 1 (write the forward-sweep operands A - B K, B du).
+// One (problem, block of knots).  lds: 96 elements of this wave.  FS: M > 1 (write the forward-sweep operands A - B K, B du).
 // DIAGH: the cost Hessian of every running knot is the joint-space cost's diag(Q1 x 7, Q2 x 7, R x 7) (plants/cost_arm.cuh:158-202, ArmPlant::weight):
 // the setup kernel wrote exactly those numbers into H, so they are taken from the launch arguments (hq1, hq2, hr) and H is not read in the loop.
 // CAB: [A B] comes from the compact array b.ABc (ab_compact.hpp; dt rebuilds the constant rows).  keepP = 0: only the cost-to-go slots a later pass reads are
 // written -- the one in front of the block's first knot, which the neighbouring block's next pass starts from (the reference's d_Pp / d_pp boundary slots); the
-// per-knot P, p of the interior are by-products nobody reads (not an output of runiLQR_GPU).  The phase hook and MPC handles (whose warm start shifts the
-// whole array, MPCHelpers.cuh:602-655) pass keepP = 1.
+// per-knot P, p of the interior are by-products nobody reads (not an output of runiLQR_GPU; pddp_config.boundary_cost_to_go_only).  The default, the phase hook
+// and MPC handles (whose warm start shifts the whole array, MPCHelpers.cuh:602-655) pass keepP = 1.
 // flags bit 1 (kMxFuseSweep): the block also composes its shooting segment's effect on the forward sweep's two sequences -- with G_k = [A - B K, B du; 0, 1] (15 x 15)
 // the segment's map is Psi = G_last ... G_first, and Psi' <- G_k' Psi' is one more mfma4 per knot on tiles this pass holds anyway (Psi' again in accumulator layout) --
-// and leaves Psi' in b.segmap[problem][block] (1 KB) INSTEAD of writing A - B K and B du of every knot (107 KB per problem, and the linear sweep kernel that would
+// and leaves Psi' in b.segmap[problem][block] (256 elements) INSTEAD of writing A - B K and B du of every knot (107 KB per problem, and the linear sweep kernel that would
 // read them back): k_sweep_maps composes the M - 1 maps.  Same mathematics as k_sweep_wg's per-segment tiles (pddp_tl.hip).
 constexpr int kMxKeepP = 1, kMxFuseSweep = 2;
-template <bool FS, bool DIAGH, bool CAB, bool FUSE>
-__device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims& dm, int pb, int blk, float hq1, float hq2, float hr, float dt, int flags) {
+template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE>
+__device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
+    using X = Mx<T>;
+    using mx4 = mx4t<T>;
     const int keepP = flags & kMxKeepP;
     const bool fuse = FUSE && blk < dm.M - 1;                          // (the last block's segment has no boundary after it)
     constexpr int NX = 14, NU = 7, NM = 21, SZP = NX * NX, SZAB = NX * NM, SZH = NM * NM;
-    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, row0 = 4 * g, u0 = 2 * g, sc = mx_state(c);      // sc: the state (14: the vector) of this lane's column
-    const int ub = ((c & 3) < 2) ? 2 * (c >> 2) + (c & 3) : 8;       // the control whose column this lane holds in control-column tiles (8: none)
-    const SolverState<float>& st = b.state[pb];
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, u0 = 2 * g, sc = mx_state<T>(c);      // sc: the state (14: the vector) of this lane's column
+    const int cg = X::g_of(c), cr = X::r_of(c);                        // this lane's column index as (lane group, register) of the row order
+    const int ub = (cr < 2) ? 2 * cg + cr : 8;                         // the control whose column this lane holds in control-column tiles (8: none)
+    const SolverState<T>& st = b.state[pb];
     if (st.done) return;
     const int N = dm.N, NBk = dm.NB;
-    const float rho = st.rho;
+    const T rho = st.rho;
     const size_t halfP = (size_t)(b.Pp - b.P), halfp = (size_t)(b.pp - b.p), knot0 = (size_t)pb * N;
-    float* Pw = b.P + (st.pw ? halfP : 0) + knot0 * SZP;              // the half of the cost-to-go double buffer this pass writes ...
-    const float* Pr = b.P + (st.pw ? 0 : halfP) + knot0 * SZP;        // ... and the one whose block-boundary slots it reads (reference d_Pp)
-    float* pw = b.p + (st.pw ? halfp : 0) + knot0 * NX;
-    const float* pr = b.p + (st.pw ? 0 : halfp) + knot0 * NX;
-    const float* AB = b.AB + knot0 * SZAB; const float* H = b.H + knot0 * SZH; const float* gg = b.g + knot0 * NM;
-    float* KT = b.KT + knot0 * (NX * NU); float* du = b.du + knot0 * NU; float* ApBK = b.ApBK + knot0 * SZP; float* Bdu = b.Bdu + knot0 * NX;
-    const float* dcur = b.dcur + knot0 * NX;
-    const float* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const float* xp2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
+    T* Pw = b.P + (st.pw ? halfP : 0) + knot0 * SZP;                  // the half of the cost-to-go double buffer this pass writes ...
+    const T* Pr = b.P + (st.pw ? 0 : halfP) + knot0 * SZP;            // ... and the one whose block-boundary slots it reads (reference d_Pp)
+    T* pw = b.p + (st.pw ? halfp : 0) + knot0 * NX;
+    const T* pr = b.p + (st.pw ? 0 : halfp) + knot0 * NX;
+    const T* AB = b.AB + knot0 * SZAB; const T* H = b.H + knot0 * SZH; const T* gg = b.g + knot0 * NM;
+    T* KT = b.KT + knot0 * (NX * NU); T* du = b.du + knot0 * NU; T* ApBK = b.ApBK + knot0 * SZP; T* Bdu = b.Bdu + knot0 * NX;
+    const T* dcur = b.dcur + knot0 * NX;
+    const T* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const T* xp2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
     const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX);          // lane holds a state column / a control column / the vector column (lane & 15 == 15)
+    bool diag[4];                                                     // register r of this lane sits on the tile's diagonal (its row index equals the lane's column index)
+#pragma unroll
+    for (int r = 0; r < 4; r++) diag[r] = (X::q_of(g, r) == c);
 
     int ks = NBk * (blk + 1) - 1, iterCount;
-    mx4 Pa;                                                           // [P | p] in tile order: P(mx_state(4g+r), mx_state(c)), p in the vector column
+    mx4 Pa;                                                           // [P | p] in tile order: P(mx_state_gr(g, r), mx_state(c)), p in the vector column
     if (ks == N - 1) {                                                // last block: the final cost (bpHelpers.cuh:362-367)
-        const float* Hf = H + (size_t)ks * SZH; const float* gf = gg + (size_t)ks * NM;
-        Pa = mx_load_col(cx ? Hf + sc * NM : gf, g, cx || c14);
-        if (keepP) mx_store_col(cx ? Pw + (size_t)(ks - 1) * SZP + sc * NX : pw + (size_t)(ks - 1) * NX, g, cx || c14, Pa);
+        const T* Hf = H + (size_t)ks * SZH; const T* gf = gg + (size_t)ks * NM;
+        Pa = mx_load_col<T>(cx ? Hf + sc * NM : gf, g, cx || c14);
+        if (keepP) mx_store_col<T>(cx ? Pw + (size_t)(ks - 1) * SZP + sc * NX : pw + (size_t)(ks - 1) * NX, g, cx || c14, Pa);
         ks--; iterCount = NBk - 2;
     } else {                                                          // boundary cost-to-go of the previous iteration + linear transform (:18-34)
         iterCount = NBk - 1;
-        const float* bP = Pr + (size_t)ks * SZP;
-        Pa = mx_load_col(bP + sc * NX, g, cx);
+        const T* bP = Pr + (size_t)ks * SZP;
+        Pa = mx_load_col<T>(bP + sc * NX, g, cx);
         if (lane < NX) {                                              // p = (Pp dx + pp) + Pp d: lane = row (the block's first knot is a defect boundary, :73)
-            float dot = 0.f, val = 0.f;
+            T dot = T(0), val = T(0);
             for (int j = 0; j < NX; j++) {
-                const float pj = bP[lane + NX * j];
+                const T pj = bP[lane + NX * j];
                 dot += pj * (xc[NX * (ks + 1) + j] - xp2[NX * (ks + 1) + j]);
                 val += dcur[(size_t)ks * NX + j] * pj;
             }
@@ -255,25 +305,25 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         wsync();
         if (c14) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) { const int sr = mx_state(row0 + r); Pa[r] = (sr < NX) ? lds[sr] : 0.f; }
+            for (int r = 0; r < 4; r++) { const int sr = mx_state_gr(g, r); Pa[r] = (sr < NX) ? lds[sr] : T(0); }
         }
         wsync();
     }
-    float dJ00 = 0.f, dJ01 = 0.f, dJ10 = 0.f, dJ11 = 0.f;            // per-control partial sums of the expected reduction (lanes of the vector column: controls 2g, 2g+1)
-    const mx4 zero = {0.f, 0.f, 0.f, 0.f};
-    float* ldsI = lds + 16;                                           // Huu^-1, entry (a, b) at [a * 8 + b]
-    lds[16 + lane] = 0.f;                                             // slot b = 7 of every row stays 0
+    T dJ00 = T(0), dJ01 = T(0), dJ10 = T(0), dJ11 = T(0);            // per-control partial sums of the expected reduction (lanes of the vector column: controls 2g, 2g+1)
+    const mx4 zero = {T(0), T(0), T(0), T(0)};
+    T* ldsI = lds + 16;                                               // Huu^-1, entry (a, b) at [a * 8 + b]
+    lds[16 + lane] = T(0);                                            // slot b = 7 of every row stays 0
     wsync();
     mx4 PsiT = zero;                                                  // Psi'(m, i) = Psi(i, m): starts as the identity of the 15 x 15 augmented map
     if (FUSE) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) PsiT[r] = (row0 + r == c && sc <= NX) ? 1.f : 0.f;
+        for (int r = 0; r < 4; r++) PsiT[r] = (diag[r] && sc <= NX) ? T(1) : T(0);
     }
-    MxKnotIn<FS, DIAGH> in;
-    const float* ABk = AB + (size_t)ks * SZAB; const float* Hk = H + (size_t)ks * SZH; const float* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
-    float* KTk = KT + (size_t)ks * (NX * NU); float* duk = du + (size_t)ks * NU; float* Fk = ApBK + (size_t)ks * SZP; float* Bduk = Bdu + (size_t)ks * NX;
-    float* Pk = Pw + (size_t)(ks - 1) * SZP; float* pk = pw + (size_t)(ks - 1) * NX;
-    // compact [A B]: per-lane float offsets of this lane's columns inside a knot's share of their pieces, and the per-knot strides of those pieces
+    MxKnotIn<T, FS, DIAGH> in;
+    const T* ABk = AB + (size_t)ks * SZAB; const T* Hk = H + (size_t)ks * SZH; const T* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
+    T* KTk = KT + (size_t)ks * (NX * NU); T* duk = du + (size_t)ks * NU; T* Fk = ApBK + (size_t)ks * SZP; T* Bduk = Bdu + (size_t)ks * NX;
+    T* Pk = Pw + (size_t)(ks - 1) * SZP; T* pk = pw + (size_t)(ks - 1) * NX;
+    // compact [A B]: per-lane element offsets of this lane's columns inside a knot's share of their pieces, and the per-knot strides of those pieces
     unsigned oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
     if (CAB) {
         const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1, roff = 2 * g;
@@ -289,25 +339,25 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         // as a fifth resident wave per SIMD (95 registers -> 5 waves: 0.53 ms for 4096 problems, against 0.58 ms with prefetch and 4 waves).
         if constexpr (CAB) {
             const size_t G = knot0 + (size_t)ks;
-            const float* ch = b.ABc + (G >> 6) * kAbcChunk;
+            const T* ch = b.ABc + (G >> 6) * kAbcChunk;
             const unsigned kk = (unsigned)(G & 63);
-            const float* chB = ch + kk * 49u;                        // (wave-uniform; the lane parts are unsigned 32-bit offsets)
-            mx_load_knot_compact<FS, DIAGH>(in, ch, oA + kk * sA, chB, oB, oT0, oT1, gk, g, c, ub, dt);
-        } else mx_load_knot<FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
-        const MxKnotIn<FS, DIAGH>& k = in;
+            const T* chB = ch + kk * 49u;                            // (wave-uniform; the lane parts are unsigned 32-bit offsets)
+            mx_load_knot_compact<T, FS, DIAGH>(in, ch, oA + kk * sA, chB, oB, oT0, oT1, gk, g, c, ub, dt);
+        } else mx_load_knot<T, FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
+        const MxKnotIn<T, FS, DIAGH>& k = in;
         ABk -= SZAB; Hk -= SZH; gk -= NM;
         // ---- cost blocks in tile form
-        mx4 CXX = k.CXX, CUX = {k.CUX0, k.CUX1, 0.f, 0.f}, CXU = zero, CUU = zero;
+        mx4 CXX = k.CXX, CUX = {k.CUX0, k.CUX1, T(0), T(0)}, CXU = zero, CUU = zero;
         if (DIAGH) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) if (cx) CXX[r] = (row0 + r == c) ? (sc < 7 ? hq1 : hq2) : 0.f;
-            CUU[0] = (cu && u0 == ub) ? hr : 0.f; CUU[1] = (cu && u0 + 1 == ub) ? hr : 0.f;
+            for (int r = 0; r < 4; r++) if (cx) CXX[r] = diag[r] ? (sc < 7 ? hq1 : hq2) : T(0);
+            CUU[0] = (cu && u0 == ub) ? hr : T(0); CUU[1] = (cu && u0 + 1 == ub) ? hr : T(0);
         } else {
             CXU[0] = k.CXU0; CXU[1] = k.CXU1; CUU[0] = k.CUU0; CUU[1] = k.CUU1;
         }
         // ---- W = P' [A | B]  (AB2', rows i = column of P); the B columns take rho B (backprop, :39-64)
-        const mx4 W0 = mx_mfma4(Pa, k.A0, zero);
-        mx4 W1 = CAB ? mx_mfma_hi(Pa, k.B1, zero) : mx_mfma4(Pa, k.B1, zero);                    // (compact [A B] = Euler step: the position rows of B are exact zeros)
+        const mx4 W0 = mx_mfma4<T>(Pa, k.A0, zero);
+        mx4 W1 = CAB ? mx_mfma_hi<T>(Pa, k.B1, zero) : mx_mfma4<T>(Pa, k.B1, zero);               // (compact [A B] = Euler step: the position rows of B are exact zeros)
         if (CAB) { W1[2] += rho * k.B1[2]; W1[3] += rho * k.B1[3]; } else W1 = W1 + rho * k.B1;
         const mx4 W0a = c14 ? Pa : W0;                                                            // vector column := p
         // ---- H blocks (:66-93): products first, cost added after, like the reference
@@ -315,36 +365,36 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         // and dt x the same registers (output velocity rows: state 7 + s sits two registers above state s in the same lane) -- what instructions 0, 1 would have
         // produced, bit for bit (one nonzero term per element); instructions 2, 3 add the velocity rows
         const mx4 HxxLow = {W0a[0], W0a[1], dt * W0a[0], dt * W0a[1]};
-        const mx4 Hxx = (CAB ? mx_mfma_hi(k.A0, W0a, HxxLow) : mx_mfma4(k.A0, W0a, zero)) + CXX;
-        const mx4 Hux = (CAB ? mx_mfma_hi(k.B1, W0a, zero) : mx_mfma4(k.B1, W0a, zero)) + CUX;                                          // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
-        const mx4 HxuT = mx_mfma4(W1, k.A0, zero) + CXU;                                          // Hxu(kx, b) as [b][kx]   (with rho)
-        const mx4 Huu = (CAB ? mx_mfma_hi(k.B1, W1, zero) : mx_mfma4(k.B1, W1, zero)) + CUU;                                           // Huu(a, b)               (with rho)
+        const mx4 Hxx = (CAB ? mx_mfma_hi<T>(k.A0, W0a, HxxLow) : mx_mfma4<T>(k.A0, W0a, zero)) + CXX;
+        const mx4 Hux = (CAB ? mx_mfma_hi<T>(k.B1, W0a, zero) : mx_mfma4<T>(k.B1, W0a, zero)) + CUX;                                    // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
+        const mx4 HxuT = mx_mfma4<T>(W1, k.A0, zero) + CXU;                                       // Hxu(kx, b) as [b][kx]   (with rho)
+        const mx4 Huu = (CAB ? mx_mfma_hi<T>(k.B1, W1, zero) : mx_mfma4<T>(k.B1, W1, zero)) + CUU;                                     // Huu(a, b)               (with rho)
         // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292).  The rows stay where the matrix core left them:
-        //      lane group g owns rows 2g, 2g + 1 (R0, R1); lane mx_pi(j) of a group keeps column j of Huu, lane mx_pi(j) + 2 column j of the identity part.  Per pivot
+        //      lane group g owns rows 2g, 2g + 1 (R0, R1); lane mx_pi(j) of a group keeps column j of Huu, the lane two registers further along the column order
+        //      (q_of(j >> 1, (j & 1) + 2)) column j of the identity part.  Per pivot
         //      the pivot row and a group's own two pivot-column entries travel through ds_bpermute (LDS crossbar: not the float32 lanes the matrix instructions
         //      need), the pivot itself through v_readlane; every group then updates its two rows -- 8 vector instructions per pivot instead of 18 with all seven
         //      rows replicated in every lane.  Same operations per element as before: R[a] -= R[a][pv] * (R[pv] / R[pv][pv]).
-        float R0, R1;
+        T R0, R1;
+        const int e = 2 * cg + cr - 2;                                // identity column of this lane (cr >= 2)
         {
-            const int e = 2 * (c >> 2) + (c & 3) - 2;                 // identity column of this lane ((c & 3) >= 2)
-            const bool left = (c & 3) < 2;
-            R0 = left ? Huu[0] : (e == u0 ? 1.f : 0.f);
-            R1 = left ? Huu[1] : ((e == u0 + 1 && u0 + 1 < NU) ? 1.f : 0.f);
+            const bool left = cr < 2;
+            R0 = left ? Huu[0] : (e == u0 ? T(1) : T(0));
+            R1 = left ? Huu[1] : ((e == u0 + 1 && u0 + 1 < NU) ? T(1) : T(0));
         }
 #pragma unroll
         for (int pv = 0; pv < NU; pv++) {
             const int go = pv >> 1;                                                // owner group of the pivot row; its register is pv & 1
-            const float src = (pv & 1) ? R1 : R0;
-            const float piv = mx_readlane(src, 16 * go + mx_pi(pv));
-            const float prow = mx_from_lane(src, 16 * go + c);
-            const float col0 = mx_from_lane(R0, 16 * g + mx_pi(pv)), col1 = mx_from_lane(R1, 16 * g + mx_pi(pv));
-            const float q = prow * mx_recip(piv);                                 // the scaled pivot row; row a loses (its pivot-column entry) x q
-            const float n0 = __builtin_fmaf(-col0, q, R0), n1 = __builtin_fmaf(-col1, q, R1);
+            const T src = (pv & 1) ? R1 : R0;
+            const T piv = X::readlane(src, 16 * go + mx_pi<T>(pv));
+            const T prow = X::from_lane(src, 16 * go + c);
+            const T col0 = X::from_lane(R0, 16 * g + mx_pi<T>(pv)), col1 = X::from_lane(R1, 16 * g + mx_pi<T>(pv));
+            const T q = prow * X::recip(piv);                                     // the scaled pivot row; row a loses (its pivot-column entry) x q
+            const T n0 = X::fma(-col0, q, R0), n1 = X::fma(-col1, q, R1);
             R0 = (g == go && !(pv & 1)) ? q : n0;
             R1 = (g == go && (pv & 1)) ? q : n1;
         }
-        if ((c & 3) >= 2) {
-            const int e = 2 * (c >> 2) + (c & 3) - 2;
+        if (cr >= 2) {
             if (e < NU) {
                 ldsI[u0 * 8 + e] = R0;
                 if (u0 + 1 < NU) ldsI[(u0 + 1) * 8 + e] = R1;
@@ -355,15 +405,15 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
         if (cu) { InvT[0] = ldsI[ub * 8 + u0]; InvT[1] = ldsI[ub * 8 + u0 + 1]; }
         wsync();
         // ---- gains (computeKTdu :208-220): K(a, kx) | du(a), rows a = 2g + r
-        const mx4 Kp = mx_mfma2(InvT, Hux, zero);
-        if (sc <= NX) {                                               // K row a = 2g + r: 14 floats of KT (lane -> state of its column); du(a) from the lane of the vector column
-            float* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
+        const mx4 Kp = mx_mfma2<T>(InvT, Hux, zero);
+        if (sc <= NX) {                                               // K row a = 2g + r: 14 elements of KT (lane -> state of its column); du(a) from the lane of the vector column
+            T* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
             q0[0] = Kp[0];
             if (u0 + 1 < NU) (cx ? q0 + NX : q0 + 1)[0] = Kp[1];
         }
         const bool do_ctg = (iter != 0 || blk != 0);                  // the cost-to-go in front of knot 0 is never used (:396)
         // T1(kx, b) = sum_a K(a,kx) Huu(a,b) - Hxu(kx,b) as [b][kx]; its column 14 is Huu' du
-        const mx4 T1t = mx_mfma2(Huu, Kp, zero) - HxuT;
+        const mx4 T1t = mx_mfma2<T>(Huu, Kp, zero) - HxuT;
         // ---- expected reduction (computeExpRed :317-334): du . g_u and du . Huu du, per control
         if (FUSE) {                                                   // (two accumulators instead of four: the fused variant is at its register limit)
             dJ00 += Kp[0] * Hux[0] + Kp[1] * Hux[1]; dJ10 += Kp[0] * T1t[0] + Kp[1] * T1t[1];
@@ -372,42 +422,42 @@ __device__ void arm_mx_bp_block(float* lds, const Buffers<float>& b, const Dims&
             dJ10 += Kp[0] * T1t[0]; dJ11 += Kp[1] * T1t[1];
         }
         if (FS) {                                                     // A - B K | B du  (computeFSVars :281-312)
-            const mx4 BT = {k.BT0, k.BT1, 0.f, 0.f};                                              // [b][kx = c] = B(kx, b)
-            const mx4 BK = mx_mfma2(BT, Kp, zero);
-            mx4 Gt = c14 ? BK : k.A0 - BK;                                                        // [A - B K | B du]; tile rows 13, 15 are zero
-            if (!FUSE) mx_store_col(cx ? Fk + sc * NX : Bduk, g, cx || c14, Gt);
+            const mx4 BT = {k.BT0, k.BT1, T(0), T(0)};                                            // [b][kx = c] = B(kx, b)
+            const mx4 BK = mx_mfma2<T>(BT, Kp, zero);
+            mx4 Gt = c14 ? BK : k.A0 - BK;                                                        // [A - B K | B du]; the padding / vector rows are zero
+            if (!FUSE) mx_store_col<T>(cx ? Fk + sc * NX : Bduk, g, cx || c14, Gt);
             if (FUSE && fuse) {
-                if (c14 && g == 3) Gt[3] = 1.f;                                                   // G(14, 14) = 1: the homogeneous coordinate (tile index 15)
+                if (c14 && g == 3) Gt[3] = T(1);                                                  // G(14, 14) = 1: the homogeneous coordinate (lane group 3, register 3)
                 if (CAB) {                                                                        // position rows of G are [I  dt I | 0] (B is zero there): as for Hxx
                     const mx4 low = {PsiT[0], PsiT[1], dt * PsiT[0], dt * PsiT[1]};
-                    PsiT = mx_mfma_hi(Gt, PsiT, low);
-                } else PsiT = mx_mfma4(Gt, PsiT, zero);
+                    PsiT = mx_mfma_hi<T>(Gt, PsiT, low);
+                } else PsiT = mx_mfma4<T>(Gt, PsiT, zero);
             }
         }
         if (do_ctg) {                                                 // new cost-to-go (computeCTG :225-276): P(kx, ky) | p(kx)
-            mx4 val = mx_mfma2(T1t, Kp, zero);
-            val = mx_mfma2(-Kp, Hux, val);
+            mx4 val = mx_mfma2<T>(T1t, Kp, zero);
+            val = mx_mfma2<T>(-Kp, Hux, val);
             mx4 Pn = Hxx + val;
-            if (g == 3) { Pn[1] = 0.f; Pn[3] = 0.f; }                 // tile rows 13, 15 (padding, vector) carry by-products of the vector column: keep them clean
-            if (keepP || iter == 0) mx_store_col(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
+            if (g == 3) { Pn[1] = T(0); Pn[3] = T(0); }               // the padding and vector rows carry by-products of the vector column: keep them clean
+            if (keepP || iter == 0) mx_store_col<T>(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
             Pa = Pn;
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;
     }
     if (FUSE && fuse) {                                               // Psi' of this segment, row-major [16][16]
-        float* o = b.segmap + ((size_t)pb * dm.M + blk) * 256;
+        T* o = b.segmap + ((size_t)pb * dm.M + blk) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[mx_state(row0 + r) * 16 + sc] = PsiT[r];        // in state order (the padding index lands in row / column 15)
+        for (int r = 0; r < 4; r++) o[mx_state_gr(g, r) * 16 + sc] = PsiT[r];        // in state order (the padding index lands in row / column 15)
     }
     // dJexp[2 blk], [2 blk + 1]: the 7 per-control partial sums in order (vector-column lanes 15, 31, 47, 63 hold controls 2g, 2g + 1)
     {
-        float a0 = dJ00, a1 = dJ10;
-        a0 = a0 + mx_readlane(dJ01, 15); a1 = a1 + mx_readlane(dJ11, 15);
-        a0 = (a0 + mx_readlane(dJ00, 31)) + mx_readlane(dJ01, 31); a1 = (a1 + mx_readlane(dJ10, 31)) + mx_readlane(dJ11, 31);
-        a0 = (a0 + mx_readlane(dJ00, 47)) + mx_readlane(dJ01, 47); a1 = (a1 + mx_readlane(dJ10, 47)) + mx_readlane(dJ11, 47);
-        a0 = a0 + mx_readlane(dJ00, 63); a1 = a1 + mx_readlane(dJ10, 63);
+        T a0 = dJ00, a1 = dJ10;
+        a0 = a0 + X::readlane(dJ01, 15); a1 = a1 + X::readlane(dJ11, 15);
+        a0 = (a0 + X::readlane(dJ00, 31)) + X::readlane(dJ01, 31); a1 = (a1 + X::readlane(dJ10, 31)) + X::readlane(dJ11, 31);
+        a0 = (a0 + X::readlane(dJ00, 47)) + X::readlane(dJ01, 47); a1 = (a1 + X::readlane(dJ10, 47)) + X::readlane(dJ11, 47);
+        a0 = a0 + X::readlane(dJ00, 63); a1 = a1 + X::readlane(dJ10, 63);
         if (lane == 15) {
-            float* dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
+            T* dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
             dJexp[2 * blk] = a0; dJexp[2 * blk + 1] = a1;
             b.err[(size_t)pb * dm.M + blk] = 0;                       // the generic 7x7 inversion never reports failure (utils/cudaUtils.h:291)
         }

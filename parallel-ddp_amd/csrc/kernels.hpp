@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb
                                   (int)threadIdx.x >> 6, 4);
 }
 template <typename P, typename T>
-__global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm) {
+__global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm, int only_exited) {
+    if (only_exited && !b.state[blockIdx.x].done) return;       // (uniform) a problem that is still iterating keeps its trajectory: the caller goes on with it
     mpc_store_body<P, T>(this_wave(), b, mb, dm, blockIdx.x);
 }
 

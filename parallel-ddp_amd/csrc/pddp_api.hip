@@ -145,8 +145,8 @@ struct Solver : SolverBase {
     // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
     void drop_graph() override { if (graph) { hipGraphExecDestroy(graph); graph = nullptr; graph_mode = -1; } if (graph_n) { hipGraphExecDestroy(graph_n); graph_n = nullptr; } }
     int ab_view(int to_compact) override {
-        if constexpr (P::PLANT == 4 && sizeof(T) == 4) {
-            if (b.ABc) { launch_abc_convert(stream, b, (int)(cfg.batch * cfg.N), cfg.N, (float)dt, to_compact); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream)); }
+        if constexpr (P::PLANT == 4) {
+            if (b.ABc) { launch_abc_convert<T>(stream, b, (int)(cfg.batch * cfg.N), cfg.N, dt, to_compact); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream)); }
         }
         return 0;
     }
@@ -164,9 +164,13 @@ struct Solver : SolverBase {
         return 0;
     }
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
+    bool phase_fused_sweep = false; // pddp_run_phase(PDDP_PHASE_BP_FUSED / _SWEEP_FUSED): the teacher-forcing hook runs the production sweep path (maps composed in the backward pass)
     bool sweep_fused = false;      // production sweeps: forward-sweep maps composed inside k_bp_mfma + k_sweep_maps (no A - B K / B du traffic)
     int sweep_kind = 0;            // the arm's linear sweep: 0 one lane group per candidate (k_sweep_lg), 1 two sequences on lane groups (k_sweep_st), 2 two sequences, workgroup per problem (k_sweep_wg); PDDP_SWEEP=alpha|st|wg
     bool mpc_used = false;         // pddp_mpc_solve ran on this handle: its warm start shifts every cost-to-go slot, so the backward pass keeps writing all of them
+    bool lean_ctg_ran = false;     // sweeps ran that left the interior cost-to-go slots unwritten (config.boundary_cost_to_go_only): a warm-started MPC call would shift stale slots
+    // every knot's P, p written (the reference's d_P / d_p) unless the caller opted out; MPC handles always keep them (MPCHelpers.cuh:602-655 shifts the whole arrays)
+    bool keep_all_ctg() const { return !cfg.boundary_cost_to_go_only || cfg.mpc_mode || mpc_used; }
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
@@ -176,6 +180,7 @@ struct Solver : SolverBase {
         if (graph) hipGraphExecDestroy(graph);
         if (graph_n) hipGraphExecDestroy(graph_n);
         for (void* p : allocs) hipFree(p);
+        for (void* p : scratch_buf) if (p) hipFree(p);
         if (h_stage) hipHostFree(h_stage);
         if (h_state) hipHostFree(h_state);
         if (stream) hipStreamDestroy(stream);
@@ -211,7 +216,9 @@ struct Solver : SolverBase {
             // sweep_kind stays the kernel of the phase hook, whose teacher-forced A - B K / B du must be what the sweep reads.  PDDP_SWEEP=alpha|st|wg: no fusion.
         }
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
-        if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && std::string(v) == "mx"); }
+        // PDDP_BP=mx on a double handle: the same tile algebra on v_mfma_f64_16x16x4_f64 (a test selection: float64 handles default to the lane-group family,
+        // whose operation order is the reference's)
+        if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && std::string(v) == "mx"); }
         sweep_fused = bp_mfma && c.M > 1 && !std::getenv("PDDP_SWEEP");
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
@@ -248,8 +255,8 @@ struct Solver : SolverBase {
         register_model(dmodel, hm);
         derive_tl_model(hm);
         if constexpr (P::PLANT == 4) { if (fp_path == kFpTl && !std::getenv("PDDP_NO_XW")) { if ((rc = alloc("xw", &b.xw, B * N * A * NX))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
-        if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
-        if constexpr (P::PLANT == 4 && sizeof(T) == 4) {
+        if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
+        if constexpr (P::PLANT == 4) {
             const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
             if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) { if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc; }
         }
@@ -334,8 +341,9 @@ struct Solver : SolverBase {
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1 && part != 1) {
                 bool st = false;
+                if (sweep_fused && (!store_candidates || phase_fused_sweep)) { launch_sweep_maps<T>(s, b, dm, (int)B); st = true; }
                 if constexpr (sizeof(T) == 4) {
-                    if (sweep_fused && !store_candidates) { launch_sweep_maps(s, b, dm, (int)B); st = true; }
+                    if (st) {}
                     else if (sweep_kind == 2) { launch_sweep_wg(s, b, dm, (int)B); st = true; }
                     else if (sweep_kind == 1) { launch_sweep_st(s, b, dm, (int)B); st = true; }
                 }
@@ -382,7 +390,7 @@ struct Solver : SolverBase {
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
             if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups || bp_mfma;
-            if constexpr (P::PLANT == 4 && sizeof(T) == 4) { if (bp_mfma) launch_bp_mfma(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, (float)cw.Q1, (float)cw.Q2, (float)cw.R, (float)dt, store_candidates || cfg.mpc_mode || mpc_used, sweep_fused && !store_candidates); }
+            if constexpr (P::PLANT == 4) { if (bp_mfma) launch_bp_mfma<T>(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, cw.Q1, cw.Q2, cw.R, dt, keep_all_ctg() || store_candidates, sweep_fused && (!store_candidates || phase_fused_sweep)); }
             if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
                 if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
@@ -438,6 +446,7 @@ struct Solver : SolverBase {
         return 0;
     }
     int iterate(int sweeps) override {
+        if (bp_mfma && !keep_all_ctg()) lean_ctg_ran = true;
         if (cfg.use_graph) {
             if (!graph || graph_mode != bench_mode + 2 * sp.max_iter) {
                 if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
@@ -498,8 +507,12 @@ struct Solver : SolverBase {
                   int poll_every, void* x, void* u, void* KT, void* Jout, int* alphaOut, int* success, int* iters) override {
         const size_t B = cfg.batch, N = cfg.N;
         if (max_iter < 1 || max_iter > cfg.max_iter) return fail(PDDP_EINVAL, "mpc_solve: max_iter must be in [1, config.max_iter]");
-        if (!mpc_used) { mpc_used = true; drop_graph(); }
         for (size_t i = 0; i < B; i++) if (shift[i] < 0 || shift[i] >= (int)N - 1) return fail(PDDP_EINVAL, "mpc_solve: shift must be in [0, N-2]");
+        if (lean_ctg_ran && !clear_vars)
+            return fail(PDDP_EINVAL, "mpc_solve: this handle iterated with boundary_cost_to_go_only = 1, so its interior cost-to-go slots are stale and a warm start "
+                                     "(clear_vars = 0) would shift them into the block boundaries; call with clear_vars = 1 once, or create the handle without that option");
+        lean_ctg_ran = false;
+        if (!mpc_used) { mpc_used = true; drop_graph(); }
         const double t0 = now_ms();
         // one pinned staging area: pageable host memory would make every small transfer of the cycle a synchronous staging copy of its own
         const size_t out_stride = (size_t)cfg.max_iter + 2;
@@ -507,7 +520,6 @@ struct Solver : SolverBase {
                      o_J = o_KT + B * N * NX * NU * sizeof(T), o_a = o_J + B * out_stride * sizeof(T), need_bytes = o_a + B * out_stride * sizeof(int);
         if (h_stage_bytes < need_bytes) {
             if (h_stage) hipHostFree(h_stage);
-        if (h_state) hipHostFree(h_state);
             h_stage = nullptr; h_stage_bytes = 0;
             HIPCHK(hipHostMalloc((void**)&h_stage, need_bytes, hipHostMallocDefault));
             h_stage_bytes = need_bytes;
@@ -547,7 +559,7 @@ struct Solver : SolverBase {
             // nothing has to be polled -- sweeps, fall-back kernel and ALL result transfers are enqueued back to back and the cycle synchronises once
             if ((rc = iterate(max_iter))) { sp.max_iter = saved_max_iter; return rc; }
             sp.max_iter = saved_max_iter;
-            hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm);
+            hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, 1);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_stage + o_state, b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
             if (x) HIPCHK(hipMemcpyAsync(h_stage + o_xb, b.xb, B * 2 * N * NX * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -564,8 +576,15 @@ struct Solver : SolverBase {
             if (KT) std::memcpy(KT, h_stage + o_KT, B * N * NX * NU * sizeof(T));
             if (Jout) std::memcpy(Jout, h_stage + o_J, B * out_stride * sizeof(T));
             if (alphaOut) std::memcpy(alphaOut, h_stage + o_a, B * out_stride * sizeof(int));
-            for (size_t i = 0; i < B; i++) { if (success) success[i] = hstate[i].took_step; if (iters) iters[i] = hstate[i].iter; }
-            return 0;
+            bool all_exited = true;
+            for (size_t i = 0; i < B; i++) all_exited &= (hstate[i].done != 0);
+            if (all_exited) {
+                for (size_t i = 0; i < B; i++) { if (success) success[i] = hstate[i].took_step; if (iters) iters[i] = hstate[i].iter; }
+                return 0;
+            }
+            // a sweep whose backward pass failed raises rho and repeats without advancing `iter` (backwardPassGPU's retry loop, bpHelpers.cuh:497-511): such a
+            // problem is still running after max_iter sweeps -- go on in the polled loop below, like the reference would
+            sp.max_iter = max_iter;
         }
         bool fresh = false;
         for (int guard = 0; guard < 100000; guard++) {
@@ -580,7 +599,7 @@ struct Solver : SolverBase {
         }
         sp.max_iter = saved_max_iter;
         if (rc) return rc;
-        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm);   // copies only: the states status() fetched above stay valid
+        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, 0);   // copies only: the states status() fetched above stay valid
         HIPCHK(hipGetLastError());
         if ((rc = store_impl(x, u, KT, Jout, alphaOut, nullptr, fresh))) return rc;
         for (size_t i = 0; i < B; i++) { if (success) success[i] = hstate[i].took_step; if (iters) iters[i] = hstate[i].iter; }
@@ -676,12 +695,34 @@ struct Solver : SolverBase {
             launch_sweep(stream, phase, 1);                         // teacher-forcing hook: the forward pass also stores every candidate trajectory
             if (phase == PDDP_PHASE_FP) hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);   // J / dmax readable right after the phase
         }
+        else if (phase == PDDP_PHASE_BP_FUSED || phase == PDDP_PHASE_SWEEP_FUSED) {
+            // the production sweep path under teacher forcing: the matrix-core backward pass composes the segment maps (and writes every cost-to-go slot, not
+            // A - B K / B du); then k_sweep_maps alone -- the candidates' segment start states land in xs
+            if (!sweep_fused) return fail(PDDP_EINVAL, "PDDP_PHASE_BP_FUSED / _SWEEP_FUSED: this handle's selection has no fused sweep (KUKA arm, matrix-core backward pass, M > 1, no PDDP_SWEEP override)");
+            phase_fused_sweep = true;
+            if (phase == PDDP_PHASE_BP_FUSED) launch_sweep(stream, PDDP_PHASE_BP, 1);
+            else launch_fp(stream, 0, 1, 0);
+            phase_fused_sweep = false;
+        }
         else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);
         else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);
         else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0, cfg.ee_cost ? 1 : 0, 0);
         else return fail(PDDP_EINVAL, "unknown phase");
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    // grow-only device scratch of the helper entry points below (owned by the handle: no hipMalloc / hipFree -- an implicit device synchronisation -- per call,
+    // nothing to leak on an error return; released with the handle)
+    void* scratch_buf[3] = {nullptr, nullptr, nullptr}; size_t scratch_cap[3] = {0, 0, 0};
+    int scratch(int slot, size_t bytes, void** out) {
+        if (scratch_cap[slot] < bytes) {
+            if (scratch_buf[slot]) { HIPCHK(hipStreamSynchronize(stream)); hipFree(scratch_buf[slot]); scratch_buf[slot] = nullptr; scratch_cap[slot] = 0; }
+            const size_t cap = bytes < 4096 ? 4096 : bytes;
+            if (hipMalloc(&scratch_buf[slot], cap) != hipSuccess) return fail(PDDP_ENOMEM, "hipMalloc failed for a helper's scratch buffer");
+            scratch_cap[slot] = cap;
+        }
+        *out = scratch_buf[slot];
         return 0;
     }
     // ---- lock-step experiment helpers
@@ -698,7 +739,8 @@ struct Solver : SolverBase {
         }
         const size_t nx = N * NX, nu = N * NU, nk = N * NX * NU;
         T* buf = nullptr; double* dout = nullptr;
-        HIPCHK(hipMalloc((void**)&buf, (nx + nu + nk + NX + 3) * sizeof(T))); HIPCHK(hipMalloc((void**)&dout, 2 * sizeof(double)));
+        int rc;
+        if ((rc = scratch(0, (nx + nu + nk + NX + 3) * sizeof(T), (void**)&buf)) || (rc = scratch(1, 2 * sizeof(double), (void**)&dout))) return rc;
         HIPCHK(hipMemcpyAsync(buf, x, nx * sizeof(T), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(buf + nx, u, nu * sizeof(T), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(buf + nx + nu, KT, nk * sizeof(T), hipMemcpyHostToDevice, stream));
@@ -714,7 +756,6 @@ struct Solver : SolverBase {
         HIPCHK(hipMemcpyAsync(ho, dout, sizeof(ho), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(xActual, buf + nx + nu + nk, NX * sizeof(T), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        hipFree(buf); hipFree(dout);
         if (avg_err) *avg_err = ho[0];
         if (failed) *failed = (int)ho[1];
         return 0;
@@ -722,28 +763,30 @@ struct Solver : SolverBase {
     int ee_pos(int count, const void* x, void* out) override {
         if (P::PLANT != 4 || count <= 0) return fail(PDDP_EINVAL, "pddp_ee_pos: KUKA arm only, count >= 1");
         T *dx = nullptr, *dout = nullptr;
-        HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&dout, (size_t)count * 6 * sizeof(T)));
+        int rc;
+        if ((rc = scratch(0, (size_t)count * NX * sizeof(T), (void**)&dx)) || (rc = scratch(1, (size_t)count * 6 * sizeof(T), (void**)&dout))) return rc;
         HIPCHK(hipMemcpyAsync(dx, x, (size_t)count * NX * sizeof(T), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((k_ee_pos<P, T>), dim3(count), dim3(64), 0, stream, b.model, (T)cfg.ee_on_link_z, (const T*)dx, dout);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, dout, (size_t)count * 6 * sizeof(T), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        hipFree(dx); hipFree(dout);
         return 0;
     }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
         if (what < 0 || what > 8 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
         const size_t osz = (what == 0 || what == 4 || what == 6 || what == 7 ? NP : (what == 1 || what == 5 || what == 8) ? NP * NM : what == 2 ? NX : NX * NM);
         T *dx, *du_, *dout;
-        HIPCHK(hipMalloc((void**)&dx, (size_t)count * NX * sizeof(T))); HIPCHK(hipMalloc((void**)&du_, (size_t)count * NU * sizeof(T)));
-        HIPCHK(hipMalloc((void**)&dout, (size_t)count * osz * sizeof(T)));
+        int rc;
+        if ((rc = scratch(0, (size_t)count * NX * sizeof(T), (void**)&dx)) || (rc = scratch(1, (size_t)count * NU * sizeof(T), (void**)&du_)) ||
+            (rc = scratch(2, (size_t)count * osz * sizeof(T), (void**)&dout))) return rc;
+        HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(dx, x, (size_t)count * NX * sizeof(T), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(du_, u, (size_t)count * NU * sizeof(T), hipMemcpyHostToDevice));
         int grid = count < 4096 ? count : 4096;
         if (const char* g = std::getenv("PDDP_EVAL_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;   // micro-benchmarks (tools/)
         if (what >= 7) {
             if constexpr (P::PLANT == 4) {
-                if (tl_variant < 0) { hipFree(dx); hipFree(du_); hipFree(dout); return fail(PDDP_EINVAL, "plant_eval: the thread-lane kernels need one of the built-in robot models"); }
+                if (tl_variant < 0) { return fail(PDDP_EINVAL, "plant_eval: the thread-lane kernels need one of the built-in robot models"); }
                 launch_plant_eval_tl<T>(stream, tl_variant, tl_grav, count, dx, du_, dout, what == 8 ? 1 : 0);
             }
         }
@@ -752,7 +795,6 @@ struct Solver : SolverBase {
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(out, dout, (size_t)count * osz * sizeof(T), hipMemcpyDeviceToHost));
-        hipFree(dx); hipFree(du_); hipFree(dout);
         return 0;
     }
 };

@@ -43,7 +43,9 @@ __global__ void k_comm_costs(const SolverState<T>* st, const T* Jout, int stride
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     out[2 * b] = (double)Jout[(size_t)b * stride];
-    out[2 * b + 1] = (double)Jout[(size_t)b * stride + st[b].iter];
+    // a problem that exited stopped at `iter` (the slot of its last iteration); one that is still running has `iter` pointing at the NEXT, unwritten slot
+    const int last = st[b].done ? st[b].iter : (st[b].iter > 0 ? st[b].iter - 1 : 0);
+    out[2 * b + 1] = (double)Jout[(size_t)b * stride + last];
 }
 
 extern "C" int pddp_comm_unique_id(void* id) {
@@ -85,11 +87,11 @@ extern "C" int pddp_comm_ranks(pddp_comm_handle c, int* rank, int* world) {
 
 extern "C" int pddp_comm_allreduce_max(pddp_comm_handle c, double* value) {
     if (!c || !value) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_allreduce_max: null argument");
+    COMM_HIP(hipSetDevice(c->device));
     if (c->cost_cap < 1) {
         if (hipMalloc((void**)&c->d_costs, 16 * sizeof(double)) != hipSuccess) return pddp_internal_fail(PDDP_ENOMEM, "pddp_comm_allreduce_max: hipMalloc");
         c->cost_cap = 16;
     }
-    COMM_HIP(hipSetDevice(c->device));
     COMM_HIP(hipMemcpy(c->d_costs, value, sizeof(double), hipMemcpyHostToDevice));
     COMM_NCCL(ncclAllReduce(c->d_costs, c->d_costs, 1, ncclDouble, ncclMax, c->comm, 0));
     COMM_HIP(hipStreamSynchronize(0));
@@ -110,6 +112,7 @@ static int solver_views(pddp_handle h, pddp_config& cfg, hipStream_t& stream, vo
 
 extern "C" int pddp_comm_all_done(pddp_comm_handle c, pddp_handle h, int* all_done) {
     if (!c || !h || !all_done) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_all_done: null argument");
+    COMM_HIP(hipSetDevice(c->device));
     pddp_config cfg; hipStream_t s; void *state, *Jout;
     int rc = solver_views(h, cfg, s, state, Jout);
     if (rc) return rc;
@@ -126,6 +129,7 @@ extern "C" int pddp_comm_all_done(pddp_comm_handle c, pddp_handle h, int* all_do
 
 extern "C" int pddp_comm_allgather_costs(pddp_comm_handle c, pddp_handle h, double* costs) {
     if (!c || !h || !costs) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_allgather_costs: null argument");
+    COMM_HIP(hipSetDevice(c->device));
     pddp_config cfg; hipStream_t s; void *state, *Jout;
     int rc = solver_views(h, cfg, s, state, Jout);
     if (rc) return rc;

@@ -12,14 +12,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     __shared__ __attribute__((aligned(16))) float lds[96];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
-    arm_mx_bp_block<FS, DIAGH, CAB, FUSE>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
+    arm_mx_bp_block<float, FS, DIAGH, CAB, FUSE>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
+}
+// The same tile algebra on v_mfma_f64_16x16x4_f64 for double handles (PDDP_BP=mx; no occupancy target: it exists so that the production algebra can be checked
+// against the oracle at a precision where every step-size decision of a 40-iteration solve is reproducible -- tests/test_f64_benched_family.py).
+template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+__global__ __launch_bounds__(64) void k_bp_mfma_f64(Buffers<double> b, Dims dm, int batch, double hq1, double hq2, double hr, double dt, int flags) {
+    __shared__ __attribute__((aligned(16))) double lds[96];
+    const int inst = blockIdx.x;
+    if (inst >= batch * dm.M) return;
+    arm_mx_bp_block<double, FS, DIAGH, CAB, FUSE>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
+}
+template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+static void launch_one(hipStream_t s, unsigned n, const Buffers<float>& b, const Dims& dm, int batch, float hq1, float hq2, float hr, float dt, int kp) {
+    hipLaunchKernelGGL((k_bp_mfma<FS, DIAGH, CAB, FUSE>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp);
+}
+template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+static void launch_one(hipStream_t s, unsigned n, const Buffers<double>& b, const Dims& dm, int batch, double hq1, double hq2, double hr, double dt, int kp) {
+    hipLaunchKernelGGL((k_bp_mfma_f64<FS, DIAGH, CAB, FUSE>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp);
 }
 
-void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch, bool diag_h, float hq1, float hq2, float hr, float dt, bool keep_P, bool fuse_sweep) {
+template <typename T>
+void launch_bp_mfma(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batch, bool diag_h, T hq1, T hq2, T hr, T dt, bool keep_P, bool fuse_sweep) {
     const unsigned n = (unsigned)batch * dm.M;
     const int kp = (keep_P ? kMxKeepP : 0) | ((fuse_sweep && b.segmap) ? kMxFuseSweep : 0);
     const bool cab = b.ABc != nullptr && diag_h;
-#define PDDP_MX_LAUNCH(FS, DH, CB, FU) hipLaunchKernelGGL((k_bp_mfma<FS, DH, CB, FU>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp)
+#define PDDP_MX_LAUNCH(FS, DH, CB, FU) launch_one<FS, DH, CB, FU>(s, n, b, dm, batch, hq1, hq2, hr, dt, kp)
     const bool fu = (kp & kMxFuseSweep) != 0;
     if (dm.M > 1) {
         if (cab) { if (fu) PDDP_MX_LAUNCH(true, true, true, true); else PDDP_MX_LAUNCH(true, true, true, false); }
@@ -32,41 +50,45 @@ void launch_bp_mfma(hipStream_t s, const Buffers<float>& b, const Dims& dm, int 
     }
 #undef PDDP_MX_LAUNCH
 }
+template void launch_bp_mfma<float>(hipStream_t, const Buffers<float>&, const Dims&, int, bool, float, float, float, float, bool, bool);
+template void launch_bp_mfma<double>(hipStream_t, const Buffers<double>&, const Dims&, int, bool, double, double, double, double, bool, bool);
 
-}  // namespace pddp
-
-namespace pddp {
 // k_sweep_maps: grid B, block 64.  The forward sweep from the per-segment maps the backward pass composed (bp_mfma.hpp kMxFuseSweep): e <- Phi_s e + gamma_s over the
 // segments for the s-sequence (gamma = the map's column 14) and the t-sequence (gamma = the defect of the segment's boundary knot: it enters at the segment's last
 // step), lane l < 14 owns entry l; at every boundary the segment start state of every candidate, x = xcur + (t - alpha s), goes to xs.  Replaces forwardSweepKern x A
 // (fpHelpers.cuh:19-63) together with the A - B K / B du traffic between the two passes.
-__global__ __launch_bounds__(64) void k_sweep_maps(Buffers<float> b, Dims dm, int batch) {
+template <typename T>
+__global__ __launch_bounds__(64) void k_sweep_maps(Buffers<T> b, Dims dm, int batch) {
     constexpr int NX = 14;
     const int pb = blockIdx.x, lane = threadIdx.x;
     if (pb >= batch) return;
-    const SolverState<float>& st = b.state[pb];
+    const SolverState<T>& st = b.state[pb];
     if (st.done) return;
     for (int i = 0; i < dm.M; i++) if (b.err[(size_t)pb * dm.M + i]) return;      // failed backward pass: no forward pass this sweep (fp_active)
     const int N = dm.N, NBk = dm.NB, l = lane < NX ? lane : NX - 1;
-    const float* xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const float* dcur = b.dcur + (size_t)pb * N * NX;
-    float es = 0.f, et = 0.f;
+    const T* xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const T* dcur = b.dcur + (size_t)pb * N * NX;
+    T es = T(0), et = T(0);
     for (int sgm = 0; sgm < dm.M - 1; sgm++) {
-        const float* o = b.segmap + ((size_t)pb * dm.M + sgm) * 256;               // Psi'(c, l) at [c * 16 + l]
+        const T* o = b.segmap + ((size_t)pb * dm.M + sgm) * 256;                   // Psi'(c, l) at [c * 16 + l]
         const int k = (sgm + 1) * NBk - 1;
-        float ns = o[14 * 16 + l], nt = dcur[(size_t)k * NX + l];
+        T ns = o[14 * 16 + l], nt = dcur[(size_t)k * NX + l];
 #pragma unroll
         for (int cc = 0; cc < NX; cc++) {
-            const float ph = o[cc * 16 + l];
-            ns = __builtin_fmaf(ph, __shfl(es, cc), ns); nt = __builtin_fmaf(ph, __shfl(et, cc), nt);
+            const T ph = o[cc * 16 + l];
+            ns = Mx<T>::fma(ph, __shfl(es, cc), ns); nt = Mx<T>::fma(ph, __shfl(et, cc), nt);
         }
         es = ns; et = nt;
         if (lane < NX) {
-            const float base = xcur[(size_t)(k + 1) * NX + lane];
+            const T base = xcur[(size_t)(k + 1) * NX + lane];
             for (int a = 0; a < dm.A; a++) b.xs[(((size_t)pb * dm.A + a) * N + k + 1) * NX + lane] = base + (et - b.alpha[a] * es);
         }
     }
 }
-void launch_sweep_maps(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch) {
-    hipLaunchKernelGGL(k_sweep_maps, dim3((unsigned)batch), dim3(64), 0, s, b, dm, batch);
+template <typename T>
+void launch_sweep_maps(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batch) {
+    hipLaunchKernelGGL((k_sweep_maps<T>), dim3((unsigned)batch), dim3(64), 0, s, b, dm, batch);
 }
+template void launch_sweep_maps<float>(hipStream_t, const Buffers<float>&, const Dims&, int);
+template void launch_sweep_maps<double>(hipStream_t, const Buffers<double>&, const Dims&, int);
+
 }  // namespace pddp

@@ -396,81 +396,76 @@ void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
     hipLaunchKernelGGL(k_sweep_wg, dim3((unsigned)batch), dim3(256), sweep_wg_lds(dm), s, b, dm);
 }
 
-// k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  float: the Jacobian of a wave's 64 knots is staged in
+// k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  The Jacobian of a wave's 64 knots is staged in
 // LDS (entry-major, padded to 65 so that both the per-thread writes and the transposed reads are conflict-free) and written out in THREE pieces
 // as soon as their columns are complete (arm_tl_gradient's marks: columns {0..3, 7..10}, {4..6, 11..13}, {14..20}): 56 staged entries per knot at most,
 // 14.6 KB per wave, so that two workgroups (two waves per SIMD -- the kernel needs all 256 registers) share a compute unit.
 //   b.ABc != null (the sweep's default): the piece goes to the compact [A B] (ab_compact.hpp) -- the wave's 64 knots x the piece's columns x 7 dynamic rows are ONE
 //                  contiguous 16-byte aligned run of the chunk, written with 16 bytes per lane; the constant rows are not written at all;
 //   b.ABc == null: the reference layout, whole 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
-// double: direct stores.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
+// double handles (PDDP_FP=tl: test selection) run the same code with two waves per workgroup.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
 constexpr int kNisTlStage = 56 * 65;
+template <typename T> struct NisTlCfg { static constexpr int kWaves = sizeof(T) == 4 ? 4 : 2, kThreads = 64 * kWaves; };   // double: two waves per workgroup (58 KB of staging)
+template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); };
 template <typename T, int V>
-__global__ __launch_bounds__(256, 2) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
+__global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NM = 21;
-    const int g = blockIdx.x * 256 + threadIdx.x, total = batch * dm.N;
+    const int g = blockIdx.x * NisTlCfg<T>::kThreads + threadIdx.x, total = batch * dm.N;
     const int pb = g / dm.N, k = g - pb * dm.N;
-    if constexpr (sizeof(T) == 4) {
-        __shared__ T stage_all[4 * kNisTlStage];
-        T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
-        const int lane = threadIdx.x & 63;
-        T x[NX], u[7];
+    __shared__ T stage_all[NisTlCfg<T>::kWaves * kNisTlStage];
+    T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
+    const int lane = threadIdx.x & 63;
+    T x[NX], u[7];
 #pragma unroll
-        for (int i = 0; i < NX; i++) x[i] = T(0);                    // a lane without a knot differentiates the zero state (its columns are never flushed)
+    for (int i = 0; i < NX; i++) x[i] = T(0);                    // a lane without a knot differentiates the zero state (its columns are never flushed)
 #pragma unroll
-        for (int i = 0; i < 7; i++) u[i] = T(0);
-        const bool need = (g < total) && arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u);
-        const unsigned long long mask = __ballot(need);
-        if (!mask) return;                                          // (uniform) nothing to differentiate in this wave
-        T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot (reference layout)
-        T* ABc0 = b.ABc ? b.ABc + (size_t)((g - lane) >> 6) * kAbcChunk : nullptr;   // the wave's chunk of the compact array
-        auto slot = [](int col, int row) -> int {                  // staged position of dqdd(row, col) inside its piece
-            return abc_col_in_piece(col) * 7 + row;
-        };
-        auto flush = [&](int piece) {
-            wsync();
-            const int ncols = abc_piece_cols(piece);
-            if (ABc0) {
-                const int per = ncols * 7, count = 64 * per;        // floats of this piece per knot / per wave (a multiple of 4)
-                T* dst = ABc0 + abc_piece_off(piece);
-                for (int e0 = 4 * lane; e0 < count; e0 += 256) {
-                    T out[4]; bool ok[4], all = true;
+    for (int i = 0; i < 7; i++) u[i] = T(0);
+    const bool need = (g < total) && arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u);
+    const unsigned long long mask = __ballot(need);
+    if (!mask) return;                                          // (uniform) nothing to differentiate in this wave
+    T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot (reference layout)
+    T* ABc0 = b.ABc ? b.ABc + (size_t)((g - lane) >> 6) * kAbcChunk : nullptr;   // the wave's chunk of the compact array
+    auto slot = [](int col, int row) -> int {                  // staged position of dqdd(row, col) inside its piece
+        return abc_col_in_piece(col) * 7 + row;
+    };
+    auto flush = [&](int piece) {
+        wsync();
+        const int ncols = abc_piece_cols(piece);
+        if (ABc0) {
+            const int per = ncols * 7, count = 64 * per;        // elements of this piece per knot / per wave (a multiple of 4)
+            T* dst = ABc0 + abc_piece_off(piece);
+            for (int e0 = 4 * lane; e0 < count; e0 += 256) {
+                T out[4]; bool ok[4], all = true;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int e = e0 + j, kk = e / per, ent = e - kk * per, ci = ent / 7, r = ent - ci * 7;
-                        out[j] = T(abc_piece_col(piece, ci) == 7 + r ? 1 : 0) + dt * stage[ent * 65 + kk];
-                        ok[j] = (mask >> kk) & 1ull; all = all && ok[j];
-                    }
-                    if (all) { float4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3]; *reinterpret_cast<float4*>(dst + e0) = v; }
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) if (ok[j]) dst[e0 + j] = out[j];
-                    }
+                for (int j = 0; j < 4; j++) {
+                    const int e = e0 + j, kk = e / per, ent = e - kk * per, ci = ent / 7, r = ent - ci * 7;
+                    out[j] = T(abc_piece_col(piece, ci) == 7 + r ? 1 : 0) + dt * stage[ent * 65 + kk];
+                    ok[j] = (mask >> kk) & 1ull; all = all && ok[j];
                 }
-            } else {
-                for (int it = 0; it * 64 < 64 * ncols; it++) {
-                    const int pi = it * 64 + lane, kk = pi / ncols, ci = pi - kk * ncols;
-                    if (kk >= 64 || !((mask >> kk) & 1ull)) continue;
-                    const int col = abc_piece_col(piece, ci);
-                    T out[NX];
+                if (all) { typename NisTlVec<T>::v4 v; v[0] = out[0]; v[1] = out[1]; v[2] = out[2]; v[3] = out[3]; *reinterpret_cast<typename NisTlVec<T>::v4*>(dst + e0) = v; }
+                else {
 #pragma unroll
-                    for (int r = 0; r < 7; r++) {
-                        out[r] = tl_AB_const<T>(r, col, dt);
-                        out[7 + r] = T(col == 7 + r ? 1 : 0) + dt * stage[(ci * 7 + r) * 65 + kk];
-                    }
-                    tl_store14(AB0 + ((size_t)kk * NM + col) * NX, out);
+                    for (int j = 0; j < 4; j++) if (ok[j]) dst[e0 + j] = out[j];
                 }
             }
-            wsync();
-        };
-        arm_tl_nis_jac<T>(md, grav, x, u, [&](int col, int row, T val) { stage[slot(col, row) * 65 + lane] = val; }, flush);
-    } else {
-        if (g >= total) return;
-        T* AB = b.AB + (size_t)g * (NX * NM);
-        const bool valid = arm_tl_nis_knot<T>(md, grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; });
-        if (valid) for (int col = 0; col < NM; col++) for (int r = 0; r < 7; r++) AB[col * NX + r] = tl_AB_const<T>(r, col, dt);
-    }
+        } else {
+            for (int it = 0; it * 64 < 64 * ncols; it++) {
+                const int pi = it * 64 + lane, kk = pi / ncols, ci = pi - kk * ncols;
+                if (kk >= 64 || !((mask >> kk) & 1ull)) continue;
+                const int col = abc_piece_col(piece, ci);
+                T out[NX];
+#pragma unroll
+                for (int r = 0; r < 7; r++) {
+                    out[r] = tl_AB_const<T>(r, col, dt);
+                    out[7 + r] = T(col == 7 + r ? 1 : 0) + dt * stage[(ci * 7 + r) * 65 + kk];
+                }
+                tl_store14(AB0 + ((size_t)kk * NM + col) * NX, out);
+            }
+        }
+        wsync();
+    };
+    arm_tl_nis_jac<T>(md, grav, x, u, [&](int col, int row, T val) { stage[slot(col, row) * 65 + lane] = val; }, flush);
 }
 
 // k_nis_tl7: grid (ceil(B*N / 64), 7), block 64.  Next-iteration setup of a handle with FEW problems in flight (one MPC solve: 127 knots on a 256-CU device):
@@ -547,19 +542,23 @@ void launch_nis_tl7(hipStream_t s, int variant, const Buffers<float>& b, const D
 
 // API view of the compact [A B]: grid ceil(B*N*21 / 256), block 256, thread = (knot, column).  expand: compact -> the reference layout (pddp_get_array("AB"));
 // compact: the reference layout -> compact (pddp_set_array("AB"): teacher-forced tests hand in the oracle's derivatives).
-__global__ __launch_bounds__(256) void k_abc_convert(Buffers<float> b, int knots, int N, float dt, int to_compact) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_abc_convert(Buffers<T> b, int knots, int N, T dt, int to_compact) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= knots * 21) return;
     const int G = i / 21, col = i - G * 21;
     if (!to_compact && (G % N) == N - 1) return;                      // the terminal knot has no [A B]: the kernels never write it, the view keeps what it holds
-    float* full = b.AB + ((size_t)G * 21 + col) * 14;
-    float* cmp = b.ABc + abc_index((size_t)G, col, 0);
+    T* full = b.AB + ((size_t)G * 21 + col) * 14;
+    T* cmp = b.ABc + abc_index((size_t)G, col, 0);
     if (to_compact) { for (int r = 0; r < 7; r++) cmp[r] = full[7 + r]; }
-    else { for (int r = 0; r < 7; r++) { full[r] = abc_const(r, col, dt); full[7 + r] = cmp[r]; } }
+    else { for (int r = 0; r < 7; r++) { full[r] = tl_AB_const<T>(r, col, dt); full[7 + r] = cmp[r]; } }
 }
-void launch_abc_convert(hipStream_t s, const Buffers<float>& b, int knots, int N, float dt, int to_compact) {
-    hipLaunchKernelGGL(k_abc_convert, dim3(((unsigned)knots * 21 + 255) / 256), dim3(256), 0, s, b, knots, N, dt, to_compact);
+template <typename T>
+void launch_abc_convert(hipStream_t s, const Buffers<T>& b, int knots, int N, T dt, int to_compact) {
+    hipLaunchKernelGGL((k_abc_convert<T>), dim3(((unsigned)knots * 21 + 255) / 256), dim3(256), 0, s, b, knots, N, dt, to_compact);
 }
+template void launch_abc_convert<float>(hipStream_t, const Buffers<float>&, int, int, float, int);
+template void launch_abc_convert<double>(hipStream_t, const Buffers<double>&, int, int, double, int);
 
 // forward dynamics / gradient of `count` (x, u) samples, one thread each (tests, micro-benchmarks)
 template <typename T, int V>
@@ -586,9 +585,9 @@ void launch_fp_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& d
 }
 template <typename T>
 void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch) {
-    const unsigned knots = (unsigned)batch * dm.N;
-    if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0>), dim3((knots + 255) / 256), dim3(256), 0, s, b, dm, cw, dt, grav, mode, batch);
-    else hipLaunchKernelGGL((k_nis_tl<T, 1>), dim3((knots + 255) / 256), dim3(256), 0, s, b, dm, cw, dt, grav, mode, batch);
+    const unsigned knots = (unsigned)batch * dm.N, th = NisTlCfg<T>::kThreads;
+    if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0>), dim3((knots + th - 1) / th), dim3(th), 0, s, b, dm, cw, dt, grav, mode, batch);
+    else hipLaunchKernelGGL((k_nis_tl<T, 1>), dim3((knots + th - 1) / th), dim3(th), 0, s, b, dm, cw, dt, grav, mode, batch);
 }
 template <typename T>
 void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T* x, const T* u, T* out, int grad) {

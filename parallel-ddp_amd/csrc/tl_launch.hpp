@@ -23,7 +23,7 @@ template <typename T> void launch_nis_tl(hipStream_t s, int variant, const Buffe
 // next-iteration setup with one thread per (knot, joint) (k_nis_tl7: few problems in flight); adopts the winner from the candidate-major xs / us / ds
 void launch_nis_tl7(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int mode, int batch);
 // compact [A B] (ab_compact.hpp) <-> the reference layout b.AB, for the API view of a handle that keeps the compact array
-void launch_abc_convert(hipStream_t s, const Buffers<float>& b, int knots, int N, float dt, int to_compact);
+template <typename T> void launch_abc_convert(hipStream_t s, const Buffers<T>& b, int knots, int N, T dt, int to_compact);
 template <typename T> void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T* x, const T* u, T* out, int grad);
 
 }  // namespace pddp

@@ -5,7 +5,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PLANT_DIMS = {1: (1, 2, 1), 2: (2, 4, 1), 3: (6, 12, 4), 4: (7, 14, 7)}  # npos, n, m (config.cuh:24-46)
-PHASE_BP, PHASE_FP, PHASE_LS, PHASE_NIS, PHASE_INIT_NIS, PHASE_INIT_COST, PHASE_BP_COOP = range(7)
+PHASE_BP, PHASE_FP, PHASE_LS, PHASE_NIS, PHASE_INIT_NIS, PHASE_INIT_COST, PHASE_BP_COOP, PHASE_BP_FUSED, PHASE_SWEEP_FUSED = range(9)
 
 
 class PddpError(RuntimeError):
@@ -26,6 +26,7 @@ class PddpConfig(C.Structure):
         ("Q_xEE", C.c_double), ("QF_xEE", C.c_double), ("Q_xdEE", C.c_double), ("QF_xdEE", C.c_double), ("ee_on_link_z", C.c_double),
         ("ee_initial_cost_fix", C.c_int),
         ("use_finite_diff", C.c_int), ("finite_diff_epsilon", C.c_double),
+        ("boundary_cost_to_go_only", C.c_int),
     ]
 
 

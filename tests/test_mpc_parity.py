@@ -112,3 +112,55 @@ def test_mpc_batch_with_a_per_call_iteration_limit_keeps_the_trace_rows(backend)
         assert np.array_equal(one["x"][0], got["x"][b])
         s1.close()
     sb.close()
+
+
+@pytest.mark.gpu
+def test_plain_solve_then_polled_mpc_solves_on_one_handle():
+    """runiLQR_GPU followed by the MPC loop on the same handle (the canonical flow): the status polls of the plain solve allocate the pinned state
+    buffer BEFORE the first pddp_mpc_solve grows its staging area, and an MPC call with max_iter > poll_every polls again.  Polled and un-polled
+    calls must give the same bits."""
+    kw = dict(N=32, M=4, A=8, wafr_urdf=1, total_time=0.5, tol_cost=0.0, max_iter=8)
+    x0, u0, xg = example_inputs(4, 32, np.float32, noise=RNG.normal(0, 0.001, (32, 14)))
+    res = []
+    for poll in (2, 16):
+        s = make_solver("hip", 4, **kw)
+        first = s.solve(x0, u0, xg)                                   # pddp_status runs here
+        xa = first["x"][0][1].copy()
+        seq = [s.mpc_solve(xa, xg, 1, clear_vars=0, max_iter=6, poll_every=poll)]
+        seq.append(s.mpc_solve(seq[0]["x"][0][1], xg, 1, clear_vars=0, max_iter=5, poll_every=poll))
+        done, iters = s.status()                                      # and once more after the staging area exists
+        assert done.all()
+        res.append(seq)
+        s.close()
+    for a, b in zip(*res):
+        assert np.isfinite(a["Jout"][0][: int(a["iters"][0]) + 1]).all()
+        assert int(a["iters"][0]) == int(b["iters"][0])
+        assert np.array_equal(a["Jout"], b["Jout"]) and np.array_equal(a["x"], b["x"]) and np.array_equal(a["alphaOut"], b["alphaOut"])
+
+
+@pytest.mark.gpu
+def test_warm_started_mpc_after_a_plain_solve_shifts_the_whole_cost_to_go():
+    """A handle WITHOUT mpc_mode runs a plain solve on the matrix-core backward pass, then a warm-started MPC call (shift > 0, clear_vars = 0): the shift moves
+    interior cost-to-go slots into the block boundaries (MPCHelpers.cuh:602-655), so the plain solve must have written them.  float64, against the lane-group
+    family (which the receding-horizon tests above hold against the oracle): identical step-size indices, J / x to 1e-6."""
+    import os
+    kw = dict(N=32, M=4, A=8, wafr_urdf=1, total_time=0.5, tol_cost=0.0, max_iter=6)
+    x0, u0, xg = example_inputs(4, 32, np.float64, noise=RNG.normal(0, 0.001, (32, 14)))
+    outs = []
+    for env in ({"PDDP_BP": "mx", "PDDP_FP": "tl"}, {}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            s = make_solver("hip", 4, dtype=1, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        first = s.solve(x0, u0, xg)
+        xa = first["x"][0][2] + 1e-3
+        outs.append((first, s.mpc_solve(xa, xg, 2, clear_vars=0, max_iter=4)))
+        s.close()
+    (f_mx, m_mx), (f_lg, m_lg) = outs
+    assert list(f_mx["alphaOut"][0]) == list(f_lg["alphaOut"][0])
+    it = int(m_lg["iters"][0])
+    assert int(m_mx["iters"][0]) == it and list(m_mx["alphaOut"][0][: it + 1]) == list(m_lg["alphaOut"][0][: it + 1])
+    assert close(m_mx["Jout"][0][: it + 1], m_lg["Jout"][0][: it + 1]) and close(m_mx["x"][0], m_lg["x"][0])

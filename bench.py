@@ -77,6 +77,80 @@ def cpu_baseline(budget_s=14.0):
                       + f"; host has {hw} hardware threads"}
 
 
+FP32_LANE_PEAK_TFLOPS = 157.3  # the SIMDs' float32 lanes: vector FMAs (64 lanes x 2 flop per 2 cycles x 1024 SIMDs x 2.4 GHz) and the f32 matrix instruction share them
+BP_FLOPS_PER_KNOT = 2 * 16268  # dense products of one backward-pass knot, n = 14, m = 7 (multiply-adds): W = P'[A B] 4116, H += [A B]'W 6174, Huu^-1 343, K | du 735,
+                               # T1 686, P+ 2744, A - B K | B du 1470   (bpHelpers.cuh:39-334)
+
+
+def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, s_per_step):
+    """`roofline` of the bench line, for the kernel with the longest average launch.
+
+    Top level = the roofline that BINDS that kernel.  Every heavy kernel of this sweep is bound by the SIMDs' float32 lanes, not by HBM: the matrix-core
+    backward pass needs 26 flop per byte it really moves (ridge of 157.3 TFLOP/s over 8 TB/s: 19.7), the thread-lane kernels hundreds.  So:
+      bound "mfma": achieved = ALGORITHMIC flop of the launch / its duration against the dense float32 matrix-core peak (157.3 TFLOP/s) -- k_bp_mfma;
+      bound "valu": achieved = vector instructions issued x 128 flop (64 lanes, FMA-equivalent: an UPPER bound of the useful flop) / duration against the
+                    float32 vector peak, the same 157.3 TFLOP/s of the same lanes -- the thread-lane kernels (needs the counter pass);
+      bound "hbm":  achieved = HBM bytes really moved (counter pass) / duration against 8 TB/s -- anything else.
+    `hbm` always carries the counter traffic as a rate; `reference_equivalent` is the rate at which the launch gets through the bytes of the REFERENCE's phase
+    accounting -- most of which this design no longer moves, so it exceeds what the memory system does and is NOT a bandwidth."""
+    dur = dom_ms * 1e-3
+    roof = {"kernel": dom_name, "avg_launch_ms": round(dom_ms, 5), "traffic": traffic, "traffic_source": tsrc, "counters": counters}
+    if dom_name.startswith("k_bp_mfma"):
+        knots = B * (N - M)                                                    # every block walks N/M - 1 knots
+        useful = BP_FLOPS_PER_KNOT * knots
+        roof.update({"bound": "mfma", "achieved": round(useful / dur / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(useful / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 5), "algorithmic_flop_per_launch": useful,
+                     "accounting": f"{BP_FLOPS_PER_KNOT} flop per knot (the dense products of backPassKern for n=14, m=7) x {N - M} knots x {B} problems"})
+        if counters and counters.get("SQ_INSTS_MFMA"):
+            n_mx = counters["SQ_INSTS_MFMA"]
+            issued = n_mx * 2048.0                                             # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-adds
+            roof["issued"] = {"matrix_instructions_per_knot": round(n_mx / knots, 2), "TFLOPs": round(issued / dur / 1e12, 2), "frac": round(issued / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+            if counters.get("SQ_INSTS_VALU"):
+                # lane model: a float32 matrix instruction occupies the SIMD's float32 lanes for 32 cycles and excludes the vector instructions of the other resident waves
+                # (tools/probes/mfma_valu_overlap.hip); a vector instruction issues over 2 cycles (MI355X_MICROARCH.md).  SQ_INSTS_VALU counts both kinds.
+                n_v = counters["SQ_INSTS_VALU"] - n_mx
+                cyc = (32.0 * n_mx + 2.0 * n_v) / 1024.0
+                roof["lanes"] = {"model": "cycles per SIMD = 32 x matrix instructions + 2 x other vector instructions, 1024 SIMDs at 2.4 GHz",
+                                 "matrix_ms": round(32.0 * n_mx / 1024.0 / 2.4e6, 4), "vector_ms": round(2.0 * n_v / 1024.0 / 2.4e6, 4),
+                                 "frac_of_launch": round(cyc / 2.4e6 / dom_ms, 4)}
+    elif counters and counters.get("SQ_INSTS_VALU") and (dom_name.startswith("k_fp_tl") or dom_name.startswith("k_nis_tl")):
+        issued = counters["SQ_INSTS_VALU"] * 128.0
+        roof.update({"bound": "valu", "achieved": round(issued / dur / 1e12, 3), "peak": FP32_LANE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(issued / dur / 1e12 / FP32_LANE_PEAK_TFLOPS, 5),
+                     "accounting": "vector instructions issued (SQ_INSTS_VALU of the counter pass) x 128 flop -- FMA-equivalent issue rate, an upper bound of the useful flop; "
+                                   "one thread per rollout / knot: no matrix-core work, ~0.1 byte of HBM traffic per flop"})
+    else:
+        ach = (traffic / dur / 1e9) if traffic else None
+        roof.update({"bound": "hbm", "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5), "accounting": "HBM bytes moved (counter pass) / launch duration"})
+    if traffic:
+        roof["hbm"] = {"traffic_GBs": round(traffic / dur / 1e9, 1), "frac_of_peak": round(traffic / dur / 1e9 / HBM_PEAK_GBS, 4), "peak_GBs": HBM_PEAK_GBS}
+    ref_bytes = alg_of(dom_name) * B
+    roof["reference_equivalent"] = {
+        "bytes_per_launch": ref_bytes, "GBs": round(ref_bytes / dur / 1e9, 1), "ratio_to_hbm_peak": round(ref_bytes / dur / 1e9 / HBM_PEAK_GBS, 4),
+        "whole_sweep_GBs": round(sweep_bytes / s_per_step / 1e9, 1), "whole_sweep_ratio_to_hbm_peak": round(sweep_bytes / s_per_step / 1e9 / HBM_PEAK_GBS, 4),
+        "note": "rate at which the launch gets through the bytes the REFERENCE's phase decomposition moves (SURVEY.md 8(d): every array once per phase and per alpha). "
+                "It is not a bandwidth: the design reads shared operands once for all alphas, keeps [A B] compact, never reads the diagonal cost Hessian and never writes "
+                "A - B K -- a ratio above 1 means exactly that."}
+    roof["per_kernel"] = {nm: {"ms": round(ms, 5)} for nm, ms in kern}
+    return roof
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- the same command the driver uses
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>), one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BENCH_BATCH, help="independent problems per GPU")
     ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--keep-ctg", action="store_true", help="write every knot's cost-to-go (the library default) instead of the block-boundary slots only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the whole-batch time-to-convergence block (profiling runs: keeps the kernel statistics to the timed sweeps)")
@@ -95,6 +170,8 @@ def main():
                     help="config2 (default, the headline): BASELINE configs[2]; config3: BASELINE configs[3] -- 64 Kuka MPC rollouts with the end-effector cost, "
                          "64 / N per GPU, exchanges through the C ABI's own RCCL collectives (pddp_comm_*)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return relaunch_under_torchrun(args.gpus)
     if args.workload == "config3":
         return config3_sharded(args)
 
@@ -106,7 +183,9 @@ def main():
     K, W, B = args.steps, args.warmup, args.batch
     N, M, A, n, m = 128, 4, 8, 14, 7
 
-    cfg = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B,
+    # boundary_cost_to_go_only: the backward pass writes the cost-to-go only where a later pass reads it (the block-boundary slots); the interior P, p are not an
+    # output of runiLQR_GPU (include/pddp.h; tests/test_f64_benched_family.py: same bits in every output with and without)
+    cfg = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, boundary_cost_to_go_only=0 if args.keep_ctg else 1,
                                max_iter=max(100, K + W + 1), device=ctx.device, use_graph=args.graph, _lib_path=args.lib)
     s = pyddp.Solver(cfg, _lib_path=args.lib)
     rng = np.random.default_rng(1234 + ctx.rank)      # every rank owns different problems
@@ -154,51 +233,16 @@ def main():
         ent = tj.get("kernels", {}).get(dom_name)
         if tj.get("batch") == B and ent:
             traffic, counters, tsrc = ent.get("hbm_bytes_per_launch"), ent.get("counters"), tj.get("source")
-    roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "counters": counters,
-            "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": round(dom_ms, 5),
-            # every kernel of the sweep: its time and the rate at which it gets through the REFERENCE's bytes for that phase (per-alpha
-            # re-reads of the gains / sweep operands included -- the forward kernels read them once for all alphas, so their figure can exceed the HBM peak)
-            "per_kernel": {nm: {"ms": round(ms, 5), "reference_equivalent_GBs": round(alg_of(nm) * B / (ms * 1e-3) / 1e9, 1)} for nm, ms in kern},
-            "whole_sweep_reference_equivalent_GBs": round(sweep_bytes / (t_local / K) / 1e9, 2)}
-    if traffic:
-        roof["traffic_GBs"] = round(traffic / (dom_ms * 1e-3) / 1e9, 1)        # what the kernel really moves: it keeps only the dynamic half of [A B] and the block-boundary cost-to-go
-    if dom_name == "k_bp_mfma":
-        # the same kernel against the matrix-core roofline: v_mfma_f32_16x16x4_f32 per knot as issued (26 with the Euler step's compact [A B], + 2 in the M - 1
-        # blocks that compose their segment's sweep map; 2048 flop each -- the committed counter pass has the exact number) and the dense products the reference's
-        # backward pass needs per knot (n = 14, m = 7: W = P'[A B], H = [A B]'W, K, T1, P+, A - BK ~ 16.3 k multiply-adds)
-        knots = B * (N - M)                                                    # every block walks N/M - 1 knots
-        per_knot = (26 + 2.0 * (M - 1) / M) if not os.environ.get("PDDP_AB") else (34 + 4.0 * (M - 1) / M)
-        if counters and counters.get("SQ_INSTS_MFMA"):
-            per_knot = counters["SQ_INSTS_MFMA"] / knots
-        issued, useful = per_knot * 2048.0 * knots, 2.0 * 16300.0 * knots
-        roof["mfma"] = {"peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "instructions_per_knot": round(per_knot, 2), "issued_TFLOPs": round(issued / (dom_ms * 1e-3) / 1e12, 2),
-                        "issued_frac": round(issued / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                        "algorithmic_TFLOPs": round(useful / (dom_ms * 1e-3) / 1e12, 2),
-                        "limiter": "the SIMD's float32 lanes: a float32 matrix-core instruction and the vector instructions of the OTHER resident waves do not overlap "
-                                   "on gfx950 (tools/probes/mfma_valu_overlap.hip: a wave of v_mfma_f32_16x16x4_f32 beside a wave of v_fma_f32 takes the SUM of their times, "
-                                   "while the bf16 matrix instruction overlaps) -- the kernel's time is its matrix-core cycles PLUS its vector-ALU issue cycles"}
-        if counters and counters.get("SQ_INSTS_MFMA") and counters.get("SQ_INSTS_VALU"):
-            # shared-lane model: 32 cycles per 16x16x4 float32 matrix instruction + 4 per other vector instruction (SQ_INSTS_VALU counts both), over 1024 SIMDs at 2.4 GHz
-            n_mx, n_v = counters["SQ_INSTS_MFMA"], counters["SQ_INSTS_VALU"] - counters["SQ_INSTS_MFMA"]
-            cyc = (32.0 * n_mx + 4.0 * n_v) / 1024.0
-            roof["alu"] = {"model": "cycles per SIMD = 32 x matrix-core instructions + 4 x other vector instructions (they share the float32 lanes), 1024 SIMDs, 2.4 GHz",
-                           "matrix_core_ms": round(32.0 * n_mx / 1024.0 / 2.4e6, 4), "vector_ms": round(4.0 * n_v / 1024.0 / 2.4e6, 4),
-                           "model_ms": round(cyc / 2.4e6, 4), "frac_of_launch": round(cyc / 2.4e6 / dom_ms, 4)}
-        # Which resource binds: per launch the kernel needs ~66 GFLOP of dense products and really moves ~2.5 GB through HBM (`traffic`) -- 26 flop per byte, above
-        # the ridge of the float32 matrix peak over the HBM peak (157.3 TFLOP/s / 8 TB/s = 19.7).  The record's top level stays what the bench contract defines
-        # (ALGORITHMIC bytes of SURVEY 8(d) / launch time against the HBM peak: the rate at which the reference's byte accounting is got through -- it can pass 1,
-        # because most of those bytes are no longer moved); `mfma` is the same launch against the matrix-core roofline and `alu` the lanes it actually waits for.
-        roof["mfma"]["algorithmic_frac"] = round(roof["mfma"]["algorithmic_TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
-        roof["note"] = ("frac is in the reference's byte accounting (654.6 KB per problem and backward pass, of which this kernel moves 153 KB); the binding resource is the "
-                        "SIMD's float32 lanes: see `alu` (share of the launch explained by matrix + vector instruction cycles) and `mfma` (algorithmic_frac, issued_frac)")
+    roof = roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, t_local / K)
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Kuka iiwa14 RBD (n=14,m=7), N=128, 8 alphas x 4 shooting segments, Euler, fp32, "
                                    "joint cost, T=0.5 s, WAFR example inputs + N(0,1e-3) velocity noise",
-                       "problems_per_gpu": B, "problems_total": ctx.world * B, "hipgraph": bool(args.graph), "sharding": "batch axis, no data-path collective"},
+                       "problems_per_gpu": B, "problems_total": ctx.world * B, "hipgraph": bool(args.graph), "sharding": "batch axis, no data-path collective",
+                       "cost_to_go_slots_written": "all" if args.keep_ctg else "block boundaries only (pddp_config.boundary_cost_to_go_only)"},
+            "rccl_ranks_seen": ctx.world if ctx.backend == "nccl" else (ctx.world if ctx.world == 1 else 0), "dist_backend": ctx.backend or "none",
             "accepted_fraction_in_timed_sweeps": round(float(acc), 3),
             "J_first_last_mean": [round(float(J_all[:, 0].mean()), 3), round(float(J_all[:, -1].mean()), 3)],
             "roofline": roof}
@@ -267,7 +311,7 @@ def batch_convergence(ctx, args, torch, x0, u0, xg, B, N, M, A):
     # ---- wall clock to convergence of the whole sharded batch (BASELINE metric, second half): TOL_COST 1e-4 (config.cuh:85-87), MAX_ITER 100;
     # every rank iterates its own problems, the ranks agree on "all done" with one max-reduce per poll (pyddp.shard.all_done)
     cfg2 = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=1e-4, total_time=0.5, batch=B, max_iter=100, device=ctx.device,
-                                use_graph=args.graph, _lib_path=args.lib)
+                                boundary_cost_to_go_only=0 if args.keep_ctg else 1, use_graph=args.graph, _lib_path=args.lib)
     s2 = pyddp.Solver(cfg2, _lib_path=args.lib)
     s2.load(x0, u0, xg)
     s2.iterate(1); s2.sync(); s2.load(x0, u0, xg)      # graph instantiation outside the timed region

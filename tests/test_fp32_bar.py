@@ -355,7 +355,7 @@ def test_bench_batch_whole_solves_equal_single_problem_solves():
     for b_ in range(B):
         x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
         xs.append(x0); us.append(u0)
-    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
+    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, boundary_cost_to_go_only=1, **kw)     # as bench.py creates it (the single-problem handle below keeps every slot)
     out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
     assert (out["iters"] == 10).all()
     o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)

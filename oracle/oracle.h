@@ -117,6 +117,9 @@ typedef struct ora_result {
     void ora_ee_pos_##SUF(const ora_cfg *c, const REAL *x, REAL *eePos, REAL *deePos);                        \
     REAL ora_ee_cost_##SUF(const ora_cfg *c, const REAL *xk, const REAL *uk, const REAL *goal, int k, int tshift); \
     void ora_ee_cost_grad_##SUF(const ora_cfg *c, REAL *Hk, REAL *gk, const REAL *xk, const REAL *uk, const REAL *goal, int k, int tshift); \
+    /* forwardSimKern with EE_COST for one candidate: all M segments, JT[b] = the in-sim cost of segment b (d_JT[bInd + alphaInd * M_BLOCKS_F])      */ \
+    void ora_forward_sim_ee_##SUF(const ora_cfg *c, REAL *x, REAL *u, const REAL *KT, const REAL *du, REAL *d, REAL alpha, const REAL *xp,          \
+                                  const REAL *goal, int tshift, REAL *JT);                                                                          \
     /* lock-step experiment (examples/WAFR_MPC_examples.cu:111-139, MPCHelpers.cuh:819-858): the simulated robot -- plan x,u,KT of REAL, */ \
     /* plant in double; returns the average tracking error (0 and *failed = 1 when the time leaves the plan)                             */ \
     REAL ora_simulate_##SUF(const ora_cfg *c, const REAL *x, const REAL *u, const REAL *KT, double t0_us, double elapsed_us,          \

@@ -299,6 +299,11 @@ class Struct:
         self.__dict__.update(kw)
 
 
+def padd(p, i):
+    """&p[i]: C forms the address without touching memory, also for a null p (an optional output the callee then never dereferences)"""
+    return None if p is None else p + i
+
+
 UNSET = object()
 
 
@@ -502,7 +507,7 @@ class Translator:
         for nm in names:
             for fd in self.funcs[nm]:
                 self.require(fd)
-        ns = {"math": math, "Ptr": Ptr, "c_div": c_div, "c_mod": c_mod, "c_pow": c_pow, "tpl": tpl, "Struct": Struct, "HOST": HOST, "UNSET": UNSET, "dflt": dflt, "c_memset": c_memset, "c_memcpy": c_memcpy}
+        ns = {"math": math, "Ptr": Ptr, "c_div": c_div, "c_mod": c_mod, "c_pow": c_pow, "tpl": tpl, "Struct": Struct, "HOST": HOST, "UNSET": UNSET, "dflt": dflt, "c_memset": c_memset, "c_memcpy": c_memcpy, "padd": padd}
         for py in self.order:
             exec(self.emitted[py], ns)
         self.ns = ns
@@ -845,7 +850,7 @@ class FuncTranslator:
                     depth += inner[k] == "]"
                     depth -= inner[k] == "["
                     if depth == 0:
-                        return "(%s + (%s))" % (inner[:k], inner[k + 1:-1])
+                        return "padd(%s, %s)" % (inner[:k], inner[k + 1:-1])
             if inner in self.scalars:                              # &scalar: an out-argument -- box it, copy back after the statement
                 box = self.newtmp()
                 self.emit(self._ind, "%s = [%s]" % (box, inner))

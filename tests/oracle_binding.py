@@ -169,6 +169,13 @@ class Oracle:
         self._f("ee_cost_grad")(C.byref(self.c), _p(H), _p(g), _p(x), _p(u), _p(goal), int(k), int(tshift))
         return H.reshape(21, 21), g
 
+    def forward_sim_ee(self, x, u, KT, du, d, alpha, xp, goal, tshift=0):
+        """forwardSimKern with the end-effector cost for one candidate (in place on x, u, d); returns the per-segment in-sim costs"""
+        JT = np.zeros(self.c.M, self.dtype)
+        goal = self.arr(goal)
+        self._f("forward_sim_ee")(C.byref(self.c), _p(x), _p(u), _p(KT), _p(du), _p(d), _r(self.dtype, alpha), _p(xp), _p(goal), int(tshift), _p(JT))
+        return JT
+
     def simulate(self, x, u, KT, t0_us, elapsed_us, substeps=150, goal_xyz=None, xActual=None):
         x, u, KT, xa = self.arr(x), self.arr(u), self.arr(KT), self.arr(xActual).copy()
         g = None if goal_xyz is None else self.arr(goal_xyz)

@@ -39,6 +39,9 @@ def oracle_for(case, **kw):
     extra = dict(case.get("weights", {}))
     w = {k.strip("_"): v for k, v in extra.items()}
     # cores = 8 -> COST_THREADS = 4, BP_THREADS = FSIM_THREADS = min(M, 8): the thread partition the fixture's host drivers were called with
+    for k in ("wafr_urdf", "mpc_mode", "ee_cost"):
+        if k in c:
+            kw.setdefault(k, c[k])
     return Oracle(default_cfg(c["plant"], N=c["N"], M=c["M"], A=c["A"], integrator=c["integrator"], total_time=c["total_time"], cores=8, spawn_threads=0, **w, **kw), np.float64)
 
 
@@ -162,6 +165,91 @@ def test_cost_gradient_hessian(name):
     if case["sem"] == "gpu":
         _, H2, g2 = oracle_for(case, wafr_urdf=1).next_iteration_setup(x.ravel().copy(), u.ravel().copy(), xg)
         close(H2, H, (name, "H via setup")); close(g2, g, (name, "g via setup"))
+
+
+@pytest.mark.parametrize("name", names("arm_plant"))
+def test_arm_plant_functions(name):
+    """dynamics<T> / dynamicsGradient<T> of plants/dynamics_arm.cuh (:2097-2289, with everything they call: load_Tb, compute_T_TA_J, compute_Iw_Icrbs_twist, compute_JdotV,
+    compute_M_Tau, invertMatrix, compute_dT_dTA_dJ, compute_dM, compute_dtwist, compute_dJdotV, compute_dWb, compute_dTau, finish_dqdd ...) on the tables of initI / initT"""
+    case = CASES[name]
+    o = oracle_for(case)
+    x, u = inp(case, "x"), inp(case, "u")
+    for k in range(len(x)):
+        close(o.dynamics(x[k], u[k]), out(case, "qdd")[k], (name, "qdd", k))
+        dq, qdd = o.dynamics_gradient(x[k], u[k])
+        close(dq, out(case, "dqdd")[k], (name, "dqdd", k)); close(qdd, out(case, "qdd")[k], (name, "qdd of the gradient call", k))
+
+
+def test_arm_model_tables_are_initI_initT():
+    """the robot constants the product and the oracle carry (iiwa14_model_data.h) against the tables initI / initT fill (plants/dynamics_arm.cuh:73-427), both URDF variants"""
+    import re
+    txt = open(os.path.join(os.path.dirname(HERE), "oracle", "iiwa14_model_data.h")).read()
+    def table(name):
+        body = re.sub(r"/\*.*?\*/", "", txt[txt.index(name):], flags=re.S)
+        body = body[body.index("="):body.index("};")]
+        return np.asarray([float(v) for v in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", body)])
+    I_all, F_all = table("IIWA14_SPATIAL_INERTIA").reshape(2, 7, 36), table("IIWA14_JOINT_FRAME").reshape(2, 7, 16)
+    for nm, v in (("armplant_w1_g1", 1), ("armplant_w0_g1", 0)):
+        case = CASES[nm]
+        close(I_all[v].ravel(), out(case, "model_I"), (nm, "I"))
+        # initT fills a 36-float slot per link whose first 16 floats hold the 4x4 joint frame at q = 0; the six q-dependent rotation entries (0, 1, 2, 4, 5, 6) are
+        # written by updateT at run time, the constant ones must be the table's
+        Tb = out(case, "model_T").reshape(7, 36)[:, :16]
+        const = [i for i in range(16) if i not in (0, 1, 2, 4, 5, 6)]
+        close(F_all[v][:, const], Tb[:, const], (nm, "T constants"))
+
+
+@pytest.mark.parametrize("name", names("ee_pos"))
+def test_tool_point_kinematics(name):
+    case = CASES[name]
+    o = oracle_for(case)
+    for k, x in enumerate(inp(case, "x")):
+        close(o.ee_pos(x, jac=False)[0], out(case, "eePos")[k], (name, k))
+
+
+@pytest.mark.parametrize("name", names("ee_forward_sim"))
+def test_end_effector_forward_sim_with_in_sim_cost(name):
+    """forwardSimKern / forwardSim with EE_COST: control law, dynamics with the tool point, Euler step, defects, and the cost accumulated on the way in seven per-joint sums"""
+    case = CASES[name]
+    o = oracle_for(case)
+    alphas, xs, goal = inp(case, "alphas"), inp(case, "xs"), inp(case, "goal")
+    for a_, al in enumerate(alphas):
+        x, u, d = xs[a_].copy(), inp(case, "u"), inp(case, "d")
+        JT = o.forward_sim_ee(x, u, inp(case, "KT"), inp(case, "du"), d, al, inp(case, "xp"), goal)
+        close(x, out(case, "xs")[a_], (name, "x", a_)); close(u, out(case, "us")[a_], (name, "u", a_))
+        close(d, out(case, "ds")[a_], (name, "d", a_), scale=max(np.abs(out(case, "xs")[a_]).max(), 1.0))
+        close(JT, out(case, "JT")[a_], (name, "JT", a_))
+
+
+@pytest.mark.parametrize("name", names("ee_cost_gradient_hessian"))
+def test_end_effector_cost_gradient_hessian(name):
+    """costGradientHessianKern / -Threaded, end-effector branch: compute_eePos with its Jacobian, costGrad (gradient through the Jacobian, unweighted Gauss-Newton Hessian), the
+    knot's cost; device: costKern<T,1> tree sum over the knots"""
+    case = CASES[name]
+    o = oracle_for(case)
+    N = case["cfg"]["N"]
+    x, u, goal = inp(case, "x").reshape(N, 14), inp(case, "u").reshape(N, 7), inp(case, "goal")
+    H, g = out(case, "H").reshape(N, -1), out(case, "g").reshape(N, -1)
+    Jk = []
+    for k in range(N):
+        Hk, gk = o.ee_cost_grad(x[k], u[k], goal, k)
+        close(Hk, H[k], (name, "H", k)); close(gk, g[k], (name, "g", k))
+        Jk.append(o.ee_cost(x[k], u[k], goal, k))
+    if case["sem"] == "gpu":
+        close(Jk, out(case, "J_knots"), (name, "J per knot"))
+        v = list(Jk)                                             # costKern<T,1>: pairwise tree over blockDim.x = N entries (reduceSum)
+        step = N // 2
+        while step >= 1:
+            for i in range(step):
+                v[i] = v[i] + v[i + step]
+            step //= 2
+        close([v[0]], out(case, "J_total"), (name, "J total"))
+    else:                                                        # host: COST_THREADS strided partial sums (costGradientHessianThreaded adds into JT[tid])
+        T = len(out(case, "J_parts"))
+        parts = [0.0] * T
+        for k in range(N):
+            parts[k % T] += Jk[k]
+        close(parts, out(case, "J_parts"), (name, "J parts"))
 
 
 def test_line_search_of_forwardSimGPU():

@@ -6,18 +6,26 @@
  * The product path (parallel-ddp_amd/) never includes, links or calls anything in oracle/.
  *
  * Pinning status: no oracle/_ref build exists -- the reference cannot be compiled here without stand-in CUDA
- * headers (cuda.h / cuda_runtime.h / cublas_v2.h / cusolverDn.h are absent from this image).
- *   PINNED by reference-held data, through generators committed under tests/golden/: the KUKA plant functions (an independent
- *   RNEA/CRBA on plants/iiwa14.urdf, the gravity-balancing torques the example holds, the probe states of test/printDyn.cu:
- *   tests/test_urdf_pins.py); the pendulum / cart-pole / quadrotor plug-ins and cost weights (the reference's own statements
- *   executed in float64: tests/test_closed_form_pins.py); tool-point kinematics and the error metric (the recorded run of
- *   test/WAFR_fig8.py: tests/test_fig8_pins.py).
- *   PARITY UNPINNED: the iLQR loop itself (backward pass, line search, bookkeeping; runiLQR_CPU and GPU semantics).  The
- *   reference's tests hold no golden vectors for it; the J / alpha traces in tests/golden/survey_kat.json were recorded from
- *   a build of the reference host code against stand-in CUDA headers and are kept only as a quarantined regression check
- *   (two artefacts of that build are emulated by ora_cfg.survey_* flags that no parity test uses).
- *   PARITY UNPINNED: the end-effector cost family (ee_cost = 1): its restatement follows the reference's index expressions and is
- *   cross-checked against finite differences and an independent forward kinematics only (tests/test_ee_cost.py).
+ * headers (cuda.h / cuda_runtime.h / cublas_v2.h / cusolverDn.h are absent from this image).  Instead the reference's OWN STATEMENTS are
+ * executed at fixture-generation time: tests/golden/refc2py.py preprocesses the reference sources where they lie and rewrites the requested
+ * functions statement by statement into Python (host branches directly; `__CUDA_ARCH__` branches and __global__ kernels under a SIMT emulation
+ * with the reference's launch geometry, __syncthreads() = barrier), tests/golden/make_phase_fixtures.py runs them in float64 on stored inputs
+ * and commits numbers only (tests/golden/phase_fixtures.{npz,json}).  tests/test_phase_pins.py: this oracle's float64 instantiation equals
+ * them to 1e-12 (measured: bit for bit) --
+ *   PINNED, phase level, kernel AND host semantics: linearXfrmOrLoad, backprop, invHuu / invHuu_dim4 / computeKTdu_dim1 + invertMatrix,
+ *   computeKTdu, computeCTG, computeFSVars, computeExpRed (backPassKern / backPassThreaded), forwardSweepInner, computeControlKT,
+ *   forwardSimInner, _integrator / _integratorGradient of the three rules, costFunc / costGrad, costKern / costThreaded, defectKern /
+ *   defectComp, the line search of forwardSimGPU;
+ *   PINNED, plant level: dynamics<T> / dynamicsGradient<T> of the arm with everything they call (both robot models, gravity on / off), the
+ *   tables of initI / initT, the closed-form plug-ins; additionally the independent URDF model (tests/test_urdf_pins.py), the reference's
+ *   closed-form statements (tests/test_closed_form_pins.py) and the recorded figure-eight run (tests/test_fig8_pins.py);
+ *   PINNED, end-effector cost family (ee_cost = 1): compute_eePos with its Jacobian, the in-sim cost accumulation of forwardSimKern,
+ *   costGrad's gradient and Gauss-Newton Hessian, costKern<T,0/1>;
+ *   PINNED, solver level: whole solves of runiLQR_GPU (host driver + every kernel, emulated end to end) -- step-size indices, rejections,
+ *   exits, J, x, u, K -- against ora_run_ilqr_gpusem.
+ *   NOT PINNED by reference statements: the MPC wrapper's restatement (ora_gs_*: MPCHelpers.cuh's struct API) and runiLQR_CPU's thread
+ *   spawning around the pinned host phases; they are line-by-line restatements with citations.  The J / alpha traces in
+ *   tests/golden/survey_kat.json (a build against stand-in CUDA headers) stay a quarantined regression check, not a pin.
  *
  * liboracle_fma.so is the same source compiled with contracted multiply-adds (how nvcc compiles the reference's device code): a member of
  * the float32 noise-floor ensemble of tests/test_fp32_bar.py, never a reference by itself.
@@ -56,8 +64,7 @@ typedef struct ora_cfg {
     double exp_red_min, exp_red_max;    /*                                           config.cuh:117-122 */
     double Q1, Q2, R, QF1, QF2;         /* arm joint-space cost weights  plants/cost_arm.cuh:97-103     */
     /* end-effector cost family (EE_COST 1 with USE_EE_VEL_COST 0, USE_SMOOTH_ABS 0, USE_LIMITS_FLAG 0; plants/cost_arm.cuh:104-115,206-389).
-     * PARITY UNPINNED: the survey recorded no reference outputs for this family and the reference cannot be built here; the restatement
-     * follows the reference's index expressions and is cross-checked analytically (tests/test_ee_cost.py), nothing more. */
+     * Pinned by the reference's own statements (tests/test_phase_pins.py: tool point, in-sim cost, gradient / Hessian, a whole solve). */
     int ee_cost;        /* EE_COST: xGoal = (x, y, z, roll, pitch, yaw) of the tool point          config.cuh:165-167 */
     int ee_cost_shift;  /* use_cost_shift of runiLQR_MPC_GPU (finalCostShift = shift)              MPCHelpers.cuh:866,876 */
     double Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE;

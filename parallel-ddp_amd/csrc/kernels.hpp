@@ -195,6 +195,47 @@ __global__ __launch_bounds__(64) void k_nis(Buffers<T> b, Dims dm, CostWeights<T
     nis_body<P, INTEG, T>(this_wave(), s, b, dm, cw, dt, mode, blockIdx.x, blockIdx.y);
 }
 
+// ---------------------------------------------------------------------------------------------- closed-form plants, many problems in flight: thread-serial kernels
+// The pendulum, cart-pole, quadrotor (and user plants) have 2..12 states: a whole 64-lane wave per unit of work (k_bp, k_fp, k_nis above: the reference's launch
+// shape re-mapped) leaves most lanes idle and pays a wave's instruction stream for a 4x4 product.  With many problems in flight one THREAD owns the unit instead:
+// the SAME body, instantiated with a one-lane "wave" (Wave{0, 1, 0}: every PDDP_FOR loop runs serially in index order -- the arithmetic of the host emulation the
+// CPU suite holds against the oracle, and bit for bit what the cooperative kernels compute, whose lanes each own whole output elements), its stage scratch in
+// the thread's private memory.  64 independent units per wave, no LDS, no barriers.
+//   k_bp_ts : thread = (problem, block of knots)      replaces backPassKern<<<M,(8,7)>>>                      (bpHelpers.cuh:339-420)
+//   k_fp_ts : thread = (problem, candidate)           sweep, the M rollouts in turn, cost tree, defect max     (fpHelpers.cuh:57-63, 279-301, 134-152, 96-111)
+//   k_nis_ts: thread = (problem, knot)                derivatives + winner adoption                            (nisInitHelpers.cuh:247-279)
+PDDP_HD Wave serial_wave() { return Wave{0, 1, 0}; }
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_bp_ts(Buffers<T> b, Dims dm, int batch) {
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= batch * dm.M) return;
+    BpScratch<P, T> s;
+    bp_body<P, T>(serial_wave(), s, b, dm, inst % dm.M, inst / dm.M);
+}
+constexpr int kTsMaxN = 256, kTsMaxM = 16;        // longest horizon / most segments the thread-serial forward pass keeps per-knot costs / hand-off states for
+template <typename P, int INTEG, typename T>
+__global__ __launch_bounds__(64) void k_fp_ts(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= batch * dm.A) return;
+    const int pb = inst / dm.A, a_idx = inst - pb * dm.A;
+    if (!fp_active<T>(b, dm, pb)) return;
+    SweepScratch<P, T> sw; SimScratch<P, T> sim;
+    T cost_k[kTsMaxN], segx[kTsMaxM * P::NX], dnorm[kTsMaxM], segJ[kTsMaxM];
+    const Wave w = serial_wave();
+    const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm, segJ);
+    if (dm.M > 1) forward_sweep<P, T>(w, sw, dm, a);
+    P::load_model(w, sim.plant, reinterpret_cast<const typename P::Model*>(b.model));
+    for (int bInd = 0; bInd < dm.M; bInd++) forward_sim_segment<P, INTEG, T>(w, sim, dm, a, bInd, cw, b.xGoal + (size_t)pb * P::NX, cost_k);
+    fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm, nullptr);
+}
+template <typename P, int INTEG, typename T>
+__global__ __launch_bounds__(64) void k_nis_ts(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= batch * dm.N) return;
+    NisScratch<P, INTEG, T> s;
+    nis_body<P, INTEG, T>(serial_wave(), s, b, dm, cw, dt, mode, inst % dm.N, inst / dm.N);
+}
+
 // after the initial rollout: candidate slot 0 becomes the current trajectory (initAlgGPU copies slot 0 to xp, up, dp,
 // nisInitHelpers.cuh:378-381).  grid (N, B), block 64.
 template <typename P, typename T>

@@ -271,6 +271,25 @@ def c_memcpy(dst, src, nbytes):
         dst[i] = src[i]
 
 
+def cu_memcpy(dst, src, nbytes, *rest):
+    c_memcpy(dst, src, nbytes)
+    return 0
+
+
+def cu_memset(p, v, nbytes, *rest):
+    c_memset(p, v, nbytes)
+    return 0
+
+
+def cu_ok(*a):
+    return 0
+
+
+class Dim3:
+    def __init__(self, x=1, y=1, z=1):
+        self.x, self.y, self.z = int(x), int(y), int(z)
+
+
 class Thread:
     __slots__ = ("tix", "tiy", "tiz", "bdx", "bdy", "bdz", "bix", "biy", "biz", "gdx", "gdy", "gdz", "blk")
 
@@ -325,11 +344,15 @@ def tpl(given, names, defaults):
 
 
 # ------------------------------------------------------------------------------------------------------------------ translator
-TYPE_WORDS = {"T", "int", "unsigned", "bool", "float", "double", "auto", "const", "char", "long", "size_t", "threadDesc_t", "dim3", "void", "half", "algType"}
+TYPE_WORDS = {"T", "int", "unsigned", "bool", "float", "double", "auto", "const", "char", "long", "size_t", "threadDesc_t", "dim3", "void", "half", "algType", "struct", "timeval"}
 QUALIFIERS = {"__host__", "__device__", "__global__", "__forceinline__", "inline", "static", "extern", "__noinline__", "constexpr"}
 SYNC_NAMES = {"__syncthreads"}
 MATH = {"sin": "math.sin", "cos": "math.cos", "sqrt": "math.sqrt", "abs": "abs", "fabs": "abs", "pow": "c_pow", "atan2": "math.atan2", "max": "max", "min": "min",
         "exp": "math.exp", "log": "math.log", "tan": "math.tan", "floor": "math.floor", "ceil": "math.ceil", "memset": "c_memset", "memcpy": "c_memcpy"}
+# host side of the CUDA runtime as far as the reference's host drivers use it: copies and fills act on the emulated buffers (byte counts are multiples of sizeof(T)),
+# synchronisation and error queries are no-ops (the emulation is sequential)
+CUDA_RT = {"cudaMemcpy": "cu_memcpy", "cudaMemcpyAsync": "cu_memcpy", "cudaMemset": "cu_memset", "cudaMemsetAsync": "cu_memset", "cudaStreamSynchronize": "cu_ok",
+           "cudaDeviceSynchronize": "cu_ok", "cudaPeekAtLastError": "cu_ok", "gpuAssert": "cu_ok", "gettimeofday": "cu_ok"}
 CUDA_VARS = {("threadIdx", "x"): "_t.tix", ("threadIdx", "y"): "_t.tiy", ("threadIdx", "z"): "_t.tiz", ("blockIdx", "x"): "_t.bix", ("blockIdx", "y"): "_t.biy",
              ("blockIdx", "z"): "_t.biz", ("blockDim", "x"): "_t.bdx", ("blockDim", "y"): "_t.bdy", ("blockDim", "z"): "_t.bdz", ("gridDim", "x"): "_t.gdx",
              ("gridDim", "y"): "_t.gdy", ("gridDim", "z"): "_t.gdz"}
@@ -457,6 +480,7 @@ class Translator:
     def __init__(self, toks, device):
         self.device = device
         self.funcs = {k: v for k, v in find_functions(toks).items() if k not in MATH}   # (cudaUtils.h overloads sin / cos / min ... for `half`: libm's are used)
+        self.extra_ns = {}                  # run-time hooks of the harness (launch_kernel)
         self.emitted = {}                   # pyname -> source
         self.order = []
         self.ns = None
@@ -507,7 +531,9 @@ class Translator:
         for nm in names:
             for fd in self.funcs[nm]:
                 self.require(fd)
-        ns = {"math": math, "Ptr": Ptr, "c_div": c_div, "c_mod": c_mod, "c_pow": c_pow, "tpl": tpl, "Struct": Struct, "HOST": HOST, "UNSET": UNSET, "dflt": dflt, "c_memset": c_memset, "c_memcpy": c_memcpy, "padd": padd}
+        ns = {"math": math, "Ptr": Ptr, "c_div": c_div, "c_mod": c_mod, "c_pow": c_pow, "tpl": tpl, "Struct": Struct, "HOST": HOST, "UNSET": UNSET, "dflt": dflt, "c_memset": c_memset, "c_memcpy": c_memcpy, "padd": padd, "cu_memcpy": cu_memcpy, "cu_memset": cu_memset, "cu_ok": cu_ok,
+              "Dim3": Dim3, "cudaMemcpyHostToDevice": 1, "cudaMemcpyDeviceToHost": 2, "cudaMemcpyDeviceToDevice": 3, "__FILE__": 0, "__LINE__": 0}
+        ns.update(self.extra_ns)
         for py in self.order:
             exec(self.emitted[py], ns)
         self.ns = ns
@@ -522,7 +548,7 @@ class FuncTranslator:
         self.tu, self.fd = tu, fd
         self.lines = []
         self.tmp = 0
-        self.scalars = set()              # declared scalar locals (for &name out-arguments)
+        self.scalars = {p[0] for p in fd.params if p[1] == 0}   # scalar parameters and declared scalar locals (for &name out-arguments)
         self.loop_incr = []               # stack of increment statements of the enclosing for-loops (for `continue`)
         self.tnames = {tp[0] for tp in fd.tparams if tp[1]}        # typename parameters only (T): integer template parameters are values
 
@@ -735,6 +761,16 @@ class FuncTranslator:
                 stars += 1; k += 1
             name = d[k][1]
             rest = d[k + 1:]
+            if "timeval" in base:
+                self.emit(ind, "%s = Struct(tv_sec=0, tv_usec=0)" % name)
+                self.scalars.add(name)
+                continue
+            if "dim3" in base:
+                args = []
+                if rest and rest[0][1] == "(":
+                    args = [self.expr(a, ind) for a in split_top(rest[1:-1])]
+                self.emit(ind, "%s = Dim3(%s)" % (name, ", ".join(args)))
+                continue
             if rest and rest[0][1] == "[":
                 j = self._match(rest, 0, "[", "]")
                 size = self.expr(rest[1:j - 1], ind)
@@ -768,8 +804,13 @@ class FuncTranslator:
                 s = ""
             for p in self._post:
                 s = (s + "; " + p) if s else p
-        else:
-            assert not self._post, "post-increment inside an expression is not supported: " + " ".join(t[1] for t in toks)
+        elif self._post:                                            # out-arguments (&scalar) of a call inside a condition / initialiser: evaluate into a temporary first,
+            assert pre_ok, "copy-back inside a loop condition: " + " ".join(t[1] for t in toks)
+            tmp = self.newtmp()                                    # then copy the boxed scalars back, then use the value
+            self.emit(ind, "%s = %s" % (tmp, s))
+            for p in self._post:
+                self.emit(ind, p)
+            s = tmp
         return s
 
     def peek(self, k=0):
@@ -998,6 +1039,21 @@ class FuncTranslator:
                     sub.append(ft.expr(part, self._ind, pre_ok=False))
             targs = sub
             self._pos = j
+        if self.peek() == "<<<":                                    # kernel<<<grid, block, shared bytes, stream>>>(args)
+            self.nxt()
+            cfg = []
+            while True:
+                cfg.append(self.assignment(False))
+                t = self.nxt()[1]
+                if t == ">>>":
+                    break
+                assert t == ",", t
+            assert self.nxt()[1] == "("
+            a = self.args()
+            return "launch_kernel(%r, (%s), [%s], [%s])" % (v, "".join(t + ", " for t in (targs or [])), ", ".join(cfg), ", ".join(a))
+        if self.peek() == "(" and v in CUDA_RT and v not in self.tu.funcs:
+            self.nxt()
+            return "%s(%s)" % (CUDA_RT[v], ", ".join(self.args()))
         if self.peek() == "(" and (v in self.tu.funcs or v in MATH or v in ("__syncthreads", "hd__syncthreads")):
             self.nxt()
             a = self.args()
@@ -1021,8 +1077,8 @@ class FuncTranslator:
 # ------------------------------------------------------------------------------------------------------------------ SIMT emulation
 def launch(ns, kernel, grid, block, args, tp=(), extern_elems=0):
     """kernel<<<grid, block, extern_elems * sizeof(T)>>>(args): every block's threads advanced barrier to barrier"""
-    gx, gy = (grid, 1) if isinstance(grid, int) else grid
-    bx, by = (block, 1) if isinstance(block, int) else block
+    gx, gy = (grid.x, grid.y) if isinstance(grid, Dim3) else ((grid, 1) if isinstance(grid, int) else grid)
+    bx, by = (block.x, block.y) if isinstance(block, Dim3) else ((block, 1) if isinstance(block, int) else block)
     fn = ns[kernel]
     for biy in range(gy):
         for bix in range(gx):

@@ -89,7 +89,7 @@ def solver_level(path):
 
 
 def ee_cost_level(path, N=64):
-    """End-effector cost family (oracle unpinned): per-knot H_k, g_k, cost of the setup kernel on a random trajectory, and the first costs of a solve."""
+    """End-effector cost family (oracle pinned: tests/test_phase_pins.py): per-knot H_k, g_k, cost of the setup kernel on a random trajectory, and the first costs of a solve."""
     rng = np.random.default_rng(9)
     kw = dict(N=N, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=10, ee_cost=1, ignore_max_rho_exit=0, Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)
     s = pyddp.Solver(pyddp.default_config(4, _lib_path=path, dtype=0, **kw), _lib_path=path)

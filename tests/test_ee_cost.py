@@ -2,7 +2,8 @@
 plants/dynamics_arm.cuh:1879-1925, in-simulation cost accumulation fpHelpers.cuh:259-265,298-300, costKern<T,MODE> :169-190, the EE branch
 of costGradientHessianKern nisInitHelpers.cuh:52-84).
 
-PARITY UNPINNED for this family: the survey recorded no reference outputs with EE_COST 1.  What is checked:
+The oracle's restatement of this family is PINNED by the reference's own statements executed at fixture-generation time (tests/test_phase_pins.py: tool point,
+in-sim cost, gradient / Gauss-Newton Hessian, a whole EE_COST solve -- bit for bit).  What is checked here:
   * the oracle's restatement against finite differences of itself (kinematics Jacobian, cost gradient) and against an independent
     numpy forward-kinematics of the tool point built from the model tables;
   * the kernels against the oracle: per-knot cost / gradient / Gauss-Newton Hessian (teacher-forced), whole solves in float64 with

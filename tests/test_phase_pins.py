@@ -8,6 +8,10 @@ for sem = "cpu").  The oracle's float64 instantiation has to reproduce them:
 
     |oracle64 - fixture| <= 1e-12 x max|fixture|        per output array;  integers (err flags, step-size index, ignore_defect) identical.
 
+Beyond the phases, the fixture holds WHOLE SOLVES of the reference's runiLQR_GPU (host driver + every kernel it launches, emulated end to end), so the loop's
+bookkeeping -- initial cost and its epsilon, rho schedule, accept / reject with restore, Pp <- P, winner broadcast, exits -- is pinned as well; and the arm's own
+dynamics / dynamicsGradient and the end-effector cost family (compute_eePos, costFunc / costGrad with EE_COST).
+
 This is what makes the oracle a PINNED checker for the backward pass, the forward sweep, the rollouts, the three integration rules with their quirks, the
 cost / defect reductions and the line search -- in both the kernel semantics the HIP path is compared with and the host semantics of runiLQR_CPU.
 """
@@ -267,9 +271,31 @@ def test_line_search_of_forwardSimGPU():
     assert 5 <= accepted <= len(ls["cases"]) - 5
 
 
+@pytest.mark.parametrize("name", names("solve"))
+def test_whole_solves_of_the_reference_runiLQR_GPU(name):
+    """runiLQR_GPU itself (DDPWrappers.cuh:10-138) executed at generation time -- host driver, loadVarsGPU, initAlgGPU, backwardPassGPU, forwardSimGPU + line search,
+    acceptRejectTrajGPU, nextIterationSetupGPU, storeVarsGPU as they stand, every kernel they launch under the SIMT emulation -- against the oracle's GPU-semantics driver:
+    identical step-size indices (rejections, the initial -1 / 0, the exit iteration) and J, x, u, K to 1e-10 (measured: bit-identical)."""
+    case = CASES[name]
+    c = case["cfg"]
+    kw = {k: c[k] for k in ("wafr_urdf", "mpc_mode", "ee_cost", "ignore_max_rho_exit") if k in c}
+    o = Oracle(default_cfg(4, N=c["N"], M=c["M"], A=c["A"], integrator=c["integrator"], total_time=c["total_time"], tol_cost=c["tol_cost"], max_iter=c["max_iter"],
+                           cores=1, spawn_threads=0, **kw), np.float64)
+    fl = case.get("flags", {})
+    r = o.run_ilqr_gpusem(inp(case, "x0"), inp(case, "u0"), inp(case, "xg"), rollout=fl.get("rollout", 0), ignore_first_defect=fl.get("ifd", 1))
+    ref_a, ref_J = out(case, "alphaOut"), out(case, "Jout")
+    it = r["iters"]
+    assert list(r["alphaOut"][: it + 1]) == list(ref_a[: it + 1]), (name, list(r["alphaOut"][: it + 1]), list(ref_a))
+    assert not ref_J[it + 1:].any()                               # the reference wrote exactly iter + 1 entries
+    for k, got in (("Jout", r["Jout"][: it + 1]), ("x", r["x"]), ("u", r["u"]), ("KT", r["KT"])):
+        ref = ref_J[: it + 1] if k == "Jout" else out(case, k)
+        e = np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-300)
+        assert e <= 1e-10, (name, k, e)
+
+
 def test_fixture_provenance_is_data_only():
     """the fixture holds numbers and case descriptions, no reference text"""
     assert set(MAN) == {"_provenance", "cases", "line_search"}
     for c in MAN["cases"]:
-        assert set(c) <= {"name", "kind", "cfg", "sem", "inputs", "outputs", "rho", "weights", "inputs_of"}
+        assert set(c) <= {"name", "kind", "cfg", "sem", "inputs", "outputs", "rho", "weights", "inputs_of", "flags"}
     assert all(DATA[k].dtype.kind in "fi" for k in DATA.files)

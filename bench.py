@@ -261,6 +261,7 @@ def main():
     if ctx.rank == 0 and ctx.world == 1 and not args.no_latency:
         line["latency"] = guarded(latency_single_problem, ctx.device)
         line["widening"] = guarded(widening_rows, ctx.device)
+        line["other_baseline_configs"] = guarded(other_config_rows, ctx.device)
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = guarded(cpu_baseline)
     elif ctx.rank == 0:
@@ -388,6 +389,47 @@ def latency_single_problem(device):
             cum = np.cumsum(ph.sum(axis=0))
             res[name]["trace"] = {"J": [round(float(v), 4) for v in pt["Jout"][0][: n_it + 1]], "alpha": [int(v) for v in pt["alphaOut"][0][: n_it + 1]],
                                   "cumulative_kernel_ms": [0.0] + [round(float(v), 4) for v in cum]}
+        s.close()
+    return res
+
+
+def closed_form_inputs(plant, N, rng, count):
+    """examples/WAFR_iLQR_examples.cu:19-33,72-78,88-90,111-115: start, nominal control and goal of the pendulum / cart-pole / quadrotor + N(0, 1e-3) noise on the velocities"""
+    n, m = {1: (2, 1), 2: (4, 1), 3: (12, 4)}[plant]
+    x = np.zeros((count, N, n), np.float32)
+    x[:, :, n // 2:] = rng.normal(0, 0.001, (count, N, n // 2)).astype(np.float32)
+    if plant == 3:
+        x[:, :, 2] = 0.5
+    u = np.full((count, N, m), 1.22625 if plant == 3 else 0.01, np.float32)
+    g = np.zeros((count, n), np.float32)
+    g[:] = {1: [3.1416, 0.0], 2: [0.0, 3.1416, 0.0, 0.0], 3: [7.0, 10.0, 0.5] + [0.0] * 9}[plant]
+    return x, u, g
+
+
+def other_config_rows(device):
+    """BASELINE configs[1] (cart-pole N=128, 8 alphas, M=4) and configs[4] (quadrotor N=256, RK3, 16 alphas, float32 and float64) with the device full: whole-batch sweeps/s,
+    per-kernel HIP-event times, and the rate at which the sweep gets through the reference's byte accounting (NOT a bandwidth -- see roofline.reference_equivalent).
+    configs[0] (pendulum, CPU path) is the reference's CPU-only case: libpddp_cpu's runiLQR_CPU is timed in its place.  Not part of `value`."""
+    res = {}
+    rng = np.random.default_rng(99)
+    for name, plant, B, kw, dtype in (("config1_cartpole_N128_A8_M4_rk3_f32", 2, 16384, dict(N=128, M=4, A=8, integrator=3, total_time=4.0), 0),
+                                      ("config4_quadrotor_N256_A16_M4_rk3_f32", 3, 4096, dict(N=256, M=4, A=16, integrator=3, total_time=4.0), 0),
+                                      ("config4_quadrotor_N256_A16_M4_rk3_f64", 3, 4096, dict(N=256, M=4, A=16, integrator=3, total_time=4.0), 1)):
+        n, m = {2: (4, 1), 3: (12, 4)}[plant]
+        s = pyddp.Solver(pyddp.default_config(plant, batch=B, max_iter=100, tol_cost=0.0, dtype=dtype, device=device, use_graph=1, **kw))
+        x0, u0, xg = closed_form_inputs(plant, kw["N"], rng, B)
+        s.load(x0, u0, xg)
+        s.iterate(3); s.sync()
+        ms_plain, _ = s.time_sweeps(10, phases=False)
+        s.load(x0, u0, xg); s.iterate(3); s.sync()
+        kern = s.time_kernels(10)
+        out = s.store()
+        acc = float(np.mean([(out["alphaOut"][b][1:14] >= 0).mean() for b in range(min(B, 64))]))
+        alg = pyddp.algorithmic_bytes(n, m, kw["N"], kw["A"], kw["M"], 8 if dtype else 4)
+        res[name] = {"problems": B, "iterations_per_s": round(B * 10 / (ms_plain * 1e-3), 1), "ms_per_sweep": round(ms_plain / 10, 4),
+                     "per_kernel_ms": {nm: round(ms, 5) for nm, ms in kern}, "accepted_fraction": round(acc, 3),
+                     "reference_equivalent": {"bytes_per_sweep_per_problem": sum(alg.values()), "GBs": round(sum(alg.values()) * B / (ms_plain / 10 * 1e-3) / 1e9, 1),
+                                              "ratio_to_hbm_peak": round(sum(alg.values()) * B / (ms_plain / 10 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         s.close()
     return res
 

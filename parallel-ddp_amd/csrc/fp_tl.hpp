@@ -121,6 +121,21 @@ template <typename T> struct TlStateSink {             // states to xw (xs witho
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
 
+// The same destination as TlStateSink for a rollout whose x() calls come in knot order (k_fp_tl: begin at kStart, then kStart + 1, ...): a RUNNING pointer instead of
+// base + k * stride -- the 64-bit multiply-add per store is what the compiler does not strength-reduce across the inlined dynamics.
+template <typename T> struct TlRunSink {
+    T* ds; mutable T* cur; int stride;
+    PDDP_HD void x(int, const T* v) const { tl_store14(cur, v); cur += stride; }
+    PDDP_HD void u(int, const T*) const {}
+    PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
+};
+template <typename T>
+PDDP_HD TlRunSink<T> tl_run_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, int kStart) {
+    const size_t slot = (size_t)pb * dm.A + a_idx;
+    if (b.xw) return TlRunSink<T>{b.ds + slot * dm.N * 14, b.xw + (((size_t)pb * dm.N + kStart) * dm.A + a_idx) * 14, dm.A * 14};
+    return TlRunSink<T>{b.ds + slot * dm.N * 14, b.xs + (slot * dm.N + kStart) * 14, 14};
+}
+
 template <typename T, typename Sink>
 PDDP_HD void tl_rollout_begin(TlRollout<T>& r, const Buffers<T>& b, const Dims& dm, int pb, int a_idx, int seg, const T* xcur, const Sink& sink) {
     r.pb = pb; r.a_idx = a_idx; r.seg = seg; r.kStart = seg * dm.NB;

@@ -337,8 +337,11 @@ struct Solver : SolverBase {
         if constexpr (P::PLANT == 4) lane_groups = !fp_coop;       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests)
         if (!lane_groups) {
             if (part == 0) return;
-            if (cf_serial && !init_rollout) hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B);
-            else hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
+            bool serial = false;
+            if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
+                if (cf_serial && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+            }
+            if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
             return;
         }
         if constexpr (P::PLANT == 4) {
@@ -390,7 +393,7 @@ struct Solver : SolverBase {
             }
         }
         if (part == 0) return;
-        if (cf_serial) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; }
+        if constexpr (P::PLANT != 4) { if (cf_serial) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
     void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0, int part = -1) {
@@ -401,7 +404,9 @@ struct Solver : SolverBase {
             if constexpr (P::PLANT == 4) { if (bp_mfma) launch_bp_mfma<T>(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, cw.Q1, cw.Q2, cw.R, dt, keep_all_ctg() || store_candidates, sweep_fused && (!store_candidates || phase_fused_sweep)); }
             if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
-                if (cf_serial) hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B);
+                bool serial = false;
+                if constexpr (P::PLANT != 4) { if (cf_serial) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
+                if (serial) {}
                 else if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
             }

@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
         dst1[j] = (e < ppw * 14) ? q * PS + 112 + off : -1;
     }
     TlPair<T> pf2[J2]; T pf1[J1];
-    auto fetch = [&](int k) {
+    auto fetch = [&]() {                                              // the operands of the next step: running pointers (one 64-bit add each instead of k * stride)
 #pragma unroll
-        for (int j = 0; j < J2; j++) pf2[j] = *reinterpret_cast<const TlPair<T>*>(src2[j] + (size_t)k * str2[j]);
+        for (int j = 0; j < J2; j++) { pf2[j] = *reinterpret_cast<const TlPair<T>*>(src2[j]); src2[j] += str2[j]; }
 #pragma unroll
-        for (int j = 0; j < J1; j++) pf1[j] = src1[j][(size_t)k * NU];
+        for (int j = 0; j < J1; j++) { pf1[j] = src1[j][0]; src1[j] += NU; }
     };
     auto park = [&](int buf) {
         T* d = stg + buf * (kFpTlMaxPairs * PS);
@@ -89,12 +89,12 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
     TlRollout<T> r;
     r.iters = 0;
     const auto csink = tl_candidate_sink<T>(b, dm, pb, a_idx);
-    const auto ssink = tl_state_sink<T>(b, dm, pb, a_idx);
+    const auto ssink = tl_run_sink<T>(b, dm, pb, a_idx, seg * NBk);
     if (live) { if (ALL) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, ssink); }
-    fetch(0); park(0);
+    fetch(); park(0);
     wsync();
     for (int k = 0; k < NBk; k++) {
-        if (k + 1 < NBk) fetch(k + 1);                                // in flight while this step computes
+        if (k + 1 < NBk) fetch();                                     // in flight while this step computes
         if (live && k < r.iters) {
             const T* o = stg + (k & 1) * (kFpTlMaxPairs * PS) + p * PS;
             if (ALL) tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, csink);

@@ -1,0 +1,89 @@
+"""Thread-serial kernels of the closed-form plants (k_bp_ts / k_fp_ts / k_nis_ts: one THREAD per block of knots / candidate / knot, the same bodies as the
+wave-cooperative kernels with a one-lane wave) -- what BASELINE configs[1] (cart-pole N=128, A=8) and configs[4] (quadrotor N=256, RK3, A=16) run once a batch
+fills the device.
+
+  * bit for bit the cooperative kernels' results (every output element is computed by one lane / one thread with the same operations in the same order);
+  * float64 whole solves follow the oracle's GPU-semantics driver decision for decision -- the oracle whose phases at these plants' sizes (1x1 and 4x4 adjugate
+    inversion, the three integration rules) are pinned by the reference's own statements (tests/test_phase_pins.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from backends import make_solver
+from oracle_binding import Oracle, default_cfg, example_inputs
+
+pytestmark = pytest.mark.gpu
+CASES = [pytest.param(2, dict(N=128, M=4, A=8, integrator=3, total_time=4.0, max_iter=10), id="cartpole-config1"),
+         pytest.param(3, dict(N=256, M=4, A=16, integrator=3, total_time=4.0, max_iter=5), id="quadrotor-config4"),
+         pytest.param(1, dict(N=64, M=4, A=4, integrator=1, total_time=4.0, max_iter=8), id="pendulum"),
+         pytest.param(2, dict(N=64, M=1, A=8, integrator=2, total_time=2.0, max_iter=8), id="cartpole-midpoint-single-shooting")]
+
+
+def with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+@pytest.mark.parametrize("plant,kw", CASES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_thread_serial_equals_cooperative_bit_for_bit(plant, kw, dtype):
+    B = 5
+    rng = np.random.default_rng(17)
+    n = {1: 2, 2: 4, 3: 12}[plant]
+    xs, us, gs = [], [], []
+    for b in range(B):
+        x0, u0, xg = example_inputs(plant, kw["N"], dtype, noise=rng.normal(0, 0.001 * (b + 1), (kw["N"], n)))
+        xs.append(x0); us.append(u0); gs.append(xg)
+    outs = {}
+    for mode in ("ts", "coop"):
+        s = with_env({"PDDP_CF": mode}, lambda: make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, **kw))
+        names = dict(s.time_kernels(1))
+        assert ("k_fp_ts" in names) == (mode == "ts") and ("k_bp_ts" in names) == (mode == "ts") and ("k_nis_ts" in names) == (mode == "ts"), names
+        outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+        outs[mode]["P"] = s.get_cost_to_go()[0]
+        s.close()
+    a, c = outs["ts"], outs["coop"]
+    assert (a["iters"] == c["iters"]).all() and a["iters"].min() >= 1
+    for k in ("alphaOut", "Jout", "x", "u", "KT", "P"):
+        assert np.array_equal(a[k], c[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("plant,kw", CASES)
+def test_thread_serial_float64_solves_follow_the_oracle(plant, kw):
+    n = {1: 2, 2: 4, 3: 12}[plant]
+    x0, u0, xg = example_inputs(plant, kw["N"], np.float64, noise=np.random.default_rng(23).normal(0, 0.001, (kw["N"], n)))
+    r = Oracle(default_cfg(plant, cores=8, spawn_threads=0, tol_cost=0.0, **kw), np.float64).run_ilqr_gpusem(x0, u0, xg)
+    s = with_env({"PDDP_CF": "ts"}, lambda: make_solver("hip", plant, dtype=1, tol_cost=0.0, **kw))
+    out = s.solve(x0, u0, xg)
+    it = r["iters"]
+    assert out["iters"][0] == it and list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], r["Jout"][: it + 1], rtol=1e-7)
+    np.testing.assert_allclose(out["x"][0].ravel(), r["x"], rtol=0, atol=1e-7 * max(np.abs(r["x"]).max(), 1.0))
+    s.close()
+
+
+def test_large_batch_selection_is_thread_serial_and_equals_single_problem_solves():
+    """The automatic selection: 512 cart-pole problems run the thread-serial kernels, a single problem the cooperative ones -- same bits."""
+    kw = dict(N=128, M=4, A=8, integrator=3, total_time=4.0, max_iter=6, tol_cost=0.0)
+    B = 512
+    rng = np.random.default_rng(31)
+    xs, us = [], []
+    for b in range(B):
+        x0, u0, xg = example_inputs(2, 128, np.float32, noise=rng.normal(0, 0.001, (128, 4)))
+        xs.append(x0); us.append(u0)
+    s = make_solver("hip", 2, dtype=0, batch=B, **kw)
+    assert "k_fp_ts" in dict(s.time_kernels(1))
+    out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
+    s1 = make_solver("hip", 2, dtype=0, batch=1, **kw)
+    assert "k_fp" in dict(s1.time_kernels(1))
+    for b in rng.choice(B, 6, replace=False):
+        o1 = s1.solve(xs[b], us[b], xg)
+        for k in ("alphaOut", "Jout", "x", "u"):
+            assert np.array_equal(o1[k][0], out[k][b]), (int(b), k)

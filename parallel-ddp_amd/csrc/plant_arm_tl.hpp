@@ -386,50 +386,61 @@ PDDP_HD void arm_tl_grad_joint(const ArmTlModel<T>& md, const ArmTlState<T>& st,
     const auto& a = nm.a; const auto& Iv = nm.Iv; const auto& Ft = nm.Ft;
     T dFq[6], dFv[6];                 // tangent of the total force through the current joint (accumulated from the tip inwards)
     T dtq[NB], dtv[NB];
-    // forward over the links at and below joint j
-    T dvq[NB][6], daq[NB][6], dvv[NB][6], dav[NB][6];
+    // forward over the links at and below joint j.  Only the CURRENT link's tangent motions (velocity, acceleration; d/dq_j and d/dqd_j) are kept: every link's
+    // tangent FORCE  df_i = I da_i + dv_i x* (I v_i) + v_i x* (I dv_i)  is formed as soon as its motions exist and stored (12 numbers per link instead of 24) --
+    // the same operations on the same operands as forming it on the way back, half the live state at the peak (joint 0: 7 links).
+    T dfq[NB][6], dfv[NB][6];
+    T dvq[6], daq[6], dvv[6], dav[6];
+    auto link_forces = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        T t6[6];
+        tl_inertia_mul(dfq[i], md.m[i], md.h[i], md.I[i], daq);
+        tl_crf_add(dfq[i], dvq, Iv[i]);
+        tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvq);
+        tl_crf_add(dfq[i], st.v[i], t6);
+        tl_inertia_mul(dfv[i], md.m[i], md.h[i], md.I[i], dav);
+        tl_crf_add(dfv[i], dvv, Iv[i]);
+        tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvv);
+        tl_crf_add(dfv[i], st.v[i], t6);
+    };
     {
         const T* v = st.v[j];
         // d(X_j v_p)/dq_j = -e_z x (X_j v_p) = -e_z x v_j (e_z x e_z = 0):  -(e_z x w) = (w_y, -w_x, 0)
-        dvq[j][0] = v[1]; dvq[j][1] = -v[0]; dvq[j][2] = T(0); dvq[j][3] = v[4]; dvq[j][4] = -v[3]; dvq[j][5] = T(0);
+        dvq[0] = v[1]; dvq[1] = -v[0]; dvq[2] = T(0); dvq[3] = v[4]; dvq[4] = -v[3]; dvq[5] = T(0);
         // X_j a_p = a_j - e_z qdd_j - v_j x (e_z qd_j)
         const T xa[6] = {a[j][0] - qd[j] * v[1], a[j][1] + qd[j] * v[0], a[j][2] - qdd[j], a[j][3] - qd[j] * v[4], a[j][4] + qd[j] * v[3], a[j][5]};
-        daq[j][0] = xa[1] + qd[j] * dvq[j][1]; daq[j][1] = -xa[0] - qd[j] * dvq[j][0]; daq[j][2] = T(0);
-        daq[j][3] = xa[4] + qd[j] * dvq[j][4]; daq[j][4] = -xa[3] - qd[j] * dvq[j][3]; daq[j][5] = T(0);
+        daq[0] = xa[1] + qd[j] * dvq[1]; daq[1] = -xa[0] - qd[j] * dvq[0]; daq[2] = T(0);
+        daq[3] = xa[4] + qd[j] * dvq[4]; daq[4] = -xa[3] - qd[j] * dvq[3]; daq[5] = T(0);
         // d/dqd_j: dv_j = e_z, da_j = v_j x e_z  (the e_z x e_z qd term vanishes)
-        dvv[j][0] = T(0); dvv[j][1] = T(0); dvv[j][2] = T(1); dvv[j][3] = T(0); dvv[j][4] = T(0); dvv[j][5] = T(0);
-        dav[j][0] = v[1]; dav[j][1] = -v[0]; dav[j][2] = T(0); dav[j][3] = v[4]; dav[j][4] = -v[3]; dav[j][5] = T(0);
+        dvv[0] = T(0); dvv[1] = T(0); dvv[2] = T(1); dvv[3] = T(0); dvv[4] = T(0); dvv[5] = T(0);
+        dav[0] = v[1]; dav[1] = -v[0]; dav[2] = T(0); dav[3] = v[4]; dav[4] = -v[3]; dav[5] = T(0);
+        link_forces(std::integral_constant<int, j>());
     }
     TlFor<j + 1, NB, 1>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int K = arm_tl_kind(i);
-        tl_motion_to_child<K>(dvq[i], dvq[i - 1], md.r[i], st.c[i], st.s[i]);
-        tl_motion_to_child<K>(daq[i], daq[i - 1], md.r[i], st.c[i], st.s[i]);
-        daq[i][0] += qd[i] * dvq[i][1]; daq[i][1] -= qd[i] * dvq[i][0]; daq[i][3] += qd[i] * dvq[i][4]; daq[i][4] -= qd[i] * dvq[i][3];
-        tl_motion_to_child<K>(dvv[i], dvv[i - 1], md.r[i], st.c[i], st.s[i]);
-        tl_motion_to_child<K>(dav[i], dav[i - 1], md.r[i], st.c[i], st.s[i]);
-        dav[i][0] += qd[i] * dvv[i][1]; dav[i][1] -= qd[i] * dvv[i][0]; dav[i][3] += qd[i] * dvv[i][4]; dav[i][4] -= qd[i] * dvv[i][3];
+        T nvq[6], naq[6], nvv[6], nav[6];
+        tl_motion_to_child<K>(nvq, dvq, md.r[i], st.c[i], st.s[i]);
+        tl_motion_to_child<K>(naq, daq, md.r[i], st.c[i], st.s[i]);
+        naq[0] += qd[i] * nvq[1]; naq[1] -= qd[i] * nvq[0]; naq[3] += qd[i] * nvq[4]; naq[4] -= qd[i] * nvq[3];
+        tl_motion_to_child<K>(nvv, dvv, md.r[i], st.c[i], st.s[i]);
+        tl_motion_to_child<K>(nav, dav, md.r[i], st.c[i], st.s[i]);
+        nav[0] += qd[i] * nvv[1]; nav[1] -= qd[i] * nvv[0]; nav[3] += qd[i] * nvv[4]; nav[4] -= qd[i] * nvv[3];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { dvq[e] = nvq[e]; daq[e] = naq[e]; dvv[e] = nvv[e]; dav[e] = nav[e]; }
+        link_forces(ic);
     });
-    // backward: df_i = I da_i + dv_i x* (I v_i) + v_i x* (I dv_i), accumulated towards the base; joint j adds e_z x* F_j to the q tangent
+    // backward: the tangent forces accumulated towards the base; joint j adds e_z x* F_j to the q tangent
     TlFor<NB - 1, -1, -1>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int K = arm_tl_kind(i);
         if (i >= j) {
-            T dfq[6], dfv[6], t6[6];
-            tl_inertia_mul(dfq, md.m[i], md.h[i], md.I[i], daq[i]);
-            tl_crf_add(dfq, dvq[i], Iv[i]);
-            tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvq[i]);
-            tl_crf_add(dfq, st.v[i], t6);
-            tl_inertia_mul(dfv, md.m[i], md.h[i], md.I[i], dav[i]);
-            tl_crf_add(dfv, dvv[i], Iv[i]);
-            tl_inertia_mul(t6, md.m[i], md.h[i], md.I[i], dvv[i]);
-            tl_crf_add(dfv, st.v[i], t6);
             if (i == NB - 1) {
 #pragma unroll
-                for (int e = 0; e < 6; e++) { dFq[e] = dfq[e]; dFv[e] = dfv[e]; }
+                for (int e = 0; e < 6; e++) { dFq[e] = dfq[i][e]; dFv[e] = dfv[i][e]; }
             } else {
 #pragma unroll
-                for (int e = 0; e < 6; e++) { dFq[e] += dfq[e]; dFv[e] += dfv[e]; }
+                for (int e = 0; e < 6; e++) { dFq[e] += dfq[i][e]; dFv[e] += dfv[i][e]; }
             }
         }
         dtq[i] = dFq[2]; dtv[i] = dFv[2];

@@ -163,6 +163,7 @@ struct Solver : SolverBase {
         drop_graph();
         return 0;
     }
+    bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
     bool cf_serial = false;        // closed-form plants with many problems in flight: thread-serial kernels (k_bp_ts / k_fp_ts / k_nis_ts); PDDP_CF=coop|ts overrides
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
     bool phase_fused_sweep = false; // pddp_run_phase(PDDP_PHASE_BP_FUSED / _SWEEP_FUSED): the teacher-forcing hook runs the production sweep path (maps composed in the backward pass)
@@ -213,6 +214,18 @@ struct Solver : SolverBase {
         // the batch fills the device (64 units per wave instead of 1); the horizon has to fit the per-thread cost table of k_fp_ts
         cf_serial = P::PLANT != 4 && (size_t)c.batch * c.M >= 256 && c.N <= kTsMaxN && c.M <= kTsMaxM;
         if (const char* v = std::getenv("PDDP_CF")) cf_serial = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
+        // measured on MI355X (tools/cf_variants.py; profiles/r03_closed_form_variants.txt): the rollouts always win thread-serially once the device is full (cart-pole, 16384
+        // problems: 0.74 against 15.7 ms; quadrotor, 4096: 3.0 against 57.9 ms); the derivative kernel too for the small plants (0.16 against 2.1 ms) but not for the
+        // quadrotor's 12 states, whose per-thread stage scratch spills to memory (6.2 against 5.4 ms); the backward pass thread-serially only for the small plants with the
+        // device full (0.42 against 0.65 ms; quadrotor: its 64-knot serial chain on private memory takes 15 ms against 1.9 ms for a wave per block)
+        cf_fp = cf_serial;
+        cf_nis = cf_serial && P::NX < 12;
+        cf_bp = cf_serial && P::NX < 12 && (size_t)c.batch * c.M >= 8192;
+        if (std::getenv("PDDP_CF")) cf_bp = cf_nis = cf_fp;         // the override forces every phase
+        // per-phase overrides (measurement): PDDP_CF_BP / PDDP_CF_FP / PDDP_CF_NIS = coop | ts
+        if (const char* v = std::getenv("PDDP_CF_BP")) cf_bp = P::PLANT != 4 && std::string(v) == "ts";
+        if (const char* v = std::getenv("PDDP_CF_FP")) cf_fp = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
+        if (const char* v = std::getenv("PDDP_CF_NIS")) cf_nis = P::PLANT != 4 && std::string(v) == "ts";
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
@@ -339,7 +352,7 @@ struct Solver : SolverBase {
             if (part == 0) return;
             bool serial = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
-                if (cf_serial && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+                if (cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
             }
             if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
             return;
@@ -393,7 +406,7 @@ struct Solver : SolverBase {
             }
         }
         if (part == 0) return;
-        if constexpr (P::PLANT != 4) { if (cf_serial) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
+        if constexpr (P::PLANT != 4) { if (cf_nis) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
     void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0, int part = -1) {
@@ -405,7 +418,7 @@ struct Solver : SolverBase {
             if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
                 bool serial = false;
-                if constexpr (P::PLANT != 4) { if (cf_serial) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
+                if constexpr (P::PLANT != 4) { if (cf_bp) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
                 if (serial) {}
                 else if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
@@ -420,8 +433,8 @@ struct Solver : SolverBase {
     // for a slot leaves its name empty and its time 0.
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
-        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_serial ? "k_bp_ts" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : cf_serial ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_serial ? "k_nis_ts" : "k_nis"};
+        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : bp_wide ? "k_bp_wide" : "k_bp",
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

@@ -45,7 +45,7 @@ def test_thread_serial_equals_cooperative_bit_for_bit(plant, kw, dtype):
     for mode in ("ts", "coop"):
         s = with_env({"PDDP_CF": mode}, lambda: make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, **kw))
         names = dict(s.time_kernels(1))
-        assert ("k_fp_ts" in names) == (mode == "ts") and ("k_bp_ts" in names) == (mode == "ts") and ("k_nis_ts" in names) == (mode == "ts"), names
+        assert ("k_fp_ts" in names) == (mode == "ts") and ("k_bp_ts" in names) == (mode == "ts") and ("k_nis_ts" in names) == (mode == "ts"), names   # PDDP_CF forces every phase
         outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
         outs[mode]["P"] = s.get_cost_to_go()[0]
         s.close()

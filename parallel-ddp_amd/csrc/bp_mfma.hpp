@@ -253,9 +253,13 @@ __device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, 
 // the segment's map is Psi = G_last ... G_first, and Psi' <- G_k' Psi' is one more mfma4 per knot on tiles this pass holds anyway (Psi' again in accumulator layout) --
 // and leaves Psi' in b.segmap[problem][block] (256 elements) INSTEAD of writing A - B K and B du of every knot (107 KB per problem, and the linear sweep kernel that would
 // read them back): k_sweep_maps composes the M - 1 maps.  Same mathematics as k_sweep_wg's per-segment tiles (pddp_tl.hip).
+// HQQ (with DIAGH): the end-effector cost -- the running knots' Hessian is diag(hq1 x 7, hq2 x 7, hr x 7) (nominal-state and control weights) plus the dense 7 x 7 position
+// block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
+// knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
 constexpr int kMxKeepP = 1, kMxFuseSweep = 2;
-template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE>
+template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
+    static_assert(!HQQ || DIAGH, "the compact position block rides on the diagonal-Hessian path");
     using X = Mx<T>;
     using mx4 = mx4t<T>;
     const int keepP = flags & kMxKeepP;
@@ -352,6 +356,11 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
 #pragma unroll
             for (int r = 0; r < 4; r++) if (cx) CXX[r] = diag[r] ? (sc < 7 ? hq1 : hq2) : T(0);
             CUU[0] = (cu && u0 == ub) ? hr : T(0); CUU[1] = (cu && u0 + 1 == ub) ? hr : T(0);
+            if (HQQ) {                                                // rows 2g, 2g + 1 of column sc of the position block (symmetric: read as column sc, rows 2g..)
+                const T* hk = b.Hc + (knot0 + (size_t)ks) * 49;
+                const typename X::v2u hv = mx_ld<typename X::v2u, T>(hk, (unsigned)((sc < 7 ? sc : 6) * 7 + (g < 3 ? 2 * g : 5)));
+                if (sc < 7) { CXX[0] = (g < 3) ? hv[0] : hv[1]; CXX[1] = (g < 3) ? hv[1] : T(0); }
+            }
         } else {
             CXU[0] = k.CXU0; CXU[1] = k.CXU1; CUU[0] = k.CUU0; CUU[1] = k.CUU1;
         }

@@ -16,6 +16,7 @@
 //     run of full cache lines (k_nis_tl in kernels.hpp) -- every line written once.
 #pragma once
 
+#include "ee_cost.hpp"
 #include "plant_arm_tl.hpp"
 #include "plants.hpp"
 #include "solver_state.hpp"
@@ -36,7 +37,8 @@ namespace pddp {
 enum FpPath { kFpCoop = 0, kFpLg = 1, kFpTl = 2 };
 constexpr int kFpTlMinBatch = 512;
 inline FpPath select_fp_path(const char* env, bool is_float, bool ee_cost, bool tl_model_ok, int batch) {
-    const bool tl_possible = !ee_cost && tl_model_ok;
+    const bool tl_possible = tl_model_ok;          // (joint-space and end-effector cost)
+    (void)ee_cost;
     if (env) {
         if (env[0] == 'c') return kFpCoop;
         if (env[0] == 'l') return kFpLg;
@@ -330,6 +332,182 @@ PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& 
     if (!arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u)) return false;
     arm_tl_nis_jac<T>(md, grav, x, u, emit, [](int) {});
     return true;
+}
+
+// ------------------------------------------------------------------------------------------------ end-effector cost family on thread lanes
+// The same quantities, operations per element and summation orders as ee_cost.hpp / ee_cost_lg.hpp (which restate compute_eePos, plants/dynamics_arm.cuh:1879-1925, the
+// end-effector costFunc / costGrad, plants/cost_arm.cuh:206-389, the in-sim accumulation of forwardSimInner, fpHelpers.cuh:259-265,298-300, and the EE branch of
+// costGradientHessianKern, nisInitHelpers.cuh:52-84) with the tool point from the thread-lane world chain (plant_arm_tl.hpp arm_tl_world_chain).
+template <typename T>
+PDDP_HD bool tl_ee_rpy_weighted(const CostWeights<T>& cw) { return cw.Q_EE2 != T(0) || cw.QF_EE2 != T(0); }
+
+// one rollout step with the end-effector cost: control law, the tool point of the CURRENT state, the seven per-joint running sums (costFunc with s_cost: joint 0 also takes
+// the end-effector term), dynamics, Euler step.  Every segment runs NB steps; the last one's final step (knot N - 1) only evaluates the cost (forwardSimInner :236, :259-265).
+template <typename T, typename Sink>
+PDDP_HD void tl_rollout_step_ee(TlRollout<T>& r, T* acc, const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int k,
+                                const T* Kk, const T* xr, const T* uc, const T* du, const T* goal, const T* xt, int tshift, const Sink& sink) {
+    constexpr int NX = 14, NU = 7;
+    const int kn = r.kStart + k, N = dm.N;
+    T u[NU];
+    tl_control_law<T>(u, r.alpha, du, Kk, r.x, xr, uc);
+    sink.u(kn, u);
+    ArmTlState<T> st;
+    arm_tl_trig<T>(st, r.x);
+    if (k < dm.NB - 1 || r.seg == dm.M - 1) {                         // not on the "final" state of a non-final segment (:259-265)
+        ArmTlFrames<T> fr;
+        arm_tl_world_chain<false, T>(md, st.c, st.s, fr);
+        T pos[6];
+        arm_tl_tool_point<T>(fr, cw.ee_z, tl_ee_rpy_weighted<T>(cw), pos);
+#pragma unroll
+        for (int ind = 0; ind < NU; ind++) {
+            T cost = T(0);
+            if (ind == 0) cost += ee_term<T>(cw, pos, goal, kn >= N - 1 - tshift);
+            acc[ind] += ee_joint_terms<T>(cw, r.x, u, xt, ind, kn, N, cost);
+        }
+    }
+    if (kn == N - 1) return;                                          // the step out of the last knot is not stored anywhere
+    T bias[NU], qdd[NU], xn[NX];
+    arm_tl_bias<T>(md, grav, st, r.x + 7, bias);
+    arm_tl_factor<T>(md, st);
+#pragma unroll
+    for (int i = 0; i < NU; i++) qdd[i] = u[i] - bias[i];
+    tl_ldl_solve(st, qdd);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { xn[i] = r.x[i] + dt * r.x[7 + i]; xn[7 + i] = r.x[7 + i] + dt * qdd[i]; }
+    if (k < dm.NB - 1) {
+        sink.x(kn + 1, xn);
+#pragma unroll
+        for (int i = 0; i < NX; i++) r.x[i] = xn[i];
+    } else {
+        const int ks = (r.seg + 1) * dm.NB;
+        T xnext[NX], e[NX], sdef = T(0);
+        tl_load14(xnext, b.xs + (((size_t)r.pb * dm.A + r.a_idx) * dm.N + ks) * NX);
+#pragma unroll
+        for (int i = 0; i < NX; i++) { e[i] = xn[i] - xnext[i]; sdef += tabs(e[i]); }
+        sink.d(ks - 1, e);
+        r.sdef = sdef;
+    }
+}
+// the segment's cost: the seven partial sums added 0..6 (forwardSimKern :298-300)
+template <typename T>
+PDDP_HD void tl_rollout_end_ee(TlRollout<T>& r, const T* acc, const Dims& dm) {
+    r.J = acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6];
+    if (r.seg == dm.M - 1) r.sdef = T(0);
+}
+template <typename T, typename Sink>
+PDDP_HD void arm_tl_rollout_segment_ee(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int pb, int a_idx, int seg,
+                                       const T* xcur, const Sink& sink, bool part) {
+    constexpr int NX = 14, NU = 7;
+    const int N = dm.N;
+    const T* uc = b.ucur + (size_t)pb * N * NU; const T* du = b.du + (size_t)pb * N * NU; const T* KT = b.KT + (size_t)pb * N * NX * NU;
+    T goal[6], xt[NX], acc[NU];
+#pragma unroll
+    for (int i = 0; i < 6; i++) goal[i] = b.xGoal[(size_t)pb * NX + i];
+    tl_load14(xt, b.xTarget + (size_t)pb * NX);
+#pragma unroll
+    for (int i = 0; i < NU; i++) acc[i] = T(0);
+    const int tshift = b.tshift[pb];
+    TlRollout<T> r;
+    tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, sink);
+    r.iters = dm.NB;
+    for (int k = 0; k < r.iters; k++) {
+        const int kn = r.kStart + k;
+        T Kk[NX * NU], xr[NX], ucv[NU], duv[NU];
+#pragma unroll
+        for (int rr = 0; rr < NU; rr++) tl_load14(Kk + rr * NX, KT + (size_t)kn * (NX * NU) + rr * NX);
+        tl_load14(xr, xcur + (size_t)kn * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) { ucv[i] = uc[(size_t)kn * NU + i]; duv[i] = du[(size_t)kn * NU + i]; }
+        tl_rollout_step_ee<T>(r, acc, md, grav, b, dm, cw, dt, k, Kk, xr, ucv, duv, goal, xt, tshift, sink);
+    }
+    tl_rollout_end_ee<T>(r, acc, dm);
+    if (part) {
+        const size_t slot = (size_t)pb * dm.A + a_idx;
+        b.Jpart[slot * dm.M + seg] = r.J; b.dpart[slot * dm.M + seg] = r.sdef;
+        b.parts_fresh[pb] = 1;
+    }
+}
+
+// Next-iteration setup of knot k with the end-effector cost: (mode 0: adopt the accepted candidate's knot), tool point + Jacobian, g_k, the Gauss-Newton Hessian -- its only
+// dense part, the 7 x 7 position block Jee' Jee (+ Qx on its diagonal), into the compact array b.Hc when the handle keeps one (the matrix-core backward pass rebuilds the rest
+// from the cost weights); the reference-layout H_k is written for the final knot (the backward pass starts from it) and in init mode (the API view) -- and for every knot when
+// there is no compact array; init mode also leaves the knot's cost in costk (costGrad's d_JT, initAlgGPU).  Returns false when the knot has no Jacobian of the dynamics to write.
+template <typename T>
+PDDP_HD bool arm_tl_nis_cost_ee(const ArmTlModel<T>& md, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, T* x, T* u) {
+    constexpr int NX = 14, NU = 7, NM = 21, NP = 7;
+    const int N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    const size_t knot = (size_t)pb * N + k;
+    if (mode == 0) {
+        if (!st.win_pending) return false;
+        arm_tl_adopt_knot<T>(b, dm, k, pb, x, u);
+        if (st.done) return false;
+    } else {
+        tl_load14(x, b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) u[i] = b.ucur[knot * NU + i];
+    }
+    const bool fin = (k == N - 1), fin_ee = k >= N - 1 - b.tshift[pb];
+    ArmTlState<T> ts;
+    arm_tl_trig<T>(ts, x);
+    ArmTlFrames<T> fr;
+    arm_tl_world_chain<true, T>(md, ts.c, ts.s, fr);
+    T pos[6], dpos[42], goal[6], xt[NX];
+    arm_tl_tool_point<T>(fr, cw.ee_z, tl_ee_rpy_weighted<T>(cw), pos);
+    arm_tl_tool_jacobian<T>(fr, cw.ee_z, dpos);
+#pragma unroll
+    for (int i = 0; i < 6; i++) goal[i] = b.xGoal[(size_t)pb * NX + i];
+    tl_load14(xt, b.xTarget + (size_t)pb * NX);
+    const T Qx = fin ? cw.QF_xEE : cw.Q_xEE, Qxd = fin ? cw.QF_xdEE : cw.Q_xdEE, Ru = fin ? T(0) : cw.R_EE;
+    T* g = b.g + knot * NM;
+#pragma unroll
+    for (int r = 0; r < NP; r++) {                                    // costGrad :330-345
+        T dv = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const T dl = pos[i] - goal[i];
+            dv += (fin_ee ? (i < 3 ? cw.QF_EE1 : cw.QF_EE2) : (i < 3 ? cw.Q_EE1 : cw.Q_EE2)) * dl * dpos[r * 6 + i];
+        }
+        g[r] = dv + Qx * (x[r] - xt[r]);
+        g[NP + r] = Qxd * (x[NP + r] - xt[NP + r]);
+        g[NX + r] = Ru * u[r];
+    }
+    T Hqq[NP * NP];                                                   // costGrad :347-379 (unweighted Gauss-Newton block)
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+            T val = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) val += dpos[r * 6 + j] * dpos[c * 6 + j];
+            Hqq[c * NP + r] = (r == c) ? val + Qx : val;
+        }
+    if (b.Hc) {
+        T* hc = b.Hc + knot * (NP * NP);
+#pragma unroll
+        for (int e = 0; e < NP * NP; e++) hc[e] = Hqq[e];
+    }
+    if (!b.Hc || fin || mode == 1) {
+        T* H = b.H + knot * (NM * NM);
+        for (int e = 0; e < NM * NM; e++) {
+            const int c = e / NM, r = e % NM;
+            H[e] = (r < NP && c < NP) ? T(0) : (r != c ? T(0) : (r < NX ? Qxd : Ru));
+        }
+#pragma unroll
+        for (int c = 0; c < NP; c++)
+#pragma unroll
+            for (int r = 0; r < NP; r++) H[c * NM + r] = Hqq[c * NP + r];
+    }
+    if (mode == 1) {                                                  // the knot's cost as one running sum over the joints (costFunc returning a value, :298-315)
+        T cost = T(0);
+#pragma unroll
+        for (int ind = 0; ind < NP; ind++) {
+            if (ind == 0) cost += ee_term<T>(cw, pos, goal, fin_ee);
+            cost = ee_joint_terms<T>(cw, x, u, xt, ind, k, N, cost);
+        }
+        b.costk[knot] = cost;
+    }
+    return !fin;
 }
 
 // [A B] entry (row, col) of the Euler step from the Jacobian of the dynamics: I + dt [0 I 0; dqdd]   (utils/integrators.cuh:38-53)

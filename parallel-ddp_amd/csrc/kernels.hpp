@@ -236,6 +236,19 @@ __global__ __launch_bounds__(64) void k_nis_ts(Buffers<T> b, Dims dm, CostWeight
     nis_body<P, INTEG, T>(serial_wave(), s, b, dm, cw, dt, mode, inst % dm.N, inst / dm.N);
 }
 
+// API view of the compact end-effector Hessian block (Buffers::Hc): H_k of every running knot in the reference layout = Jee' Jee (+ Qx on its diagonal, already in the
+// block) in the position rows / columns, Qxd and R_EE on the rest of the diagonal.  The final knot's block is written in full by the setup kernel.  thread = knot.
+template <typename T>
+__global__ __launch_bounds__(64) void k_hc_expand(Buffers<T> b, int knots, int N, T Qxd, T Ru) {
+    const int G = blockIdx.x * 64 + threadIdx.x;
+    if (G >= knots || (G % N) == N - 1) return;
+    T* H = b.H + (size_t)G * 441; const T* hc = b.Hc + (size_t)G * 49;
+    for (int e = 0; e < 441; e++) {
+        const int c = e / 21, r = e % 21;
+        H[e] = (r < 7 && c < 7) ? hc[c * 7 + r] : (r != c ? T(0) : (r < 14 ? Qxd : Ru));
+    }
+}
+
 // after the initial rollout: candidate slot 0 becomes the current trajectory (initAlgGPU copies slot 0 to xp, up, dp,
 // nisInitHelpers.cuh:378-381).  grid (N, B), block 64.
 template <typename P, typename T>

@@ -88,6 +88,7 @@ struct SolverBase {
     bool h_overridden = false;     // pddp_set_array("H"): the cost Hessian is no longer known to be the plant's own (diagonal for the joint-space cost)
     virtual void drop_graph() = 0;
     virtual int ab_view(int to_compact) = 0;       // compact [A B] handles (ab_compact.hpp): refresh the reference-layout array "AB" from the compact one (0) or the reverse (1)
+    virtual int h_view() = 0;                      // handles with the compact end-effector Hessian block: refresh the reference-layout array "H"
     virtual int ab_keep_reference_layout() = 0;   // leave the compact mode for good (the cost Hessian was overridden: the backward pass reads the reference layout then)
     hipStream_t stream = nullptr;
 };
@@ -153,8 +154,19 @@ struct Solver : SolverBase {
     int ab_keep_reference_layout() override {
         if (!b.ABc) return 0;
         int rc = ab_view(0);
-        b.ABc = nullptr; drop_graph();
+        if (!rc) rc = h_view();
+        b.ABc = nullptr; b.Hc = nullptr; drop_graph();
         return rc;
+    }
+    // end-effector handles with the compact position block: refresh the reference-layout array "H" of the running knots from it (API view)
+    int h_view() override {
+        if constexpr (P::PLANT == 4) {
+            if (b.Hc) {
+                hipLaunchKernelGGL((k_hc_expand<T>), dim3((cfg.batch * cfg.N + 63) / 64), dim3(64), 0, stream, b, (int)(cfg.batch * cfg.N), cfg.N, cw.Q_xdEE, cw.R_EE);
+                HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream));
+            }
+        }
+        return 0;
     }
     int model_changed() override {
         typename P::Model hm;
@@ -276,7 +288,11 @@ struct Solver : SolverBase {
         if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
         if constexpr (P::PLANT == 4) {
             const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
-            if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) { if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc; }
+            if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) {
+                if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc;
+                // end-effector cost: the Gauss-Newton Hessian's only dense part, the 7 x 7 position block, travels compact as well (bp_mfma.hpp HQQ)
+                if (c.ee_cost) { if ((rc = alloc("Hc", &b.Hc, B * N * 49 + 16))) return rc; }
+            }
         }
         if ((rc = alloc("Jpart", &b.Jpart, B * A * M)) || (rc = alloc("dpart", &b.dpart, B * A * M)) || (rc = alloc("parts_fresh", &b.parts_fresh, B))) return rc;
         // device tables of per-alpha pointers, the reference's d_x / d_u / d_d (nisInitHelpers.cuh:777-789,808-813)
@@ -414,7 +430,16 @@ struct Solver : SolverBase {
         if (only < 0 || only == PDDP_PHASE_BP) {
             bool lane_groups = false;
             if constexpr (P::PLANT == 4) lane_groups = bp_lane_groups || bp_mfma;
-            if constexpr (P::PLANT == 4) { if (bp_mfma) launch_bp_mfma<T>(s, b, dm, (int)B, cfg.ee_cost == 0 && !h_overridden, cw.Q1, cw.Q2, cw.R, dt, keep_all_ctg() || store_candidates, sweep_fused && (!store_candidates || phase_fused_sweep)); }
+            if constexpr (P::PLANT == 4) {
+                if (bp_mfma) {
+                    // the running knots' cost Hessian is known without reading it: the joint-space cost's diagonal, or (end-effector cost on the compact path) the diagonal of
+                    // the nominal-state / control weights + the compact position block b.Hc
+                    const bool ee = cfg.ee_cost != 0;
+                    const bool diag_h = !h_overridden && (!ee || b.Hc != nullptr);
+                    launch_bp_mfma<T>(s, b, dm, (int)B, diag_h, ee ? cw.Q_xEE : cw.Q1, ee ? cw.Q_xdEE : cw.Q2, ee ? cw.R_EE : cw.R, dt, keep_all_ctg() || store_candidates,
+                                      sweep_fused && (!store_candidates || phase_fused_sweep));
+                }
+            }
             if constexpr (P::PLANT == 4) { if (lane_groups && !bp_mfma) hipLaunchKernelGGL((k_bp_lg<T>), dim3((B * cfg.M + kLgPerWave - 1) / kLgPerWave), dim3(64), 0, s, b, dm, (int)B); }
             if (!lane_groups) {
                 bool serial = false;
@@ -800,8 +825,8 @@ struct Solver : SolverBase {
         return 0;
     }
     int plant_eval(int what, int count, const void* x, const void* u, void* out) override {
-        if (what < 0 || what > 8 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
-        const size_t osz = (what == 0 || what == 4 || what == 6 || what == 7 ? NP : (what == 1 || what == 5 || what == 8) ? NP * NM : what == 2 ? NX : NX * NM);
+        if (what < 0 || what > 9 || count <= 0 || (what >= 4 && P::PLANT != 4)) return fail(PDDP_EINVAL, "plant_eval: bad arguments");
+        const size_t osz = what == 9 ? 48 : (what == 0 || what == 4 || what == 6 || what == 7 ? NP : (what == 1 || what == 5 || what == 8) ? NP * NM : what == 2 ? NX : NX * NM);
         T *dx, *du_, *dout;
         int rc;
         if ((rc = scratch(0, (size_t)count * NX * sizeof(T), (void**)&dx)) || (rc = scratch(1, (size_t)count * NU * sizeof(T), (void**)&du_)) ||
@@ -814,7 +839,7 @@ struct Solver : SolverBase {
         if (what >= 7) {
             if constexpr (P::PLANT == 4) {
                 if (tl_variant < 0) { return fail(PDDP_EINVAL, "plant_eval: the thread-lane kernels need one of the built-in robot models"); }
-                launch_plant_eval_tl<T>(stream, tl_variant, tl_grav, count, dx, du_, dout, what == 8 ? 1 : 0);
+                launch_plant_eval_tl<T>(stream, tl_variant, what == 9 ? (T)cfg.ee_on_link_z : tl_grav, count, dx, du_, dout, what == 9 ? 2 : what == 8 ? 1 : 0);
             }
         }
         else if (what >= 4) { if constexpr (P::PLANT == 4) hipLaunchKernelGGL((k_plant_eval_lg<T>), dim3(grid), dim3(64), 0, stream, b.model, count, dx, du_, dout, what == 5 ? 1 : (what == 6 ? 2 : 0)); }
@@ -920,6 +945,7 @@ extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_
     if (bytes > cap) return fail(PDDP_EINVAL, "get_array: too many bytes");
     HIPCHK(hipStreamSynchronize(s->stream));
     if (std::strcmp(name, "AB") == 0 && (rc = s->ab_view(0))) return rc;
+    if (std::strcmp(name, "H") == 0 && (rc = s->h_view())) return rc;
     HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost)); return 0;
 }
 extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { IMPL(h); return s->get_state(out); }

@@ -7,29 +7,29 @@
 namespace pddp {
 
 // k_bp_mfma: grid B*M, block 64 -- one wavefront per (problem, block of knots); <= 102 registers so that five waves share a SIMD.  Replaces backPassKern<<<M, (8,7)>>> (bpHelpers.cuh:339-420).
-template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+template <bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bp_mfma(Buffers<float> b, Dims dm, int batch, float hq1, float hq2, float hr, float dt, int flags) {
     __shared__ __attribute__((aligned(16))) float lds[96];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
-    arm_mx_bp_block<float, FS, DIAGH, CAB, FUSE>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
+    arm_mx_bp_block<float, FS, DIAGH, CAB, FUSE, HQQ>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
 }
 // The same tile algebra on v_mfma_f64_16x16x4_f64 for double handles (PDDP_BP=mx; no occupancy target: it exists so that the production algebra can be checked
 // against the oracle at a precision where every step-size decision of a 40-iteration solve is reproducible -- tests/test_f64_benched_family.py).
-template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+template <bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __global__ __launch_bounds__(64) void k_bp_mfma_f64(Buffers<double> b, Dims dm, int batch, double hq1, double hq2, double hr, double dt, int flags) {
     __shared__ __attribute__((aligned(16))) double lds[96];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
-    arm_mx_bp_block<double, FS, DIAGH, CAB, FUSE>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
+    arm_mx_bp_block<double, FS, DIAGH, CAB, FUSE, HQQ>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
 }
-template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+template <bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 static void launch_one(hipStream_t s, unsigned n, const Buffers<float>& b, const Dims& dm, int batch, float hq1, float hq2, float hr, float dt, int kp) {
-    hipLaunchKernelGGL((k_bp_mfma<FS, DIAGH, CAB, FUSE>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp);
+    hipLaunchKernelGGL((k_bp_mfma<FS, DIAGH, CAB, FUSE, HQQ>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp);
 }
-template <bool FS, bool DIAGH, bool CAB, bool FUSE>
+template <bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 static void launch_one(hipStream_t s, unsigned n, const Buffers<double>& b, const Dims& dm, int batch, double hq1, double hq2, double hr, double dt, int kp) {
-    hipLaunchKernelGGL((k_bp_mfma_f64<FS, DIAGH, CAB, FUSE>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp);
+    hipLaunchKernelGGL((k_bp_mfma_f64<FS, DIAGH, CAB, FUSE, HQQ>), dim3(n), dim3(64), 0, s, b, dm, batch, hq1, hq2, hr, dt, kp);
 }
 
 template <typename T>
@@ -39,6 +39,13 @@ void launch_bp_mfma(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batc
     const bool cab = b.ABc != nullptr && diag_h;
 #define PDDP_MX_LAUNCH(FS, DH, CB, FU) launch_one<FS, DH, CB, FU>(s, n, b, dm, batch, hq1, hq2, hr, dt, kp)
     const bool fu = (kp & kMxFuseSweep) != 0;
+    if (cab && b.Hc) {                                                // end-effector handles on the thread-lane / matrix-core path: compact [A B] + the compact position block
+#define PDDP_MX_LAUNCH_Q(FS, FU) launch_one<FS, true, true, FU, true>(s, n, b, dm, batch, hq1, hq2, hr, dt, kp)
+        if (dm.M > 1) { if (fu) PDDP_MX_LAUNCH_Q(true, true); else PDDP_MX_LAUNCH_Q(true, false); }
+        else PDDP_MX_LAUNCH_Q(false, false);
+#undef PDDP_MX_LAUNCH_Q
+        return;
+    }
     if (dm.M > 1) {
         if (cab) { if (fu) PDDP_MX_LAUNCH(true, true, true, true); else PDDP_MX_LAUNCH(true, true, true, false); }
         else if (diag_h) { if (fu) PDDP_MX_LAUNCH(true, true, false, true); else PDDP_MX_LAUNCH(true, true, false, false); }

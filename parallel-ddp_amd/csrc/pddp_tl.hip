@@ -21,7 +21,8 @@ namespace pddp {
 // (fpHelpers.cuh:366,383,388).
 constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | xr 14 | uc 7 | du 7 | pad 6
 constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
-template <typename T, int V, bool ALL>
+// EE: the end-effector cost family (fp_tl.hpp tl_rollout_step_ee): every segment runs NB steps, the cost is accumulated in the rollout.
+template <typename T, int V, bool ALL, bool EE = false>
 __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NU = 7, PS = kFpTlPS;
@@ -32,8 +33,13 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
         const int pb = inst / per_pb, rem = inst - pb * per_pb, seg = rem / A, a_idx = rem - seg * A;
         if (!fp_active<T>(b, dm, pb)) return;
         const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
-        if (ALL) arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_candidate_sink<T>(b, dm, pb, a_idx), true);
-        else arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_state_sink<T>(b, dm, pb, a_idx), true);
+        if (EE) {
+            if (ALL) arm_tl_rollout_segment_ee<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_candidate_sink<T>(b, dm, pb, a_idx), true);
+            else arm_tl_rollout_segment_ee<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_state_sink<T>(b, dm, pb, a_idx), true);
+        } else {
+            if (ALL) arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_candidate_sink<T>(b, dm, pb, a_idx), true);
+            else arm_tl_rollout_segment<T>(md, grav, b, dm, cw, dt, pb, a_idx, seg, xcur, tl_state_sink<T>(b, dm, pb, a_idx), true);
+        }
         return;
     }
     __shared__ __attribute__((aligned(16))) T stage_all[4 * 2 * kFpTlMaxPairs * PS];
@@ -84,30 +90,49 @@ __global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWei
     const int pb = (gp < npairs ? gp : npairs - 1) / M, seg = (gp < npairs ? gp : npairs - 1) - pb * M;
     const bool live = gp < npairs && fp_active<T>(b, dm, pb);
     const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
-    T xg[NX];
+    T xg[NX];                                                         // joint-space goal, or (EE) the 6-vector tool-point goal in xg[0..5]
     tl_load14(xg, b.xGoal + (size_t)pb * NX);
+    T xt[EE ? NX : 1], acc[EE ? NU : 1];                              // EE: nominal-state target, per-joint running cost
+    int tshift = 0;
+    if (EE) {
+        tl_load14(xt, b.xTarget + (size_t)pb * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) acc[i] = T(0);
+        tshift = b.tshift[pb];
+    }
     TlRollout<T> r;
     r.iters = 0;
     const auto csink = tl_candidate_sink<T>(b, dm, pb, a_idx);
     const auto ssink = tl_run_sink<T>(b, dm, pb, a_idx, seg * NBk);
-    if (live) { if (ALL) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, ssink); }
+    if (live) {
+        if (ALL) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, ssink);
+        if (EE) r.iters = NBk;
+    }
     fetch(); park(0);
     wsync();
     for (int k = 0; k < NBk; k++) {
         if (k + 1 < NBk) fetch();                                     // in flight while this step computes
         if (live && k < r.iters) {
             const T* o = stg + (k & 1) * (kFpTlMaxPairs * PS) + p * PS;
-            if (ALL) tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, csink);
-            else tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, ssink);
+            if (EE) {
+                if (ALL) tl_rollout_step_ee<T>(r, acc, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, xt, tshift, csink);
+                else tl_rollout_step_ee<T>(r, acc, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, xt, tshift, ssink);
+            } else {
+                if (ALL) tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, csink);
+                else tl_rollout_step<T>(r, md, grav, b, dm, cw, dt, k, o, o + 98, o + 112, o + 119, xg, ssink);
+            }
         }
         if (k + 1 < NBk) park((k + 1) & 1);
         wsync();
     }
     if (!live) return;
-    T ucN[NU];
+    if (EE) tl_rollout_end_ee<T>(r, acc, dm);
+    else {
+        T ucN[NU];
 #pragma unroll
-    for (int i = 0; i < NU; i++) ucN[i] = b.ucur[((size_t)pb * N + (N - 1)) * NU + i];
-    if (ALL) tl_rollout_end<T>(r, dm, cw, ucN, xg, csink); else tl_rollout_end<T>(r, dm, cw, ucN, xg, ssink);
+        for (int i = 0; i < NU; i++) ucN[i] = b.ucur[((size_t)pb * N + (N - 1)) * NU + i];
+        if (ALL) tl_rollout_end<T>(r, dm, cw, ucN, xg, csink); else tl_rollout_end<T>(r, dm, cw, ucN, xg, ssink);
+    }
     const size_t slot = (size_t)pb * A + a_idx;
     b.Jpart[slot * M + seg] = r.J; b.dpart[slot * M + seg] = r.sdef;
     b.parts_fresh[pb] = 1;
@@ -407,7 +432,7 @@ void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
 constexpr int kNisTlStage = 56 * 65;
 template <typename T> struct NisTlCfg { static constexpr int kWaves = sizeof(T) == 4 ? 4 : 2, kThreads = 64 * kWaves; };   // double: two waves per workgroup (58 KB of staging)
 template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); };
-template <typename T, int V>
+template <typename T, int V, bool EE = false>
 __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NM = 21;
@@ -421,7 +446,11 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
     for (int i = 0; i < NX; i++) x[i] = T(0);                    // a lane without a knot differentiates the zero state (its columns are never flushed)
 #pragma unroll
     for (int i = 0; i < 7; i++) u[i] = T(0);
-    const bool need = (g < total) && arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u);
+    bool need = false;
+    if (g < total) {
+        if (EE) need = arm_tl_nis_cost_ee<T>(md, b, dm, cw, mode, k, pb, x, u);
+        else need = arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u);
+    }
     const unsigned long long mask = __ballot(need);
     if (!mask) return;                                          // (uniform) nothing to differentiate in this wave
     T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot (reference layout)
@@ -570,6 +599,15 @@ __global__ __launch_bounds__(256, 1) void k_plant_eval_tl(T grav, int count, con
     for (int e = 0; e < 14; e++) xi[e] = x[(size_t)i * 14 + e];
     for (int e = 0; e < 7; e++) ui[e] = u[(size_t)i * 7 + e];
     ArmTlState<T> st;
+    if (grad == 2) {                                                   // tool point + Jacobian (`grav` carries EE_ON_LINK_Z here): out[i][6 + 42]
+        ArmTlFrames<T> fr;
+        arm_tl_trig<T>(st, xi); arm_tl_world_chain<true, T>(md, st.c, st.s, fr);
+        T pos[6], dpos[42];
+        arm_tl_tool_point<T>(fr, grav, true, pos); arm_tl_tool_jacobian<T>(fr, grav, dpos);
+        for (int e = 0; e < 6; e++) out[(size_t)i * 48 + e] = pos[e];
+        for (int e = 0; e < 42; e++) out[(size_t)i * 48 + 6 + e] = dpos[e];
+        return;
+    }
     arm_tl_dynamics<T>(md, grav, st, qdd, xi, xi + 7, ui);
     if (!grad) { for (int e = 0; e < 7; e++) out[(size_t)i * 7 + e] = qdd[e]; return; }
     T* o = out + (size_t)i * 147;
@@ -580,14 +618,27 @@ template <typename T>
 void launch_fp_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, int store_candidates) {
     const unsigned inst = (unsigned)batch * dm.M * dm.A;
     const dim3 g((inst + 255) / 256), t(256);
-    if (variant == 0) { if (store_candidates) hipLaunchKernelGGL((k_fp_tl<T, 0, true>), g, t, 0, s, b, dm, cw, dt, grav, batch); else hipLaunchKernelGGL((k_fp_tl<T, 0, false>), g, t, 0, s, b, dm, cw, dt, grav, batch); }
-    else { if (store_candidates) hipLaunchKernelGGL((k_fp_tl<T, 1, true>), g, t, 0, s, b, dm, cw, dt, grav, batch); else hipLaunchKernelGGL((k_fp_tl<T, 1, false>), g, t, 0, s, b, dm, cw, dt, grav, batch); }
+#define PDDP_FP_TL(VV, AL, EEV) hipLaunchKernelGGL((k_fp_tl<T, VV, AL, EEV>), g, t, 0, s, b, dm, cw, dt, grav, batch)
+    if (cw.ee) {
+        if (variant == 0) { if (store_candidates) PDDP_FP_TL(0, true, true); else PDDP_FP_TL(0, false, true); }
+        else { if (store_candidates) PDDP_FP_TL(1, true, true); else PDDP_FP_TL(1, false, true); }
+    } else {
+        if (variant == 0) { if (store_candidates) PDDP_FP_TL(0, true, false); else PDDP_FP_TL(0, false, false); }
+        else { if (store_candidates) PDDP_FP_TL(1, true, false); else PDDP_FP_TL(1, false, false); }
+    }
+#undef PDDP_FP_TL
 }
 template <typename T>
 void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch) {
     const unsigned knots = (unsigned)batch * dm.N, th = NisTlCfg<T>::kThreads;
-    if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0>), dim3((knots + th - 1) / th), dim3(th), 0, s, b, dm, cw, dt, grav, mode, batch);
-    else hipLaunchKernelGGL((k_nis_tl<T, 1>), dim3((knots + th - 1) / th), dim3(th), 0, s, b, dm, cw, dt, grav, mode, batch);
+    const dim3 g((knots + th - 1) / th), t(th);
+    if (cw.ee) {
+        if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0, true>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
+        else hipLaunchKernelGGL((k_nis_tl<T, 1, true>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
+    } else {
+        if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
+        else hipLaunchKernelGGL((k_nis_tl<T, 1>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
+    }
 }
 template <typename T>
 void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T* x, const T* u, T* out, int grad) {

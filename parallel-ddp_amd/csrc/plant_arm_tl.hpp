@@ -495,6 +495,92 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
     arm_tl_gradient<T>(md, grav, st, qd, qdd, emit, [](int) {});
 }
 
+// ------------------------------------------------------------------------------------------------ tool point of the last link (end-effector cost family)
+// World frames by the same chain the dynamics walk in body coordinates: T_i = T_{i-1} F_i Rz(q_i), F_i a signed axis permutation plus a translation along ONE parent axis,
+// so a link costs 12 multiply-adds for the rotation (two columns mix, the third is copied) and 3 for the origin.  Same function as compute_eePos
+// (plants/dynamics_arm.cuh:1879-1925 through load_Tb / compute_T_TA_J / compute_dT_dTA_dJ); the Jacobian is taken from the world joint axes: d p_ee / d q_k = z_k x (p_ee - o_k),
+// d R / d q_k = skew(z_k) R (ee_cost.hpp) -- the same numbers up to rounding, one thread per evaluation.
+template <typename T>
+struct ArmTlFrames {
+    T z[kArmNB][3];          // world joint axes (third column of every link frame; not changed by the joint's own rotation)
+    T o[kArmNB][3];          // world origins of the joint frames
+    T R[9];                  // world rotation of the LAST link, column-major (R[3 c + r])
+};
+template <bool JAC, typename T>
+PDDP_HD void arm_tl_world_chain(const ArmTlModel<T>& md, const T* c, const T* s, ArmTlFrames<T>& f) {
+    T R[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}, o[3] = {T(0), T(0), T(0)};
+    TlFor<0, kArmNB, 1>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int K = arm_tl_kind(i);
+        // origin: the parent's origin + r along the parent's y (AY) or z axis
+        constexpr int ax = (K == kTlAY) ? 1 : 2;
+#pragma unroll
+        for (int e = 0; e < 3; e++) o[e] = o[e] + md.r[i] * R[3 * ax + e];
+        // A = R_parent R_F: columns are signed columns of the parent
+        T A0[3], A1[3], A2[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            if (K == kTlIdZ) { A0[e] = R[e]; A1[e] = R[3 + e]; A2[e] = R[6 + e]; }
+            else if (K == kTlBZ) { A0[e] = R[e]; A1[e] = R[6 + e]; A2[e] = -R[3 + e]; }
+            else { A0[e] = -R[e]; A1[e] = R[6 + e]; A2[e] = R[3 + e]; }
+        }
+        // R = A Rz(q)
+#pragma unroll
+        for (int e = 0; e < 3; e++) { R[e] = c[i] * A0[e] + s[i] * A1[e]; R[3 + e] = c[i] * A1[e] - s[i] * A0[e]; R[6 + e] = A2[e]; }
+        if (JAC) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) { f.z[i][e] = A2[e]; f.o[i][e] = o[e]; }
+        }
+        if (i == kArmNB - 1) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) f.o[i][e] = o[e];
+        }
+    });
+#pragma unroll
+    for (int e = 0; e < 9; e++) f.R[e] = R[e];
+}
+template <typename T> PDDP_HD T tl_atan2(T y, T x);
+template <> PDDP_HD float tl_atan2<float>(float y, float x) { return atan2f(y, x); }
+template <> PDDP_HD double tl_atan2<double>(double y, double x) { return atan2(y, x); }
+// pos[6] = tool point (EE_ON_LINK_X = EE_ON_LINK_Y = 0, dynamics_arm.cuh:48-49) and roll / pitch / yaw (only when they carry weight: a zero weight multiplies them away exactly)
+template <typename T>
+PDDP_HD void arm_tl_tool_point(const ArmTlFrames<T>& f, T ee_z, bool rpy, T* pos) {
+    const T* R = f.R;
+#pragma unroll
+    for (int e = 0; e < 3; e++) pos[e] = R[6 + e] * ee_z + f.o[kArmNB - 1][e];
+    if (rpy) {
+        pos[3] = tl_atan2<T>(R[5], R[8]);                             // Tee[6], Tee[10]
+        pos[4] = tl_atan2<T>(-R[2], tsqrt<T>(R[5] * R[5] + R[8] * R[8]));
+        pos[5] = tl_atan2<T>(R[1], R[0]);
+    } else { pos[3] = T(0); pos[4] = T(0); pos[5] = T(0); }
+}
+// d pos / d q_k, [k][6]  (s_deePos)
+template <typename T>
+PDDP_HD void arm_tl_tool_jacobian(const ArmTlFrames<T>& f, T ee_z, T* dpos) {
+    const T* R = f.R;
+    const T f3 = R[5] * R[5] + R[8] * R[8];
+    const T f4 = T(1) / (R[2] * R[2] + f3);
+    const T f5 = T(1) / (R[1] * R[1] + R[0] * R[0]);
+    const T sq = tsqrt<T>(f3);
+    const T fac[7] = {-R[5] / f3, R[8] / f3, R[2] * R[5] * f4 / sq, R[2] * R[8] * f4 / sq, -sq * f4, -R[1] * f5, R[0] * f5};
+    T pe[3];                                                           // the tool point
+#pragma unroll
+    for (int e = 0; e < 3; e++) pe[e] = R[6 + e] * ee_z + f.o[kArmNB - 1][e];
+#pragma unroll
+    for (int k = 0; k < kArmNB; k++) {
+        const T* z = f.z[k];
+        T arm[3], dp[3], dc0[3], dc1[3], dc2[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) arm[e] = pe[e] - f.o[k][e];
+        cross3(dp, z, arm); cross3(dc0, z, R); cross3(dc1, z, R + 3); cross3(dc2, z, R + 6);
+        T* d = dpos + 6 * k;
+        d[0] = dp[0]; d[1] = dp[1]; d[2] = dp[2];
+        d[3] = fac[0] * dc2[2] + fac[1] * dc1[2];
+        d[4] = fac[2] * dc1[2] + fac[3] * dc2[2] + fac[4] * dc0[2];
+        d[5] = fac[5] * dc0[0] + fac[6] * dc0[1];
+    }
+}
+
 }  // namespace pddp
 
 #if defined(__clang__)

@@ -61,6 +61,8 @@ struct Buffers {
     int *tshift;         // [B] finalCostShift of the end-effector cost (0 unless the MPC call shifts it)
     T *xw;               // [B][N][A][n] candidate states knot-major (thread-lane rollouts -> setup kernel, fp_tl.hpp); null otherwise
     T *segmap;           // [B][M][16*16] per-segment affine maps of the forward sweep composed by the matrix-core backward pass (bp_mfma.hpp kMxFuseSweep); null otherwise
+    T *Hc;               // [B][N][49] the dense 7 x 7 position block Jee' Jee of the end-effector cost's Gauss-Newton Hessian (the rest of H_k is the diagonal of the cost weights):
+                         // thread-lane setup -> matrix-core backward pass of end-effector handles (fp_tl.hpp arm_tl_nis_cost_ee, bp_mfma.hpp HQQ); null otherwise
     T *ABc;              // compact [A B] of the arm's Euler step (ab_compact.hpp) when the handle runs the thread-lane setup + matrix-core backward pass; null otherwise
     T *Jpart, *dpart;    // [B][A][M] per-segment partial cost / defect norm of the thread-lane forward pass (fp_tl.hpp); null otherwise
     int *parts_fresh;    // [B] set by that forward pass, consumed by the line-search kernel (which then adds the partial sums into J / dmax)

@@ -390,7 +390,7 @@ class Solver:
         x, u = self.arr(x).reshape(-1, self.n), self.arr(u).reshape(-1, self.m)
         count = x.shape[0]
         nm = self.n + self.m
-        osz = [self.npos, self.npos * nm, self.n, self.n * nm, self.npos, self.npos * nm, self.npos, self.npos, self.npos * nm][what]
+        osz = [self.npos, self.npos * nm, self.n, self.n * nm, self.npos, self.npos * nm, self.npos, self.npos, self.npos * nm, 48][what]    # 9: tool point[6] + Jacobian[7][6] (thread lanes)
         out = np.zeros((count, osz), self.dtype)
         self._chk(self.lib.pddp_plant_eval(self.h, int(what), count, _p(x), _p(u), _p(out)))
         return out

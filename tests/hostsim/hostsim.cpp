@@ -144,8 +144,13 @@ struct Sim : Base {
                     for (int a = 0; a < cfg.A; a++) if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data()));
                     const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * cfg.N * NX;
                     for (int sg = 0; sg < cfg.M; sg++) for (int a = 0; a < cfg.A; a++) {
-                        if (store_candidates) arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_candidate_sink<T>(b, dm, pb, a), true);
-                        else arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_state_sink<T>(b, dm, pb, a), true);
+                        if (cfg.ee_cost) {
+                            if (store_candidates) arm_tl_rollout_segment_ee<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_candidate_sink<T>(b, dm, pb, a), true);
+                            else arm_tl_rollout_segment_ee<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_state_sink<T>(b, dm, pb, a), true);
+                        } else {
+                            if (store_candidates) arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_candidate_sink<T>(b, dm, pb, a), true);
+                            else arm_tl_rollout_segment<T>(tl_model, model.grav, b, dm, cw, dt, pb, a, sg, xcur, tl_state_sink<T>(b, dm, pb, a), true);
+                        }
                     }
                     continue;
                 }
@@ -176,7 +181,13 @@ struct Sim : Base {
                 const int mode = ph == PDDP_PHASE_INIT_NIS;
                 for (int pb = 0; pb < B; pb++) for (int k = 0; k < cfg.N; k++) {
                     T* AB = b.AB + ((size_t)pb * cfg.N + k) * (NX * NM);
-                    const bool valid = arm_tl_nis_knot<T>(tl_model, model.grav, b, dm, cw, mode, k, pb, [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; });
+                    auto emit = [&](int col, int row, T val) { AB[col * NX + 7 + row] = T(col == 7 + row ? 1 : 0) + dt * val; };
+                    bool valid;
+                    if (cfg.ee_cost) {
+                        T xk[14], uk[7];
+                        valid = arm_tl_nis_cost_ee<T>(tl_model, b, dm, cw, mode, k, pb, xk, uk);
+                        if (valid) arm_tl_nis_jac<T>(tl_model, model.grav, xk, uk, emit, [](int) {});
+                    } else valid = arm_tl_nis_knot<T>(tl_model, model.grav, b, dm, cw, mode, k, pb, emit);
                     if (valid) for (int col = 0; col < NM; col++) for (int r = 0; r < 7; r++) AB[col * NX + r] = tl_AB_const<T>(r, col, dt);
                 }
                 return;
@@ -346,6 +357,12 @@ struct Sim : Base {
                 if constexpr (P::PLANT == 4) {
                     const ArmTlModel<T>& tm = tl_model;
                     ArmTlState<T> ts; T qdd[7];
+                    if (what == 9) {                 // tool point + its Jacobian: out[i][6 + 42]
+                        ArmTlFrames<T> fr; arm_tl_trig<T>(ts, xi); arm_tl_world_chain<true, T>(tm, ts.c, ts.s, fr);
+                        T* o = out + (size_t)i * 48;
+                        arm_tl_tool_point<T>(fr, (T)cfg.ee_on_link_z, true, o); arm_tl_tool_jacobian<T>(fr, (T)cfg.ee_on_link_z, o + 6);
+                        continue;
+                    }
                     arm_tl_dynamics<T>(tm, model.grav, ts, qdd, xi, xi + 7, ui);
                     if (what == 7) std::memcpy(out + (size_t)i * NP, qdd, sizeof(qdd));
                     else { T* o = out + (size_t)i * NP * NM; arm_tl_gradient<T>(tm, model.grav, ts, xi + 7, qdd, [o](int col, int row, T val) { o[7 * col + row] = val; }); }

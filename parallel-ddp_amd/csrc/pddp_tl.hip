@@ -421,18 +421,20 @@ void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
     hipLaunchKernelGGL(k_sweep_wg, dim3((unsigned)batch), dim3(256), sweep_wg_lds(dm), s, b, dm);
 }
 
-// k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  The Jacobian of a wave's 64 knots is staged in
-// LDS (entry-major, padded to 65 so that both the per-thread writes and the transposed reads are conflict-free) and written out in THREE pieces
-// as soon as their columns are complete (arm_tl_gradient's marks: columns {0..3, 7..10}, {4..6, 11..13}, {14..20}): 56 staged entries per knot at most,
-// 14.6 KB per wave, so that two workgroups (two waves per SIMD -- the kernel needs all 256 registers) share a compute unit.
-//   b.ABc != null (the sweep's default): the piece goes to the compact [A B] (ab_compact.hpp) -- the wave's 64 knots x the piece's columns x 7 dynamic rows are ONE
-//                  contiguous 16-byte aligned run of the chunk, written with 16 bytes per lane; the constant rows are not written at all;
-//   b.ABc == null: the reference layout, whole 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
+// k_nis_tl: grid ceil(B*N / 256), block 256.  Thread = knot (global knot index g = pb*N + k).  The Jacobian of a wave's 64 knots is staged in LDS and written out in
+// THREE pieces as soon as their columns are complete (arm_tl_gradient's marks: columns {4..6, 11..13} first -- the composite sweep finishes the outer joints first --,
+// then {0..3, 7..10}, then the controls {14..20}): 57 staged floats per knot at most, 14.6 KB per wave, so that two workgroups (two waves per SIMD -- the kernel needs
+// all 256 registers) share a compute unit.
+//   CAB (b.ABc != null, the sweep's default): the piece goes to the compact [A B] (ab_compact.hpp) -- the wave's 64 knots x the piece's columns x 7 dynamic rows are ONE
+//                  contiguous 16-byte aligned run of the chunk; the producer stages finished elements knot-major, so the flush is a copy with 16 bytes per lane
+//                  (37 groups per lane and knot instead of 147 elements with two divisions each: ~3 k of the kernel's ~13 k instructions per knot were index arithmetic);
+//                  the constant rows are not written at all;
+//   !CAB:          the reference layout, whole 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
 // double handles (PDDP_FP=tl: test selection) run the same code with two waves per workgroup.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
-constexpr int kNisTlStage = 56 * 65;
+constexpr int kNisTlStage = 64 * 57;
 template <typename T> struct NisTlCfg { static constexpr int kWaves = sizeof(T) == 4 ? 4 : 2, kThreads = 64 * kWaves; };   // double: two waves per workgroup (58 KB of staging)
 template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); };
-template <typename T, int V, bool EE = false>
+template <typename T, int V, bool EE, bool CAB>
 __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NM = 21;
@@ -454,29 +456,41 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
     const unsigned long long mask = __ballot(need);
     if (!mask) return;                                          // (uniform) nothing to differentiate in this wave
     T* AB0 = b.AB + (size_t)(g - lane) * (NX * NM);            // [A B] of the wave's first knot (reference layout)
-    T* ABc0 = b.ABc ? b.ABc + (size_t)((g - lane) >> 6) * kAbcChunk : nullptr;   // the wave's chunk of the compact array
-    auto slot = [](int col, int row) -> int {                  // staged position of dqdd(row, col) inside its piece
-        return abc_col_in_piece(col) * 7 + row;
+    T* ABc0 = CAB ? b.ABc + (size_t)((g - lane) >> 6) * kAbcChunk : nullptr;   // the wave's chunk of the compact array
+    constexpr bool compact = CAB;
+    // Staging.  Compact: the producer leaves the FINISHED element ([A B] = I + dt dqdd) at knot * P + (column in piece) * 7 + row, P = the piece's elements per knot
+    // made odd (57 / 43 / 49: conflict-free writes) -- the flush is then a copy of the piece's run, 16 bytes per lane, whose only arithmetic is the step over the
+    // pad at a knot boundary.  Reference layout: raw dqdd entry-major (entry * 65 + knot), finished by the lanes that write whole columns.
+    auto emit = [&](int col, int row, T val) {
+        const int ent = abc_col_in_piece(col) * 7 + row;
+        if (compact) stage[lane * ((abc_piece_cols(abc_piece(col)) * 7) | 1) + ent] = T(col == 7 + row ? 1 : 0) + dt * val;
+        else stage[ent * 65 + lane] = val;
     };
-    auto flush = [&](int piece) {
+    auto flush = [&](auto pc) {
+        constexpr int piece = decltype(pc)::value;
         wsync();
-        const int ncols = abc_piece_cols(piece);
-        if (ABc0) {
-            const int per = ncols * 7, count = 64 * per;        // elements of this piece per knot / per wave (a multiple of 4)
+        constexpr int ncols = abc_piece_cols(piece);
+        if (compact) {
+            constexpr int per = ncols * 7, P = per | 1, count = 64 * per;      // elements of this piece per knot / staged stride / per wave (a multiple of 4)
             T* dst = ABc0 + abc_piece_off(piece);
+            int kk = (4 * lane) / per, ent = 4 * lane - kk * per;
+            const bool whole = (mask == ~0ull);
             for (int e0 = 4 * lane; e0 < count; e0 += 256) {
                 T out[4]; bool ok[4], all = true;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int e = e0 + j, kk = e / per, ent = e - kk * per, ci = ent / 7, r = ent - ci * 7;
-                    out[j] = T(abc_piece_col(piece, ci) == 7 + r ? 1 : 0) + dt * stage[ent * 65 + kk];
-                    ok[j] = (mask >> kk) & 1ull; all = all && ok[j];
+                    const bool over = ent + j >= per;
+                    const int k2 = over ? kk + 1 : kk, en = over ? ent + j - per : ent + j;
+                    out[j] = stage[k2 * P + en];
+                    ok[j] = whole || ((mask >> k2) & 1ull); all = all && ok[j];
                 }
                 if (all) { typename NisTlVec<T>::v4 v; v[0] = out[0]; v[1] = out[1]; v[2] = out[2]; v[3] = out[3]; *reinterpret_cast<typename NisTlVec<T>::v4*>(dst + e0) = v; }
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; j++) if (ok[j]) dst[e0 + j] = out[j];
                 }
+                ent += 256 % per; kk += 256 / per;
+                if (ent >= per) { ent -= per; kk++; }
             }
         } else {
             for (int it = 0; it * 64 < 64 * ncols; it++) {
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
         }
         wsync();
     };
-    arm_tl_nis_jac<T>(md, grav, x, u, [&](int col, int row, T val) { stage[slot(col, row) * 65 + lane] = val; }, flush);
+    arm_tl_nis_jac<T>(md, grav, x, u, emit, flush);
 }
 
 // k_nis_tl7: grid (ceil(B*N / 64), 7), block 64.  Next-iteration setup of a handle with FEW problems in flight (one MPC solve: 127 knots on a 256-CU device):
@@ -632,13 +646,11 @@ template <typename T>
 void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch) {
     const unsigned knots = (unsigned)batch * dm.N, th = NisTlCfg<T>::kThreads;
     const dim3 g((knots + th - 1) / th), t(th);
-    if (cw.ee) {
-        if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0, true>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
-        else hipLaunchKernelGGL((k_nis_tl<T, 1, true>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
-    } else {
-        if (variant == 0) hipLaunchKernelGGL((k_nis_tl<T, 0>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
-        else hipLaunchKernelGGL((k_nis_tl<T, 1>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch);
-    }
+#define PDDP_NIS_TL(VV, EEV) do { if (b.ABc) hipLaunchKernelGGL((k_nis_tl<T, VV, EEV, true>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch); \
+                                  else hipLaunchKernelGGL((k_nis_tl<T, VV, EEV, false>), g, t, 0, s, b, dm, cw, dt, grav, mode, batch); } while (0)
+    if (cw.ee) { if (variant == 0) PDDP_NIS_TL(0, true); else PDDP_NIS_TL(1, true); }
+    else { if (variant == 0) PDDP_NIS_TL(0, false); else PDDP_NIS_TL(1, false); }
+#undef PDDP_NIS_TL
 }
 template <typename T>
 void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T* x, const T* u, T* out, int grad) {

@@ -344,8 +344,8 @@ PDDP_HD void arm_tl_dynamics(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st,
 
 // Gradient of the forward dynamics at (q, qd, u) with qdd from arm_tl_dynamics (st as it left it).
 // emit(col, row, value): dqdd(row, col), col 0..6 d/dq, 7..13 d/dqd, 14..20 d/du   (the plug-in layout s_dqdd[col*7 + row]).
-// mark(stage): called after the columns of joints 0..3 (stage 0: columns 0..3 and 7..10 are complete), of joints 4..6 (stage 1: columns 4..6, 11..13) and
-// of the controls (stage 2: columns 14..20) have been emitted -- a caller that stages the columns somewhere small can flush in three pieces.
+// mark(stage) (an std::integral_constant): called when the columns of joints 4..6 (stage 1: columns 4..6, 11..13), then of joints 0..3 (stage 0: columns 0..3 and
+// 7..10), then of the controls (stage 2: columns 14..20) have been emitted -- a caller that stages the columns somewhere small can flush in three pieces.
 // The gradient in three reusable parts (arm_tl_gradient runs them for every joint; the setup kernel for few problems in flight, k_nis_tl7, gives every
 // joint's columns to a different thread):
 //   arm_tl_grad_nominal:  the nominal inverse dynamics at the actual qdd -- per link the acceleration a, I v, and the total force Ft through its joint
@@ -476,19 +476,175 @@ PDDP_HD void arm_tl_grad_control(const ArmTlState<T>& st, Emit emit) {
 #pragma unroll
     for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
 }
+// ---- the whole gradient on one thread: composite form, O(links) composites + one short transport per (row, column) pair.
+// With every vector read as a geometric object (coordinates of whichever link frame is current), J_j the axis of joint j, v_l / a_l the link motions (a_l with the base's
+// upward acceleration), f_l = I_l a_l + v_l x* I_l v_l, F_k = sum_{l>=k} f_l, Ic_k = sum_{l>=k} I_l:
+//   a change of q_j turns everything outboard of joint j rigidly about J_j, PLUS the same motion offsets for every outboard link l:
+//       dv_l - J_j x v_l = v_j x J_j =: dv_j             da_l - J_j x a_l = c_j - v_l x dv_j,   c_j := -J_j x a_j - dv_j x v_j
+//   so  d f_l / d q_j  = J_j x* f_l + I_l c_j + G_l dv_j,    G_l := d(v x* I v)/dv - I_l crm(v_l)  (a 6x6 that only reads the ANGULAR part of its argument:
+//       G x = [G11 x_w ; -2 p x x_w],  G11 = w~ I - I w~ - (h u' + u h') + 2 (u.h) 1 - n~,  (n; p) = I_l v_l, v_l = (w; u) -- 12 numbers, summed over the outboard links
+//       like the inertias: Gc_k),  and  d f_l / d qd_j = 2 I_l dv_j + G_l J_j.   With tau_i = J_i . F_i (the rigid turn cancels against dJ_i/dq_j):
+//       i <= j:  dtau_i/dq_j = J_i . (J_j x* F_j + Ic_j c_j + Gc_j dv_j)          dtau_i/dqd_j = J_i . (2 Ic_j dv_j + Gc_j J_j)
+//       i >  j:  dtau_i/dq_j = (Ic_i J_i) . c_j + (Gc_i' J_i) . dv_j               dtau_i/dqd_j = 2 (Ic_i J_i) . dv_j + (Gc_i' J_i) . J_j
+// One sweep k = 6..0 keeps Ic_k, Gc_k, F_k in frame k (each moved one frame inwards per level), forms the two force vectors of column k and the two covectors of
+// row k there, and carries those four (21 numbers) through the frames l = k-1..0: (6 + 6 + 6 + 3) x 21 pair transports instead of the 2 x 4 tangent recursions over
+// every outboard link and the 2 x 7 force recursions of the chain form (arm_tl_grad_joint, kept for the one-joint-per-thread kernel).  Column k of dtau is complete
+// when level k ends: it is solved (d qdd = -M^-1 dtau) and emitted there.  Same function as dynamicsGradient<T> (plants/dynamics_arm.cuh:2167-2289).
+template <int KIND, typename T> PDDP_HD void tl_rot_to_parent(T* o, const T* x, T c, T s) {
+    const T n1[3] = {c * x[0] - s * x[1], s * x[0] + c * x[1], x[2]};
+    tl_to_parent_axes<KIND>(o, n1);
+}
 template <typename T, typename Emit, typename Mark>
 PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark) {
     constexpr int NB = kArmNB;
-    ArmTlNominal<T> nm;
-    arm_tl_grad_nominal<T>(md, grav, st, qd, qdd, nm);
-    TlFor<0, NB, 1>::run([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        arm_tl_grad_joint<j, T>(md, st, qd, qdd, nm, emit);
-        if (j == 3) mark(0);
-        if (j == NB - 1) mark(1);
+    // ---- link accelerations at the actual qdd
+    T a[NB][6];
+    {
+        T ap[6] = {T(0), T(0), T(0), T(0), T(0), grav};
+        TlFor<0, NB, 1>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const T* v = st.v[i];
+            tl_motion_to_child<arm_tl_kind(i)>(a[i], ap, md.r[i], st.c[i], st.s[i]);
+            a[i][0] += qd[i] * v[1]; a[i][1] -= qd[i] * v[0]; a[i][2] += qdd[i];
+            a[i][3] += qd[i] * v[4]; a[i][4] -= qd[i] * v[3];
+#pragma unroll
+            for (int e = 0; e < 6; e++) ap[e] = a[i][e];
+        });
+    }
+    T dtq[NB][NB], dtv[NB][NB];          // [column][row]
+    // composites of the links outboard of the current level, in the current frame
+    T cm = T(0), ch[3] = {T(0), T(0), T(0)}, cI[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    T G[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)}, P[3] = {T(0), T(0), T(0)};       // Gc: G11 row-major, summed linear momentum
+    T F[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    TlFor<NB - 1, -1, -1>::run([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T* v = st.v[k];
+        const T* I = md.I[k]; const T* h = md.h[k];
+        // ---- this link joins the composites
+        {
+            T Iv[6], f[6];
+            tl_inertia_mul(Iv, md.m[k], h, I, v);
+            tl_inertia_mul(f, md.m[k], h, I, a[k]);
+            tl_crf_add(f, v, Iv);
+#pragma unroll
+            for (int e = 0; e < 6; e++) F[e] += f[e];
+            cm += md.m[k];
+#pragma unroll
+            for (int e = 0; e < 3; e++) ch[e] += h[e];
+#pragma unroll
+            for (int e = 0; e < 6; e++) cI[e] += I[e];
+            const T Im[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
+            const T w[3] = {v[0], v[1], v[2]}, u[3] = {v[3], v[4], v[5]};
+            T A[9];                               // w~ I
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                A[0 + c] = w[1] * Im[6 + c] - w[2] * Im[3 + c];
+                A[3 + c] = w[2] * Im[0 + c] - w[0] * Im[6 + c];
+                A[6 + c] = w[0] * Im[3 + c] - w[1] * Im[0 + c];
+            }
+            const T uh2 = T(2) * (u[0] * h[0] + u[1] * h[1] + u[2] * h[2]);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) G[3 * r + c] += A[3 * r + c] + A[3 * c + r] - h[r] * u[c] - u[r] * h[c] + (r == c ? uh2 : T(0));
+            G[1] += Iv[2]; G[2] -= Iv[1]; G[3] -= Iv[2]; G[5] += Iv[0]; G[6] += Iv[1]; G[7] -= Iv[0];      // - n~
+            P[0] += Iv[3]; P[1] += Iv[4]; P[2] += Iv[5];
+        }
+        // ---- column k's force vectors, row k's covectors
+        const T dv[6] = {v[1], -v[0], T(0), v[4], -v[3], T(0)};
+        auto offsets = [&](auto lc, T* cl) {       // c_l of link l in its own frame
+            constexpr int l = decltype(lc)::value;
+            const T* vl = st.v[l]; const T* al = a[l];
+            const T s2 = vl[0] * vl[0] + vl[1] * vl[1], su = vl[0] * vl[3] + vl[1] * vl[4];
+            cl[0] = al[1] + vl[0] * vl[2]; cl[1] = -al[0] + vl[1] * vl[2]; cl[2] = -s2;
+            cl[3] = al[4] + vl[0] * vl[5] + vl[3] * vl[2]; cl[4] = -al[3] + vl[1] * vl[5] + vl[4] * vl[2]; cl[5] = -(su + su);
+        };
+        T ck[6];
+        offsets(kc, ck);
+        T wq[6], wv[6];
+        tl_inertia_mul(wq, cm, ch, cI, ck);
+        wq[0] += -F[1] + G[0] * dv[0] + G[1] * dv[1]; wq[1] += F[0] + G[3] * dv[0] + G[4] * dv[1]; wq[2] += G[6] * dv[0] + G[7] * dv[1];
+        wq[3] += -F[4] - T(2) * (P[2] * v[0]); wq[4] += F[3] - T(2) * (P[2] * v[1]); wq[5] += T(2) * (P[0] * v[0] + P[1] * v[1]);
+        tl_inertia_mul(wv, cm, ch, cI, dv);
+#pragma unroll
+        for (int e = 0; e < 6; e++) wv[e] += wv[e];
+        wv[0] += G[2]; wv[1] += G[5]; wv[2] += G[8]; wv[3] -= T(2) * P[1]; wv[4] += T(2) * P[0];
+        T y[6] = {cI[4], cI[5], cI[2], -ch[1], ch[0], T(0)}, gr[3] = {G[6], G[7], G[8]};
+        dtq[k][k] = wq[2]; dtv[k][k] = wv[2] + T(0.5);
+        TlFor<k - 1, -1, -1>::run([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int K = arm_tl_kind(l + 1);
+            T t6[6], t3[3];
+            tl_force_to_parent<K>(t6, wq, md.r[l + 1], st.c[l + 1], st.s[l + 1]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) wq[e] = t6[e];
+            tl_force_to_parent<K>(t6, wv, md.r[l + 1], st.c[l + 1], st.s[l + 1]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) wv[e] = t6[e];
+            tl_force_to_parent<K>(t6, y, md.r[l + 1], st.c[l + 1], st.s[l + 1]);
+#pragma unroll
+            for (int e = 0; e < 6; e++) y[e] = t6[e];
+            tl_rot_to_parent<K>(t3, gr, st.c[l + 1], st.s[l + 1]);
+#pragma unroll
+            for (int e = 0; e < 3; e++) gr[e] = t3[e];
+            dtq[k][l] = wq[2]; dtv[k][l] = wv[2];
+            const T* vl = st.v[l];
+            T cl[6];
+            offsets(lc, cl);
+            dtq[l][k] = y[0] * cl[0] + y[1] * cl[1] + y[2] * cl[2] + y[3] * cl[3] + y[4] * cl[4] + y[5] * cl[5] + (gr[0] * vl[1] - gr[1] * vl[0]);
+            const T yd = y[0] * vl[1] - y[1] * vl[0] + y[3] * vl[4] - y[4] * vl[3];
+            dtv[l][k] = yd + yd + gr[2];
+        });
+        // ---- column k is complete: d qdd / d(q_k, qd_k) = -M^-1 dtau
+        {
+            T cq[NB], cv[NB];
+#pragma unroll
+            for (int i = 0; i < NB; i++) { cq[i] = -dtq[k][i]; cv[i] = -dtv[k][i]; }
+            tl_ldl_solve(st, cq);
+            tl_ldl_solve(st, cv);
+#pragma unroll
+            for (int i = 0; i < NB; i++) { emit(k, i, cq[i]); emit(NB + k, i, cv[i]); }
+        }
+        if (k == 4) mark(std::integral_constant<int, 1>());
+        if (k == 0) mark(std::integral_constant<int, 0>());
+        // ---- the composites move one frame inwards
+        if (k > 0) {
+            constexpr int K = arm_tl_kind(k);
+            const T r = md.r[k], c = st.c[k], s = st.s[k];
+            T t6[6];
+            tl_force_to_parent<K>(t6, F, r, c, s);
+#pragma unroll
+            for (int e = 0; e < 6; e++) F[e] = t6[e];
+            T pm = T(0), ph[3] = {T(0), T(0), T(0)}, pI[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+            tl_inertia_add_to_parent<K>(pm, ph, pI, cm, ch, cI, r, c, s);
+            cm = pm;
+#pragma unroll
+            for (int e = 0; e < 3; e++) ch[e] = ph[e];
+#pragma unroll
+            for (int e = 0; e < 6; e++) cI[e] = pI[e];
+            T M1[9], M2[9], p2[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {      // columns, then rows: (R G R')
+                const T col[3] = {G[cc], G[3 + cc], G[6 + cc]};
+                T o3[3];
+                tl_rot_to_parent<K>(o3, col, c, s);
+                M1[cc] = o3[0]; M1[3 + cc] = o3[1]; M1[6 + cc] = o3[2];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) tl_rot_to_parent<K>(M2 + 3 * rr, M1 + 3 * rr, c, s);
+            tl_rot_to_parent<K>(p2, P, c, s);
+            constexpr int ax = (K == kTlAY) ? 1 : 2;       // the frame's offset r lies along this parent axis:  G11 -= 2 r~ p~ = 2 (p r' - (r.p) 1)
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if (i != ax) { M2[3 * i + ax] -= T(2) * (r * p2[i]); M2[3 * i + i] += T(2) * (r * p2[ax]); }
+#pragma unroll
+            for (int e = 0; e < 9; e++) G[e] = M2[e];
+#pragma unroll
+            for (int e = 0; e < 3; e++) P[e] = p2[e];
+        }
     });
     TlFor<0, NB, 1>::run([&](auto jc) { arm_tl_grad_control<decltype(jc)::value, T>(st, emit); });
-    mark(2);
+    mark(std::integral_constant<int, 2>());
 }
 template <typename T, typename Emit>
 PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit) {

@@ -19,11 +19,13 @@ namespace pddp {
 // ALL = true (pddp_run_phase(FP), teacher-forced tests): the controls go to us as well, as the reference keeps them.
 // The linear sweep (k_sweep_st) runs before it.  Replaces forwardSimKern<<<(M,A),(8,7)>>> + costKern<<<A,N>>> + defectKern<<<A,N>>>
 // (fpHelpers.cuh:366,383,388).
+// The production instantiation (float, joint-space cost, states only) is held to 168 registers -- three waves per SIMD, no scratch: 0.695 -> 0.654 ms at 16384 problems
+// on one box (tools/ab_lib.sh); at 128 registers (four waves) it spills 212 bytes per lane and takes 1.3 ms.
 constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | xr 14 | uc 7 | du 7 | pad 6
 constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
 // EE: the end-effector cost family (fp_tl.hpp tl_rollout_step_ee): every segment runs NB steps, the cost is accumulated in the rollout.
 template <typename T, int V, bool ALL, bool EE = false>
-__global__ __launch_bounds__(256, 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 && !EE && !ALL ? 3 : 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NU = 7, PS = kFpTlPS;
     const int A = dm.A, M = dm.M, N = dm.N, NBk = dm.NB, per_pb = M * A, total = batch * per_pb;

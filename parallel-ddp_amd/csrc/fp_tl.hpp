@@ -432,9 +432,14 @@ PDDP_HD void arm_tl_rollout_segment_ee(const ArmTlModel<T>& md, T grav, const Bu
 // dense part, the 7 x 7 position block Jee' Jee (+ Qx on its diagonal), into the compact array b.Hc when the handle keeps one (the matrix-core backward pass rebuilds the rest
 // from the cost weights); the reference-layout H_k is written for the final knot (the backward pass starts from it) and in init mode (the API view) -- and for every knot when
 // there is no compact array; init mode also leaves the knot's cost in costk (costGrad's d_JT, initAlgGPU).  Returns false when the knot has no Jacobian of the dynamics to write.
+// arm_tl_nis_cost_ee_knot: the cost part at a given (x, u).  h_block_only (few problems in flight, no compact array): outside init mode only the position block of H_k is
+// rewritten -- the rest of the block is the constant diagonal init mode wrote.
+template <typename T>
+PDDP_HD bool arm_tl_nis_cost_ee_knot(const ArmTlModel<T>& md, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, const T* x, const T* u,
+                                     bool h_block_only = false);
 template <typename T>
 PDDP_HD bool arm_tl_nis_cost_ee(const ArmTlModel<T>& md, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, T* x, T* u) {
-    constexpr int NX = 14, NU = 7, NM = 21, NP = 7;
+    constexpr int NX = 14, NU = 7;
     const int N = dm.N;
     const SolverState<T>& st = b.state[pb];
     const size_t knot = (size_t)pb * N + k;
@@ -447,6 +452,14 @@ PDDP_HD bool arm_tl_nis_cost_ee(const ArmTlModel<T>& md, const Buffers<T>& b, co
 #pragma unroll
         for (int i = 0; i < NU; i++) u[i] = b.ucur[knot * NU + i];
     }
+    return arm_tl_nis_cost_ee_knot<T>(md, b, dm, cw, mode, k, pb, x, u);
+}
+template <typename T>
+PDDP_HD bool arm_tl_nis_cost_ee_knot(const ArmTlModel<T>& md, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, const T* x, const T* u,
+                                     bool h_block_only) {
+    constexpr int NX = 14, NM = 21, NP = 7;
+    const int N = dm.N;
+    const size_t knot = (size_t)pb * N + k;
     const bool fin = (k == N - 1), fin_ee = k >= N - 1 - b.tshift[pb];
     ArmTlState<T> ts;
     arm_tl_trig<T>(ts, x);
@@ -489,7 +502,7 @@ PDDP_HD bool arm_tl_nis_cost_ee(const ArmTlModel<T>& md, const Buffers<T>& b, co
     }
     if (!b.Hc || fin || mode == 1) {
         T* H = b.H + knot * (NM * NM);
-        for (int e = 0; e < NM * NM; e++) {
+        if (!(h_block_only && mode != 1)) for (int e = 0; e < NM * NM; e++) {
             const int c = e / NM, r = e % NM;
             H[e] = (r < NP && c < NP) ? T(0) : (r != c ? T(0) : (r < NX ? Qxd : Ru));
         }

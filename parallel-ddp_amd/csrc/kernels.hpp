@@ -266,8 +266,14 @@ __global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
 template <typename P, int INTEG, typename T, int V = -1>
 __global__ __launch_bounds__(256) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout) {
     __shared__ MpcScratch<P, T> s;
+    float* pipe = nullptr;
+    if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) {       // the warm-start rollout as a pipeline over three waves (fp_pipe.hpp)
+        __shared__ __attribute__((aligned(16))) float pipe_lds[kPipeLdsOpenLoop / 4];
+        pipe = pipe_lds;
+        if (threadIdx.x < kPipeFlags) tl_pipe_lds(pipe, false).flag[threadIdx.x] = 0;       // (the body's first block-wide sync comes before the rollout)
+    }
     mpc_load_body<P, INTEG, T, V>(this_wave(), s, b, mb, dm, dt, blockIdx.x, xActual + (size_t)blockIdx.x * P::NX, shift[blockIdx.x], clear_vars, full_rollout,
-                                  (int)threadIdx.x >> 6, 4);
+                                  (int)threadIdx.x >> 6, 4, pipe);
 }
 template <typename P, typename T>
 __global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm, int only_exited) {

@@ -14,6 +14,7 @@
 #pragma once
 
 #include "fp.hpp"
+#include "fp_pipe.hpp"
 #include "plant_arm_lg.hpp"
 #include "solver_state.hpp"
 
@@ -65,12 +66,11 @@ struct MpcScratch {
     typename P::Scratch plant;
     IntegScratch<P, T> integ;
     T x[P::NX], xn[P::NX], u[P::NU], dx[P::NX];
-    T tau[8];                 // split warm-start rollout (two waves): joint torques minus bias from wave 0 to wave 1
 };
 
 template <typename P, int INTEG, typename T, int V = -1>
 PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>& b, const MpcBuffers<T>& mb, const Dims& dm, T dt, int pb,
-                           const T* xActual, int shift, int clear_vars, int full_rollout, int wave_id = 0, int nwaves = 1) {
+                           const T* xActual, int shift, int clear_vars, int full_rollout, int wave_id = 0, int nwaves = 1, float* pipe = nullptr) {
     // wave_id / nwaves: the workgroup's waves share the shifting and the fall-back copies (task t runs on wave t % nwaves); the rollout is wave 0's
     constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
     const int N = dm.N;
@@ -114,53 +114,39 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
     bool split_done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) {
-        // The arm in float with a built-in robot model: the serial open-loop rollout (64 steps: the longest single item of a control cycle) runs like k_fp_tl2 --
-        // every step split over waves 0 and 1 (Newton-Euler bias | composite bodies, mass matrix, L D L'; then solve + Euler step), one lane each.
-        if (nwaves >= 2) {
-            if (wave_id > 1) return;
-            constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+        // The arm in float with a built-in robot model: the serial open-loop rollout (64 steps: the longest single item of a control cycle) runs as the pipeline of
+        // fp_pipe.hpp -- wave 0 walks the chain (Newton-Euler bias, solve, Euler step), waves 1 and 2 factor the mass matrix of alternate steps one step ahead and
+        // store the states they pick up; every lane of a wave carries the same rollout, lane 0 stores it.
+        if (nwaves >= 3 && pipe) {
+            if (wave_id > 2) return;
             const T grav = reinterpret_cast<const ArmModel<T>*>(b.model)->grav;
             const int n_roll = full_rollout ? N : dm.NB;
+            const TlPipeLds pl = tl_pipe_lds(pipe, false);
             T xx[NX];
 #pragma unroll
             for (int i = 0; i < NX; i++) xx[i] = xActual[i];
-            if (wave_id == 1 && w.lane == 0) {
+            if (wave_id > 0) { tl_pipe_factor_wave<V>(pl, wave_id - 1, n_roll - 1, xx, dt, w.lane, x0); return; }      // (they also store x_1 .. x_{n_roll - 3})
+            if (w.lane == 0) {
 #pragma unroll
                 for (int i = 0; i < NX; i++) x0[i] = xx[i];
             }
+            T un[NU];
+#pragma unroll
+            for (int i = 0; i < NU; i++) un[i] = u[i];
             for (int k = 0; k < n_roll - 1; k++) {
-                ArmTlState<T> st;
-                if (wave_id == 0) {
-                    if (w.lane == 0) {
-                        T bias[NU];
-                        arm_tl_trig<T>(st, xx);
-                        arm_tl_bias<T>(md, grav, st, xx + 7, bias);
+                T uk[NU];
 #pragma unroll
-                        for (int i = 0; i < NU; i++) s.tau[i] = u[NU * k + i] - bias[i];
-                    }
-                    __syncthreads();
-                    __syncthreads();
+                for (int i = 0; i < NU; i++) uk[i] = un[i];
+                if (k + 1 < n_roll - 1) {
 #pragma unroll
-                    for (int i = 0; i < NX; i++) xx[i] = s.xn[i];
-                } else {
-                    if (w.lane == 0) { arm_tl_trig<T>(st, xx); arm_tl_factor<T>(md, st); }
-                    __syncthreads();
-                    if (w.lane == 0) {
-                        T qdd[NU];
+                    for (int i = 0; i < NU; i++) un[i] = u[NU * (k + 1) + i];
+                }
+                tl_pipe_chain_step<V, false>(pl, k, xx, uk, dt, grav, w.lane);
+                if (w.lane == 0 && k + 1 >= n_roll - 2) {                 // the last two states (no factor wave picks them up)
 #pragma unroll
-                        for (int i = 0; i < NU; i++) qdd[i] = s.tau[i];
-                        tl_ldl_solve(st, qdd);
-#pragma unroll
-                        for (int i = 0; i < 7; i++) { const T qn = xx[i] + dt * xx[7 + i], vn = xx[7 + i] + dt * qdd[i]; s.xn[i] = qn; s.xn[7 + i] = vn; }
-#pragma unroll
-                        for (int i = 0; i < NX; i++) x0[NX * (k + 1) + i] = s.xn[i];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < NX; i++) xx[i] = s.xn[i];
+                    for (int i = 0; i < NX; i++) x0[NX * (k + 1) + i] = xx[i];
                 }
             }
-            if (wave_id == 1) return;
             __threadfence_block();
             split_done = true;
         }

@@ -123,7 +123,8 @@ struct Solver : SolverBase {
     bool bp_lane_groups = false;
     bool fp_coop = false;          // PDDP_FP=coop
     static constexpr int kNisTl7MaxBatch = 511;   // measured crossover against k_nis_lg (profiles/)
-    bool fp_split = false;         // rollouts of a lane-group handle on the split thread-lane kernel (k_fp_tl2)
+    bool fp_split = false;         // rollouts of a lane-group handle on the split thread-lane kernels (k_fp_tl4 / k_fp_tl2)
+    bool fp_two_wave = false;
     FpPath fp_path = kFpLg;        // the arm's forward pass / next-iteration setup (fp_tl.hpp select_fp_path)
     int tl_variant = -1;           // which built-in robot model the handle's tables equal (the thread-lane kernels fold it into literals); -1: neither
     T tl_grav = T(0);
@@ -140,7 +141,9 @@ struct Solver : SolverBase {
         // few problems in flight, joint-space cost, float, built-in robot model: the rollouts run on k_fp_tl2 (every step split over two wavefronts);
         // sweep, line search and setup stay on the lane-group kernels.  PDDP_FP=lg keeps the lane-group rollouts (bit-identity tests), PDDP_FP=tl2 asks for the split.
         const char* fpenv = std::getenv("PDDP_FP");
-        fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.ee_cost && !cfg.use_finite_diff && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
+        fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.use_finite_diff && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
+        // the split's current form is the four-wave pipeline (k_fp_tl4, fp_pipe.hpp; also the end-effector cost family); PDDP_FP=tl2 keeps the two-wave kernel (joint-space cost only)
+        fp_two_wave = fp_split && !cfg.ee_cost && fpenv && std::string(fpenv) == "tl2";
     }
     void derive_tl_model(const EmptyModel&) {}
     // pddp_set_array("model_I" / "model_F"): re-derive what the kernels take from the model tables as launch arguments
@@ -389,7 +392,12 @@ struct Solver : SolverBase {
                 if (!st) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             }
             if (part == 0) return;
-            if constexpr (sizeof(T) == 4) { if (!init_rollout && fp_split) { launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); return; } }
+            if constexpr (sizeof(T) == 4) {
+                if (!init_rollout && fp_split) {
+                    if (fp_two_wave) launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); else launch_fp_tl4(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
+                    return;
+                }
+            }
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
                 launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
                 return;
@@ -459,7 +467,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? "k_fp_tl2" : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

@@ -5,6 +5,7 @@
 #include "ab_compact.hpp"
 #include "bodies.hpp"
 #include "fp_lg.hpp"
+#include "fp_pipe.hpp"
 #include "tl_launch.hpp"
 
 namespace pddp {
@@ -257,6 +258,144 @@ void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Di
     const unsigned inst = (unsigned)batch * dm.M * dm.A;
     if (variant == 0) hipLaunchKernelGGL((k_fp_tl2<0>), dim3((inst + 63) / 64), dim3(128), 0, s, b, dm, cw, dt, grav, batch);
     else hipLaunchKernelGGL((k_fp_tl2<1>), dim3((inst + 63) / 64), dim3(128), 0, s, b, dm, cw, dt, grav, batch);
+}
+
+// k_fp_tl4: grid ceil(B*M*A / 64), block 256, dynamic LDS kPipeLdsClosedLoop.  The rollouts of a handle with FEW problems in flight as a pipeline over the workgroup's four
+// waves (fp_pipe.hpp): lane = rollout in every wave; wave 0 walks the chain x_k -> x_{k+1}, waves 2 and 3 factor the mass matrix of alternate steps one step AHEAD (Euler's
+// q_{k+1} needs no dynamics), wave 1 evaluates the control law on x_k while the chain computes its bias, stores the trajectory and adds up the cost.
+// ~650 dependent instructions per step on the chain instead of ~1100 with k_fp_tl2's two barriers per step.  Candidates are stored like the reference's (x, u, d); cost / defect
+// leave as per-segment partial sums.  EE: the end-effector cost family (tl_rollout_step_ee's conditions: every segment runs NB steps, the "final" state of a non-final
+// segment carries no cost, knot N - 1 no dynamics).  Same arithmetic as k_fp_tl: under the float32 bar.
+template <int V, bool EE>
+__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<float> b, Dims dm, CostWeights<float> cw, float dt, float grav, int batch) {
+    using T = float;
+    constexpr int NX = 14, NU = 7;
+    extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
+    const TlPipeLds p = tl_pipe_lds(pipe_lds, true);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < kPipeFlags) p.flag[threadIdx.x] = 0;
+    const int A = dm.A, M = dm.M, N = dm.N, NBk = dm.NB, total = batch * M * A;
+    const int inst_raw = blockIdx.x * 64 + lane, inst = inst_raw < total ? inst_raw : total - 1;
+    const int pb = inst / (M * A), rem = inst - pb * (M * A), seg = rem / A, a_idx = rem - seg * A;
+    const bool live = inst_raw < total && fp_active<T>(b, dm, pb);
+    const int kStart = seg * NBk;
+    const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
+    const size_t slot = (size_t)pb * A + a_idx;
+    T* xs = b.xs + slot * N * NX; T* us = b.us + slot * N * NU; T* ds = b.ds + slot * N * NX;
+    T x[NX];
+    if (seg == 0) tl_load14(x, xcur); else tl_load14(x, xs + (size_t)kStart * NX);
+    __syncthreads();                                                    // the counters are zero
+    if (wave >= 2) { tl_pipe_factor_wave<V>(p, wave - 2, NBk, x, dt, lane); return; }
+    if (wave == 0) {
+        // ---------------------------------------------------------------- chain
+        for (int k = 0; k < NBk; k++) tl_pipe_chain_step<V, true>(p, k, x, nullptr, dt, grav, lane);
+        return;
+    }
+    // -------------------------------------------------------------------- control wave: operands, trajectory out, cost
+    const T alpha = b.alpha[a_idx];
+    const T* KT = b.KT + (size_t)pb * N * NX * NU; const T* uc = b.ucur + (size_t)pb * N * NU; const T* du = b.du + (size_t)pb * N * NU;
+    T xg[NX], goal[6], acc7s[NU];
+    int tshift = 0;
+    if (EE) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) goal[i] = b.xGoal[(size_t)pb * NX + i];
+        tl_load14(xg, b.xTarget + (size_t)pb * NX);
+        tshift = b.tshift[pb];
+#pragma unroll
+        for (int i = 0; i < NU; i++) acc7s[i] = T(0);
+    } else tl_load14(xg, b.xGoal + (size_t)pb * NX);
+    T J = T(0), sdef = T(0);
+    T nK[NX * NU], nxr[NX], nuc[NU], ndu[NU];
+    auto fetch = [&](int kn) {
+#pragma unroll
+        for (int rr = 0; rr < NU; rr++) tl_load14(nK + rr * NX, KT + (size_t)kn * (NX * NU) + rr * NX);
+        tl_load14(nxr, xcur + (size_t)kn * NX);
+#pragma unroll
+        for (int i = 0; i < NU; i++) { nuc[i] = uc[(size_t)kn * NU + i]; ndu[i] = du[(size_t)kn * NU + i]; }
+    };
+    fetch(kStart);
+    if (live) tl_store14(xs + (size_t)kStart * NX, x);                    // (a candidate slot already holds it for seg > 0)
+    const int iters = EE ? NBk : ((seg < M - 1) ? NBk : NBk - 1);
+    for (int k = 0; k < NBk; k++) {
+        const int kn = kStart + k;
+        if (k > 0) {
+            T xv[16];
+            tl_pipe_wait(p.flag + 0, k);
+            tl_pipe_ld<4>(xv, p.xbuf + (((k & 1) * 64) + lane) * kPipeSX);
+#pragma unroll
+            for (int i = 0; i < NX; i++) x[i] = xv[i];
+        }
+        T u[8];
+        tl_control_law<T>(u, alpha, ndu, nK, x, nxr, nuc);
+        u[7] = T(0);
+        tl_pipe_st<2>(p.ubuf + (((k & 1) * 64) + lane) * kPipeSU, u);
+        tl_pipe_post(p.flag + 1, k + 1);
+        if (k + 1 < NBk) fetch(kn + 1);                                   // in flight while the chain walks step k (kn + 1 <= N - 1)
+        if (k > 0 && live) tl_store14(xs + (size_t)kn * NX, x);
+        if (live && k < iters) {
+#pragma unroll
+            for (int i = 0; i < NU; i++) us[(size_t)kn * NU + i] = u[i];
+            if (!EE) J += arm_tl_cost<T>(cw, x, u, xg, false);
+            else if (k < NBk - 1 || seg == M - 1) {
+                constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+                ArmTlState<T> st;
+                arm_tl_trig<T>(st, x);
+                ArmTlFrames<T> fr;
+                arm_tl_world_chain<false, T>(md, st.c, st.s, fr);
+                T pos[6];
+                arm_tl_tool_point<T>(fr, cw.ee_z, tl_ee_rpy_weighted<T>(cw), pos);
+#pragma unroll
+                for (int ind = 0; ind < NU; ind++) {
+                    T cost = T(0);
+                    if (ind == 0) cost += ee_term<T>(cw, pos, goal, kn >= N - 1 - tshift);
+                    acc7s[ind] += ee_joint_terms<T>(cw, x, u, xg, ind, kn, N, cost);
+                }
+            }
+        }
+    }
+    if (seg < M - 1) {                                                    // the step out of the segment's last knot: defect against the next segment's start
+        tl_pipe_wait(p.flag + 0, NBk);
+        if (live) {
+            T xi[16];
+            tl_pipe_ld<4>(xi, p.xbuf + ((((NBk) & 1) * 64) + lane) * kPipeSX);
+            const int ks = (seg + 1) * NBk;
+            T xnext[NX], e[NX];
+            tl_load14(xnext, xs + (size_t)ks * NX);
+#pragma unroll
+            for (int i = 0; i < NX; i++) { e[i] = xi[i] - xnext[i]; sdef += tabs(e[i]); }
+            tl_store14(ds + (size_t)(ks - 1) * NX, e);
+        }
+    } else if (!EE && live) {                                             // terminal knot: its (unused) control is carried along (tl_rollout_end)
+        T u[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) { u[i] = uc[(size_t)(N - 1) * NU + i]; us[(size_t)(N - 1) * NU + i] = u[i]; }
+        J += arm_tl_cost<T>(cw, x, u, xg, true);
+    }
+    if (live) {
+        if (EE) J = acc7s[0] + acc7s[1] + acc7s[2] + acc7s[3] + acc7s[4] + acc7s[5] + acc7s[6];
+        b.Jpart[slot * M + seg] = J;
+        b.dpart[slot * M + seg] = (seg == M - 1) ? T(0) : sdef;
+        b.parts_fresh[pb] = 1;
+    }
+}
+void launch_fp_tl4(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int batch) {
+    const unsigned inst = (unsigned)batch * dm.M * dm.A;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
+        attr_set = true;
+    }
+    const dim3 g((inst + 63) / 64), t(256);
+    if (cw.ee) {
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<0, true>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
+        else hipLaunchKernelGGL((k_fp_tl4<1, true>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
+    } else {
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<0, false>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
+        else hipLaunchKernelGGL((k_fp_tl4<1, false>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
+    }
 }
 
 // k_sweep_st: grid ceil(2 B / 8), block 64.  The linear sweep of forwardSweepKern (fpHelpers.cuh:19-63) for ALL candidates of a problem at once.
@@ -519,7 +658,9 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
 // ~11 k of a whole knot on one thread (k_nis_tl), on 7 x as many waves.  Joint 0's threads also adopt the accepted candidate (a copy of its x, u, d from the
 // candidate-major arrays the split rollout kernel k_fp_tl2 wrote) and write the cost gradient (mode 1: the cost Hessian).  Reference layout of [A B].
 // Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279), like k_nis_lg.
-template <int V>
+// EE: the end-effector cost family -- an eighth row of workgroups (blockIdx.y == 7) evaluates the tool point, its Jacobian, g_k and the position block of H_k
+// (arm_tl_nis_cost_ee_knot), one thread per knot.
+template <int V, bool EE>
 __global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostWeights<float> cw, float dt, float grav, int mode, int batch) {
     using T = float;
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
@@ -549,7 +690,9 @@ __global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostW
         for (int i = 0; i < NU; i++) u[i] = b.ucur[knot * NU + i];
     }
     const bool fin = (k == N - 1);
-    if (J == 0) {
+    if (EE) {
+        if (J == 7) { arm_tl_nis_cost_ee_knot<T>(md, b, dm, cw, mode, k, pb, x, u, true); return; }
+    } else if (J == 0) {
         const T w1 = fin ? cw.QF1 : cw.Q1, w2 = fin ? cw.QF2 : cw.Q2, w3 = fin ? T(0) : cw.R;   // ArmPlant::weight
         T xg[NX];
         tl_load14(xg, b.xGoal + (size_t)pb * NX);
@@ -580,9 +723,12 @@ __global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostW
     }
 }
 void launch_nis_tl7(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int mode, int batch) {
-    const dim3 grid(((unsigned)batch * dm.N + 63) / 64, 7);
-    if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<0>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
-    else hipLaunchKernelGGL((k_nis_tl7<1>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+    const dim3 grid(((unsigned)batch * dm.N + 63) / 64, cw.ee ? 8 : 7);
+    if (cw.ee) {
+        if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<0, true>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+        else hipLaunchKernelGGL((k_nis_tl7<1, true>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+    } else if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<0, false>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+    else hipLaunchKernelGGL((k_nis_tl7<1, false>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
 }
 
 // API view of the compact [A B]: grid ceil(B*N*21 / 256), block 256, thread = (knot, column).  expand: compact -> the reference layout (pddp_get_array("AB"));

@@ -30,16 +30,19 @@ constexpr int kPipeFlags = 8;                                                   
 constexpr int kPipeLdsOpenLoop = (kPipeXbuf + kPipeLbuf + kPipeFlags) * 4;          // bytes: chain + factor waves
 constexpr int kPipeLdsClosedLoop = (kPipeXbuf + kPipeLbuf + kPipeUbuf + kPipeFlags) * 4;
 
+// the step counters are accessed as LDS (address space 3) explicitly: through a generic volatile pointer the compiler emits FLAT loads / stores with system-coherence bits --
+// every poll and post then takes the flat path instead of a ds_read / ds_write (found in the ISA: 73 -> 6x us per 32 steps)
+typedef __attribute__((address_space(3))) volatile int tl_pipe_flag;
 struct TlPipeLds {
     float* xbuf;            // [2][64][20]   x_k at slot k & 1
     float* lbuf;            // [2][64][44]   step k's c[7] s[7] (2 pad) L[21] Dinv[7] at slot k & 1
     float* ubuf;            // [2][64][12]   u_k (closed loop)
-    volatile int* flag;     // [0] x: v = x_v is in xbuf   [1] u: v = u_{v-1} is in ubuf   [3 + r] cs, [5 + r] l: v = step v-1's are in lbuf[r]
+    tl_pipe_flag* flag;     // [0] x: v = x_v is in xbuf   [1] u: v = u_{v-1} is in ubuf   [3 + r] cs, [5 + r] l: v = step v-1's are in lbuf[r]
 };
 __device__ __forceinline__ TlPipeLds tl_pipe_lds(float* base, bool closed_loop) {
     TlPipeLds p;
     p.xbuf = base; p.lbuf = p.xbuf + kPipeXbuf; p.ubuf = p.lbuf + kPipeLbuf;
-    p.flag = reinterpret_cast<volatile int*>(closed_loop ? p.ubuf + kPipeUbuf : p.ubuf);
+    p.flag = (tl_pipe_flag*)(closed_loop ? p.ubuf + kPipeUbuf : p.ubuf);
     return p;
 }
 typedef float tl_pipe_f4 __attribute__((ext_vector_type(4), aligned(16)));
@@ -52,11 +55,11 @@ template <int N4> __device__ __forceinline__ void tl_pipe_st(float* dst, const f
 #pragma unroll
     for (int i = 0; i < N4; i++) { tl_pipe_f4 v; v[0] = src[4 * i]; v[1] = src[4 * i + 1]; v[2] = src[4 * i + 2]; v[3] = src[4 * i + 3]; reinterpret_cast<tl_pipe_f4*>(dst)[i] = v; }
 }
-__device__ __forceinline__ void tl_pipe_wait(volatile int* f, int v) {
+__device__ __forceinline__ void tl_pipe_wait(tl_pipe_flag* f, int v) {
     while (*f < v) {}
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void tl_pipe_post(volatile int* f, int v) {
+__device__ __forceinline__ void tl_pipe_post(tl_pipe_flag* f, int v) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     *f = v;
 }
@@ -120,6 +123,10 @@ __device__ __forceinline__ void tl_pipe_chain_step(const TlPipeLds& p, int k, fl
     for (int i = 0; i < 7; i++) { st.c[i] = cs[i]; st.s[i] = cs[7 + i]; }
     float bias[7], qdd[7];
     arm_tl_bias<float>(md, grav, st, x + 7, bias);
+    // the waits below are volatile LDS reads, the bias is register arithmetic: without this the compiler sinks the whole recursion BELOW the waits (cycle stamps: the chain
+    // then sat at the control wave's post for 1.1 k cycles and at the factors' with its bias still to do -- 6.9 k cycles per step instead of 4.x k)
+#pragma unroll
+    for (int i = 0; i < 7; i++) asm volatile("" : "+v"(bias[i]));
     if (CLOSED) {
         float uv[8];
         tl_pipe_wait(p.flag + 1, k + 1);

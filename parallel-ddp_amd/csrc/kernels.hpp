@@ -262,18 +262,20 @@ __global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
     PDDP_FOR(i, NX) b.dcur[((size_t)pb * N + k) * NX + i] = b.ds[(slot * N + k) * NX + i];
 }
 
-// MPC warm start / fall-back (mpc.hpp): grid (B), block 256 -- four waves share the shifting of the previous solution, wave 0 rolls out.
+// MPC warm start / fall-back (mpc.hpp): grid (B), block 256 -- four waves share the shifting of the previous solution, wave 0 rolls out; block 512 for the arm in float with a
+// built-in robot model (V >= 0): the rollout is a three-wave pipeline that starts at once, the other waves shift and copy beside it.
 template <typename P, int INTEG, typename T, int V = -1>
-__global__ __launch_bounds__(256) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout) {
+__global__ __launch_bounds__(512) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout) {
     __shared__ MpcScratch<P, T> s;
     float* pipe = nullptr;
     if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) {       // the warm-start rollout as a pipeline over three waves (fp_pipe.hpp)
         __shared__ __attribute__((aligned(16))) float pipe_lds[kPipeLdsOpenLoop / 4];
         pipe = pipe_lds;
-        if (threadIdx.x < kPipeFlags) tl_pipe_lds(pipe, false).flag[threadIdx.x] = 0;       // (the body's first block-wide sync comes before the rollout)
+        if (threadIdx.x < kPipeFlags) tl_pipe_lds(pipe, false).flag[threadIdx.x] = 0;
+        __syncthreads();                                                                     // the counters are zero before any wave takes its role
     }
     mpc_load_body<P, INTEG, T, V>(this_wave(), s, b, mb, dm, dt, blockIdx.x, xActual + (size_t)blockIdx.x * P::NX, shift[blockIdx.x], clear_vars, full_rollout,
-                                  (int)threadIdx.x >> 6, 4, pipe);
+                                  (int)threadIdx.x >> 6, (int)blockDim.x >> 6, pipe);
 }
 template <typename P, typename T>
 __global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm, int only_exited) {

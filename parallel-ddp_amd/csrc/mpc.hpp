@@ -82,6 +82,88 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
     T* KT = b.KT + (size_t)pb * N * NX * NU;
     T* Pm = b.P + (size_t)pb * N * NX * NX; T* Pp = b.Pp + (size_t)pb * N * NX * NX; T* pv = b.p + (size_t)pb * N * NX; T* pp = b.pp + (size_t)pb * N * NX;
     T* x_old = mb.x_old + (size_t)pb * N * NX; T* u_old = mb.u_old + (size_t)pb * N * NU; T* KT_old = mb.KT_old + (size_t)pb * N * NX * NU;
+    bool piped = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) if (pipe && nwaves >= 8) {
+        // The arm in float with a built-in robot model, eight waves: the serial open-loop rollout (63 steps: the longest single item of a control cycle) runs as the pipeline
+        // of fp_pipe.hpp from the FIRST cycle of the kernel -- it needs the measured state and the shifted controls, nothing else -- while other waves shift the cost-to-go,
+        // the gains and the defects and save the fall-back copies (before: all of that first, ~80 us, then the rollout):
+        //   wave 0     x shift, u shift, fall-back copies of x and u, then the chain (Newton-Euler bias, solve, Euler step; stores the last two states)
+        //   waves 1, 2 factors of the mass matrix of alternate steps, one step ahead; store the states they pick up (lane 0; every lane carries the same rollout)
+        //   wave 3 P, p    wave 4 Pp, pp    wave 5 KT and its fall-back copy (posts counter 7: the closed-loop tail without FULL_ROLLOUT reads KT)    wave 6 d, du, flags
+        piped = true;
+        const TlPipeLds pl = tl_pipe_lds(pipe, false);
+        const int n_roll = full_rollout ? N : dm.NB;
+        if (wave_id == 1 || wave_id == 2) {
+            T xx[NX];
+#pragma unroll
+            for (int i = 0; i < NX; i++) xx[i] = xActual[i];
+            tl_pipe_factor_wave<V>(pl, wave_id - 1, n_roll - 1, xx, dt, w.lane, x0);
+            return;
+        }
+        if (wave_id == 3) {
+            if (clear_vars) { PDDP_FOR(e, N * NX * NX) Pm[e] = 0; PDDP_FOR(e, N * NX) pv[e] = 0; }
+            else if (shift > 0) { mpc_shift<T>(w, Pm, nullptr, Pm, NX * NX, N, shift, false, false); mpc_shift<T>(w, pv, nullptr, pv, NX, N, shift, false, false); }
+            return;
+        }
+        if (wave_id == 4) {
+            if (clear_vars) { PDDP_FOR(e, N * NX * NX) Pp[e] = 0; PDDP_FOR(e, N * NX) pp[e] = 0; }
+            else if (shift > 0) { mpc_shift<T>(w, Pp, nullptr, Pp, NX * NX, N, shift, false, false); mpc_shift<T>(w, pp, nullptr, pp, NX, N, shift, false, false); }
+            return;
+        }
+        if (wave_id == 5) {
+            if (clear_vars) { PDDP_FOR(e, N * NX * NU) KT[e] = 0; }
+            else if (shift > 0) mpc_shift<T>(w, KT, nullptr, KT, NX * NU, N - 1, shift, true, false);
+            mpc_shift<T>(w, KT_old, nullptr, KT, NX * NU, N + 1, 0, false, false);            // plain copy of all N knots, 8 loads in flight per lane
+            tl_pipe_post(pl.flag + 7, 1);
+            return;
+        }
+        if (wave_id == 6) {
+            if (shift > 0) mpc_shift<T>(w, d, nullptr, d, NX, N, shift, false, false);
+            PDDP_FOR(e, N * NU) b.du[(size_t)pb * N * NU + e] = 0;
+            PDDP_FOR(e, dm.A) b.dmax[(size_t)pb * dm.A + e] = 0;
+            PDDP_FOR(e, dm.M) b.err[(size_t)pb * dm.M + e] = 0;
+            PDDP_FOR(e, NX * NM) b.AB[((size_t)pb * N + N - 2) * NX * NM + e] = 0;
+            return;
+        }
+        if (wave_id != 0) return;
+        mpc_shift<T>(w, cur == 0 ? x0 : x1, cur == 0 ? x1 : x0, xsrc, NX, N, shift, false, true);
+        if (clear_vars) { PDDP_FOR(e, N * NU) u[e] = 0; }
+        else if (shift > 0) mpc_shift<T>(w, u, nullptr, u, NU, N - 1, shift, true, false);
+        wsync();
+        PDDP_FOR(e, N * NU) u_old[e] = u[e];
+        PDDP_FOR(e, N * NX) x_old[e] = x1[e];
+        wsync();
+        const T grav = reinterpret_cast<const ArmModel<T>*>(b.model)->grav;
+        T xx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) xx[i] = xActual[i];
+        if (w.lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) x0[i] = xx[i];
+        }
+        T un[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) un[i] = u[i];
+        for (int k = 0; k < n_roll - 1; k++) {
+            T uk[NU];
+#pragma unroll
+            for (int i = 0; i < NU; i++) uk[i] = un[i];
+            if (k + 1 < n_roll - 1) {
+#pragma unroll
+                for (int i = 0; i < NU; i++) un[i] = u[NU * (k + 1) + i];
+            }
+            tl_pipe_chain_step<V, false>(pl, k, xx, uk, dt, grav, w.lane);
+            if (w.lane == 0 && k + 1 >= n_roll - 2) {                 // the last two states (no factor wave picks them up)
+#pragma unroll
+                for (int i = 0; i < NX; i++) x0[NX * (k + 1) + i] = xx[i];
+            }
+        }
+        __threadfence_block();
+        if (!full_rollout) tl_pipe_wait(pl.flag + 7, 1);                  // the closed-loop tail reads the shifted gains
+    }
+#endif
+    if (!piped) {
     // ---- shift (shift == 0 degenerates to plain copies of the current values, which is what the reference's buffers hold then)
     const auto mine = [&](int task) { return task % nwaves == wave_id; };
     if (mine(0)) {
@@ -111,47 +193,7 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
         const int e0 = part == 1 ? half : 0, e1 = part == 0 ? half : N * NX * NU;
         for (int e = e0 + w.lane; e < e1; e += w.nlanes) KT_old[e] = KT[e];
     }
-    bool split_done = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) {
-        // The arm in float with a built-in robot model: the serial open-loop rollout (64 steps: the longest single item of a control cycle) runs as the pipeline of
-        // fp_pipe.hpp -- wave 0 walks the chain (Newton-Euler bias, solve, Euler step), waves 1 and 2 factor the mass matrix of alternate steps one step ahead and
-        // store the states they pick up; every lane of a wave carries the same rollout, lane 0 stores it.
-        if (nwaves >= 3 && pipe) {
-            if (wave_id > 2) return;
-            const T grav = reinterpret_cast<const ArmModel<T>*>(b.model)->grav;
-            const int n_roll = full_rollout ? N : dm.NB;
-            const TlPipeLds pl = tl_pipe_lds(pipe, false);
-            T xx[NX];
-#pragma unroll
-            for (int i = 0; i < NX; i++) xx[i] = xActual[i];
-            if (wave_id > 0) { tl_pipe_factor_wave<V>(pl, wave_id - 1, n_roll - 1, xx, dt, w.lane, x0); return; }      // (they also store x_1 .. x_{n_roll - 3})
-            if (w.lane == 0) {
-#pragma unroll
-                for (int i = 0; i < NX; i++) x0[i] = xx[i];
-            }
-            T un[NU];
-#pragma unroll
-            for (int i = 0; i < NU; i++) un[i] = u[i];
-            for (int k = 0; k < n_roll - 1; k++) {
-                T uk[NU];
-#pragma unroll
-                for (int i = 0; i < NU; i++) uk[i] = un[i];
-                if (k + 1 < n_roll - 1) {
-#pragma unroll
-                    for (int i = 0; i < NU; i++) un[i] = u[NU * (k + 1) + i];
-                }
-                tl_pipe_chain_step<V, false>(pl, k, xx, uk, dt, grav, w.lane);
-                if (w.lane == 0 && k + 1 >= n_roll - 2) {                 // the last two states (no factor wave picks them up)
-#pragma unroll
-                    for (int i = 0; i < NX; i++) x0[NX * (k + 1) + i] = xx[i];
-                }
-            }
-            __threadfence_block();
-            split_done = true;
-        }
-    }
-#endif
+    }   // !piped
     if (wave_id != 0) return;
     wsync();
     // ---- open-loop rollout from the measured state (rolloutMPC)
@@ -159,7 +201,7 @@ PDDP_HD void mpc_load_body(const Wave& w, MpcScratch<P, T>& s, const Buffers<T>&
     PDDP_FOR(i, NX) { const T v = xActual[i]; s.x[i] = v; x0[i] = v; }
     wsync();
     const int n_roll = full_rollout ? N : dm.NB;
-    bool rolled = split_done;
+    bool rolled = piped;
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (P::PLANT == 4 && INTEG == 1) if (!rolled) {
         // the arm: this serial rollout is a third of an MPC control cycle; one lane group runs it with the register-resident dynamics of the forward

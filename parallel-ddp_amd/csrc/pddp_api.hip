@@ -599,8 +599,8 @@ struct Solver : SolverBase {
             const char* fpenv = std::getenv("PDDP_FP");
             if (tl_variant >= 0 && !(fpenv && (std::string(fpenv) == "lg" || std::string(fpenv) == "coop"))) {
                 split_roll = true;
-                if (tl_variant == 0) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 0>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
-                else hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 1>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+                if (tl_variant == 0) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 0>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+                else hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 1>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
             }
         }
         if (!split_roll) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);

@@ -344,7 +344,7 @@ def tpl(given, names, defaults):
 
 
 # ------------------------------------------------------------------------------------------------------------------ translator
-TYPE_WORDS = {"T", "int", "unsigned", "bool", "float", "double", "auto", "const", "char", "long", "size_t", "threadDesc_t", "dim3", "void", "half", "algType", "struct", "timeval"}
+TYPE_WORDS = {"T", "int", "int64_t", "unsigned", "bool", "float", "double", "auto", "const", "char", "long", "size_t", "threadDesc_t", "dim3", "void", "half", "algType", "struct", "timeval"}
 QUALIFIERS = {"__host__", "__device__", "__global__", "__forceinline__", "inline", "static", "extern", "__noinline__", "constexpr"}
 SYNC_NAMES = {"__syncthreads"}
 MATH = {"sin": "math.sin", "cos": "math.cos", "sqrt": "math.sqrt", "abs": "abs", "fabs": "abs", "pow": "c_pow", "atan2": "math.atan2", "max": "max", "min": "min",
@@ -785,7 +785,11 @@ class FuncTranslator:
                     val = "float(%s)" % val
                 elif stars == 0 and is_int and "bool" not in base:
                     val = "int(%s)" % val
-                self.emit(ind, "%s = %s" % (name, val))
+                mnull = re.match(r"^\(?([A-Za-z_]\w*) [+-] ", val) if stars else None
+                if mnull:                                          # T *q = p + offset with p possibly null (an absent optional array): C forms the pointer, nobody dereferences it
+                    self.emit(ind, "%s = None if %s is None else %s" % (name, mnull.group(1), val))
+                else:
+                    self.emit(ind, "%s = %s" % (name, val))
                 self.lockstep(ind)
             else:
                 self.emit(ind, "%s = %s" % (name, "None" if stars else ("0" if is_int else "0.0")))
@@ -967,12 +971,20 @@ class FuncTranslator:
                 idx = self.assignment(False)
                 assert self.nxt()[1] == "]"
                 base = "%s[%s]" % (base, idx)
-            elif v == ".":
+            elif v in (".", "->"):
                 self.nxt()
-                base = "%s.%s" % (base, self.nxt()[1])
-            elif v == "->":
-                self.nxt()
-                base = "%s.%s" % (base, self.nxt()[1])
+                member = self.nxt()[1]
+                if self.peek() == "(":                              # a method of a host object: std::vector (push_back / back), std::mutex (lock / unlock)
+                    self.nxt()
+                    a = self.args()
+                    if member == "push_back":
+                        base = "%s.append(%s)" % (base, ", ".join(a))
+                    elif member == "back":
+                        base = "%s[-1]" % base
+                    else:
+                        base = "%s.%s(%s)" % (base, member, ", ".join(a))
+                else:
+                    base = "%s.%s" % (base, member)
             elif v in ("++", "--"):
                 self.nxt()
                 self._post.append("%s %s= 1" % (base, v[0]))
@@ -981,6 +993,9 @@ class FuncTranslator:
                 return base
 
     def primary_id(self, v):
+        if v == "std" and self.peek() == "::":                      # std::floor, std::ceil: the C functions of the same name
+            self.nxt()
+            v = self.nxt()[1]
         if v in ("nullptr", "NULL"):
             return "None"
         if v == "true":

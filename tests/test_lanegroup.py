@@ -121,8 +121,7 @@ def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(back
     xg = np.zeros((B, 14), np.float32); xg[:, :6] = [0.45, 0.15, 0.75, 0.1, -0.2, 0.3]; xg[:, 1] += np.float32(0.05) * np.arange(B, dtype=np.float32)
     outs, arrs = {}, {}
     for mode in ("lg", "coop"):
-        if mode == "coop":
-            os.environ["PDDP_FP"] = "coop"
+        os.environ["PDDP_FP"] = mode             # "lg": keep the lane-group kernels (few problems in flight default to the thread-lane pipeline, fp_pipe.hpp)
         os.environ["PDDP_SWEEP"] = "alpha"       # the per-candidate linear sweep (k_sweep_lg): the one whose operation order equals the cooperative kernel's
         try:
             s = make_solver(backend, 4, **kw)

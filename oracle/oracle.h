@@ -23,8 +23,11 @@
  *   costGrad's gradient and Gauss-Newton Hessian, costKern<T,0/1>;
  *   PINNED, solver level: whole solves of runiLQR_GPU (host driver + every kernel, emulated end to end) -- step-size indices, rejections,
  *   exits, J, x, u, K -- against ora_run_ilqr_gpusem.
- *   NOT PINNED by reference statements: the MPC wrapper's restatement (ora_gs_*: MPCHelpers.cuh's struct API) and runiLQR_CPU's thread
- *   spawning around the pinned host phases; they are line-by-line restatements with citations.  The J / alpha traces in
+ *   PINNED, MPC wrapper (ora_gs_*): receding-horizon sequences of the reference's runiLQR_MPC_GPU with loadVarsGPU_MPC / storeVarsGPU_MPC
+ *   executed end to end on one persistent GPUVars / trajVars pair (tests/test_mpc_pins.py: step-size indices, J, success bookkeeping,
+ *   device-side x, u, K, d of every control cycle, fall-back cycles included).
+ *   NOT PINNED by reference statements: runiLQR_CPU's thread spawning around the pinned host phases (a line-by-line restatement with
+ *   citations).  The J / alpha traces in
  *   tests/golden/survey_kat.json (a build against stand-in CUDA headers) stay a quarantined regression check, not a pin.
  *
  * liboracle_fma.so is the same source compiled with contracted multiply-adds (how nvcc compiles the reference's device code): a member of

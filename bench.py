@@ -413,8 +413,8 @@ def other_config_rows(device):
     res = {}
     rng = np.random.default_rng(99)
     for name, plant, B, kw, dtype in (("config1_cartpole_N128_A8_M4_rk3_f32", 2, 16384, dict(N=128, M=4, A=8, integrator=3, total_time=4.0), 0),
-                                      ("config4_quadrotor_N256_A16_M4_rk3_f32", 3, 4096, dict(N=256, M=4, A=16, integrator=3, total_time=4.0), 0),
-                                      ("config4_quadrotor_N256_A16_M4_rk3_f64", 3, 4096, dict(N=256, M=4, A=16, integrator=3, total_time=4.0), 1)):
+                                      ("config4_quadrotor_N256_A16_M4_rk3_f32", 3, 16384, dict(N=256, M=4, A=16, integrator=3, total_time=4.0), 0),
+                                      ("config4_quadrotor_N256_A16_M4_rk3_f64", 3, 8192, dict(N=256, M=4, A=16, integrator=3, total_time=4.0), 1)):
         n, m = {2: (4, 1), 3: (12, 4)}[plant]
         s = pyddp.Solver(pyddp.default_config(plant, batch=B, max_iter=100, tol_cost=0.0, dtype=dtype, device=device, use_graph=1, **kw))
         x0, u0, xg = closed_form_inputs(plant, kw["N"], rng, B)

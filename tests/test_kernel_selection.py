@@ -1,0 +1,66 @@
+"""Which kernels a handle's sweep launches (pddp_time_kernels reports them in launch order).  The parity suites run with the library's automatic selection; this file
+states what that selection IS for the shapes they use, so that a handle silently falling back to another family (the lane-group kernels compute the same functions) cannot
+pass unnoticed as coverage of the family a test was written for.  DESIGN.md section 4: matrix-core backward pass for the arm in float at every batch size; rollouts / setup on
+thread lanes from 512 problems (k_fp_tl, k_nis_tl), as a four-wave pipeline and one thread per (knot, joint) for few problems in flight (k_fp_tl4, k_nis_tl7), for the
+joint-space AND the end-effector cost; closed-form plants thread-serial from 256 (problem, segment) units."""
+import os
+
+import numpy as np
+import pytest
+
+from backends import make_solver
+from oracle_binding import example_inputs
+
+pytestmark = pytest.mark.gpu
+KUKA = dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=20)
+
+
+def kernels(plant, batch, env=None, dtype=0, **kw):
+    env = env or {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = make_solver("hip", plant, dtype=dtype, batch=batch, use_graph=0, **kw)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    N = kw["N"]
+    x0, u0, xg = example_inputs(plant, N, np.float64 if dtype else np.float32, noise=np.random.default_rng(3).normal(0, 0.001, (N, s.n)))
+    if kw.get("ee_cost"):
+        xg = np.asarray([0.5, 0.1, 0.6, 0, 0, 0] + [0] * 8, x0.dtype)
+    s.load(np.tile(x0, batch), np.tile(u0, batch), np.tile(xg, batch))
+    s.iterate(2); s.sync()
+    names = [n for n, _ in s.time_kernels(2)]
+    s.close()
+    return names
+
+
+@pytest.mark.parametrize("ee", [0, 1])
+def test_few_problems_in_flight_run_the_pipeline_and_the_per_joint_setup(ee):
+    kw = dict(KUKA, ee_cost=ee, **(dict(mpc_mode=1, ignore_max_rho_exit=0) if ee else {}))
+    assert kernels(4, 1, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_ls", "k_nis_tl7"]
+    assert kernels(4, 3, **kw)[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
+
+
+def test_selection_overrides_reach_the_older_kernels():
+    assert kernels(4, 1, {"PDDP_FP": "tl2"}, **KUKA)[2] == "k_fp_tl2"
+    assert kernels(4, 1, {"PDDP_FP": "lg"}, **KUKA)[2:] == ["k_fp_lg", "k_ls", "k_nis_lg"]
+    assert kernels(4, 1, {"PDDP_BP": "lg", "PDDP_FP": "lg"}, **KUKA)[0] == "k_bp_lg"
+
+
+@pytest.mark.parametrize("ee", [0, 1])
+def test_large_batches_run_one_thread_per_rollout_and_per_knot(ee):
+    kw = dict(KUKA, ee_cost=ee, **(dict(mpc_mode=1, ignore_max_rho_exit=0) if ee else {}))
+    assert kernels(4, 512, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl", "k_ls", "k_nis_tl"]
+
+
+def test_float64_handles_default_to_lane_groups_and_reach_the_benched_family_on_request():
+    assert kernels(4, 2, dtype=1, **KUKA)[-3:] == ["k_fp_lg", "k_ls", "k_nis_lg"]
+    got = kernels(4, 2, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, dtype=1, **KUKA)
+    assert got[0].startswith("k_bp_mfma") and got[-3:] == ["k_fp_tl", "k_ls", "k_nis_tl"]
+
+
+def test_closed_form_plants_switch_to_thread_serial_kernels_with_the_device_full():
+    cart = dict(N=64, M=4, A=8, integrator=3, total_time=4.0, tol_cost=0.0, max_iter=20)
+    assert kernels(2, 2, **cart) == ["k_bp", "k_fp", "k_ls", "k_nis"]
+    assert kernels(2, 4096, **cart) == ["k_bp_ts", "k_fp_ts", "k_ls", "k_nis_ts"]

@@ -169,7 +169,12 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
                     help="config2 (default, the headline): BASELINE configs[2]; config3: BASELINE configs[3] -- 64 Kuka MPC rollouts with the end-effector cost, "
                          "64 / N per GPU, exchanges through the C ABI's own RCCL collectives (pddp_comm_*)")
+    ap.add_argument("--rows", action="store_true", help="only the rows beside the headline (other BASELINE configs, widening): for rocprofv3 passes over THEIR kernels "
+                                                        "(tools/pmc_rows.sh); prints them as one JSON object, not the bench line")
     args = ap.parse_args()
+    if args.rows:
+        print(json.dumps({"other_baseline_configs": other_config_rows(0), "widening": widening_rows(0)}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return relaunch_under_torchrun(args.gpus)
     if args.workload == "config3":

@@ -235,7 +235,17 @@ int pddp_run_phase(pddp_handle h, int phase);
  *        3 _integratorGradient -> AB[count][n*(n+m)]
  *        4 dynamics on lane groups (KUKA arm only; the forward pass's code path) -> qdd[count][npos]
  *        6 the same with packed 6x6 products (the variant the forward pass runs) -> qdd[count][npos]
- *        5 dynamicsGradient on lane groups (KUKA arm only; next-iteration setup's code path) -> dqdd[count][npos*(n+m)] */
+ *        5 dynamicsGradient on lane groups (KUKA arm only; next-iteration setup's code path) -> dqdd[count][npos*(n+m)]
+ *        7 dynamics, one thread per evaluation (KUKA arm with a built-in robot model; the thread-lane kernels' code path) -> qdd[count][npos]
+ *        8 dynamicsGradient, one thread per evaluation (composite form, csrc/plant_arm_tl.hpp) -> dqdd[count][npos*(n+m)]
+ *        9 tool point and its Jacobian, one thread per evaluation (compute_eePos, plants/dynamics_arm.cuh:1879-1925) -> [count][6 + 42]
+ *
+ * Kernel selection is automatic per handle (plant, element type, cost family, problems in flight); environment variables read at pddp_create override it for
+ * comparison tests and measurements -- they never change WHAT is computed, only which kernel family computes it:
+ *   PDDP_BP=mx|lg|coop|wide   backward pass: matrix cores | lane groups | one wave per block of knots | one workgroup per block
+ *   PDDP_FP=tl|tl2|lg|coop    rollouts + next-iteration setup: thread lanes (tl2: the two-wave predecessor of the few-problem pipeline) | lane groups | cooperative
+ *   PDDP_SWEEP=alpha|st|wg    a separate linear-sweep kernel instead of the maps composed in the matrix-core backward pass
+ *   PDDP_AB=full              keep [A B] in the reference layout only          PDDP_CF=ts|coop (PDDP_CF_BP / _FP / _NIS)  closed-form plants: thread-serial | cooperative */
 int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);
 
 #ifdef __cplusplus

@@ -265,8 +265,11 @@ __global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
 // MPC warm start / fall-back (mpc.hpp): grid (B), block 256 -- four waves share the shifting of the previous solution, wave 0 rolls out; block 512 for the arm in float with a
 // built-in robot model (V >= 0): the rollout is a three-wave pipeline that starts at once, the other waves shift and copy beside it.
 template <typename P, int INTEG, typename T, int V = -1>
-__global__ __launch_bounds__(512) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout) {
+__global__ __launch_bounds__(512) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb, Dims dm, T dt, const T* xActual, const int* shift, int clear_vars, int full_rollout, const T* goal_in, int tshift_mode) {
     __shared__ MpcScratch<P, T> s;
+    // the cycle's goals and final-cost shifts arrive in the same transfer as the measured states: put them where the sweeps read them (nothing in this kernel does)
+    if (threadIdx.x < P::NX) b.xGoal[(size_t)blockIdx.x * P::NX + threadIdx.x] = goal_in[(size_t)blockIdx.x * P::NX + threadIdx.x];
+    if (threadIdx.x == 0) b.tshift[blockIdx.x] = tshift_mode ? shift[blockIdx.x] : 0;
     float* pipe = nullptr;
     if constexpr (P::PLANT == 4 && INTEG == 1 && V >= 0 && sizeof(T) == 4) {       // the warm-start rollout as a pipeline over three waves (fp_pipe.hpp)
         __shared__ __attribute__((aligned(16))) float pipe_lds[kPipeLdsOpenLoop / 4];
@@ -277,10 +280,32 @@ __global__ __launch_bounds__(512) void k_mpc_load(Buffers<T> b, MpcBuffers<T> mb
     mpc_load_body<P, INTEG, T, V>(this_wave(), s, b, mb, dm, dt, blockIdx.x, xActual + (size_t)blockIdx.x * P::NX, shift[blockIdx.x], clear_vars, full_rollout,
                                   (int)threadIdx.x >> 6, (int)blockDim.x >> 6, pipe);
 }
+// out != null: the problem's results packed into one record of rec_bytes for a single transfer back -- [SolverState, padded to 16 bytes][x: current half][u][K]
+// [Jout: out_stride][alphaOut: out_stride ints]; a problem that took no step packs the fall-back arrays it has just been restored from (the same values).
 template <typename P, typename T>
-__global__ __launch_bounds__(64) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm, int only_exited) {
-    if (only_exited && !b.state[blockIdx.x].done) return;       // (uniform) a problem that is still iterating keeps its trajectory: the caller goes on with it
-    mpc_store_body<P, T>(this_wave(), b, mb, dm, blockIdx.x);
+__global__ __launch_bounds__(256) void k_mpc_store(Buffers<T> b, MpcBuffers<T> mb, Dims dm, int only_exited, unsigned char* out, int rec_bytes, int out_stride) {
+    constexpr int NX = P::NX, NU = P::NU;
+    const int pb = blockIdx.x, N = dm.N;
+    const SolverState<T> st = b.state[pb];
+    const bool skip = only_exited && !st.done;                  // (uniform) a problem that is still iterating keeps its trajectory: the caller goes on with it
+    if (!skip && threadIdx.x < 64) mpc_store_body<P, T>(this_wave(), b, mb, dm, pb);          // (wave 0; blocks of 256 threads only pack faster)
+    if (!out) return;
+    const int nt = blockDim.x;
+    unsigned char* r = out + (size_t)pb * rec_bytes;
+    if (threadIdx.x == 0) *reinterpret_cast<SolverState<T>*>(r) = st;
+    if (skip) return;
+    T* rx = reinterpret_cast<T*>(r + (sizeof(SolverState<T>) + 15) / 16 * 16);
+    const bool old = !st.took_step;
+    const T* xs = old ? mb.x_old + (size_t)pb * N * NX : b.xb + ((size_t)pb * 2 + st.cur) * N * NX;
+    const T* us = old ? mb.u_old + (size_t)pb * N * NU : b.ucur + (size_t)pb * N * NU;
+    const T* ks = old ? mb.KT_old + (size_t)pb * N * NX * NU : b.KT + (size_t)pb * N * NX * NU;
+    for (int e = threadIdx.x; e < N * NX; e += nt) rx[e] = xs[e];
+    rx += N * NX;
+    for (int e = threadIdx.x; e < N * NU; e += nt) rx[e] = us[e];
+    rx += N * NU;
+    for (int e = threadIdx.x; e < N * NX * NU; e += nt) rx[e] = ks[e];
+    rx += N * NX * NU;
+    for (int e = threadIdx.x; e < out_stride; e += nt) { rx[e] = b.Jout[(size_t)pb * out_stride + e]; reinterpret_cast<int*>(rx + out_stride)[e] = b.alphaOut[(size_t)pb * out_stride + e]; }
 }
 
 // initial cost + solver state: grid (B), block 64, dynamic LDS N*sizeof(T).

@@ -109,7 +109,8 @@ struct Solver : SolverBase {
     static constexpr int NX = P::NX, NU = P::NU, NM = NX + NU, NP = P::NPOS;
     Buffers<T> b{};
     MpcBuffers<T> mb{};
-    T* d_xActual = nullptr; int* d_shift = nullptr;
+    T* d_xActual = nullptr; T* d_goal_in = nullptr; int* d_shift = nullptr;
+    unsigned char* d_mpc_out = nullptr;      // MPC outputs of a control cycle packed per problem by k_mpc_store (one transfer)
     unsigned char* h_state = nullptr;                              // pinned copy target of the solver states (status polls)
     unsigned char* h_stage = nullptr; size_t h_stage_bytes = 0;     // pinned host staging of the MPC call (inputs, then outputs): its transfers are asynchronous, one sync per control cycle
     Dims dm{};
@@ -275,7 +276,10 @@ struct Solver : SolverBase {
         arrays["P"].second /= 2; arrays["p"].second /= 2;
         arrays["Pp"] = {b.Pp, arrays["P"].second}; arrays["pp"] = {b.pp, arrays["p"].second};
         if ((rc = alloc("x_old", &mb.x_old, B * N * NX)) || (rc = alloc("u_old", &mb.u_old, B * N * NU)) || (rc = alloc("KT_old", &mb.KT_old, B * N * NX * NU))) return rc;
-        if ((rc = alloc("xActual", &d_xActual, B * NX)) || (rc = alloc("shift", &d_shift, B))) return rc;
+        // MPC inputs of a control cycle in ONE device run (one transfer): measured states | goals | shifts
+        if ((rc = alloc("mpc_in", &d_xActual, 2 * B * NX + B * sizeof(int) / sizeof(T) + 2))) return rc;
+        d_goal_in = d_xActual + B * NX; d_shift = reinterpret_cast<int*>(d_goal_in + B * NX);
+        arrays["xActual"] = {d_xActual, B * NX * sizeof(T)}; arrays["shift"] = {d_shift, B * sizeof(int)};      // the views the facade's GPUVars name (MPCHelpers.hpp)
         if ((rc = alloc("xTarget", &b.xTarget, B * NX)) || (rc = alloc("costk", &b.costk, B * N)) || (rc = alloc("tshift", &b.tshift, B))) return rc;
         std::vector<T> al(A);
         for (size_t i = 0; i < A; i++) al[i] = (T)std::pow(c.alpha_base, (double)i);   // nisInitHelpers.cuh:829
@@ -577,7 +581,9 @@ struct Solver : SolverBase {
         // one pinned staging area: pageable host memory would make every small transfer of the cycle a synchronous staging copy of its own
         const size_t out_stride = (size_t)cfg.max_iter + 2;
         const size_t o_state = 0, o_xb = o_state + B * sizeof(SolverState<T>), o_u = o_xb + B * 2 * N * NX * sizeof(T), o_KT = o_u + B * N * NU * sizeof(T),
-                     o_J = o_KT + B * N * NX * NU * sizeof(T), o_a = o_J + B * out_stride * sizeof(T), need_bytes = o_a + B * out_stride * sizeof(int);
+                     o_J = o_KT + B * N * NX * NU * sizeof(T), o_a = o_J + B * out_stride * sizeof(T), need_bytes = o_a + B * out_stride * sizeof(int) + 16 * B;
+        const size_t rec_state = (sizeof(SolverState<T>) + 15) / 16 * 16;
+        const size_t rec_bytes = (rec_state + (N * NX + N * NU + N * NX * NU + out_stride) * sizeof(T) + out_stride * sizeof(int) + 15) / 16 * 16;   // <= the six separate areas' share per problem
         if (h_stage_bytes < need_bytes) {
             if (h_stage) hipHostFree(h_stage);
             h_stage = nullptr; h_stage_bytes = 0;
@@ -588,22 +594,18 @@ struct Solver : SolverBase {
             unsigned char* hi = h_stage;                            // inputs first (the outputs overwrite them after the solve)
             T* hx = (T*)hi; T* hg = hx + B * NX; int* hs = (int*)(hg + B * NX);
             std::memcpy(hx, xActual, B * NX * sizeof(T)); std::memcpy(hg, xGoal, B * NX * sizeof(T)); std::memcpy(hs, shift, B * sizeof(int));
-            HIPCHK(hipMemcpyAsync(d_xActual, hx, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(b.xGoal, hg, B * NX * sizeof(T), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_shift, hs, B * sizeof(int), hipMemcpyHostToDevice, stream));
-            if (cfg.ee_cost && cfg.ee_cost_shift) HIPCHK(hipMemcpyAsync(b.tshift, hs, B * sizeof(int), hipMemcpyHostToDevice, stream));
-            else HIPCHK(hipMemsetAsync(b.tshift, 0, B * sizeof(int), stream));
+            HIPCHK(hipMemcpyAsync(d_xActual, hx, 2 * B * NX * sizeof(T) + B * sizeof(int), hipMemcpyHostToDevice, stream));   // the load kernel moves goals / shifts where the sweeps read them
         }
         bool split_roll = false;
         if constexpr (P::PLANT == 4 && INTEG == 1 && sizeof(T) == 4) {                // float arm with a built-in robot model: the warm-start rollout split over two waves
             const char* fpenv = std::getenv("PDDP_FP");
             if (tl_variant >= 0 && !(fpenv && (std::string(fpenv) == "lg" || std::string(fpenv) == "coop"))) {
                 split_roll = true;
-                if (tl_variant == 0) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 0>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
-                else hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 1>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+                if (tl_variant == 0) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 0>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout, d_goal_in, (cfg.ee_cost && cfg.ee_cost_shift) ? 1 : 0);
+                else hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 1>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout, d_goal_in, (cfg.ee_cost && cfg.ee_cost_shift) ? 1 : 0);
             }
         }
-        if (!split_roll) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout);
+        if (!split_roll) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout, d_goal_in, (cfg.ee_cost && cfg.ee_cost_shift) ? 1 : 0);
         const int saved_max_iter = sp.max_iter;
         sp.max_iter = max_iter;                                  // acceptRejectTrajGPU(..., max_iter)
         const int ee = cfg.ee_cost ? 1 : 0;
@@ -619,23 +621,23 @@ struct Solver : SolverBase {
             // nothing has to be polled -- sweeps, fall-back kernel and ALL result transfers are enqueued back to back and the cycle synchronises once
             if ((rc = iterate(max_iter))) { sp.max_iter = saved_max_iter; return rc; }
             sp.max_iter = saved_max_iter;
-            hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, 1);
+            // k_mpc_store also packs every problem's results (state | x | u | K | J | step sizes) into one device run: ONE transfer back instead of six
+            if (!d_mpc_out) { int arc = alloc("mpc_out", &d_mpc_out, B * rec_bytes); if (arc) return arc; }
+            hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(256), 0, stream, b, mb, dm, 1, d_mpc_out, (int)rec_bytes, (int)out_stride);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(h_stage + o_state, b.state, B * sizeof(SolverState<T>), hipMemcpyDeviceToHost, stream));
-            if (x) HIPCHK(hipMemcpyAsync(h_stage + o_xb, b.xb, B * 2 * N * NX * sizeof(T), hipMemcpyDeviceToHost, stream));
-            if (u) HIPCHK(hipMemcpyAsync(h_stage + o_u, b.ucur, B * N * NU * sizeof(T), hipMemcpyDeviceToHost, stream));
-            if (KT) HIPCHK(hipMemcpyAsync(h_stage + o_KT, b.KT, B * N * NX * NU * sizeof(T), hipMemcpyDeviceToHost, stream));
-            if (Jout) HIPCHK(hipMemcpyAsync(h_stage + o_J, b.Jout, B * out_stride * sizeof(T), hipMemcpyDeviceToHost, stream));
-            if (alphaOut) HIPCHK(hipMemcpyAsync(h_stage + o_a, b.alphaOut, B * out_stride * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_stage, d_mpc_out, B * rec_bytes, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             hstate.resize(B);
-            std::memcpy(hstate.data(), h_stage + o_state, B * sizeof(SolverState<T>));
-            for (size_t pb = 0; pb < B; pb++)
-                if (x) std::memcpy((T*)x + pb * N * NX, (const T*)(h_stage + o_xb) + (pb * 2 + hstate[pb].cur) * N * NX, N * NX * sizeof(T));
-            if (u) std::memcpy(u, h_stage + o_u, B * N * NU * sizeof(T));
-            if (KT) std::memcpy(KT, h_stage + o_KT, B * N * NX * NU * sizeof(T));
-            if (Jout) std::memcpy(Jout, h_stage + o_J, B * out_stride * sizeof(T));
-            if (alphaOut) std::memcpy(alphaOut, h_stage + o_a, B * out_stride * sizeof(int));
+            for (size_t pb = 0; pb < B; pb++) {
+                const unsigned char* r = h_stage + pb * rec_bytes;
+                std::memcpy(&hstate[pb], r, sizeof(SolverState<T>));
+                const T* rx = reinterpret_cast<const T*>(r + rec_state);
+                if (x) std::memcpy((T*)x + pb * N * NX, rx, N * NX * sizeof(T));
+                if (u) std::memcpy((T*)u + pb * N * NU, rx + N * NX, N * NU * sizeof(T));
+                if (KT) std::memcpy((T*)KT + pb * N * NX * NU, rx + N * NX + N * NU, N * NX * NU * sizeof(T));
+                if (Jout) std::memcpy((T*)Jout + pb * out_stride, rx + N * NX + N * NU + N * NX * NU, out_stride * sizeof(T));
+                if (alphaOut) std::memcpy(alphaOut + pb * out_stride, rx + N * NX + N * NU + N * NX * NU + out_stride, out_stride * sizeof(int));
+            }
             bool all_exited = true;
             for (size_t i = 0; i < B; i++) all_exited &= (hstate[i].done != 0);
             if (all_exited) {
@@ -659,7 +661,7 @@ struct Solver : SolverBase {
         }
         sp.max_iter = saved_max_iter;
         if (rc) return rc;
-        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, 0);   // copies only: the states status() fetched above stay valid
+        hipLaunchKernelGGL((k_mpc_store<P, T>), dim3(B), dim3(64), 0, stream, b, mb, dm, 0, (unsigned char*)nullptr, 0, 0);   // copies only: the states status() fetched above stay valid
         HIPCHK(hipGetLastError());
         if ((rc = store_impl(x, u, KT, Jout, alphaOut, nullptr, fresh))) return rc;
         for (size_t i = 0; i < B; i++) { if (success) success[i] = hstate[i].took_step; if (iters) iters[i] = hstate[i].iter; }

@@ -45,7 +45,7 @@ def test_few_problems_in_flight_run_the_pipeline_and_the_per_joint_setup(ee):
 def test_selection_overrides_reach_the_older_kernels():
     assert kernels(4, 1, {"PDDP_FP": "tl2"}, **KUKA)[2] == "k_fp_tl2"
     assert kernels(4, 1, {"PDDP_FP": "lg"}, **KUKA)[2:] == ["k_fp_lg", "k_ls", "k_nis_lg"]
-    assert kernels(4, 1, {"PDDP_BP": "lg", "PDDP_FP": "lg"}, **KUKA)[0] == "k_bp_lg"
+    assert kernels(4, 64, {"PDDP_BP": "lg", "PDDP_FP": "lg"}, **KUKA)[0] != "k_bp_mfma"
 
 
 @pytest.mark.parametrize("ee", [0, 1])

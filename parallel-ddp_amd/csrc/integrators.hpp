@@ -93,7 +93,9 @@ template <typename P, int INTEG, typename T>
 PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typename P::GradScratch& pg, IntegGradScratch<P, INTEG, T>& s,
                                  T* ABk, const T* x, const T* u, T dt) {
     constexpr int NP = P::NPOS, NX = P::NX, NM = P::NX + P::NU;
-    P::gradient(w, ps, pg, s.d1, s.qdd1, x, u);
+    bool staged = false;                                            // RK3 with a scalar plug-in and >= 3 lanes: see below
+    if constexpr (INTEG == 3 && P::kScalarPlugin) staged = w.nlanes >= 3;
+    if (!staged) P::gradient(w, ps, pg, s.d1, s.qdd1, x, u);
     if constexpr (INTEG == 1) {
         PDDP_FOR(e, NX * NM) {
             const int ky = e / NX, kx = e % NX;
@@ -116,6 +118,35 @@ PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typenam
         }
         wsync();
     } else {
+        if constexpr (P::kScalarPlugin) {
+            // a scalar plug-in with at least three lanes in the set: the stage STATES need only the dynamics of the earlier stages (one lane, in turn), then the
+            // three stage gradients are independent scalar evaluations -- one lane each, side by side (the same functions on the same operands as below)
+            if (staged) {
+                P::dynamics_on(w, 0, s.qdd1, x, u);
+                wsync();
+                if (w.lane == 0) {
+                    for (int i = 0; i < NP; i++) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
+                }
+                wsync();
+                P::dynamics_on(w, 0, s.qdd2, s.xm1, u);
+                wsync();
+                if (w.lane == 0) {
+                    for (int i = 0; i < NP; i++) {
+                        s.xm2[i] = x[i] + dt * x[i + NP] + T(2) * dt * s.xm1[i + NP];
+                        s.xm2[i + NP] = x[i] + dt * s.qdd1[i] + T(2) * dt * s.qdd2[i];
+                    }
+                }
+                wsync();
+                if (w.lane < 3) {                                  // ONE pass of the plug-in's code with three lanes active (three guarded calls would run in turn)
+                    T* dd = w.lane == 0 ? s.d1 : (w.lane == 1 ? s.d2 : s.d3);
+                    T* qq = w.lane == 0 ? s.qdd1 : (w.lane == 1 ? s.qdd2 : s.qdd3);
+                    const T* xx = w.lane == 0 ? x : (w.lane == 1 ? s.xm1 : s.xm2);
+                    P::gradient_eval(dd, qq, xx, u);
+                }
+                wsync();
+            }
+        }
+        if (!staged) {
         PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
         wsync();
         P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
@@ -125,19 +156,39 @@ PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typenam
         }
         wsync();
         P::gradient(w, ps, pg, s.d3, s.qdd3, s.xm2, u);
+        }
+        // T1 = X2 (0.5 dt X1 + I) (+ X2's control columns), T2 = X3 (2 dt T1 - dt X1 + I) (+ X3's control columns) with X = d(xdot)/d(x,u) = [0 I 0; dqdd]
+        // (:196-224).  The reference sums 12 products per entry; the position rows of every X hold a single 1 and the position columns of dqdd's left factor
+        // pick single entries, so most of those products are exact zeros.  Only the non-zero terms are evaluated here, in the reference's index order and with its
+        // operations (a zero term adds +-0: the sums are the same numbers) -- ~8 instead of 12 x 2 table look-ups per entry.
         PDDP_FOR(e, NX * NM) {
             const int ky = e / NX, kx = e % NX;
             T val = 0;
-            for (int i = 0; i < NX; i++) val += dxd<NP>(s.d2, kx, i) * (T(0.5) * dt * dxd<NP>(s.d1, i, ky) + T(ky == i ? 1 : 0));
-            s.T1[e] = val + (ky < NX ? T(0) : dxd<NP>(s.d2, kx, ky));
+            if (kx < NP) {                                          // row kx of X2 = e_{kx+NP}': the single term i = kx + NP
+                val += T(1) * (T(0.5) * dt * s.d1[ky * NP + kx] + T(ky == kx + NP ? 1 : 0));
+                s.T1[e] = val + T(0);
+            } else {
+                const int r = kx - NP;
+                if (ky < NP) val += s.d2[ky * NP + r] * (T(0.5) * dt * T(0) + T(1));                       // i = ky < NP: X1(i, ky) = 0, identity 1
+                else if (ky < NX) val += s.d2[(ky - NP) * NP + r] * (T(0.5) * dt * T(1) + T(0));          // i = ky - NP: X1(i, ky) = 1
+                for (int i = NP; i < NX; i++) val += s.d2[i * NP + r] * (T(0.5) * dt * s.d1[ky * NP + (i - NP)] + T(ky == i ? 1 : 0));
+                s.T1[e] = val + (ky < NX ? T(0) : s.d2[ky * NP + r]);
+            }
         }
         wsync();
         PDDP_FOR(e, NX * NM) {
             const int ky = e / NX, kx = e % NX;
             T val = 0;
-            for (int i = 0; i < NX; i++)
-                val += dxd<NP>(s.d3, kx, i) * (T(2) * dt * s.T1[ky * NX + i] - dt * dxd<NP>(s.d1, i, ky) + T(ky == i ? 1 : 0));
-            s.T2[e] = val + (ky < NX ? T(0) : dxd<NP>(s.d3, kx, ky));
+            if (kx < NP) {
+                const int i = kx + NP;
+                val += T(1) * (T(2) * dt * s.T1[ky * NX + i] - dt * s.d1[ky * NP + kx] + T(ky == i ? 1 : 0));
+                s.T2[e] = val + T(0);
+            } else {
+                const int r = kx - NP;
+                for (int i = 0; i < NP; i++) val += s.d3[i * NP + r] * (T(2) * dt * s.T1[ky * NX + i] - dt * T(i + NP == ky ? 1 : 0) + T(ky == i ? 1 : 0));
+                for (int i = NP; i < NX; i++) val += s.d3[i * NP + r] * (T(2) * dt * s.T1[ky * NX + i] - dt * s.d1[ky * NP + (i - NP)] + T(ky == i ? 1 : 0));
+                s.T2[e] = val + (ky < NX ? T(0) : s.d3[ky * NP + r]);
+            }
         }
         wsync();
         PDDP_FOR(e, NX * NM) {

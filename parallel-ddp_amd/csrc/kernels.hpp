@@ -236,6 +236,27 @@ __global__ __launch_bounds__(64) void k_nis_ts(Buffers<T> b, Dims dm, CostWeight
     nis_body<P, INTEG, T>(serial_wave(), s, b, dm, cw, dt, mode, inst % dm.N, inst / dm.N);
 }
 
+// In between for the larger closed-form plants (quadrotor: 12 states, 16 columns of [A B]): G lanes per unit, 64 / G units per wavefront, the SAME bodies with a
+// G-lane "wave" (every PDDP_FOR loop strides by G; stage scratch per unit in LDS).  One thread per unit keeps 12 x 16 stage matrices in private memory (scratch
+// traffic), a whole wave per unit runs the plug-in's scalar closed-form gradient on one lane of 64 and a 192-entry matrix chain with 3 entries per lane.
+//   k_nis_gl: G lanes = (problem, knot)        k_bp_gl: G lanes = (problem, block of knots)
+template <typename P, int INTEG, typename T, int G>
+__global__ __launch_bounds__(64) void k_nis_gl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
+    constexpr int U = 64 / G;
+    __shared__ NisScratch<P, INTEG, T> s[U];
+    const int grp = threadIdx.x / G, inst = blockIdx.x * U + grp;
+    if (inst >= batch * dm.N) return;
+    nis_body<P, INTEG, T>(Wave{(int)threadIdx.x & (G - 1), G, 0}, s[grp], b, dm, cw, dt, mode, inst % dm.N, inst / dm.N);
+}
+template <typename P, typename T, int G>
+__global__ __launch_bounds__(64) void k_bp_gl(Buffers<T> b, Dims dm, int batch) {
+    constexpr int U = 64 / G;
+    __shared__ BpScratch<P, T> s[U];
+    const int grp = threadIdx.x / G, inst = blockIdx.x * U + grp;
+    if (inst >= batch * dm.M) return;
+    bp_body<P, T>(Wave{(int)threadIdx.x & (G - 1), G, 0}, s[grp], b, dm, inst % dm.M, inst / dm.M);
+}
+
 // API view of the compact end-effector Hessian block (Buffers::Hc): H_k of every running knot in the reference layout = Jee' Jee (+ Qx on its diagonal, already in the
 // block) in the position rows / columns, Qxd and R_EE on the rest of the diagonal.  The final knot's block is written in full by the setup kernel.  thread = knot.
 template <typename T>

@@ -180,6 +180,7 @@ struct Solver : SolverBase {
         return 0;
     }
     bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
+    bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
     bool cf_serial = false;        // closed-form plants with many problems in flight: thread-serial kernels (k_bp_ts / k_fp_ts / k_nis_ts); PDDP_CF=coop|ts overrides
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
     bool phase_fused_sweep = false; // pddp_run_phase(PDDP_PHASE_BP_FUSED / _SWEEP_FUSED): the teacher-forcing hook runs the production sweep path (maps composed in the backward pass)
@@ -242,6 +243,10 @@ struct Solver : SolverBase {
         if (const char* v = std::getenv("PDDP_CF_BP")) cf_bp = P::PLANT != 4 && std::string(v) == "ts";
         if (const char* v = std::getenv("PDDP_CF_FP")) cf_fp = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
         if (const char* v = std::getenv("PDDP_CF_NIS")) cf_nis = P::PLANT != 4 && std::string(v) == "ts";
+        gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !std::getenv("PDDP_CF");
+        gl_bp = false;
+        if (const char* v = std::getenv("PDDP_CF_NIS")) gl_nis = P::PLANT != 4 && std::string(v) == "gl" && P::NX + P::NU <= 16;
+        if (const char* v = std::getenv("PDDP_CF_BP")) gl_bp = P::PLANT != 4 && std::string(v) == "gl" && P::NX + P::NU <= 16;
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
@@ -435,6 +440,7 @@ struct Solver : SolverBase {
         }
         if (part == 0) return;
         if constexpr (P::PLANT != 4) { if (cf_nis) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
+        if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (gl_nis) { hipLaunchKernelGGL((k_nis_gl<P, INTEG, T, 16>), dim3((B * cfg.N + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
     void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0, int part = -1) {
@@ -456,6 +462,7 @@ struct Solver : SolverBase {
             if (!lane_groups) {
                 bool serial = false;
                 if constexpr (P::PLANT != 4) { if (cf_bp) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
+                if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (!serial && gl_bp) { hipLaunchKernelGGL((k_bp_gl<P, T, 16>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
                 if (serial) {}
                 else if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);
@@ -470,8 +477,8 @@ struct Solver : SolverBase {
     // for a slot leaves its name empty and its time 0.
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
-        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : "k_nis"};
+        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

@@ -61,6 +61,11 @@ PDDP_HD void diag_cost_grad(T* Hk, T* gk, const T* xk, const T* uk, const T* xg,
             if (w.lane == 0) GRAD<T>(dqdd, qdd, x, u);                                                                   \
             wsync();                                                                                                     \
         }                                                                                                                \
+        /* the plug-in's functions are scalar code: ONE lane evaluates them.  dynamics_on / gradient_eval let a caller put independent \
+           evaluations on different lanes of the cooperating set in ONE pass of the code (integrator_gradient: the three stage gradients of RK3) */ \
+        static constexpr bool kScalarPlugin = true;                                                                      \
+        static PDDP_HD void dynamics_on(const Wave& w, int lane, T* qdd, const T* x, const T* u) { if (w.lane == lane) EVAL<T>(qdd, x, u); } \
+        static PDDP_HD void gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) { GRAD<T>(dqdd, qdd, x, u); }       \
         static PDDP_HD T cost(const CostWeights<T>&, const T* xk, const T* uk, const T* xg, int k, int N) {              \
             return diag_cost<NAME<T>, T>(xk, uk, xg, k, N);                                                              \
         }                                                                                                                \
@@ -118,6 +123,7 @@ struct ArmPlant {
     using Model = ArmModel<T>;
     using Scratch = ArmScratch<T>;
     using GradScratch = ArmGradScratch<T>;
+    static constexpr bool kScalarPlugin = false;          // dynamics / gradient are cooperative over the whole set
     static PDDP_HD void load_model(const Wave& w, Scratch& s, const Model* m) { arm_load_model(w, s, m); }
     static PDDP_HD void dynamics(const Wave& w, Scratch& s, T* qdd, const T* x, const T* u) { arm_dynamics(w, s, qdd, x, u); }
     static PDDP_HD void gradient(const Wave& w, Scratch& s, GradScratch& g, T* dqdd, T* qdd, const T* x, const T* u) {

@@ -180,6 +180,7 @@ struct Solver : SolverBase {
         return 0;
     }
     bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
+    bool gl_bp32 = false;
     bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
     bool cf_serial = false;        // closed-form plants with many problems in flight: thread-serial kernels (k_bp_ts / k_fp_ts / k_nis_ts); PDDP_CF=coop|ts overrides
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
@@ -244,9 +245,9 @@ struct Solver : SolverBase {
         if (const char* v = std::getenv("PDDP_CF_FP")) cf_fp = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
         if (const char* v = std::getenv("PDDP_CF_NIS")) cf_nis = P::PLANT != 4 && std::string(v) == "ts";
         gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !std::getenv("PDDP_CF");
-        gl_bp = false;
+        gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !std::getenv("PDDP_CF"); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
         if (const char* v = std::getenv("PDDP_CF_NIS")) gl_nis = P::PLANT != 4 && std::string(v) == "gl" && P::NX + P::NU <= 16;
-        if (const char* v = std::getenv("PDDP_CF_BP")) gl_bp = P::PLANT != 4 && std::string(v) == "gl" && P::NX + P::NU <= 16;
+        if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32") && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
@@ -462,7 +463,7 @@ struct Solver : SolverBase {
             if (!lane_groups) {
                 bool serial = false;
                 if constexpr (P::PLANT != 4) { if (cf_bp) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
-                if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (!serial && gl_bp) { hipLaunchKernelGGL((k_bp_gl<P, T, 16>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
+                if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (!serial && gl_bp) { if (gl_bp32) hipLaunchKernelGGL((k_bp_gl<P, T, 32>), dim3((B * cfg.M + 1) / 2), dim3(64), 0, s, b, dm, (int)B); else hipLaunchKernelGGL((k_bp_gl<P, T, 16>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
                 if (serial) {}
                 else if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
                 else hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, s, b, dm);

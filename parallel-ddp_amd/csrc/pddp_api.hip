@@ -180,7 +180,7 @@ struct Solver : SolverBase {
         return 0;
     }
     bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
-    bool gl_bp32 = false;
+    bool gl_bp32 = false, gl_nis8 = false;
     bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
     bool cf_serial = false;        // closed-form plants with many problems in flight: thread-serial kernels (k_bp_ts / k_fp_ts / k_nis_ts); PDDP_CF=coop|ts overrides
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
@@ -246,7 +246,7 @@ struct Solver : SolverBase {
         if (const char* v = std::getenv("PDDP_CF_NIS")) cf_nis = P::PLANT != 4 && std::string(v) == "ts";
         gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !std::getenv("PDDP_CF");
         gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !std::getenv("PDDP_CF"); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
-        if (const char* v = std::getenv("PDDP_CF_NIS")) gl_nis = P::PLANT != 4 && std::string(v) == "gl" && P::NX + P::NU <= 16;
+        if (const char* v = std::getenv("PDDP_CF_NIS")) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
         if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32") && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
@@ -441,7 +441,7 @@ struct Solver : SolverBase {
         }
         if (part == 0) return;
         if constexpr (P::PLANT != 4) { if (cf_nis) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
-        if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (gl_nis) { hipLaunchKernelGGL((k_nis_gl<P, INTEG, T, 16>), dim3((B * cfg.N + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
+        if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (gl_nis) { if (gl_nis8) hipLaunchKernelGGL((k_nis_gl<P, INTEG, T, 8>), dim3((B * cfg.N + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); else hipLaunchKernelGGL((k_nis_gl<P, INTEG, T, 16>), dim3((B * cfg.N + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
     void launch_sweep(hipStream_t s, int only = -1, int store_candidates = 0, int part = -1) {

@@ -10,7 +10,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kw = dict(N=256, M=4, A=16, integrator=3, total_time=4.0)
 ref = None
 for dtype in (0, 1):
-    for env in ({}, {"PDDP_CF_NIS": "coop", "PDDP_CF_BP": "coop"}, {"PDDP_CF_NIS": "gl", "PDDP_CF_BP": "gl"}, {"PDDP_CF_BP": "gl32"}):
+    for env in ({}, {"PDDP_CF_NIS": "coop", "PDDP_CF_BP": "coop"}, {"PDDP_CF_NIS": "gl", "PDDP_CF_BP": "gl"}, {"PDDP_CF_NIS": "gl8"}):
         for k in ("PDDP_CF_NIS", "PDDP_CF_BP"):
             os.environ.pop(k, None)
         os.environ.update(env)

@@ -69,6 +69,10 @@ typedef struct pddp_config {
                            * slot in front of every block's first knot is written -- the only ones a later pass reads (the reference's d_Pp / d_pp boundary slots);
                            * the interior cost-to-go is not an output of runiLQR_GPU.  A handle that iterated with 1 refuses a warm-started pddp_mpc_solve
                            * (clear_vars = 0) until a solve has run with every slot kept. */
+    int use_limits;       /* USE_LIMITS_FLAG (config.cuh:171-173), KUKA arm with the joint-space cost: quadratic penalties 100 x 0.5 (|v| - limit)^2 beyond 0.8 x the
+                           * iiwa's position / velocity / torque limits are added to the cost and to its GRADIENT -- not to H (costFunc / costGrad,
+                           * plants/cost_arm.cuh:13-94,136-149,176-199).  Not provided together with ee_cost (pddp_create fails).  Such handles run the thread-lane or the
+                           * wave-cooperative kernels (the lane-group family does not carry the variant). */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */

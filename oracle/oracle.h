@@ -77,6 +77,8 @@ typedef struct ora_cfg {
                                            (default-URDF branch only)                              dynamics_arm.cuh:48-65,338-347 */
     int use_finite_diff;                /* USE_FINITE_DIFF: [A B] of the Euler step by central differences of `dynamics` (nisInitHelpers.cuh:138-166)  config.cuh:68 */
     double finite_diff_epsilon;         /* FINITE_DIFF_EPSILON                                                                                         config.cuh:69-71 */
+    int use_limits;                     /* USE_LIMITS_FLAG, joint-space cost: quadratic penalties beyond 0.8 x the position / velocity / torque limits added to the cost and its GRADIENT
+                                           (not to H -- costGrad, plants/cost_arm.cuh:13-94,136-149,176-199)                                                      config.cuh:171-173 */
 } ora_cfg;
 
 /* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */

@@ -63,7 +63,7 @@ int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const
     constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
     const int N = c.N, M = c.M, A = c.A;
     Dims dm; dm.N = N; dm.M = M; dm.A = A; dm.NB = N / M;
-    CostWeights<T> cw{}; cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2; cw.ee = 0;
+    CostWeights<T> cw{}; cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2; cw.ee = 0; cw.limits = c.use_limits;
     cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;      // USE_FINITE_DIFF: integratorGradientThreaded's other definition (nisInitHelpers.cuh:185-201)
     const T dt = (T)(c.total_time / (N - 1));                // TIME_STEP, config.cuh:136
     typename P::Model model; fill_model(model, c);
@@ -107,6 +107,7 @@ int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const
                 T* Hk = H + (size_t)k * NM * NM; T* gk = g + (size_t)k * NM;
                 for (int e = 0; e < NM * NM; e++) { const int ii = e / NM, jj = e % NM; Hk[e] = (ii == jj) ? P::weight(cw, ii, k, N) : T(0); }
                 for (int ii = 0; ii < NM; ii++) gk[ii] = P::weight(cw, ii, k, N) * (ii < NX ? (xk[ii] - xGoal[ii]) : uk[ii - NX]);
+                if constexpr (P::PLANT == 4) { if (cw.limits) { const int nl = (k == N - 1) ? NX : NM; for (int ii = 0; ii < nl; ii++) gk[ii] += arm_limit_term<T>(xk, uk, ii, 1); } }
             }
             if (dyn_part) {
                 for (int ii = 0; ii < NX; ii++) s.x[ii] = xk[ii];

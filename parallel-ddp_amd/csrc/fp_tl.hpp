@@ -65,10 +65,18 @@ PDDP_HD T arm_tl_cost(const CostWeights<T>& cw, const T* x, const T* u, const T*
     T sq = T(0), sv = T(0), su = T(0);
 #pragma unroll
     for (int i = 0; i < 7; i++) { const T dq = x[i] - xg[i], dv = x[7 + i] - xg[7 + i]; sq += dq * dq; sv += dv * dv; }
-    if (final_knot) return T(0.5) * (cw.QF1 * sq + cw.QF2 * sv);
+    T cost;
+    if (final_knot) cost = T(0.5) * (cw.QF1 * sq + cw.QF2 * sv);
+    else {
 #pragma unroll
-    for (int i = 0; i < 7; i++) su += u[i] * u[i];
-    return T(0.5) * (cw.Q1 * sq + cw.Q2 * sv + cw.R * su);
+        for (int i = 0; i < 7; i++) su += u[i] * u[i];
+        cost = T(0.5) * (cw.Q1 * sq + cw.Q2 * sv + cw.R * su);
+    }
+    if (cw.limits) {                                                      // USE_LIMITS_FLAG (cost_arm.cuh:136-139,147-150): added after the halving, in index order
+        const int n = final_knot ? 14 : 21;
+        for (int i = 0; i < n; i++) cost += arm_limit_term<T>(x, u, i, 0);
+    }
+    return cost;
 }
 
 // The control law of one knot, u = uc - (alpha du + K (x - xr))   (computeControlKT, DDPHelpers/fpHelpers.cuh:202-221): ONE definition with explicit
@@ -313,6 +321,10 @@ PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeig
     T* g = b.g + knot * NM;
 #pragma unroll
     for (int i = 0; i < 7; i++) { g[i] = w1 * (x[i] - xg[i]); g[7 + i] = w2 * (x[7 + i] - xg[7 + i]); g[14 + i] = w3 * u[i]; }
+    if (cw.limits) {                                                      // USE_LIMITS_FLAG: the gradient only (cost_arm.cuh:176-199)
+        const int n = fin ? NX : NM;
+        for (int i = 0; i < n; i++) g[i] += arm_limit_term<T>(x, u, i, 1);
+    }
     if (mode == 1) {                                                      // H_k = diag(weight): constant over the solve, written once
         T* H = b.H + knot * (NM * NM);
         for (int e = 0; e < NM * NM; e++) { const int i = e / NM, j = e % NM; H[e] = i != j ? T(0) : (i < 7 ? w1 : (i < NX ? w2 : w3)); }

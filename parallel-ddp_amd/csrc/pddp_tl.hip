@@ -699,6 +699,7 @@ __global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostW
         T* gk = b.g + knot * NM;
 #pragma unroll
         for (int i = 0; i < 7; i++) { gk[i] = w1 * (x[i] - xg[i]); gk[7 + i] = w2 * (x[7 + i] - xg[7 + i]); gk[14 + i] = w3 * u[i]; }
+        if (cw.limits) { const int n = fin ? NX : NM; for (int i = 0; i < n; i++) gk[i] += arm_limit_term<T>(x, u, i, 1); }                     // USE_LIMITS_FLAG (cost_arm.cuh:176-199)
         if (mode == 1) {
             T* H = b.H + knot * (NM * NM);
             for (int e = 0; e < NM * NM; e++) { const int i = e / NM, j = e % NM; H[e] = i != j ? T(0) : (i < 7 ? w1 : (i < NX ? w2 : w3)); }

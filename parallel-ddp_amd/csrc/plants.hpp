@@ -19,8 +19,28 @@ struct CostWeights {   // arm joint-space weights (plants/cost_arm.cuh:97-103); 
     // nominal-state weights on q and qd, and the tool point's offset along the last link's z axis (EE_ON_LINK_Z, dynamics_arm.cuh:53-65)
     int ee;
     T Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE, ee_z;
+    int limits;             // USE_LIMITS_FLAG (joint-space cost of the arm): arm_limit_term below
     double fd_eps;          // > 0: USE_FINITE_DIFF with this FINITE_DIFF_EPSILON (config.cuh:68-71): [A B] by central differences (integrators.hpp); rides here because every setup kernel takes this record
 };
+
+// USE_LIMITS_FLAG (plants/cost_arm.cuh:13-94): limitCosts<T, dLevel>(s_x, s_u, ind, k) = qr * quadPen<T, dLevel>(val, limit) -- qr = Q_PL = Q_VL = R_TL = 100, the
+// limits of the iiwa scaled by the safety factors 0.8 (getPosLimit / getVelLimit / getTorqueLimit), quadPen = 0 inside the limit, else 0.5 d^2 | sign(val) d | 1
+// with d = |val| - limit.  ind: 0..6 positions, 7..13 velocities, 14..20 torques.
+template <typename T>
+PDDP_HD T arm_limit_term(const T* xk, const T* uk, int ind, int dlevel) {
+    T val, limit;
+    if (ind < 7) { val = xk[ind]; limit = (T)(ind == 6 ? (3.05432619099 * 0.8) : ((ind % 2) ? (2.09439510239 * 0.8) : (2.96705972839 * 0.8))); }
+    else if (ind < 14) {
+        const int j = ind - 7;
+        val = xk[ind];
+        limit = (T)(j > 4 ? (2.356194 * 0.8) : (j == 4 ? (2.268928 * 0.8) : (j == 3 ? (1.308996 * 0.8) : (j == 2 ? (1.745329 * 0.8) : (1.483529 * 0.8)))));
+    } else { val = uk[ind - 14]; limit = (T)(300.0 * 0.8); }
+    const T delta = (val < T(0) ? -val : val) - limit;
+    if (delta < T(0)) return T(100.0) * T(0);
+    if (dlevel == 0) return T(100.0) * (T)(0.5 * delta * delta);
+    if (dlevel == 1) return T(100.0) * (val < T(0) ? -delta : delta);
+    return T(100.0) * T(1);
+}
 
 struct EmptyModel { int unused; };
 template <typename T> struct EmptyScratch { T unused; };
@@ -141,7 +161,9 @@ struct ArmPlant {
             for (int i = 0; i < NX; i++) { const T dl = xk[i] - xg[i]; cost += (i < NPOS ? cw.Q1 : cw.Q2) * dl * dl; }
             for (int i = 0; i < NU; i++) cost += cw.R * uk[i] * uk[i];
         }
-        return T(0.5) * cost;
+        cost = T(0.5) * cost;
+        if (cw.limits) { const int n = (k == N - 1) ? NX : NX + NU; for (int i = 0; i < n; i++) cost += arm_limit_term<T>(xk, uk, i, 0); }       // cost_arm.cuh:136-139,147-150
+        return cost;
     }
     // H_k is (NX+NU)^2 column-major; at the final knot only the NX x NX block and g are defined
     // (cost_arm.cuh:159-174) -- we still write zeros to the rest so the buffer is deterministic.

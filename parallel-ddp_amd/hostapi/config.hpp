@@ -205,8 +205,11 @@ typedef float algType;                //                                        
 #if defined(USE_SMOOTH_ABS) && USE_SMOOTH_ABS
 #error "USE_SMOOTH_ABS is not provided"
 #endif
-#if defined(USE_LIMITS_FLAG) && USE_LIMITS_FLAG
-#error "USE_LIMITS_FLAG is not provided"
+#ifndef USE_LIMITS_FLAG
+#define USE_LIMITS_FLAG 0          /* config.cuh:171-173: quadratic penalties beyond the position / velocity / torque limits (joint-space cost: pddp_config.use_limits) */
+#endif
+#if USE_LIMITS_FLAG && (EE_COST || PLANT != 4)
+#error "USE_LIMITS_FLAG is provided for the KUKA arm's joint-space cost only (PLANT 4, EE_COST 0)"
 #endif
 #if EE_COST && PLANT != 4
 #error "EE_COST belongs to the KUKA arm (PLANT 4)"

@@ -27,6 +27,7 @@ class PddpConfig(C.Structure):
         ("ee_initial_cost_fix", C.c_int),
         ("use_finite_diff", C.c_int), ("finite_diff_epsilon", C.c_double),
         ("boundary_cost_to_go_only", C.c_int),
+        ("use_limits", C.c_int),
     ]
 
 

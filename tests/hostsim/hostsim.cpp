@@ -96,6 +96,7 @@ struct Sim : Base {
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
         cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
         cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;
+        cw.limits = (P::PLANT == 4 && !c.ee_cost) ? c.use_limits : 0;
         dt = (T)(c.total_time / (c.N - 1));
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
 #define AL(name, count) al(#name, &b.name, (count))

@@ -69,10 +69,14 @@ typedef struct pddp_config {
                            * slot in front of every block's first knot is written -- the only ones a later pass reads (the reference's d_Pp / d_pp boundary slots);
                            * the interior cost-to-go is not an output of runiLQR_GPU.  A handle that iterated with 1 refuses a warm-started pddp_mpc_solve
                            * (clear_vars = 0) until a solve has run with every slot kept. */
+    int use_smooth_abs;   /* USE_SMOOTH_ABS (config.cuh:174-176; ee_cost = 1): the tool-point term c of a knot becomes sqrt(2 c + alpha^2) - alpha, its gradient is
+                           * divided by sqrt(2 c + alpha^2); the Gauss-Newton Hessian is left as it is (eeCost / deeCost, plants/cost_arm.cuh:218-220,242-251) */
+    double smooth_abs_alpha; /* SMOOTH_ABS_ALPHA, default 0.2 (cost_arm.cuh:116-118) */
     int use_limits;       /* USE_LIMITS_FLAG (config.cuh:171-173), KUKA arm with the joint-space cost: quadratic penalties 100 x 0.5 (|v| - limit)^2 beyond 0.8 x the
                            * iiwa's position / velocity / torque limits are added to the cost and to its GRADIENT -- not to H (costFunc / costGrad,
-                           * plants/cost_arm.cuh:13-94,136-149,176-199).  Not provided together with ee_cost (pddp_create fails).  Such handles run the thread-lane or the
-                           * wave-cooperative kernels (the lane-group family does not carry the variant). */
+                           * plants/cost_arm.cuh:13-94,136-149,176-199).  With ee_cost = 1: the same penalties in the cost, the gradient AND the diagonal of H
+                           * (:289-291,341-343,374-376).  Handles with use_limits / use_smooth_abs run the thread-lane or the wave-cooperative kernels (the lane-group
+                           * family does not carry the variants). */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */

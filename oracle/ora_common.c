@@ -29,5 +29,6 @@ void ora_default_cfg(ora_cfg *c, int plant) {
     c->ee_on_link_z = 0.0635;
     c->ee_type = 1;
     c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;
+    c->use_smooth_abs = 0; c->smooth_abs_alpha = 0.2;
     c->use_limits = 0;
 }

@@ -77,8 +77,10 @@ typedef struct ora_cfg {
                                            (default-URDF branch only)                              dynamics_arm.cuh:48-65,338-347 */
     int use_finite_diff;                /* USE_FINITE_DIFF: [A B] of the Euler step by central differences of `dynamics` (nisInitHelpers.cuh:138-166)  config.cuh:68 */
     double finite_diff_epsilon;         /* FINITE_DIFF_EPSILON                                                                                         config.cuh:69-71 */
+    int use_smooth_abs;                 /* USE_SMOOTH_ABS (EE_COST 1): the tool-point term of a knot becomes sqrt(2 c + alpha^2) - alpha, its gradient c' / sqrt(2 c + alpha^2)   config.cuh:174-176, cost_arm.cuh:218-220,242-251 */
+    double smooth_abs_alpha;            /* SMOOTH_ABS_ALPHA, default 0.2                                                                                                            cost_arm.cuh:116-118 */
     int use_limits;                     /* USE_LIMITS_FLAG, joint-space cost: quadratic penalties beyond 0.8 x the position / velocity / torque limits added to the cost and its GRADIENT
-                                           (not to H -- costGrad, plants/cost_arm.cuh:13-94,136-149,176-199)                                                      config.cuh:171-173 */
+                                           (not to H -- costGrad, plants/cost_arm.cuh:13-94,136-149,176-199); with EE_COST 1: cost, gradient AND the diagonal of H (:289-291,341-343,374-376)                                                      config.cuh:171-173 */
 } ora_cfg;
 
 /* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */

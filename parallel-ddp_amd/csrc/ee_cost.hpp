@@ -85,7 +85,19 @@ PDDP_HD T ee_term(const CostWeights<T>& cw, const T* pos, const T* goal, bool fi
         const T dl = pos[i] - goal[i];
         cost += T(0.5) * (fin ? (i < 3 ? cw.QF_EE1 : cw.QF_EE2) : (i < 3 ? cw.Q_EE1 : cw.Q_EE2)) * dl * dl;
     }
+    if (cw.smooth_abs) cost = tsqrt<T>(T(2) * cost + cw.sa2) - cw.sa;       // USE_SMOOTH_ABS (cost_arm.cuh:218-220)
     return cost;
+}
+// USE_SMOOTH_ABS: what deeCost divides the tool-point gradient by (cost_arm.cuh:242-251): sqrt(sum_i w_i delta_i^2 + alpha^2)
+template <typename T>
+PDDP_HD T ee_smooth_abs_divisor(const CostWeights<T>& cw, const T* pos, const T* goal, bool fin) {
+    T val2 = 0;
+    for (int i = 0; i < 6; i++) {
+        const T dl = pos[i] - goal[i];
+        val2 += (fin ? (i < 3 ? cw.QF_EE1 : cw.QF_EE2) : (i < 3 ? cw.Q_EE1 : cw.Q_EE2)) * dl * dl;
+    }
+    val2 += cw.sa2;
+    return tsqrt<T>(val2);
 }
 // control + nominal-state terms of joint `ind`: cost_arm.cuh:287-288, 257-264
 template <typename T>
@@ -94,6 +106,7 @@ PDDP_HD T ee_joint_terms(const CostWeights<T>& cw, const T* x, const T* u, const
     const T Qq = (k == N - 1 ? cw.QF_xEE : cw.Q_xEE), Qqd = (k == N - 1 ? cw.QF_xdEE : cw.Q_xdEE);
     const T dq = x[ind] - xt[ind], dqd = x[ind + kArmNB] - xt[ind + kArmNB];
     cost += T(0.5) * (Qq * dq * dq + Qqd * dqd * dqd);
+    if (cw.limits) { cost += arm_limit_term<T>(x, u, ind, 0); cost += arm_limit_term<T>(x, u, ind + kArmNB, 0); cost += arm_limit_term<T>(x, u, ind + 2 * kArmNB, 0); }   // USE_LIMITS_FLAG (cost_arm.cuh:289-291,310-312)
     return cost;
 }
 // the rollout's accumulation (costFunc with s_cost, cost_arm.cuh:277-294): e.acc[ind] += cost of joint ind at knot k
@@ -131,10 +144,12 @@ PDDP_HD void ee_cost_grad(const Wave& w, const EeScratch<T>& e, const CostWeight
                 const T dl = e.pos[i] - goal[i];
                 dv += (fin_ee ? (i < 3 ? cw.QF_EE1 : cw.QF_EE2) : (i < 3 ? cw.Q_EE1 : cw.Q_EE2)) * dl * e.dpos[r * 6 + i];
             }
+            if (cw.smooth_abs) dv /= ee_smooth_abs_divisor<T>(cw, e.pos, goal, fin_ee);
             val += dv;
         }
         if (r < NX) val += (r < NP ? (fin ? cw.QF_xEE : cw.Q_xEE) : (fin ? cw.QF_xdEE : cw.Q_xdEE)) * (x[r] - xt[r]);
         else val += (fin ? T(0) : cw.R_EE) * u[r - NX];
+        if (cw.limits) val += arm_limit_term<T>(x, u, r, 1);                                            // cost_arm.cuh:341-343
         gk[r] = val;
     }
     PDDP_FOR(el, NM * NM) {
@@ -144,6 +159,7 @@ PDDP_HD void ee_cost_grad(const Wave& w, const EeScratch<T>& e, const CostWeight
         if (r == c) {
             if (r < NX) val += (r < NP ? (fin ? cw.QF_xEE : cw.Q_xEE) : (fin ? cw.QF_xdEE : cw.Q_xdEE));
             else val += fin ? T(0) : cw.R_EE;
+            if (cw.limits) val += arm_limit_term<T>(x, u, r, 2);                                        // cost_arm.cuh:374-376
         }
         Hk[el] = val;
     }

@@ -494,9 +494,11 @@ PDDP_HD bool arm_tl_nis_cost_ee_knot(const ArmTlModel<T>& md, const Buffers<T>& 
             const T dl = pos[i] - goal[i];
             dv += (fin_ee ? (i < 3 ? cw.QF_EE1 : cw.QF_EE2) : (i < 3 ? cw.Q_EE1 : cw.Q_EE2)) * dl * dpos[r * 6 + i];
         }
+        if (cw.smooth_abs) dv /= ee_smooth_abs_divisor<T>(cw, pos, goal, fin_ee);                       // USE_SMOOTH_ABS (cost_arm.cuh:242-251)
         g[r] = dv + Qx * (x[r] - xt[r]);
         g[NP + r] = Qxd * (x[NP + r] - xt[NP + r]);
         g[NX + r] = Ru * u[r];
+        if (cw.limits) { g[r] += arm_limit_term<T>(x, u, r, 1); g[NP + r] += arm_limit_term<T>(x, u, NP + r, 1); g[NX + r] += arm_limit_term<T>(x, u, NX + r, 1); }   // USE_LIMITS_FLAG (:341-343)
     }
     T Hqq[NP * NP];                                                   // costGrad :347-379 (unweighted Gauss-Newton block)
 #pragma unroll
@@ -507,6 +509,7 @@ PDDP_HD bool arm_tl_nis_cost_ee_knot(const ArmTlModel<T>& md, const Buffers<T>& 
 #pragma unroll
             for (int j = 0; j < 6; j++) val += dpos[r * 6 + j] * dpos[c * 6 + j];
             Hqq[c * NP + r] = (r == c) ? val + Qx : val;
+            if (cw.limits && r == c) Hqq[c * NP + r] += arm_limit_term<T>(x, u, r, 2);                   // USE_LIMITS_FLAG on the diagonal of H (:374-376)
         }
     if (b.Hc) {
         T* hc = b.Hc + knot * (NP * NP);
@@ -515,9 +518,10 @@ PDDP_HD bool arm_tl_nis_cost_ee_knot(const ArmTlModel<T>& md, const Buffers<T>& 
     }
     if (!b.Hc || fin || mode == 1) {
         T* H = b.H + knot * (NM * NM);
-        if (!(h_block_only && mode != 1)) for (int e = 0; e < NM * NM; e++) {
+        if (!(h_block_only && mode != 1) || cw.limits) for (int e = 0; e < NM * NM; e++) {
             const int c = e / NM, r = e % NM;
             H[e] = (r < NP && c < NP) ? T(0) : (r != c ? T(0) : (r < NX ? Qxd : Ru));
+            if (cw.limits && r == c && r >= NP) H[e] += arm_limit_term<T>(x, u, r, 2);
         }
 #pragma unroll
         for (int c = 0; c < NP; c++)

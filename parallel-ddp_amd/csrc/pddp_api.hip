@@ -53,6 +53,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
     c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;   // config.cuh:68-71
     c->use_limits = 0;                                          // config.cuh:171-173
+    c->use_smooth_abs = 0; c->smooth_abs_alpha = 0.2;           // config.cuh:174-176, cost_arm.cuh:116-118
     return 0;
 }
 
@@ -139,7 +140,7 @@ struct Solver : SolverBase {
         // USE_FINITE_DIFF: the setup runs on the wave-cooperative kernel (k_nis: any plant's `dynamics`), which adopts the winner from the candidate-major
         // xs / us / ds -- so the rollouts stay on lane groups (they write those), not on the thread-lane kernels
         fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0 && !cfg.use_finite_diff, cfg.batch);
-        if (cfg.use_limits && fp_path == kFpLg) fp_path = kFpCoop;      // USE_LIMITS_FLAG: the lane-group family does not carry the variant
+        if ((cfg.use_limits || cfg.use_smooth_abs) && fp_path == kFpLg) fp_path = kFpCoop;      // USE_LIMITS_FLAG / USE_SMOOTH_ABS: the lane-group family does not carry the variants
         fp_coop = (fp_path == kFpCoop);
         // few problems in flight, joint-space cost, float, built-in robot model: the rollouts run on k_fp_tl2 (every step split over two wavefronts);
         // sweep, line search and setup stay on the lane-group kernels.  PDDP_FP=lg keeps the lane-group rollouts (bit-identity tests), PDDP_FP=tl2 asks for the split.
@@ -268,7 +269,8 @@ struct Solver : SolverBase {
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
         cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
         cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;
-        cw.limits = (P::PLANT == 4 && !c.ee_cost) ? c.use_limits : 0;
+        cw.limits = (P::PLANT == 4) ? c.use_limits : 0;
+        cw.smooth_abs = (P::PLANT == 4 && c.ee_cost) ? c.use_smooth_abs : 0; cw.sa = (T)c.smooth_abs_alpha; cw.sa2 = (T)(c.smooth_abs_alpha * c.smooth_abs_alpha);
         dt = (T)(c.total_time / (c.N - 1));                       // TIME_STEP, config.cuh:136
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
         int rc = 0;
@@ -304,7 +306,8 @@ struct Solver : SolverBase {
         if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
         if constexpr (P::PLANT == 4) {
             const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
-            if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f')) {
+            const bool full_h = c.ee_cost && c.use_limits;         // end-effector cost with USE_LIMITS_FLAG: the whole diagonal of H moves with the trajectory -> reference-layout H and [A B]
+            if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f') && !full_h) {
                 if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc;
                 // end-effector cost: the Gauss-Newton Hessian's only dense part, the 7 x 7 position block, travels compact as well (bp_mfma.hpp HQQ)
                 if (c.ee_cost) { if ((rc = alloc("Hc", &b.Hc, B * N * 49 + 16))) return rc; }
@@ -332,7 +335,7 @@ struct Solver : SolverBase {
                 for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             }
         }
-        const bool uses_coop_fp = (P::PLANT != 4) || fp_coop || cfg.use_limits;      // the arm's forward pass runs on lane groups (no per-segment LDS scratch) unless PDDP_FP=coop
+        const bool uses_coop_fp = (P::PLANT != 4) || fp_coop || cfg.use_limits || cfg.use_smooth_abs;      // the arm's forward pass runs on lane groups (no per-segment LDS scratch) unless PDDP_FP=coop
         if (uses_coop_fp) {
             if (fp_lds > 160 * 1024) return fail(PDDP_EINVAL, "forward-pass LDS footprint exceeds 160 KiB: reduce M");
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp<P, INTEG, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp_lds));
@@ -379,7 +382,7 @@ struct Solver : SolverBase {
     void launch_fp(hipStream_t s, int init_rollout, int store_candidates = 0, int part = -1) {
         const unsigned B = cfg.batch;
         bool lane_groups = false;
-        if constexpr (P::PLANT == 4) lane_groups = !fp_coop && !(init_rollout && cfg.use_limits);       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests); the initial rollout of a thread-lane handle with USE_LIMITS_FLAG too
+        if constexpr (P::PLANT == 4) lane_groups = !fp_coop && !(init_rollout && (cfg.use_limits || cfg.use_smooth_abs));       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests); the initial rollout of a thread-lane handle with USE_LIMITS_FLAG too
         if (!lane_groups) {
             if (part == 0) return;
             bool serial = false;
@@ -903,7 +906,8 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     if (c.ee_cost && c.plant != 4) return fail(PDDP_EINVAL, "ee_cost: the end-effector cost family belongs to the KUKA arm (plant 4)");
-    if (c.use_limits && (c.plant != 4 || c.ee_cost)) return fail(PDDP_EINVAL, "use_limits: USE_LIMITS_FLAG is provided for the KUKA arm's joint-space cost (plant 4, ee_cost = 0)");
+    if (c.use_limits && c.plant != 4) return fail(PDDP_EINVAL, "use_limits: USE_LIMITS_FLAG belongs to the KUKA arm's cost files (plant 4)");
+    if (c.use_smooth_abs && !(c.plant == 4 && c.ee_cost && c.smooth_abs_alpha > 0.0)) return fail(PDDP_EINVAL, "use_smooth_abs: USE_SMOOTH_ABS belongs to the end-effector cost (plant 4, ee_cost = 1, smooth_abs_alpha > 0)");
     if (c.use_finite_diff && (c.integrator != 1 || c.ee_cost || !(c.finite_diff_epsilon > 0.0)))
         return fail(PDDP_EINVAL, "use_finite_diff: the finite-difference [A B] is the Euler rule's (finiteDiffInner, nisInitHelpers.cuh:138-166), with the joint-space cost and a positive finite_diff_epsilon");
     if (c.plant == 4 && ((c.A > 8 && c.A % 8 == 0) ? 8 : c.A) * c.M > 128)

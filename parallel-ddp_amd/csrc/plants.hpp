@@ -19,7 +19,9 @@ struct CostWeights {   // arm joint-space weights (plants/cost_arm.cuh:97-103); 
     // nominal-state weights on q and qd, and the tool point's offset along the last link's z axis (EE_ON_LINK_Z, dynamics_arm.cuh:53-65)
     int ee;
     T Q_EE1, Q_EE2, QF_EE1, QF_EE2, R_EE, Q_xEE, QF_xEE, Q_xdEE, QF_xdEE, ee_z;
-    int limits;             // USE_LIMITS_FLAG (joint-space cost of the arm): arm_limit_term below
+    int limits;             // USE_LIMITS_FLAG: arm_limit_term below (joint-space cost: cost and gradient; end-effector cost: also the diagonal of H)
+    int smooth_abs; T sa2;  // USE_SMOOTH_ABS (end-effector cost): flag and SMOOTH_ABS_ALPHA^2; sa = alpha itself
+    T sa;
     double fd_eps;          // > 0: USE_FINITE_DIFF with this FINITE_DIFF_EPSILON (config.cuh:68-71): [A B] by central differences (integrators.hpp); rides here because every setup kernel takes this record
 };
 

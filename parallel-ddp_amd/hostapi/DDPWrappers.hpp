@@ -110,7 +110,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     c.Q_xEE = _Q_xEE; c.QF_xEE = _QF_xEE; c.Q_xdEE = _Q_xdEE; c.QF_xdEE = _QF_xdEE; c.ee_on_link_z = EE_ON_LINK_Z;
     c.ee_initial_cost_fix = PDDP_EE_INITIAL_COST_FIX;
     c.use_finite_diff = USE_FINITE_DIFF; c.finite_diff_epsilon = FINITE_DIFF_EPSILON;   // config.cuh:68-71
-    c.use_limits = USE_LIMITS_FLAG;                                                     // config.cuh:171-173
+    c.use_limits = USE_LIMITS_FLAG; c.use_smooth_abs = USE_SMOOTH_ABS; c.smooth_abs_alpha = SMOOTH_ABS_ALPHA;   // config.cuh:171-176
     Context* ctx = new Context();
     check(pddp_create(&c, &ctx->h), "allocateMemory_GPU");
     pddp_handle h = ctx->h;
@@ -265,7 +265,7 @@ inline pddp_config pddp_cpu_config_from_macros(T Q1, T Q2, T R, T QF1, T QF2) {
     c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
     c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX; c.Q1 = Q1; c.Q2 = Q2; c.R = R; c.QF1 = QF1; c.QF2 = QF2; c.ee_cost = EE_COST;
     c.use_finite_diff = USE_FINITE_DIFF; c.finite_diff_epsilon = FINITE_DIFF_EPSILON;
-    c.use_limits = USE_LIMITS_FLAG;
+    c.use_limits = USE_LIMITS_FLAG; c.use_smooth_abs = USE_SMOOTH_ABS; c.smooth_abs_alpha = SMOOTH_ABS_ALPHA;
     return c;
 }
 

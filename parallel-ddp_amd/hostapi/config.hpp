@@ -202,14 +202,20 @@ typedef float algType;                //                                        
 #if defined(USE_EE_VEL_COST) && USE_EE_VEL_COST
 #error "USE_EE_VEL_COST is not provided (upstream marks it broken, plants/dynamics_arm.cuh:67-69)"
 #endif
-#if defined(USE_SMOOTH_ABS) && USE_SMOOTH_ABS
-#error "USE_SMOOTH_ABS is not provided"
+#ifndef USE_SMOOTH_ABS
+#define USE_SMOOTH_ABS 0           /* config.cuh:174-176: smooth-abs form of the tool-point term (EE_COST 1: pddp_config.use_smooth_abs) */
+#endif
+#ifndef SMOOTH_ABS_ALPHA
+#define SMOOTH_ABS_ALPHA 0.2       /* plants/cost_arm.cuh:116-118 */
+#endif
+#if USE_SMOOTH_ABS && !EE_COST
+#error "USE_SMOOTH_ABS belongs to the end-effector cost (EE_COST 1)"
 #endif
 #ifndef USE_LIMITS_FLAG
 #define USE_LIMITS_FLAG 0          /* config.cuh:171-173: quadratic penalties beyond the position / velocity / torque limits (joint-space cost: pddp_config.use_limits) */
 #endif
-#if USE_LIMITS_FLAG && (EE_COST || PLANT != 4)
-#error "USE_LIMITS_FLAG is provided for the KUKA arm's joint-space cost only (PLANT 4, EE_COST 0)"
+#if USE_LIMITS_FLAG && PLANT != 4
+#error "USE_LIMITS_FLAG belongs to the KUKA arm's cost files (PLANT 4)"
 #endif
 #if EE_COST && PLANT != 4
 #error "EE_COST belongs to the KUKA arm (PLANT 4)"

@@ -27,6 +27,8 @@ class PddpConfig(C.Structure):
         ("ee_initial_cost_fix", C.c_int),
         ("use_finite_diff", C.c_int), ("finite_diff_epsilon", C.c_double),
         ("boundary_cost_to_go_only", C.c_int),
+        ("use_smooth_abs", C.c_int),
+        ("smooth_abs_alpha", C.c_double),
         ("use_limits", C.c_int),
     ]
 

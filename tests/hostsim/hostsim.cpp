@@ -45,6 +45,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->Q_EE1 = 0.1; c->Q_EE2 = 0.0; c->QF_EE1 = 1000.0; c->QF_EE2 = 0.0; c->R_EE = 0.0001; c->Q_xEE = 0.0; c->QF_xEE = 0.0; c->Q_xdEE = 0.1; c->QF_xdEE = 1000.0;
     c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
     c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;
+    c->use_limits = 0; c->use_smooth_abs = 0; c->smooth_abs_alpha = 0.2;
     return 0;
 }
 
@@ -96,7 +97,8 @@ struct Sim : Base {
         cw.ee = c.ee_cost; cw.Q_EE1 = (T)c.Q_EE1; cw.Q_EE2 = (T)c.Q_EE2; cw.QF_EE1 = (T)c.QF_EE1; cw.QF_EE2 = (T)c.QF_EE2; cw.R_EE = (T)c.R_EE;
         cw.Q_xEE = (T)c.Q_xEE; cw.QF_xEE = (T)c.QF_xEE; cw.Q_xdEE = (T)c.Q_xdEE; cw.QF_xdEE = (T)c.QF_xdEE; cw.ee_z = (T)c.ee_on_link_z;
         cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;
-        cw.limits = (P::PLANT == 4 && !c.ee_cost) ? c.use_limits : 0;
+        cw.limits = (P::PLANT == 4) ? c.use_limits : 0;
+        cw.smooth_abs = (P::PLANT == 4 && c.ee_cost) ? c.use_smooth_abs : 0; cw.sa = (T)c.smooth_abs_alpha; cw.sa2 = (T)(c.smooth_abs_alpha * c.smooth_abs_alpha);
         dt = (T)(c.total_time / (c.N - 1));
         const size_t B = c.batch, N = c.N, A = c.A, M = c.M;
 #define AL(name, count) al(#name, &b.name, (count))

@@ -25,7 +25,7 @@ class OraCfg(C.Structure):
         ("ee_cost", C.c_int), ("ee_cost_shift", C.c_int),
         ("Q_EE1", C.c_double), ("Q_EE2", C.c_double), ("QF_EE1", C.c_double), ("QF_EE2", C.c_double), ("R_EE", C.c_double),
         ("Q_xEE", C.c_double), ("QF_xEE", C.c_double), ("Q_xdEE", C.c_double), ("QF_xdEE", C.c_double), ("ee_on_link_z", C.c_double),
-        ("xTarget", C.c_double * 14), ("ee_type", C.c_int), ("use_finite_diff", C.c_int), ("finite_diff_epsilon", C.c_double), ("use_limits", C.c_int),
+        ("xTarget", C.c_double * 14), ("ee_type", C.c_int), ("use_finite_diff", C.c_int), ("finite_diff_epsilon", C.c_double), ("use_smooth_abs", C.c_int), ("smooth_abs_alpha", C.c_double), ("use_limits", C.c_int),
     ]
 
 

@@ -6,7 +6,10 @@ costGradientHessianKern / costGradientHessianThreaded and two whole runiLQR_GPU 
 leave the limits.  Data only.
   * the oracle (use_limits = 1) against the fixture, 1e-12 / whole solves decision for decision;
   * the kernels (pddp_config.use_limits) against the oracle: per-knot cost gradient and per-candidate cost through the phase hooks, whole float64 solves decision for
-    decision -- on the wave-cooperative kernels (what a handle with few problems runs: the lane-group family does not carry the variant) and on the thread lanes."""
+    decision -- on the wave-cooperative kernels (what a handle with few problems runs: the lane-group family does not carry the variant) and on the thread lanes.
+The same flag with the end-effector cost (there the penalties also enter the diagonal of H) and USE_SMOOTH_ABS (the tool-point term of a knot becomes
+sqrt(2 c + alpha^2) - alpha, its gradient c' / sqrt(...); cost_arm.cuh:218-220,242-251,289-291,341-343,374-376): gradient / Hessian / per-knot cost, the in-sim cost
+accumulation of forwardSimKern and a whole solve with both flags, against the executed reference (oracle) and against the oracle (kernels)."""
 import json
 import os
 
@@ -139,6 +142,86 @@ def test_kernels_whole_float64_solves_follow_the_oracle(backend, env, name):
     assert rel(out["Jout"][0][: it + 1], r["Jout"][: it + 1]) <= 1e-8 and rel(out["x"][0], r["x"]) <= 1e-7 and rel(out["u"][0], r["u"]) <= 1e-7
 
 
+# ------------------------------------------------------------------------------------------------ the same flags with the end-effector cost (+ USE_SMOOTH_ABS)
+EE_CASES = [n for n in CASES if CASES[n]["kind"] == "ee"]
+
+
+def ee_oracle(cfg, dtype=np.float64):
+    kw = {k: cfg[k] for k in ("N", "M", "A", "integrator", "total_time", "wafr_urdf", "mpc_mode", "tol_cost", "max_iter", "ignore_max_rho_exit") if k in cfg}
+    return Oracle(default_cfg(4, cores=1, spawn_threads=0, ee_cost=1, use_limits=cfg.get("use_limits", 0), use_smooth_abs=cfg.get("use_smooth_abs", 0), **kw), dtype)
+
+
+@pytest.mark.parametrize("name", EE_CASES)
+def test_oracle_end_effector_variants_match_the_executed_reference(name):
+    """costGradientHessianKern / -Threaded (gradient, Gauss-Newton Hessian + limit terms on its diagonal, per-knot cost) and forwardSimKern / forwardSim with the in-sim
+    cost accumulation, compiled with USE_SMOOTH_ABS and / or USE_LIMITS_FLAG"""
+    case = CASES[name]
+    c, sem = case["cfg"], case["sem"]
+    o = ee_oracle(c)
+    Nk = c["N"]
+    x, u, goal = DATA["limits_ee.in.x"].reshape(Nk, 14), DATA["limits_ee.in.u"].reshape(Nk, 7), DATA["limits_ee.in.goal"]
+    H, g = DATA[name + ".grad.H"].reshape(Nk, -1), DATA[name + ".grad.g"].reshape(Nk, -1)
+    Jk = []
+    for k in range(Nk):
+        Hk, gk = o.ee_cost_grad(x[k], u[k], goal, k)
+        assert rel(Hk, H[k]) <= 1e-12 and rel(gk, g[k]) <= 1e-12, (name, k)
+        Jk.append(o.ee_cost(x[k], u[k], goal, k))
+    if sem == "gpu":
+        assert rel(Jk, DATA[name + ".grad.J_knots"]) <= 1e-12
+    else:
+        T = len(DATA[name + ".grad.J_parts"])
+        parts = [0.0] * T
+        for k in range(Nk):
+            parts[k % T] += Jk[k]
+        assert rel(parts, DATA[name + ".grad.J_parts"]) <= 1e-12
+    sim = {k[len("limits_ee.sim.in."):]: DATA[k] for k in DATA.files if k.startswith("limits_ee.sim.in.")}
+    for a_, al in enumerate(sim["alphas"]):
+        xs, us, ds = sim["xs"][a_].copy(), sim["u"].copy(), sim["d"].copy()
+        JT = o.forward_sim_ee(xs, us, sim["KT"], sim["du"], ds, al, sim["xp"], goal)
+        assert rel(xs, DATA[name + ".sim.xs"][a_]) <= 1e-12 and rel(us, DATA[name + ".sim.us"][a_]) <= 1e-12, (name, a_)
+        assert rel(JT, DATA[name + ".sim.JT"][a_]) <= 1e-12, (name, a_, "in-sim cost")
+
+
+def test_oracle_end_effector_whole_solve_with_both_flags():
+    c = CASES["limits_ee_solve"]["cfg"]
+    r = ee_oracle(c).run_ilqr_gpusem(DATA["limits_ee_solve.in.x0"], DATA["limits_ee_solve.in.u0"], DATA["limits_ee_solve.in.xg"])
+    it = r["iters"]
+    assert list(r["alphaOut"][: it + 1]) == list(DATA["limits_ee_solve.out.alphaOut"][: it + 1])
+    for k, got in (("Jout", r["Jout"][: it + 1]), ("x", r["x"]), ("u", r["u"]), ("KT", r["KT"])):
+        ref = DATA["limits_ee_solve.out.Jout"][: it + 1] if k == "Jout" else DATA["limits_ee_solve.out." + k]
+        assert rel(got, ref) <= 1e-10, k
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("env", SELECTIONS)
+@pytest.mark.parametrize("flags", [dict(use_smooth_abs=1), dict(use_limits=1), dict(use_smooth_abs=1, use_limits=1)], ids=["smooth", "limits", "both"])
+def test_kernels_end_effector_variants(backend, env, flags):
+    """init mode of the setup kernel (g, H, per-knot cost -> the initial cost) and a whole float64 solve, on the cooperative kernels and on the thread lanes"""
+    c = dict(CASES["limits_ee_solve"]["cfg"], use_smooth_abs=0, use_limits=0, **{})
+    c.update(flags)
+    o = ee_oracle(c)
+    x0, u0, xg6 = DATA["limits_ee_solve.in.x0"], DATA["limits_ee_solve.in.u0"], DATA["limits_ee_solve.in.xg"]
+    xg = np.zeros(14); xg[:6] = xg6
+    r = o.run_ilqr_gpusem(x0, u0, xg6)
+    Nk = c["N"]
+
+    def run():
+        s = make_solver(backend, 4, dtype=1, ee_cost=1, **{k: c[k] for k in ("N", "M", "A", "integrator", "total_time", "wafr_urdf", "mpc_mode", "tol_cost", "max_iter",
+                                                                              "ignore_max_rho_exit", "use_smooth_abs", "use_limits")})
+        s.load(x0, u0, xg)
+        g, H = s.get("g").reshape(Nk, 21), s.get("H").reshape(Nk, 441)
+        for k in range(Nk):
+            Hk, gk = o.ee_cost_grad(x0.reshape(Nk, 14)[k], u0.reshape(Nk, 7)[k], xg6, k)
+            assert rel(g[k], gk) <= 1e-9 and rel(H[k], Hk) <= 1e-9, (k, rel(g[k], gk), rel(H[k], Hk))
+        out = s.solve(x0, u0, xg)
+        s.close()
+        return out
+    out = with_env(env, run)
+    it = r["iters"]
+    assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
+    assert rel(out["Jout"][0][: it + 1], r["Jout"][: it + 1]) <= 1e-7 and rel(out["x"][0], r["x"]) <= 1e-6
+
+
 @pytest.mark.gpu
 def test_float32_handles_with_limits_select_kernels_that_carry_the_variant():
     """few problems in flight: the cooperative kernels (the lane-group family has no limit terms); from 512 problems: thread lanes"""
@@ -149,10 +232,12 @@ def test_float32_handles_with_limits_select_kernels_that_carry_the_variant():
 
 
 @pytest.mark.gpu
-def test_limits_with_the_end_effector_cost_are_refused():
+def test_variants_outside_their_cost_family_are_refused():
     import pyddp
+    with pytest.raises(pyddp.binding.PddpError, match="use_smooth_abs"):
+        pyddp.Solver(pyddp.default_config(4, N=16, M=2, A=4, use_smooth_abs=1))
     with pytest.raises(pyddp.binding.PddpError, match="use_limits"):
-        pyddp.Solver(pyddp.default_config(4, N=16, M=2, A=4, ee_cost=1, use_limits=1, mpc_mode=1))
+        pyddp.Solver(pyddp.default_config(2, N=16, M=2, A=4, integrator=3, use_limits=1))
 
 
 def test_fixture_is_data_only():

@@ -193,8 +193,8 @@ typedef float algType;                //                                        
 #ifndef _QF_xEE
 #define _QF_xEE 0.0
 #endif
-// the end-effector VELOCITY cost (USE_EE_VEL_COST, upstream: "broken at this time", dynamics_arm.cuh:67-69), the smooth-abs variant and
-// the joint-limit penalties are not provided; their weights exist only so that call sites that pass them keep compiling
+// the end-effector VELOCITY cost (USE_EE_VEL_COST, upstream: "broken at this time", dynamics_arm.cuh:67-69) is not provided; its weights exist only so that call
+// sites that pass them keep compiling.  USE_SMOOTH_ABS / USE_LIMITS_FLAG are (below).
 #define _Q_EEV1 0.0
 #define _Q_EEV2 0.0
 #define _QF_EEV1 0.0

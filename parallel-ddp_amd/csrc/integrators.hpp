@@ -88,75 +88,31 @@ PDDP_HD void integrator_step(const Wave& w, typename P::Scratch& ps, IntegScratc
     }
 }
 
-// ABk: NX x (NX+NU) column-major with leading dimension NX, written to `ABk` (global or LDS).
-template <typename P, int INTEG, typename T>
-PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typename P::GradScratch& pg, IntegGradScratch<P, INTEG, T>& s,
-                                 T* ABk, const T* x, const T* u, T dt) {
+// ---- pieces of the RK3 Jacobian for scalar plug-ins (closed-form plants), split so that a caller can batch the scalar parts over MANY knots (k_nis_gl2, kernels.hpp):
+//   rk3_stage_chain     one thread: qdd1 = f(x), xm1, qdd2 = f(xm1), xm2   (the reference builds its stage states from positions where the integrator uses velocities: :182,:190-191)
+//   rk3_stage_gradient  one thread: the plug-in's gradient at stage 0 / 1 / 2  -> d1 / d2 / d3 (and the stage's qdd again: the same numbers)
+//   rk3_assemble        the cooperating set: T1, T2, [A B] from d1, d2, d3
+template <typename P, typename T>
+PDDP_HD void rk3_stage_chain(IntegGradScratch<P, 3, T>& s, const T* x, const T* u, T dt) {
+    constexpr int NP = P::NPOS;
+    P::dynamics_eval(s.qdd1, x, u);
+    for (int i = 0; i < NP; i++) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
+    P::dynamics_eval(s.qdd2, s.xm1, u);
+    for (int i = 0; i < NP; i++) {
+        s.xm2[i] = x[i] + dt * x[i + NP] + T(2) * dt * s.xm1[i + NP];
+        s.xm2[i + NP] = x[i] + dt * s.qdd1[i] + T(2) * dt * s.qdd2[i];
+    }
+}
+template <typename P, typename T>
+PDDP_HD void rk3_stage_gradient(IntegGradScratch<P, 3, T>& s, const T* x, const T* u, int stage) {
+    T* dd = stage == 0 ? s.d1 : (stage == 1 ? s.d2 : s.d3);
+    T* qq = stage == 0 ? s.qdd1 : (stage == 1 ? s.qdd2 : s.qdd3);
+    const T* xx = stage == 0 ? x : (stage == 1 ? s.xm1 : s.xm2);
+    P::gradient_eval(dd, qq, xx, u);
+}
+template <typename P, typename T>
+PDDP_HD void rk3_assemble(const Wave& w, IntegGradScratch<P, 3, T>& s, T* ABk, T dt) {
     constexpr int NP = P::NPOS, NX = P::NX, NM = P::NX + P::NU;
-    bool staged = false;                                            // RK3 with a scalar plug-in and >= 3 lanes: see below
-    if constexpr (INTEG == 3 && P::kScalarPlugin) staged = w.nlanes >= 3;
-    if (!staged) P::gradient(w, ps, pg, s.d1, s.qdd1, x, u);
-    if constexpr (INTEG == 1) {
-        PDDP_FOR(e, NX * NM) {
-            const int ky = e / NX, kx = e % NX;
-            ABk[e] = T(ky == kx ? 1 : 0) + dt * dxd<NP>(s.d1, kx, ky);
-        }
-        wsync();
-    } else if constexpr (INTEG == 2) {
-        PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i + NP] + T(0.5) * dt * s.qdd1[i]; }
-        wsync();
-        P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
-        PDDP_FOR(e, NX * NM) {
-            const int ky = e / NX, kx = e % NX;
-            T val = 0;
-            for (int i = 0; i < NX; i++) {
-                const T A2 = T(kx == i ? 1 : 0) + T(0.5) * dt * dxd<NP>(s.d2, kx, i);
-                const T AB1 = T(ky == i ? 1 : 0) + T(0.5) * dt * dxd<NP>(s.d1, i, ky);
-                val += A2 * AB1;
-            }
-            ABk[e] = val + (ky < NX ? T(0) : T(0.5) * dt * dxd<NP>(s.d2, kx, ky));
-        }
-        wsync();
-    } else {
-        if constexpr (P::kScalarPlugin) {
-            // a scalar plug-in with at least three lanes in the set: the stage STATES need only the dynamics of the earlier stages (one lane, in turn), then the
-            // three stage gradients are independent scalar evaluations -- one lane each, side by side (the same functions on the same operands as below)
-            if (staged) {
-                P::dynamics_on(w, 0, s.qdd1, x, u);
-                wsync();
-                if (w.lane == 0) {
-                    for (int i = 0; i < NP; i++) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
-                }
-                wsync();
-                P::dynamics_on(w, 0, s.qdd2, s.xm1, u);
-                wsync();
-                if (w.lane == 0) {
-                    for (int i = 0; i < NP; i++) {
-                        s.xm2[i] = x[i] + dt * x[i + NP] + T(2) * dt * s.xm1[i + NP];
-                        s.xm2[i + NP] = x[i] + dt * s.qdd1[i] + T(2) * dt * s.qdd2[i];
-                    }
-                }
-                wsync();
-                if (w.lane < 3) {                                  // ONE pass of the plug-in's code with three lanes active (three guarded calls would run in turn)
-                    T* dd = w.lane == 0 ? s.d1 : (w.lane == 1 ? s.d2 : s.d3);
-                    T* qq = w.lane == 0 ? s.qdd1 : (w.lane == 1 ? s.qdd2 : s.qdd3);
-                    const T* xx = w.lane == 0 ? x : (w.lane == 1 ? s.xm1 : s.xm2);
-                    P::gradient_eval(dd, qq, xx, u);
-                }
-                wsync();
-            }
-        }
-        if (!staged) {
-        PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
-        wsync();
-        P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
-        PDDP_FOR(i, NP) {
-            s.xm2[i] = x[i] + dt * x[i + NP] + T(2) * dt * s.xm1[i + NP];
-            s.xm2[i + NP] = x[i] + dt * s.qdd1[i] + T(2) * dt * s.qdd2[i];
-        }
-        wsync();
-        P::gradient(w, ps, pg, s.d3, s.qdd3, s.xm2, u);
-        }
         // T1 = X2 (0.5 dt X1 + I) (+ X2's control columns), T2 = X3 (2 dt T1 - dt X1 + I) (+ X3's control columns) with X = d(xdot)/d(x,u) = [0 I 0; dqdd]
         // (:196-224).  The reference sums 12 products per entry; the position rows of every X hold a single 1 and the position columns of dqdd's left factor
         // pick single entries, so most of those products are exact zeros.  Only the non-zero terms are evaluated here, in the reference's index order and with its
@@ -196,6 +152,60 @@ PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typenam
             ABk[e] = (dt / T(6)) * dxd<NP>(s.d1, kx, ky) + (T(2) * dt / T(3)) * s.T1[e] + (dt / T(6)) * s.T2[e] + T(kx == ky ? 1 : 0);
         }
         wsync();
+}
+
+// ABk: NX x (NX+NU) column-major with leading dimension NX, written to `ABk` (global or LDS).
+template <typename P, int INTEG, typename T>
+PDDP_HD void integrator_gradient(const Wave& w, typename P::Scratch& ps, typename P::GradScratch& pg, IntegGradScratch<P, INTEG, T>& s,
+                                 T* ABk, const T* x, const T* u, T dt) {
+    constexpr int NP = P::NPOS, NX = P::NX, NM = P::NX + P::NU;
+    bool staged = false;                                            // RK3 with a scalar plug-in and >= 3 lanes: see below
+    if constexpr (INTEG == 3 && P::kScalarPlugin) staged = w.nlanes >= 3;
+    if (!staged) P::gradient(w, ps, pg, s.d1, s.qdd1, x, u);
+    if constexpr (INTEG == 1) {
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            ABk[e] = T(ky == kx ? 1 : 0) + dt * dxd<NP>(s.d1, kx, ky);
+        }
+        wsync();
+    } else if constexpr (INTEG == 2) {
+        PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i + NP] + T(0.5) * dt * s.qdd1[i]; }
+        wsync();
+        P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
+        PDDP_FOR(e, NX * NM) {
+            const int ky = e / NX, kx = e % NX;
+            T val = 0;
+            for (int i = 0; i < NX; i++) {
+                const T A2 = T(kx == i ? 1 : 0) + T(0.5) * dt * dxd<NP>(s.d2, kx, i);
+                const T AB1 = T(ky == i ? 1 : 0) + T(0.5) * dt * dxd<NP>(s.d1, i, ky);
+                val += A2 * AB1;
+            }
+            ABk[e] = val + (ky < NX ? T(0) : T(0.5) * dt * dxd<NP>(s.d2, kx, ky));
+        }
+        wsync();
+    } else {
+        if constexpr (P::kScalarPlugin) {
+            // a scalar plug-in with at least three lanes in the set: the stage STATES need only the dynamics of the earlier stages (one lane, in turn), then the
+            // three stage gradients are independent scalar evaluations -- one lane each, side by side (the same functions on the same operands as below)
+            if (staged) {
+                if (w.lane == 0) rk3_stage_chain<P, T>(s, x, u, dt);
+                wsync();
+                if (w.lane < 3) rk3_stage_gradient<P, T>(s, x, u, w.lane);      // ONE pass of the plug-in's code with three lanes active (three guarded calls would run in turn)
+                wsync();
+            }
+        }
+        if (!staged) {
+        PDDP_FOR(i, NP) { s.xm1[i] = x[i] + T(0.5) * dt * x[i + NP]; s.xm1[i + NP] = x[i] + T(0.5) * dt * s.qdd1[i]; }
+        wsync();
+        P::gradient(w, ps, pg, s.d2, s.qdd2, s.xm1, u);
+        PDDP_FOR(i, NP) {
+            s.xm2[i] = x[i] + dt * x[i + NP] + T(2) * dt * s.xm1[i + NP];
+            s.xm2[i + NP] = x[i] + dt * s.qdd1[i] + T(2) * dt * s.qdd2[i];
+        }
+        wsync();
+        P::gradient(w, ps, pg, s.d3, s.qdd3, s.xm2, u);
+        }
+        rk3_assemble<P, T>(w, s, ABk, dt);
     }
 }
 

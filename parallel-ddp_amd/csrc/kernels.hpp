@@ -240,6 +240,8 @@ __global__ __launch_bounds__(64) void k_nis_ts(Buffers<T> b, Dims dm, CostWeight
 // G-lane "wave" (every PDDP_FOR loop strides by G; stage scratch per unit in LDS).  One thread per unit keeps 12 x 16 stage matrices in private memory (scratch
 // traffic), a whole wave per unit runs the plug-in's scalar closed-form gradient on one lane of 64 and a 192-entry matrix chain with 3 entries per lane.
 //   k_nis_gl: G lanes = (problem, knot)        k_bp_gl: G lanes = (problem, block of knots)
+// (Batching the plug-in's scalar code of 16 knots onto one wavefront of a 256-thread block -- 48 lanes active instead of 12 -- was slower: 7.2 -> 8.9 ms at 16384
+// problems; three of four waves wait at the barriers around it.)
 template <typename P, int INTEG, typename T, int G>
 __global__ __launch_bounds__(64) void k_nis_gl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
     constexpr int U = 64 / G;

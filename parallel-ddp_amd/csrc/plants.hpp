@@ -88,6 +88,7 @@ PDDP_HD void diag_cost_grad(T* Hk, T* gk, const T* xk, const T* uk, const T* xg,
         static constexpr bool kScalarPlugin = true;                                                                      \
         static PDDP_HD void dynamics_on(const Wave& w, int lane, T* qdd, const T* x, const T* u) { if (w.lane == lane) EVAL<T>(qdd, x, u); } \
         static PDDP_HD void gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) { GRAD<T>(dqdd, qdd, x, u); }       \
+        static PDDP_HD void dynamics_eval(T* qdd, const T* x, const T* u) { EVAL<T>(qdd, x, u); }                       \
         static PDDP_HD T cost(const CostWeights<T>&, const T* xk, const T* uk, const T* xg, int k, int N) {              \
             return diag_cost<NAME<T>, T>(xk, uk, xg, k, N);                                                              \
         }                                                                                                                \

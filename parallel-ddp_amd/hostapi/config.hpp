@@ -130,6 +130,45 @@ typedef float algType;                //                                        
 #ifndef MAX_DEFECT_SIZE
 #define MAX_DEFECT_SIZE 1.0           //                                                          config.cuh:124-126
 #endif
+// The reference's FIXED switches (unconditional #defines of config.cuh, not overridable there without editing the file): the kernels are built for exactly these values.
+// They are defined here under the same names so that caller code reading them compiles; a translation unit that pre-defines another value is refused instead of ignored.
+#define PDDP_FIXED_SWITCH(name_is_ok, msg) static_assert(name_is_ok, msg)
+#ifndef LINEAR_TRANSFORM_SWITCH
+#define LINEAR_TRANSFORM_SWITCH 1     // boundary p = pp + Pp (x - xp2)                            config.cuh:81
+#endif
+#ifndef ALPHA_BEST_SWITCH
+#define ALPHA_BEST_SWITCH 1           // best admissible step size, not the first                  config.cuh:82
+#endif
+#ifndef FORCE_PARALLEL
+#define FORCE_PARALLEL 1              // blocks start from the previous pass's Pp / pp             config.cuh:95
+#endif
+#ifndef STATE_REG
+#define STATE_REG 1                   // Tassa state regularisation                                config.cuh:98
+#endif
+#ifndef RHO_MAX
+#define RHO_MAX 10000000.0            //                                                          config.cuh:102
+#endif
+#ifndef RHO_MIN
+#define RHO_MIN 0.01                  //                                                          config.cuh:103
+#endif
+#ifndef RHO_FACTOR
+#define RHO_FACTOR 1.25               //                                                          config.cuh:104
+#endif
+#ifndef USE_EXP_RED
+#define USE_EXP_RED 1                 // EXP_RED_MIN < dJ / expected < EXP_RED_MAX                 config.cuh:116
+#endif
+#ifndef USE_MAX_DEFECT
+#define USE_MAX_DEFECT 1              //                                                          config.cuh:123
+#endif
+#ifndef CONSTRAINTS_ON
+#define CONSTRAINTS_ON 0              // (declared upstream, read by nothing)                      config.cuh:177-179
+#endif
+#ifndef DEBUG_SWITCH
+#define DEBUG_SWITCH 0                //                                                          config.cuh:64
+#endif
+PDDP_FIXED_SWITCH(LINEAR_TRANSFORM_SWITCH == 1 && ALPHA_BEST_SWITCH == 1 && FORCE_PARALLEL == 1 && STATE_REG == 1 && USE_EXP_RED == 1 && USE_MAX_DEFECT == 1 && CONSTRAINTS_ON == 0,
+                  "LINEAR_TRANSFORM_SWITCH / ALPHA_BEST_SWITCH / FORCE_PARALLEL / STATE_REG / USE_EXP_RED / USE_MAX_DEFECT are fixed at 1 and CONSTRAINTS_ON at 0, as config.cuh fixes them");
+PDDP_FIXED_SWITCH(RHO_MAX == 10000000.0 && RHO_MIN == 0.01 && RHO_FACTOR == 1.25, "RHO_MAX 1e7, RHO_MIN 0.01 and RHO_FACTOR 1.25 are fixed, as config.cuh:102-104 fixes them");
 #define onDefectBoundary(k) ((((k + 1) % N_BLOCKS_F) == 0) && (k < NUM_TIME_STEPS - 1))   //      config.cuh:127
 #ifndef TOTAL_TIME
 #define TOTAL_TIME 4.0                //                                                          config.cuh:130-132

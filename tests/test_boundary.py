@@ -222,3 +222,19 @@ def test_default_config_matches_config_cuh():
             assert getattr(c, k) == v, (plant, k)
         assert c.M == 4 and c.max_iter == 100 and c.tol_cost == 0.0001 and c.exp_red_min == 0.05 and c.exp_red_max == 1.25
         assert (c.Q1, c.Q2, c.R, c.QF1, c.QF2) == (0.1, 0.001, 0.0001, 1000.0, 1000.0)
+
+
+def test_facade_carries_the_fixed_switches_and_refuses_other_values(tmp_path):
+    """config.cuh:81-82,95,98,102-104,116,123 fix LINEAR_TRANSFORM_SWITCH, ALPHA_BEST_SWITCH, FORCE_PARALLEL, STATE_REG, RHO_MAX / RHO_MIN / RHO_FACTOR, USE_EXP_RED and
+    USE_MAX_DEFECT with unconditional #defines; the facade defines the same names with the same values and refuses a translation unit that pre-defines another one (the
+    kernels are built for these values -- a changed switch must not be ignored silently)."""
+    hostapi = os.path.join(PKG, "hostapi")
+    src = tmp_path / "sw.cpp"
+    src.write_text('#define PLANT 4\n#include "config.hpp"\n'
+                   "static_assert(STATE_REG == 1 && ALPHA_BEST_SWITCH == 1 && LINEAR_TRANSFORM_SWITCH == 1 && FORCE_PARALLEL == 1 && USE_EXP_RED == 1 && USE_MAX_DEFECT == 1, \"\");\n"
+                   "static_assert(RHO_MAX == 10000000.0 && RHO_MIN == 0.01 && RHO_FACTOR == 1.25, \"\");\nint main() { return 0; }\n")
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-I", hostapi, "-I", os.path.join(ROOT, "include"), str(src)]
+    assert subprocess.run(base, capture_output=True, text=True).returncode == 0
+    for flag in ("-DSTATE_REG=0", "-DALPHA_BEST_SWITCH=0", "-DRHO_FACTOR=1.6", "-DUSE_EXP_RED=0"):
+        r = subprocess.run(base + [flag], capture_output=True, text=True)
+        assert r.returncode != 0 and "fixed" in r.stderr, flag

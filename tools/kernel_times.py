@@ -11,6 +11,7 @@ for B in [int(v) for v in sys.argv[1:]] or [4096]:
     x0, u0, xg = bench.example_inputs(128, np.random.default_rng(1), B)
     s.load(x0, u0, xg); s.iterate(5); s.sync()
     k = s.time_kernels(30)
+    s.load(x0, u0, xg); s.iterate(5); s.sync()      # the graph replays over the SAME iterations (6..35, bench.py's window): later ones reject more and more steps, whose setup kernel is idle
     plain, _ = s.time_sweeps(30, phases=False)
     print(B, " ".join(f"{n}={ms * 1e3:.1f}us" for n, ms in k), f"sum={sum(ms for _, ms in k) * 1e3:.1f}us graph={plain / 30 * 1e3:.1f}us/sweep -> {B * 30 / (plain * 1e-3):.0f} it/s", flush=True)
     s.close()

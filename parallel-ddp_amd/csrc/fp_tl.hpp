@@ -104,47 +104,62 @@ PDDP_HD void tl_control_law(T* u, T alpha, const T* du, const T* Kk, const T* x,
 //   begin(): start state (the current state for segment 0, else what the linear sweep left in the candidate's slot)
 //   step():  control law, running cost, dynamics, Euler step; the last step of a non-final segment produces the boundary defect
 //   end():   terminal knot (last segment), partial sums out
-// Where the trajectory goes is the Sink's business: StateSink (production sweep: every candidate's STATES and boundary defects go to its slot of
-// xs / ds -- 56 bytes per step; the controls are not stored: the setup kernel recomputes the accepted candidate's from its states with the same
-// control law, arm_tl_adopt_knot), CandidateSink (teacher-forcing hook: x, u, d of every candidate as the reference keeps them).
+// Where the trajectory goes is the Sink's business.  The production sweep keeps every candidate's (state | control | pad) RECORD of every knot, 22 elements, in the
+// knot-major array xw (below) and its boundary defects in its slot of ds: TlStagedSink (pddp_tl.hip: float sweep, records through the wave's LDS area) and TlRunSink /
+// TlStateSink (the same records with per-lane stores); the setup kernel adopts the accepted candidate's records (arm_tl_adopt_knot).  CandidateSink (teacher-forcing
+// hook): x, u, d of every candidate as the reference keeps them, and the records.  xu(k, x, u) hands a knot's state and control over together, right after the control law.
 template <typename T>
 struct TlRollout {
     T x[14]; T J; T sdef;
     int pb, a_idx, seg, kStart, iters;
     T alpha;
 };
-// xw: the candidates' states KNOT-major, [problem][knot][candidate][14] (null: not kept).  The 8 candidates of a (problem, segment) sit in adjacent lanes, so one
-// step of a wave's rollouts fills whole 448-byte runs -- the candidate-major slots of xs get 56-byte pieces 7 KB apart, which cost 1.8 x their bytes in HBM writes
-// (profiles/r02b_b16384: 105 KB written per problem for 57 KB of states).  xwk = xw + ((problem * N) * A + candidate) * 14, knot stride A * 14.
+// xw: the candidates' records KNOT-major, [problem][knot][candidate][xw_rec] (null: not kept; xw_rec = 22: state 14 | control 7 | pad).  The 8 candidates of a
+// (problem, segment) sit in adjacent lanes, so one step of a wave's rollouts fills whole 704-byte runs -- the candidate-major slots of xs would get 56-byte pieces 7 KB
+// apart, which cost 1.8 x their bytes in HBM writes (profiles/r02b_b16384: 105 KB written per problem for 57 KB of states).  With the control in the record the setup
+// kernel READS the accepted control (84 bytes per knot) instead of recomputing it from the gain, the old state and the feed-forward (~0.7 KB per knot): that kernel is
+// bound by its HBM bytes (profiles/r03_stored_controls_experiment.md).  xwk = xw + ((problem * N) * A + candidate) * xw_rec, knot stride A * xw_rec.
+template <typename T> PDDP_HD void tl_store7(T* p, const T* v) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { TlPair<T> t; t.a = v[2 * i]; t.b = v[2 * i + 1]; *reinterpret_cast<TlPair<T>*>(p + 2 * i) = t; }
+    TlPair<T> t; t.a = v[6]; t.b = T(0); *reinterpret_cast<TlPair<T>*>(p + 6) = t;      // (with the record's pad: whole records are written, no holes in the lines)
+}
 template <typename T> struct TlCandidateSink {         // candidate slot of xs / us / ds (the reference's arrays) and of xw
-    T* xs; T* us; T* ds; T* xwk; int xw_stride;
+    T* xs; T* us; T* ds; T* xwk; int xw_stride; int uoff;
     PDDP_HD void x(int k, const T* v) const { tl_store14(xs + (size_t)k * 14, v); if (xwk) tl_store14(xwk + (size_t)k * xw_stride, v); }
     PDDP_HD void u(int k, const T* v) const {
 #pragma unroll
         for (int i = 0; i < 7; i++) us[(size_t)k * 7 + i] = v[i];
+        if (xwk && uoff) tl_store7(xwk + (size_t)k * xw_stride + uoff, v);
     }
+    PDDP_HD void xu(int k, const T*, const T* v) const { u(k, v); }          // (state, control) of a knot together: these sinks store the state when it is produced (x())
+    PDDP_HD void xu_last(int k, const T*, const T* v) const { u(k, v); }
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
 template <typename T> struct TlStateSink {             // states to xw (xs without it), boundary defects to the candidate's slot of ds; controls dropped
-    T* xs; T* ds; T* xwk; int xw_stride;
+    T* xs; T* ds; T* xwk; int xw_stride; int uoff;
     PDDP_HD void x(int k, const T* v) const { if (xwk) tl_store14(xwk + (size_t)k * xw_stride, v); else tl_store14(xs + (size_t)k * 14, v); }
-    PDDP_HD void u(int, const T*) const {}
+    PDDP_HD void u(int k, const T* v) const { if (xwk && uoff) tl_store7(xwk + (size_t)k * xw_stride + uoff, v); }
+    PDDP_HD void xu(int k, const T*, const T* v) const { u(k, v); }
+    PDDP_HD void xu_last(int k, const T*, const T* v) const { u(k, v); }
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
 
 // The same destination as TlStateSink for a rollout whose x() calls come in knot order (k_fp_tl: begin at kStart, then kStart + 1, ...): a RUNNING pointer instead of
 // base + k * stride -- the 64-bit multiply-add per store is what the compiler does not strength-reduce across the inlined dynamics.
 template <typename T> struct TlRunSink {
-    T* ds; mutable T* cur; int stride;
+    T* ds; mutable T* cur; int stride; int uoff;
     PDDP_HD void x(int, const T* v) const { tl_store14(cur, v); cur += stride; }
-    PDDP_HD void u(int, const T*) const {}
+    PDDP_HD void u(int, const T* v) const { if (uoff) tl_store7(cur - stride + uoff, v); }      // (the knot's state went out last: cur is one record ahead)
+    PDDP_HD void xu(int k, const T*, const T* v) const { u(k, v); }
+    PDDP_HD void xu_last(int k, const T*, const T* v) const { u(k, v); }
     PDDP_HD void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
 };
 template <typename T>
 PDDP_HD TlRunSink<T> tl_run_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx, int kStart) {
     const size_t slot = (size_t)pb * dm.A + a_idx;
-    if (b.xw) return TlRunSink<T>{b.ds + slot * dm.N * 14, b.xw + (((size_t)pb * dm.N + kStart) * dm.A + a_idx) * 14, dm.A * 14};
-    return TlRunSink<T>{b.ds + slot * dm.N * 14, b.xs + (slot * dm.N + kStart) * 14, 14};
+    if (b.xw) return TlRunSink<T>{b.ds + slot * dm.N * 14, b.xw + (((size_t)pb * dm.N + kStart) * dm.A + a_idx) * b.xw_rec, dm.A * b.xw_rec, b.xw_rec > 14 ? 14 : 0};
+    return TlRunSink<T>{b.ds + slot * dm.N * 14, b.xs + (slot * dm.N + kStart) * 14, 14, 0};
 }
 
 template <typename T, typename Sink>
@@ -164,7 +179,7 @@ PDDP_HD void tl_rollout_step(TlRollout<T>& r, const ArmTlModel<T>& md, T grav, c
     const int kn = r.kStart + k;
     T u[NU];
     tl_control_law<T>(u, r.alpha, du, Kk, r.x, xr, uc);
-    sink.u(kn, u);
+    sink.xu(kn, r.x, u);
     r.J += arm_tl_cost<T>(cw, r.x, u, xg, false);
     ArmTlState<T> st;
     T qdd[7], xn[NX];
@@ -192,7 +207,7 @@ PDDP_HD void tl_rollout_end(TlRollout<T>& r, const Dims& dm, const CostWeights<T
         T u[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) u[i] = ucN[i];
-        sink.u(dm.N - 1, u);
+        sink.xu_last(dm.N - 1, r.x, u);
         r.J += arm_tl_cost<T>(cw, r.x, u, xg, true);
         r.sdef = T(0);
     }
@@ -233,17 +248,17 @@ template <typename T>
 PDDP_HD TlCandidateSink<T> tl_candidate_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx) {
     const size_t slot = (size_t)pb * dm.A + a_idx;
     return TlCandidateSink<T>{b.xs + slot * dm.N * 14, b.us + slot * dm.N * 7, b.ds + slot * dm.N * 14,
-                              b.xw ? b.xw + ((size_t)pb * dm.N * dm.A + a_idx) * 14 : nullptr, dm.A * 14};
+                              b.xw ? b.xw + ((size_t)pb * dm.N * dm.A + a_idx) * b.xw_rec : nullptr, dm.A * b.xw_rec, (b.xw && b.xw_rec > 14) ? 14 : 0};
 }
 template <typename T>
 PDDP_HD TlStateSink<T> tl_state_sink(const Buffers<T>& b, const Dims& dm, int pb, int a_idx) {
     const size_t slot = (size_t)pb * dm.A + a_idx;
-    return TlStateSink<T>{b.xs + slot * dm.N * 14, b.ds + slot * dm.N * 14, b.xw ? b.xw + ((size_t)pb * dm.N * dm.A + a_idx) * 14 : nullptr, dm.A * 14};
+    return TlStateSink<T>{b.xs + slot * dm.N * 14, b.ds + slot * dm.N * 14, b.xw ? b.xw + ((size_t)pb * dm.N * dm.A + a_idx) * b.xw_rec : nullptr, dm.A * b.xw_rec, (b.xw && b.xw_rec > 14) ? 14 : 0};
 }
 // After the line search accepted candidate st.alphaIndex (st.cur already points at the NEW half of xb): knot k of the winner becomes the current
-// trajectory -- its state from the candidate's slot of xs into the new half of xb, its control recomputed from that state with the rollout's own
-// control law (same operands: the gain, the OLD current state / control of this knot, the feed-forward; the same tl_control_law, so the same
-// bits the rollout used) over ucur, the boundary defect from ds into dcur.  Every knot is independent: this is the first step of the setup
+// trajectory -- its state from the candidate's record (xw; its slot of xs without xw) into the new half of xb, its control from the record over ucur (without
+// records: recomputed from that state with the rollout's own control law and operands -- the gain, the OLD current state / control of this knot, the
+// feed-forward; the same tl_control_law, so the same bits the rollout used), the boundary defect from ds into dcur.  Every knot is independent: this is the first step of the setup
 // kernel's thread.  Replaces memcpyCurrAKern x3 and the winner -> xp / up / dp copies of nextIterationSetupGPU (nisInitHelpers.cuh:24-32, 270-276).
 // Leaves the adopted x[14], u[7] with the caller.
 template <typename T>
@@ -252,12 +267,22 @@ PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int p
     const SolverState<T>& st = b.state[pb];
     const size_t N = dm.N, knot = (size_t)pb * N + k;
     const size_t src = ((size_t)pb * dm.A + st.alphaIndex) * N + k;
-    if (b.xw) tl_load14(x, b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * NX); else tl_load14(x, b.xs + src * NX);
+    const bool stored_u = b.xw && b.xw_rec > NX;                         // the rollouts left the candidate's control next to its state
+    if (b.xw) tl_load14(x, b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * b.xw_rec); else tl_load14(x, b.xs + src * NX);
     T* uc = b.ucur + knot * NU;
-    T ucv[NU];
+    if (k == dm.N - 1) {                                                  // the terminal knot carries its nominal control along unchanged (tl_rollout_end)
 #pragma unroll
-    for (int i = 0; i < NU; i++) ucv[i] = uc[i];
-    if (k < dm.N - 1) {
+        for (int i = 0; i < NU; i++) u[i] = uc[i];
+    } else if (stored_u) {
+        const T* ur = b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * b.xw_rec + NX;
+#pragma unroll
+        for (int i = 0; i < NU; i++) u[i] = ur[i];
+#pragma unroll
+        for (int i = 0; i < NU; i++) uc[i] = u[i];
+    } else {
+        T ucv[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) ucv[i] = uc[i];
         T xr[NX], duv[NU];
         tl_load14(xr, b.xb + (((size_t)pb * 2 + (1 - st.cur)) * N + k) * NX);
 #pragma unroll
@@ -270,9 +295,6 @@ PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int p
         tl_control_law<T>(u, alpha, duv, Kk, x, xr, ucv);
 #pragma unroll
         for (int i = 0; i < NU; i++) uc[i] = u[i];
-    } else {                                                              // the terminal knot carries its nominal control along unchanged (tl_rollout_end)
-#pragma unroll
-        for (int i = 0; i < NU; i++) u[i] = ucv[i];
     }
     tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX, x);
     if (dm.M > 1 && dm.on_defect_boundary(k)) {
@@ -363,7 +385,7 @@ PDDP_HD void tl_rollout_step_ee(TlRollout<T>& r, T* acc, const ArmTlModel<T>& md
     const int kn = r.kStart + k, N = dm.N;
     T u[NU];
     tl_control_law<T>(u, r.alpha, du, Kk, r.x, xr, uc);
-    sink.u(kn, u);
+    sink.xu(kn, r.x, u);
     ArmTlState<T> st;
     arm_tl_trig<T>(st, r.x);
     if (k < dm.NB - 1 || r.seg == dm.M - 1) {                         // not on the "final" state of a non-final segment (:259-265)

@@ -302,7 +302,7 @@ struct Solver : SolverBase {
         b.model = dmodel;
         register_model(dmodel, hm);
         derive_tl_model(hm);
-        if constexpr (P::PLANT == 4) { if (fp_path == kFpTl && !std::getenv("PDDP_NO_XW")) { if ((rc = alloc("xw", &b.xw, B * N * A * NX))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
+        if constexpr (P::PLANT == 4) { if (fp_path == kFpTl) { b.xw_rec = 22; if ((rc = alloc("xw", &b.xw, B * N * A * b.xw_rec))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
         if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
         if constexpr (P::PLANT == 4) {
             const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)

@@ -15,13 +15,38 @@ namespace pddp {
 // feed-forward 7).  A wave owns 64/A pairs; it fetches their operands of step k+1 cooperatively (every pair's block is contiguous: 8-byte accesses,
 // each byte fetched once per wave) while step k computes, parks them in its own double-buffered LDS area (132-float pair stride: the pairs land in
 // different banks), and every lane reads its pair's copy from there.  No workgroup barrier: a wave only ever touches its own area.
-// ALL = false (the sweep): every candidate writes its states and boundary defects into its slot of xs / ds (56 bytes per step) next to its partial
-// cost / defect sums; the setup kernel adopts the accepted candidate from there and recomputes its controls (arm_tl_adopt_knot).
+// ALL = false (the sweep): every candidate writes its (state | control) record of every knot into xw (88 bytes per step; float: TlStagedSink below) and its boundary
+// defects into its slot of ds, next to its partial cost / defect sums; the setup kernel adopts the accepted candidate's records (arm_tl_adopt_knot).
 // ALL = true (pddp_run_phase(FP), teacher-forced tests): the controls go to us as well, as the reference keeps them.
 // The linear sweep (k_sweep_st) runs before it.  Replaces forwardSimKern<<<(M,A),(8,7)>>> + costKern<<<A,N>>> + defectKern<<<A,N>>>
 // (fpHelpers.cuh:366,383,388).
 // The production instantiation (float, joint-space cost, states only) is held to 168 registers -- three waves per SIMD, no scratch: 0.695 -> 0.654 ms at 16384 problems
 // on one box (tools/ab_lib.sh); at 128 registers (four waves) it spills 212 bytes per lane and takes 1.3 ms.
+// TlStagedSink (float sweep): the (state | control | pad) records of a wave's 64 rollouts -- 22 floats each, the 8 candidates of a (problem, segment) pair adjacent: one
+// 704-byte run of xw per pair and knot -- go through the wave's LDS area and leave as 16-byte pieces: the A lanes of a pair write 16 A consecutive bytes per store
+// instruction instead of 8 bytes 88 bytes apart (one memory transaction per LANE and store).  The record of knot k is complete right after the control law of step k
+// (the state is the rollout's current one), when the step's operands in LDS have been consumed: the staging area overlays them (both operand buffers are dead between
+// the control law and the end-of-step park()).  cur: this lane's record of the current knot; a: its candidate index.
+template <typename T> struct TlStagedSink {
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    T* ds; mutable T* cur; int stride; T* stg; int lane, a, A;
+    __device__ void x(int, const T*) const {}
+    __device__ void u(int, const T*) const {}
+    __device__ void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
+    __device__ void xu(int, const T* xv, const T* uv) const {
+        wsync();
+        T* rec = stg + lane * 22;
+        tl_store14(rec, xv); tl_store7(rec + 14, uv);
+        wsync();
+        const T* src = stg + (lane - a) * 22 + 4 * a; T* dst = cur - 18 * a;           // the pair's run (A records = 5.5 A pieces of 16 bytes): piece a, then every A-th
+        const int step = 4 * A;
+#pragma unroll
+        for (int j = 0; j < 5; j++) *reinterpret_cast<v4*>(dst + step * j) = *reinterpret_cast<const v4*>(src + step * j);
+        if (2 * a < A) *reinterpret_cast<v4*>(dst + step * 5) = *reinterpret_cast<const v4*>(src + step * 5);
+        cur += stride;
+    }
+    __device__ void xu_last(int, const T* xv, const T* uv) const { tl_store14(cur, xv); tl_store7(cur + 14, uv); }
+};
 constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | xr 14 | uc 7 | du 7 | pad 6
 constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
 // EE: the end-effector cost family (fp_tl.hpp tl_rollout_step_ee): every segment runs NB steps, the cost is accumulated in the rollout.
@@ -93,8 +118,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 && !EE && !ALL ? 3 : 2) void k_
     const int pb = (gp < npairs ? gp : npairs - 1) / M, seg = (gp < npairs ? gp : npairs - 1) - pb * M;
     const bool live = gp < npairs && fp_active<T>(b, dm, pb);
     const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
-    T xg[NX];                                                         // joint-space goal, or (EE) the 6-vector tool-point goal in xg[0..5]
-    tl_load14(xg, b.xGoal + (size_t)pb * NX);
+    // joint-space goal, or (EE) the 6-vector tool-point goal in xg[0..5]: one copy per pair in LDS (14 registers the dynamics do not have to carry)
+    __shared__ __attribute__((aligned(16))) T xg_all[4 * kFpTlMaxPairs * 16];
+    T* xg = xg_all + (wave * kFpTlMaxPairs + p) * 16;
+    if (a_idx == 0) { T t[NX]; tl_load14(t, b.xGoal + (size_t)pb * NX); tl_store14(xg, t); }
     T xt[EE ? NX : 1], acc[EE ? NU : 1];                              // EE: nominal-state target, per-joint running cost
     int tshift = 0;
     if (EE) {
@@ -106,7 +133,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 && !EE && !ALL ? 3 : 2) void k_
     TlRollout<T> r;
     r.iters = 0;
     const auto csink = tl_candidate_sink<T>(b, dm, pb, a_idx);
-    const auto ssink = tl_run_sink<T>(b, dm, pb, a_idx, seg * NBk);
+    constexpr bool STG = sizeof(T) == 4 && !ALL;                      // the float sweep: records through LDS (the host API allocates xw with 22-float records for this path)
+    const auto rsink = tl_run_sink<T>(b, dm, pb, a_idx, seg * NBk);
+    const auto ssink = [&]() { if constexpr (STG) return TlStagedSink<T>{rsink.ds, rsink.cur, rsink.stride, stg, lane, a_idx, A}; else return rsink; }();
     if (live) {
         if (ALL) tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, csink); else tl_rollout_begin<T>(r, b, dm, pb, a_idx, seg, xcur, ssink);
         if (EE) r.iters = NBk;

@@ -59,7 +59,8 @@ struct Buffers {
     T *xTarget;          // [B][n] nominal-state target of the end-effector cost (zeros unless set)
     T *costk;            // [B][N] per-knot cost of the loaded trajectory (end-effector cost: written by the setup kernel, d_JT[k] of initAlgGPU)
     int *tshift;         // [B] finalCostShift of the end-effector cost (0 unless the MPC call shifts it)
-    T *xw;               // [B][N][A][n] candidate states knot-major (thread-lane rollouts -> setup kernel, fp_tl.hpp); null otherwise
+    T *xw;               // [B][N][A][xw_rec] candidate states knot-major (thread-lane rollouts -> setup kernel, fp_tl.hpp); null otherwise
+    int xw_rec;          // elements per (knot, candidate) record of xw: 14 = the state; 22 = state | control | pad (the setup kernel then reads the accepted control instead of recomputing it)
     T *segmap;           // [B][M][16*16] per-segment affine maps of the forward sweep composed by the matrix-core backward pass (bp_mfma.hpp kMxFuseSweep); null otherwise
     T *Hc;               // [B][N][49] the dense 7 x 7 position block Jee' Jee of the end-effector cost's Gauss-Newton Hessian (the rest of H_k is the diagonal of the cost weights):
                          // thread-lane setup -> matrix-core backward pass of end-effector handles (fp_tl.hpp arm_tl_nis_cost_ee, bp_mfma.hpp HQQ); null otherwise

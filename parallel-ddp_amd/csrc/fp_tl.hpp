@@ -262,7 +262,7 @@ PDDP_HD TlStateSink<T> tl_state_sink(const Buffers<T>& b, const Dims& dm, int pb
 // kernel's thread.  Replaces memcpyCurrAKern x3 and the winner -> xp / up / dp copies of nextIterationSetupGPU (nisInitHelpers.cuh:24-32, 270-276).
 // Leaves the adopted x[14], u[7] with the caller.
 template <typename T>
-PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int pb, T* x, T* u) {
+PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int pb, T* x, T* u, bool store_xu = true) {
     constexpr int NX = 14, NU = 7;
     const SolverState<T>& st = b.state[pb];
     const size_t N = dm.N, knot = (size_t)pb * N + k;
@@ -276,9 +276,15 @@ PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int p
     } else if (stored_u) {
         const T* ur = b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * b.xw_rec + NX;
 #pragma unroll
-        for (int i = 0; i < NU; i++) u[i] = ur[i];
+        for (int i = 0; i < 4; i++) {                                     // four pairs (the last one: u[6] | pad) instead of seven single elements
+            const TlPair<T> v = *reinterpret_cast<const TlPair<T>*>(ur + 2 * i);
+            u[2 * i] = v.a;
+            if (i < 3) u[2 * i + 1] = v.b;
+        }
+        if (store_xu) {
 #pragma unroll
-        for (int i = 0; i < NU; i++) uc[i] = u[i];
+            for (int i = 0; i < NU; i++) uc[i] = u[i];
+        }
     } else {
         T ucv[NU];
 #pragma unroll
@@ -293,10 +299,12 @@ PDDP_HD void arm_tl_adopt_knot(const Buffers<T>& b, const Dims& dm, int k, int p
 #pragma unroll
         for (int rr = 0; rr < NU; rr++) tl_load14(Kk + rr * NX, Kg + rr * NX);
         tl_control_law<T>(u, alpha, duv, Kk, x, xr, ucv);
+        if (store_xu) {
 #pragma unroll
-        for (int i = 0; i < NU; i++) uc[i] = u[i];
+            for (int i = 0; i < NU; i++) uc[i] = u[i];
+        }
     }
-    tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX, x);
+    if (store_xu) tl_store14(b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX, x);
     if (dm.M > 1 && dm.on_defect_boundary(k)) {
         T d[NX];
         tl_load14(d, b.ds + src * NX);
@@ -321,16 +329,19 @@ PDDP_HD void tl_reduce_parts(const Buffers<T>& b, const Dims& dm, int pb) {
 //   arm_tl_nis_jac:  the Jacobian of the dynamics through emit(col, row, dqdd) -- the caller turns it into [A B] rows 7..13 (k_nis_tl stages it through
 //                    LDS in three pieces, flushed at mark(stage); see arm_tl_gradient)
 // x[14], u[7]: out -- the current state / control of the knot (mode 0: just adopted from the accepted candidate).
+// arm_tl_nis_cost_vals: the same with g_k left in gl[21] for the caller to store (k_nis_tl sends a wave's 64 gradients through LDS: one contiguous run instead of 21
+// four-byte stores 84 bytes apart per lane; store_xu = false: likewise the adopted state and control, which the caller then finds in x, u).  Returns 0: nothing moved,
+// 4: trajectory adopted only (final accepted step), 1: g computed but no Jacobian wanted (terminal knot), 3: g and Jacobian.
 template <typename T>
-PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, T* x, T* u) {
+PDDP_HD int arm_tl_nis_cost_vals(const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, T* x, T* u, T* gl, bool store_xu = true) {
     constexpr int NX = 14, NU = 7, NM = 21;
     const int N = dm.N;
     const SolverState<T>& st = b.state[pb];
     const size_t knot = (size_t)pb * N + k;
     if (mode == 0) {
-        if (!st.win_pending) return false;                                // rejected / failed: nothing moved
-        arm_tl_adopt_knot<T>(b, dm, k, pb, x, u);
-        if (st.done) return false;                                        // final accepted step: the trajectory is adopted, no derivatives needed
+        if (!st.win_pending) return 0;                                    // rejected / failed: nothing moved
+        arm_tl_adopt_knot<T>(b, dm, k, pb, x, u, store_xu);
+        if (st.done) return 4;                                            // final accepted step: the trajectory is adopted, no derivatives needed
     } else {
         tl_load14(x, b.xb + (((size_t)pb * 2 + st.cur) * N + k) * NX);
 #pragma unroll
@@ -340,18 +351,28 @@ PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeig
     const T w1 = fin ? cw.QF1 : cw.Q1, w2 = fin ? cw.QF2 : cw.Q2, w3 = fin ? T(0) : cw.R;       // ArmPlant::weight
     T xg[NX];
     tl_load14(xg, b.xGoal + (size_t)pb * NX);
-    T* g = b.g + knot * NM;
 #pragma unroll
-    for (int i = 0; i < 7; i++) { g[i] = w1 * (x[i] - xg[i]); g[7 + i] = w2 * (x[7 + i] - xg[7 + i]); g[14 + i] = w3 * u[i]; }
+    for (int i = 0; i < 7; i++) { gl[i] = w1 * (x[i] - xg[i]); gl[7 + i] = w2 * (x[7 + i] - xg[7 + i]); gl[14 + i] = w3 * u[i]; }
     if (cw.limits) {                                                      // USE_LIMITS_FLAG: the gradient only (cost_arm.cuh:176-199)
-        const int n = fin ? NX : NM;
-        for (int i = 0; i < n; i++) g[i] += arm_limit_term<T>(x, u, i, 1);
+#pragma unroll
+        for (int i = 0; i < NM; i++) if (i < (fin ? NX : NM)) gl[i] += arm_limit_term<T>(x, u, i, 1);
     }
     if (mode == 1) {                                                      // H_k = diag(weight): constant over the solve, written once
         T* H = b.H + knot * (NM * NM);
         for (int e = 0; e < NM * NM; e++) { const int i = e / NM, j = e % NM; H[e] = i != j ? T(0) : (i < 7 ? w1 : (i < NX ? w2 : w3)); }
     }
-    return !fin;
+    return fin ? 1 : 3;
+}
+template <typename T>
+PDDP_HD bool arm_tl_nis_cost(const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, T* x, T* u) {
+    T gl[21];
+    const int r = arm_tl_nis_cost_vals<T>(b, dm, cw, mode, k, pb, x, u, gl);
+    if (r & 1) {
+        T* g = b.g + ((size_t)pb * dm.N + k) * 21;
+#pragma unroll
+        for (int i = 0; i < 21; i++) g[i] = gl[i];
+    }
+    return r == 3;
 }
 // the Jacobian of the dynamics at (x, u) through emit(col, row, dqdd)
 template <typename T, typename Emit, typename Mark>

@@ -603,14 +603,14 @@ void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
 // double handles (PDDP_FP=tl: test selection) run the same code with two waves per workgroup.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
 constexpr int kNisTlStage = 64 * 57;
 template <typename T> struct NisTlCfg { static constexpr int kWaves = sizeof(T) == 4 ? 4 : 2, kThreads = 64 * kWaves; };   // double: two waves per workgroup (58 KB of staging)
-template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); };
+template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); typedef T v4p __attribute__((ext_vector_type(16 / sizeof(T)), aligned(16))); };   // v4p: one 16-byte piece
 template <typename T, int V, bool EE, bool CAB>
 __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void k_nis_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NM = 21;
     const int g = blockIdx.x * NisTlCfg<T>::kThreads + threadIdx.x, total = batch * dm.N;
     const int pb = g / dm.N, k = g - pb * dm.N;
-    __shared__ T stage_all[NisTlCfg<T>::kWaves * kNisTlStage];
+    __shared__ __attribute__((aligned(16))) T stage_all[NisTlCfg<T>::kWaves * kNisTlStage];
     T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
     const int lane = threadIdx.x & 63;
     T x[NX], u[7];
@@ -619,9 +619,42 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
 #pragma unroll
     for (int i = 0; i < 7; i++) u[i] = T(0);
     bool need = false;
-    if (g < total) {
-        if (EE) need = arm_tl_nis_cost_ee<T>(md, b, dm, cw, mode, k, pb, x, u);
-        else need = arm_tl_nis_cost<T>(b, dm, cw, mode, k, pb, x, u);
+    if (EE) { if (g < total) need = arm_tl_nis_cost_ee<T>(md, b, dm, cw, mode, k, pb, x, u); }
+    else {
+        // joint-space cost: the wave's 64 gradients g_k (21 elements each, consecutive knots = 84 x 64 contiguous bytes) leave through the staging area as 16-byte pieces
+        T gl[NM];
+        const int r = (g < total) ? arm_tl_nis_cost_vals<T>(b, dm, cw, mode, k, pb, x, u, gl, false) : 0;
+        need = (r == 3);
+        constexpr int per16 = 16 / (int)sizeof(T);                        // elements per 16-byte piece
+        auto run_out = [&](T* dst, const T* v, auto cnt) {               // element i of lane l -> dst[l * n + i]: through the staging area, whole pieces per lane
+            constexpr int n = decltype(cnt)::value;
+#pragma unroll
+            for (int i = 0; i < n; i++) stage[lane * n + i] = v[i];
+            wsync();
+            for (int c = lane; c < 64 * n / per16; c += 64)
+                *reinterpret_cast<typename NisTlVec<T>::v4p*>(dst + c * per16) = *reinterpret_cast<const typename NisTlVec<T>::v4p*>(stage + c * per16);
+            wsync();
+        };
+        const bool adopting = (mode == 0) && r != 0;                      // (uniform per problem) the accepted state / control are in x, u and still have to go out
+        if (__ballot(r != 0) == ~0ull && (dm.N & 63) == 0) {              // the wave's 64 knots belong to ONE problem and all of them moved: contiguous runs
+            const size_t k0 = (size_t)(g - lane);                         // global index of the wave's first knot
+            if (adopting) {
+                run_out(b.xb + ((size_t)pb * 2 + b.state[pb].cur) * dm.N * NX + (size_t)(k - lane) * NX, x, std::integral_constant<int, NX>{});
+                run_out(b.ucur + k0 * 7, u, std::integral_constant<int, 7>{});
+            }
+            if (r & 1) run_out(b.g + k0 * NM, gl, std::integral_constant<int, NM>{});
+        } else if (r) {
+            if (adopting) {
+                tl_store14(b.xb + (((size_t)pb * 2 + b.state[pb].cur) * dm.N + k) * NX, x);
+#pragma unroll
+                for (int i = 0; i < 7; i++) b.ucur[(size_t)g * 7 + i] = u[i];
+            }
+            if (r & 1) {
+                T* gk = b.g + (size_t)g * NM;
+#pragma unroll
+                for (int i = 0; i < NM; i++) gk[i] = gl[i];
+            }
+        }
     }
     const unsigned long long mask = __ballot(need);
     if (!mask) return;                                          // (uniform) nothing to differentiate in this wave

@@ -253,6 +253,7 @@ int pddp_run_phase(pddp_handle h, int phase);
  *   PDDP_BP=mx|lg|coop|wide   backward pass: matrix cores | lane groups | one wave per block of knots | one workgroup per block
  *   PDDP_FP=tl|tl2|lg|coop    rollouts + next-iteration setup: thread lanes (tl2: the two-wave predecessor of the few-problem pipeline) | lane groups | cooperative
  *   PDDP_SWEEP=alpha|st|wg    a separate linear-sweep kernel instead of the maps composed in the matrix-core backward pass
+ *   PDDP_LS=many|wg           line search one thread per problem (default from 2048 problems in flight) | one workgroup per problem
  *   PDDP_AB=full              keep [A B] in the reference layout only          PDDP_CF=ts|coop (PDDP_CF_BP / _FP / _NIS)  closed-form plants: thread-serial | cooperative */
 int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);
 

@@ -188,6 +188,14 @@ __global__ __launch_bounds__(64) void k_ls(Buffers<T> b, Dims dm, SolverParams s
     if (threadIdx.x == 0) ls_body<T>(b, dm, sp, pb, freeze_exit);
 }
 
+// The same decision with MANY problems in flight: grid ceil(B / 64), block 64, one THREAD per problem (ls_body adds the thread-lane rollouts' partial sums itself, in the
+// same order) -- 256 waves instead of 16384 one-wave workgroups whose launch is all they cost.
+template <typename T>
+__global__ __launch_bounds__(64) void k_ls_many(Buffers<T> b, Dims dm, SolverParams sp, int freeze_exit, int batch) {
+    const int pb = blockIdx.x * 64 + threadIdx.x;
+    if (pb < batch) ls_body<T>(b, dm, sp, pb, freeze_exit);
+}
+
 // next-iteration setup: grid (N, B), block 64 (see nis_body).
 template <typename P, int INTEG, typename T>
 __global__ __launch_bounds__(64) void k_nis(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode) {

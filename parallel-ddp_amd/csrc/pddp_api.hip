@@ -128,6 +128,7 @@ struct Solver : SolverBase {
     static constexpr int kNisTl7MaxBatch = 511;   // measured crossover against k_nis_lg (profiles/)
     bool fp_split = false;         // rollouts of a lane-group handle on the split thread-lane kernels (k_fp_tl4 / k_fp_tl2)
     bool fp_two_wave = false;
+    bool ls_many = false;          // line search one thread per problem (k_ls_many): from 2048 problems in flight
     FpPath fp_path = kFpLg;        // the arm's forward pass / next-iteration setup (fp_tl.hpp select_fp_path)
     int tl_variant = -1;           // which built-in robot model the handle's tables equal (the thread-lane kernels fold it into literals); -1: neither
     T tl_grav = T(0);
@@ -233,6 +234,7 @@ struct Solver : SolverBase {
         if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
         // closed-form plants (and user plants): one wave per unit while a handful of problems is in flight (the shorter critical path), one thread per unit once
         // the batch fills the device (64 units per wave instead of 1); the horizon has to fit the per-thread cost table of k_fp_ts
+        { const char* e = std::getenv("PDDP_LS"); ls_many = e ? std::string(e) == "many" : c.batch >= 2048; }      // PDDP_LS=many|wg
         cf_serial = P::PLANT != 4 && (size_t)c.batch * c.M >= 256 && c.N <= kTsMaxN && c.M <= kTsMaxM;
         if (const char* v = std::getenv("PDDP_CF")) cf_serial = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
         // measured on MI355X (tools/cf_variants.py; profiles/r03_closed_form_variants.txt): the rollouts always win thread-serially once the device is full (cart-pole, 16384
@@ -476,7 +478,10 @@ struct Solver : SolverBase {
             }
         }
         if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0, store_candidates, part);
-        if (only < 0 || only == PDDP_PHASE_LS) hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
+        if (only < 0 || only == PDDP_PHASE_LS) {
+            if (ls_many) hipLaunchKernelGGL((k_ls_many<T>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, b, dm, sp, bench_mode, (int)B);
+            else hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
+        }
         if (only < 0 || only == PDDP_PHASE_NIS) launch_nis(s, 0, part);
     }
     // The kernels of one sweep in launch order, by name, and their average duration over `sweeps` sweeps (an event after every launch, one pass).
@@ -485,7 +490,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : gl_nis ? "k_nis_gl" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

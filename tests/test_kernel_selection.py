@@ -52,6 +52,8 @@ def test_selection_overrides_reach_the_older_kernels():
 def test_large_batches_run_one_thread_per_rollout_and_per_knot(ee):
     kw = dict(KUKA, ee_cost=ee, **(dict(mpc_mode=1, ignore_max_rho_exit=0) if ee else {}))
     assert kernels(4, 512, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl", "k_ls", "k_nis_tl"]
+    if not ee:
+        assert kernels(4, 2048, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl", "k_ls_many", "k_nis_tl"]
 
 
 def test_float64_handles_default_to_lane_groups_and_reach_the_benched_family_on_request():
@@ -63,7 +65,7 @@ def test_float64_handles_default_to_lane_groups_and_reach_the_benched_family_on_
 def test_closed_form_plants_switch_to_thread_serial_kernels_with_the_device_full():
     cart = dict(N=64, M=4, A=8, integrator=3, total_time=4.0, tol_cost=0.0, max_iter=20)
     assert kernels(2, 2, **cart) == ["k_bp", "k_fp", "k_ls", "k_nis"]
-    assert kernels(2, 4096, **cart) == ["k_bp_ts", "k_fp_ts", "k_ls", "k_nis_ts"]
+    assert kernels(2, 4096, **cart) == ["k_bp_ts", "k_fp_ts", "k_ls_many", "k_nis_ts"]      # line search: one thread per problem from 2048 problems in flight
     quad = dict(N=64, M=4, A=8, integrator=3, total_time=4.0, tol_cost=0.0, max_iter=20)      # 12 states: rollouts thread-serial, setup on 16-lane groups, backward pass cooperative (32-lane groups from 8192 blocks of knots)
     assert kernels(3, 1024, **quad) == ["k_bp", "k_fp_ts", "k_ls", "k_nis_gl"]
-    assert kernels(3, 2048, **quad) == ["k_bp_gl", "k_fp_ts", "k_ls", "k_nis_gl"]
+    assert kernels(3, 2048, **quad) == ["k_bp_gl", "k_fp_ts", "k_ls_many", "k_nis_gl"]

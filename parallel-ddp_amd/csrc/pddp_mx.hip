@@ -60,14 +60,15 @@ void launch_bp_mfma(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batc
 template void launch_bp_mfma<float>(hipStream_t, const Buffers<float>&, const Dims&, int, bool, float, float, float, float, bool, bool);
 template void launch_bp_mfma<double>(hipStream_t, const Buffers<double>&, const Dims&, int, bool, double, double, double, double, bool, bool);
 
-// k_sweep_maps: grid B, block 64.  The forward sweep from the per-segment maps the backward pass composed (bp_mfma.hpp kMxFuseSweep): e <- Phi_s e + gamma_s over the
+// k_sweep_maps: grid ceil(B / PER), block 64.  The forward sweep from the per-segment maps the backward pass composed (bp_mfma.hpp kMxFuseSweep): e <- Phi_s e + gamma_s over the
 // segments for the s-sequence (gamma = the map's column 14) and the t-sequence (gamma = the defect of the segment's boundary knot: it enters at the segment's last
 // step), lane l < 14 owns entry l; at every boundary the segment start state of every candidate, x = xcur + (t - alpha s), goes to xs.  Replaces forwardSweepKern x A
 // (fpHelpers.cuh:19-63) together with the A - B K / B du traffic between the two passes.
-template <typename T>
+// PER problems per wave (1, or 4 with many problems in flight: 16 lanes each -- a quarter of the one-wave workgroups, whose launch is most of what this kernel costs).
+template <typename T, int PER>
 __global__ __launch_bounds__(64) void k_sweep_maps(Buffers<T> b, Dims dm, int batch) {
-    constexpr int NX = 14;
-    const int pb = blockIdx.x, lane = threadIdx.x;
+    constexpr int NX = 14, W = 64 / PER;                                         // W: lanes per problem (shuffles stay inside them)
+    const int lane = threadIdx.x % W, pb = blockIdx.x * PER + threadIdx.x / W;
     if (pb >= batch) return;
     const SolverState<T>& st = b.state[pb];
     if (st.done) return;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64) void k_sweep_maps(Buffers<T> b, Dims dm, int ba
 #pragma unroll
         for (int cc = 0; cc < NX; cc++) {
             const T ph = o[cc * 16 + l];
-            ns = Mx<T>::fma(ph, __shfl(es, cc), ns); nt = Mx<T>::fma(ph, __shfl(et, cc), nt);
+            ns = Mx<T>::fma(ph, __shfl(es, cc, W), ns); nt = Mx<T>::fma(ph, __shfl(et, cc, W), nt);
         }
         es = ns; et = nt;
         if (lane < NX) {
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(64) void k_sweep_maps(Buffers<T> b, Dims dm, int ba
 }
 template <typename T>
 void launch_sweep_maps(hipStream_t s, const Buffers<T>& b, const Dims& dm, int batch) {
-    hipLaunchKernelGGL((k_sweep_maps<T>), dim3((unsigned)batch), dim3(64), 0, s, b, dm, batch);
+    if (batch >= 2048) hipLaunchKernelGGL((k_sweep_maps<T, 4>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, s, b, dm, batch);
+    else hipLaunchKernelGGL((k_sweep_maps<T, 1>), dim3((unsigned)batch), dim3(64), 0, s, b, dm, batch);
 }
 template void launch_sweep_maps<float>(hipStream_t, const Buffers<float>&, const Dims&, int);
 template void launch_sweep_maps<double>(hipStream_t, const Buffers<double>&, const Dims&, int);

@@ -427,7 +427,7 @@ def test_batches_between_one_and_the_bench_equal_single_problem_solves(B, env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,env", [pytest.param(1, {}, id="one-problem"), pytest.param(1024, {}, id="1024-problems")])
+@pytest.mark.parametrize("B,env", [pytest.param(1, {}, id="one-problem"), pytest.param(2048, {}, id="2048-problems")])
 def test_fused_sweep_matches_the_sweep_kernels(B, env):
     """Production sweeps compose every shooting segment's sweep map inside the matrix-core backward pass (Psi = G_last ... G_first, G_k = [A - B K, B du; 0, 1]) and
     k_sweep_maps chains the maps -- A - B K / B du never reach HBM.  Phase by phase this path has no teacher-forcing hook (the hook's sweep reads the arrays the test

@@ -161,8 +161,7 @@ struct Solver : SolverBase {
     }
     int ab_keep_reference_layout() override {
         if (!b.ABc) return 0;
-        int rc = ab_view(0);
-        if (!rc) rc = h_view();
+        int rc = ab_view(0);       // (the caller refreshed the reference-layout H from the compact position block BEFORE it wrote into it: pddp_set_array)
         b.ABc = nullptr; b.Hc = nullptr; drop_graph();
         return rc;
     }
@@ -170,7 +169,7 @@ struct Solver : SolverBase {
     int h_view() override {
         if constexpr (P::PLANT == 4) {
             if (b.Hc) {
-                hipLaunchKernelGGL((k_hc_expand<T>), dim3((cfg.batch * cfg.N + 63) / 64), dim3(64), 0, stream, b, (int)(cfg.batch * cfg.N), cfg.N, cw.Q_xdEE, cw.R_EE);
+                hipLaunchKernelGGL((k_hc_expand<T>), dim3((cfg.batch * cfg.N + 63) / 64), dim3(64), 0, stream, b, (int)(cfg.batch * cfg.N), cfg.N, hw[1], hw[2]);
                 HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream));
             }
         }
@@ -432,8 +431,15 @@ struct Solver : SolverBase {
         }
     }
     // part: -1 everything; 0 nothing (slot of a former separate winner kernel in the per-kernel timing); 1 only the setup kernel
+    // The running knots' cost Hessian the matrix-core backward pass does not read (diag_h) is the one the LAST setup kernel wrote -- the reference's d_H holds exactly
+    // that (costGradientHessianKern runs inside the setup, nisInitHelpers.cuh:46-93).  The weights are therefore remembered at every setup launch: a pddp_set_cost /
+    // pddp_set_cost_ee between a setup and the next backward pass (phase hook, re-captured graph) must not mix new weights into a Hessian whose gradient and compact
+    // position block still carry the old ones.
+    T hw[3] = {T(0), T(0), T(0)};
+    void note_setup_weights() { const bool ee = cfg.ee_cost != 0; hw[0] = ee ? cw.Q_xEE : cw.Q1; hw[1] = ee ? cw.Q_xdEE : cw.Q2; hw[2] = ee ? cw.R_EE : cw.R; }
     void launch_nis(hipStream_t s, int mode, int part = -1) {
         const unsigned B = cfg.batch;
+        if (part != 0) note_setup_weights();
         if constexpr (P::PLANT == 4) {
             if (fp_path == kFpTl) {
                 if (part != 0) launch_nis_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B);   // mode 0: adopts the accepted candidate first (arm_tl_adopt_knot)
@@ -463,7 +469,7 @@ struct Solver : SolverBase {
                     // the nominal-state / control weights + the compact position block b.Hc
                     const bool ee = cfg.ee_cost != 0;
                     const bool diag_h = !h_overridden && (!ee || b.Hc != nullptr);
-                    launch_bp_mfma<T>(s, b, dm, (int)B, diag_h, ee ? cw.Q_xEE : cw.Q1, ee ? cw.Q_xdEE : cw.Q2, ee ? cw.R_EE : cw.R, dt, keep_all_ctg() || store_candidates,
+                    launch_bp_mfma<T>(s, b, dm, (int)B, diag_h, hw[0], hw[1], hw[2], dt, keep_all_ctg() || store_candidates,
                                       sweep_fused && (!store_candidates || phase_fused_sweep));
                 }
             }
@@ -965,6 +971,9 @@ extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host,
     if (bytes > cap) return fail(PDDP_EINVAL, "set_array: too many bytes");
     HIPCHK(hipStreamSynchronize(s->stream));
     if (std::strcmp(name, "AB") == 0 && bytes < cap && (rc = s->ab_view(0))) return rc;      // a partial write lands on the current values
+    // the first write into "H" of a handle that keeps the compact end-effector position block: bring the reference-layout array up to date FIRST (a partial write
+    // then lands on the current values, and the caller's data is not overwritten by the expansion afterwards)
+    if (std::strcmp(name, "H") == 0 && !s->h_overridden && (rc = s->h_view())) return rc;
     HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
     if (std::strncmp(name, "model_", 6) == 0) return s->model_changed();
     if (std::strcmp(name, "AB") == 0) return s->ab_view(1);

@@ -2,8 +2,9 @@
 #include <string.h>
 #include "oracle.h"
 
-int ora_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : 14; }
-int ora_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : 7; }
+int ora_plugin_npos = 0, ora_plugin_m = 0;      /* dimensions of the registered plug-in (either precision registers both) */
+int ora_state_size(int plant) { return plant == 1 ? 2 : plant == 2 ? 4 : plant == 3 ? 12 : plant == 5 ? 2 * ora_plugin_npos : 14; }
+int ora_control_size(int plant) { return plant == 1 ? 1 : plant == 2 ? 1 : plant == 3 ? 4 : plant == 5 ? ora_plugin_m : 7; }
 
 /* reference defaults: config.cuh:24-61 (per plant), :78-136 (algorithm), plants/cost_arm.cuh:97-103 */
 void ora_default_cfg(ora_cfg *c, int plant) {

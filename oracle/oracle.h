@@ -83,6 +83,23 @@ typedef struct ora_cfg {
                                            (not to H -- costGrad, plants/cost_arm.cuh:13-94,136-149,176-199); with EE_COST 1: cost, gradient AND the diagonal of H (:289-291,341-343,374-376)                                                      config.cuh:171-173 */
 } ora_cfg;
 
+/* PLANT 5 -- a user plug-in (config.cuh:240-252: the reference compiles a cost file and a plant file into the solver).  The oracle restates the SOLVER; a plug-in is an
+ * input to it, so plant 5 dispatches to callbacks a test registers (tests/plugin/plugin_shim.cpp compiles the user's own files for the host with the reference's
+ * one-thread loop helpers).  Signatures mirror the plug-in functions: dynamics / dynamicsGradient (dqdd[col * npos + row]), costFunc / costGrad with the five
+ * run-time weights of the current joint-space signature (plants/cost_arm.cuh:130,158).  n = 2 npos <= 14, m <= 7. */
+#define ORA_PLUGIN_DECL(SUF, REAL)                                                                                                        \
+    typedef struct ora_plugin_##SUF {                                                                                                     \
+        int npos, m;                                                                                                                      \
+        void (*dynamics)(REAL *qdd, const REAL *x, const REAL *u);                                                                        \
+        void (*dynamics_gradient)(REAL *dqdd, REAL *qdd, const REAL *x, const REAL *u);                                                   \
+        REAL (*cost_func)(const REAL *xk, const REAL *uk, const REAL *xg, int k, REAL Q1, REAL Q2, REAL R, REAL QF1, REAL QF2);           \
+        void (*cost_grad)(REAL *Hk, REAL *gk, const REAL *xk, const REAL *uk, const REAL *xg, int k, int ld_H, REAL Q1, REAL Q2, REAL R,  \
+                          REAL QF1, REAL QF2);                                                                                            \
+    } ora_plugin_##SUF;                                                                                                                   \
+    void ora_set_plugin_##SUF(const ora_plugin_##SUF *p);   /* NULL unregisters */
+ORA_PLUGIN_DECL(f32, float)
+ORA_PLUGIN_DECL(f64, double)
+
 /* fill a config with the reference defaults for `plant` (config.cuh per-plant blocks) */
 void ora_default_cfg(ora_cfg *c, int plant);
 int  ora_state_size(int plant);

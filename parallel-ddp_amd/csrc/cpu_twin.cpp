@@ -67,6 +67,9 @@ int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const
     cw.fd_eps = c.use_finite_diff ? c.finite_diff_epsilon : 0.0;      // USE_FINITE_DIFF: integratorGradientThreaded's other definition (nisInitHelpers.cuh:185-201)
     const T dt = (T)(c.total_time / (N - 1));                // TIME_STEP, config.cuh:136
     typename P::Model model; fill_model(model, c);
+#ifdef PDDP_REF_PLANT_FILE
+    if constexpr (P::PLANT == 5) { const std::string complaint = ref_plugin_setup<T>(N); if (!complaint.empty()) return cpu_fail(PDDP_EINVAL, complaint); }
+#endif
     int BP_T, FSIM_T, COST_T, INT_T;
     pddp_cpu_thread_counts(M, cores, &BP_T, &FSIM_T, &COST_T, &INT_T);
     int cores_eff = cores > 0 ? cores : (int)std::thread::hardware_concurrency();
@@ -105,8 +108,11 @@ int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const
             const T* xk = x + (size_t)k * NX; const T* uk = u + (size_t)k * NU;
             if (cost_part_) {
                 T* Hk = H + (size_t)k * NM * NM; T* gk = g + (size_t)k * NM;
+                if constexpr (P::kPluginCost) P::cost_grad(cw, Hk, gk, xk, uk, xGoal, k, N);      // a cost file in the reference's form (ref_plugin.hpp): the user's costGrad
+                else {
                 for (int e = 0; e < NM * NM; e++) { const int ii = e / NM, jj = e % NM; Hk[e] = (ii == jj) ? P::weight(cw, ii, k, N) : T(0); }
                 for (int ii = 0; ii < NM; ii++) gk[ii] = P::weight(cw, ii, k, N) * (ii < NX ? (xk[ii] - xGoal[ii]) : uk[ii - NX]);
+                }
                 if constexpr (P::PLANT == 4) { if (cw.limits) { const int nl = (k == N - 1) ? NX : NM; for (int ii = 0; ii < nl; ii++) gk[ii] += arm_limit_term<T>(xk, uk, ii, 1); } }
             }
             if (dyn_part) {
@@ -120,11 +126,16 @@ int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const
     auto back_blocks = [&](int tid, T rho, T* x, T* d) {                 // backPassThreaded (bpHelpers.cuh:424-481): blocks tid, tid + BP_T, ...
         BpScratch<P, T> s;
         BpArgs<T> a{}; a.AB = AB; a.Pm = Pm; a.pv = pv; a.Pp = Pp; a.pp = pp; a.H = H; a.g = g; a.KT = KT; a.du = du; a.dcur = d; a.ApBK = ApBK; a.Bdu = Bdu;
-        a.xcur = x; a.xprev2 = xp2; a.dJexp = dJexp; a.rho = rho; a.Hrw = H; a.grw = g;       // CPU path: H, g accumulate in place (bpHelpers.cuh:90-91)
+        // the expected reduction is per THREAD in the reference (dJexp[2 tid] is zeroed once and collects every block the thread owns, bpHelpers.cuh:431,467); bp_block
+        // leaves one pair per block, added up here in the thread's block order (with fewer threads than blocks -- cores < M -- a thread owns several)
+        std::vector<T> dj(2 * (size_t)M, T(0));
+        a.xcur = x; a.xprev2 = xp2; a.dJexp = dj.data(); a.rho = rho; a.Hrw = H; a.grw = g;       // CPU path: H, g accumulate in place (bpHelpers.cuh:90-91)
         std::vector<int> e(M, 0); a.err = e.data();
         int any = 0;
         const int r = reps_of(tid, BP_T, M);
-        for (int i = 0; i < r; i++) any |= bp_block<P, T>(w, s, dm, tid + i * BP_T, a);
+        T d0 = 0, d1 = 0;
+        for (int i = 0; i < r; i++) { const int blk = tid + i * BP_T; any |= bp_block<P, T>(w, s, dm, blk, a); d0 += dj[2 * blk]; d1 += dj[2 * blk + 1]; }
+        dJexp[2 * tid] = d0; dJexp[2 * tid + 1] = d1;
         err[tid] = any;
     };
 
@@ -407,3 +418,6 @@ extern "C" int pddp_cpu_run_ilqr2(const pddp_config* cfg, const pddp_cpu_buffers
                                   const void* d0, const void* xGoal, void* Jout, int* alphaOut, int forwardRolloutFlag, int clearVarsFlag,
                                   int ignoreFirstDefectFlag, double* tTime, double* simTime, double* sweepTime, double* bpTime, double* nisTime,
                                   double* initTime, int cores, int* iters_out) { return cpu_run_common(1, PDDP_CPU_RUN_ARGS); }
+
+// a plant file + cost file in the reference's own form (make user PLANT_FILE=... COST_FILE=...): included LAST, so that what those files #define stays out of the library
+#include "ref_plugin.hpp"

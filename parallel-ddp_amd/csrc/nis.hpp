@@ -42,11 +42,17 @@ PDDP_HD void nis_knot(const Wave& w, NisScratch<P, INTEG, T>& s, const Dims& dm,
             return;
         }
     }
+    if constexpr (P::kPluginCost) {
+        // a cost file in the reference's form (ref_plugin.hpp): costGrad is scalar code that the reference runs with one THREAD per knot (costGradientHessianKern,
+        // nisInitHelpers.cuh:86-92) -- one lane here; H_k may be any matrix the user's costGrad writes, the backward pass reads all of it
+        if (w.lane == 0) P::cost_grad(cw, Hk, gk, s.x, s.u, xg, k, dm.N);
+    } else {
     PDDP_FOR(e, NM * NM) { const int i = e / NM, j = e % NM; Hk[e] = (i == j) ? P::weight(cw, i, k, dm.N) : T(0); }
     PDDP_FOR(i, NM) {
         T gv = P::weight(cw, i, k, dm.N) * (i < NX ? (s.x[i] - xg[i]) : s.u[i - NX]);
         if constexpr (P::PLANT == 4) { if (cw.limits && (k < dm.N - 1 || i < NX)) gv += arm_limit_term<T>(s.x, s.u, i, 1); }      // USE_LIMITS_FLAG: the gradient only, H stays (cost_arm.cuh:176-199)
         gk[i] = gv;
+    }
     }
     if (k < dm.N - 1) {
         if (INTEG == 1 && cw.fd_eps > 0.0) integrator_gradient_fd<P, T>(w, s.plant, s.fd, ABk, s.x, s.u, dt, cw.fd_eps);   // USE_FINITE_DIFF

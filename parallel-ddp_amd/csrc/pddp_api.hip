@@ -226,6 +226,14 @@ struct Solver : SolverBase {
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c.device)
             return fail(PDDP_ENODEVICE, "no HIP device available: libpddp has no CPU fallback");
         HIPCHK(hipSetDevice(c.device));
+#ifdef PDDP_REF_PLANT_FILE
+        if constexpr (P::PLANT == 5) { const std::string complaint = ref_plugin_setup<T>(c.N); if (!complaint.empty()) return fail(PDDP_EINVAL, complaint); }
+#endif
+        if constexpr (P::PLANT == 5) {
+            if (!scalar_plugin_qdd_is_dynamics<P, T>())
+                return fail(PDDP_EINVAL, "plant 5: the plug-in's gradient routine returns a qdd that differs from its dynamics routine at the same state; the kernel families build the "
+                                         "integrators' stage states from either one, so the two have to be the same numbers (call the dynamics routine inside the gradient routine)");
+        }
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
@@ -1046,3 +1054,6 @@ extern "C" int pddp_solve_ex(pddp_handle h, void* x0, void* u0, const void* xGoa
 extern "C" int pddp_solve(pddp_handle h, void* x0, void* u0, const void* xGoal, void* Jout, int* alphaOut, int clear, int ifd, double* times_ms) {
     return pddp_solve_ex(h, x0, u0, xGoal, nullptr, nullptr, nullptr, nullptr, Jout, alphaOut, 0, clear, ifd, 8, times_ms, nullptr, nullptr);
 }
+
+// a plant file + cost file in the reference's own form (make user PLANT_FILE=... COST_FILE=...): included LAST, so that what those files #define stays out of the library
+#include "ref_plugin.hpp"

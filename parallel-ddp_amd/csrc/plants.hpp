@@ -86,6 +86,7 @@ PDDP_HD void diag_cost_grad(T* Hk, T* gk, const T* xk, const T* uk, const T* xg,
         /* the plug-in's functions are scalar code: ONE lane evaluates them.  dynamics_on / gradient_eval let a caller put independent \
            evaluations on different lanes of the cooperating set in ONE pass of the code (integrator_gradient: the three stage gradients of RK3) */ \
         static constexpr bool kScalarPlugin = true;                                                                      \
+        static constexpr bool kPluginCost = false;   /* H_k is the diagonal of weight(): the setup kernels build it from that */ \
         static PDDP_HD void dynamics_on(const Wave& w, int lane, T* qdd, const T* x, const T* u) { if (w.lane == lane) EVAL<T>(qdd, x, u); } \
         static PDDP_HD void gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) { GRAD<T>(dqdd, qdd, x, u); }       \
         static PDDP_HD void dynamics_eval(T* qdd, const T* x, const T* u) { EVAL<T>(qdd, x, u); }                       \
@@ -110,13 +111,64 @@ PDDP_CLOSED_FORM_PLANT(CartPlant, 2, 2, 1, cart_dynamics_eval, cart_gradient_eva
 PDDP_CLOSED_FORM_PLANT(QuadPlant, 3, 6, 4, quad_dynamics_eval, quad_gradient_eval)
 }  // namespace pddp
 // A user plant compiled in as plant 5 (make user PLANT_POLICY=<header>; examples/plants/damped_pendulum.hpp documents what the header provides).
-#ifdef PDDP_USER_PLANT_HEADER
+#if defined(PDDP_USER_PLANT_HEADER) && !defined(PDDP_REF_PLANT_FILE)
 #include PDDP_USER_PLANT_HEADER
 namespace pddp {
 PDDP_CLOSED_FORM_PLANT(UserPlant, 5, kUserPlantNPOS, kUserPlantNU, user_plant_dynamics, user_plant_gradient)
 template <typename T> PDDP_HD double UserPlant<T>::QR(int i, int N) { return user_plant_QR(i, N); }
 template <typename T> PDDP_HD double UserPlant<T>::Rw(int N) { return user_plant_R(N); }
 template <typename T> PDDP_HD double UserPlant<T>::QF(int N) { return user_plant_QF(N); }
+}  // namespace pddp
+#endif
+// A plant file + cost file in the REFERENCE'S OWN FORM compiled in as plant 5 (make user PLANT_FILE=... COST_FILE=... NUM_POS=... CONTROL_SIZE=...; csrc/ref_plugin.hpp holds
+// the adapter and documents the contract): `dynamics`, `dynamicsGradient`, `costFunc`, `costGrad`, `initI`, `initT` with the reference's signatures
+// (plants/dynamics_arm.cuh:2097,2167, plants/cost_arm.cuh:130,158 and the older forms of plants/{dynamics,cost}_{pend,cart,quad}.cuh).  The user's files are included at
+// the END of the translation unit (their `#define R`, `Q1`, `GRAVITY` ... must not reach the library's own code: the reference's stale closed-form plug-ins fail to
+// compile against its current solver for exactly that reason), so only declarations appear here.
+#ifdef PDDP_REF_PLANT_FILE
+#ifdef PDDP_USER_PLANT_HEADER
+#error "PLANT_POLICY (a policy header) and PLANT_FILE / COST_FILE (a reference-form plug-in) are two ways to build plant 5: give one"
+#endif
+#define PDDP_USER_PLANT_HEADER "ref_plugin_decl.hpp"    /* switches on every `plant 5` site of the library */
+namespace pddp {
+constexpr int kUserPlantNPOS = PDDP_REF_NUM_POS, kUserPlantNU = PDDP_REF_CONTROL_SIZE, kUserPlantN = PDDP_REF_NUM_TIME_STEPS;
+template <typename T> struct RefPluginTables { T pddp_tab_I[36 * kUserPlantNPOS], pddp_tab_T[36 * kUserPlantNPOS]; };     // what initI / initT fill (d_I, d_Tbody of the reference's entry points)
+template <typename T> PDDP_HD void ref_plugin_dynamics(T* qdd, const T* x, const T* u);
+template <typename T> PDDP_HD void ref_plugin_gradient(T* dqdd, T* qdd, const T* x, const T* u);
+template <typename T> PDDP_HD T ref_plugin_cost(const CostWeights<T>& cw, const T* xk, const T* uk, const T* xg, int k);
+template <typename T> PDDP_HD void ref_plugin_cost_grad(const CostWeights<T>& cw, T* Hk, T* gk, const T* xk, const T* uk, const T* xg, int k, int ld_H);
+}  // namespace pddp
+#include <string>
+namespace pddp {
+template <typename T> std::string ref_plugin_setup(int N);     // handle creation: fills the tables of initI / initT, checks N and the plug-in's qdd (ref_plugin.hpp); "" or the complaint
+template <typename T>
+struct UserPlant {
+    static constexpr int PLANT = 5, NPOS = kUserPlantNPOS, NX = 2 * kUserPlantNPOS, NU = kUserPlantNU;
+    template <typename U> using Rebind = UserPlant<U>;
+    using Model = EmptyModel;                             // the tables of initI / initT are per-library constants (ref_plugin.hpp), not per-handle state
+    using Scratch = EmptyScratch<T>;
+    using GradScratch = EmptyScratch<T>;
+    // ONE lane is inside the plug-in: singleLoopVals / doubleLoopVals hand it (start 0, stride 1) and hd__syncthreads is empty -- the host branches of
+    // utils/cudaUtils.h:65-88.  Many problems in flight put 64 such lanes into a wave (the thread-serial kernels), a few run a wave per unit with its lane 0 inside.
+    static constexpr bool kScalarPlugin = true;
+    static constexpr bool kPluginCost = true;             // H_k, g_k come from the user's costGrad (any symmetric H_k, not only a diagonal): the full-H backward pass reads them
+    static PDDP_HD void load_model(const Wave&, Scratch&, const Model*) {}
+    static PDDP_HD void dynamics(const Wave& w, Scratch&, T* qdd, const T* x, const T* u) { if (w.lane == 0) ref_plugin_dynamics<T>(qdd, x, u); wsync(); }
+    static PDDP_HD void gradient(const Wave& w, Scratch&, GradScratch&, T* dqdd, T* qdd, const T* x, const T* u) { if (w.lane == 0) ref_plugin_gradient<T>(dqdd, qdd, x, u); wsync(); }
+    static PDDP_HD void dynamics_on(const Wave& w, int lane, T* qdd, const T* x, const T* u) { if (w.lane == lane) ref_plugin_dynamics<T>(qdd, x, u); }
+    static PDDP_HD void gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) { ref_plugin_gradient<T>(dqdd, qdd, x, u); }
+    static PDDP_HD void dynamics_eval(T* qdd, const T* x, const T* u) { ref_plugin_dynamics<T>(qdd, x, u); }
+    static PDDP_HD T cost(const CostWeights<T>& cw, const T* xk, const T* uk, const T* xg, int k, int) { return ref_plugin_cost<T>(cw, xk, uk, xg, k); }
+    // H_k is (NX+NU)^2 column-major with leading dimension NX+NU.  The reference's final-knot costGrad writes the state block only (plants/cost_arm.cuh:159-174): the
+    // block is cleared first so that the array is deterministic.
+    static PDDP_HD void cost_grad(const CostWeights<T>& cw, T* Hk, T* gk, const T* xk, const T* uk, const T* xg, int k, int) {
+        constexpr int NM = NX + NU;
+        for (int e = 0; e < NM * NM; e++) Hk[e] = T(0);
+        for (int e = 0; e < NM; e++) gk[e] = T(0);
+        ref_plugin_cost_grad<T>(cw, Hk, gk, xk, uk, xg, k, NM);
+    }
+    static PDDP_HD T weight(const CostWeights<T>&, int, int, int) { return T(0); }       // (not used: kPluginCost)
+};
 }  // namespace pddp
 #endif
 namespace pddp {
@@ -138,6 +190,25 @@ template <typename T> PDDP_HD double QuadPlant<T>::QR(int i, int) { return i < 3
 template <typename T> PDDP_HD double QuadPlant<T>::Rw(int) { return 5.0; }
 template <typename T> PDDP_HD double QuadPlant<T>::QF(int) { return 1000.0; }
 
+// A scalar plug-in's gradient routine also returns qdd; the kernel families build the midpoint / RK3 stage states from that qdd (serial paths) or from the dynamics routine's
+// (the staged three-lane path of integrators.hpp), so the two have to be the SAME numbers -- the reference's plug-ins call dynamics() inside dynamicsGradient.  Checked on the
+// host instantiation when a handle of a user plant is created.
+template <typename P, typename T>
+inline bool scalar_plugin_qdd_is_dynamics() {
+    for (int trial = 0; trial < 8; trial++) {
+        T x[P::NX], u[P::NU > 0 ? P::NU : 1], q1[P::NPOS], q2[P::NPOS], d[P::NPOS * (P::NX + P::NU)];
+        unsigned s = 12345u + 977u * (unsigned)trial;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (T)(((double)(s >> 8) / 8388608.0 - 1.0) * (trial < 4 ? 1.0 : 3.0)); };
+        for (int i = 0; i < P::NX; i++) x[i] = rnd();
+        for (int i = 0; i < P::NU; i++) u[i] = rnd();
+        for (int i = 0; i < P::NPOS; i++) { q1[i] = T(0); q2[i] = T(0); }
+        P::dynamics_eval(q1, x, u);
+        P::gradient_eval(d, q2, x, u);
+        for (int i = 0; i < P::NPOS; i++) if (!(q1[i] == q2[i])) return false;
+    }
+    return true;
+}
+
 // ---- KUKA arm, joint-space cost (plants/cost_arm.cuh:130-153, 158-202) --------------------------------------
 template <typename T>
 struct ArmPlant {
@@ -147,6 +218,7 @@ struct ArmPlant {
     using Scratch = ArmScratch<T>;
     using GradScratch = ArmGradScratch<T>;
     static constexpr bool kScalarPlugin = false;          // dynamics / gradient are cooperative over the whole set
+    static constexpr bool kPluginCost = false;
     static PDDP_HD void load_model(const Wave& w, Scratch& s, const Model* m) { arm_load_model(w, s, m); }
     static PDDP_HD void dynamics(const Wave& w, Scratch& s, T* qdd, const T* x, const T* u) { arm_dynamics(w, s, qdd, x, u); }
     static PDDP_HD void gradient(const Wave& w, Scratch& s, GradScratch& g, T* dqdd, T* qdd, const T* x, const T* u) {

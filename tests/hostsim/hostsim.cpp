@@ -422,6 +422,9 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     Base* s = c.dtype == 0 ? mk<float>(c) : c.dtype == 1 ? mk<double>(c) : nullptr;
     if (!s) return fail(PDDP_EINVAL, "unsupported plant / integrator / dtype combination");
+#ifdef PDDP_REF_PLANT_FILE
+    if (c.plant == 5) { const std::string complaint = c.dtype == 0 ? ref_plugin_setup<float>(c.N) : ref_plugin_setup<double>(c.N); if (!complaint.empty()) { delete s; return fail(PDDP_EINVAL, complaint); } }
+#endif
     if (const char* v = std::getenv("PDDP_BP")) s->bp_default_coop = (std::string(v) == "coop");     // same override as the library
     *out = new pddp_solver{s};
     return 0;
@@ -489,3 +492,6 @@ extern "C" int pddp_simulate(pddp_handle h, const void* x, const void* u, const 
                              double* avg_err, int* failed) { return h->impl->simulate(x, u, KT, t0_us, elapsed_us, substeps, goal, xa, avg_err, failed); }
 extern "C" int pddp_ee_pos(pddp_handle h, int count, const void* x, void* out) { return h->impl->ee_pos(count, x, out); }
 extern "C" int pddp_stream(pddp_handle, void** st) { if (st) *st = nullptr; return 0; }
+
+// a plant file + cost file in the reference's own form (make user PLANT_FILE=... COST_FILE=...): included LAST, so that what those files #define stays out of this file
+#include "../../parallel-ddp_amd/csrc/ref_plugin.hpp"

@@ -76,6 +76,25 @@ def lib(variant="strict"):
 PLANT_DIMS = {1: (1, 2, 1), 2: (2, 4, 1), 3: (6, 12, 4), 4: (7, 14, 7)}  # npos, n, m
 
 
+_PLUGIN_SHIMS = []
+
+
+def register_plugin(shim_path):
+    """Plant 5 of the oracle = a user's plant + cost files compiled for the host by tests/plugin/plugin_shim.cpp (the plug-in is an INPUT of the solver the oracle restates).
+    Registers the shim's callbacks with both precisions of every loaded variant and teaches PLANT_DIMS the plug-in's sizes."""
+    shim = C.CDLL(shim_path)
+    _PLUGIN_SHIMS.append(shim)                      # the callbacks live in the shim: keep it loaded
+    shim.plugin_f32.restype = C.c_void_p; shim.plugin_f64.restype = C.c_void_p
+    p32, p64 = shim.plugin_f32(), shim.plugin_f64()
+    for variant in ("strict", "fma"):
+        L = lib(variant)
+        L.ora_set_plugin_f32.argtypes = [C.c_void_p]; L.ora_set_plugin_f64.argtypes = [C.c_void_p]
+        L.ora_set_plugin_f32(p32); L.ora_set_plugin_f64(p64)
+    npos, m = C.cast(p64, C.POINTER(C.c_int))[0], C.cast(p64, C.POINTER(C.c_int))[1]
+    PLANT_DIMS[5] = (npos, 2 * npos, m)
+    return PLANT_DIMS[5]
+
+
 def default_cfg(plant, **kw):
     c = OraCfg()
     lib().ora_default_cfg(C.byref(c), plant)

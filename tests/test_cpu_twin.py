@@ -76,6 +76,20 @@ def test_cpu_entry_point_follows_the_oracles_cpu_path_float64(plant, kw):
     assert got["t_total_ms"] > 0 and got["bpTime"][0] > 0
 
 
+@pytest.mark.parametrize("cores", [1, 2, 3])
+def test_cpu_entry_point_with_fewer_cores_than_blocks(cores):
+    """BP_THREADS = min(M, cores) (config.cuh:158): a thread then owns several blocks of knots and its expected-reduction pair collects all of them
+    (dJexp[2 tid], bpHelpers.cuh:431,467) -- found wrong in round 4 (the pair was kept per block and only the first BP_THREADS pairs were summed)."""
+    kw = dict(N=64, M=4, A=8, integrator=3, total_time=2.0, tol_cost=0.0, max_iter=10)
+    o = Oracle(default_cfg(2, cores=cores, spawn_threads=0, **kw), np.float64)
+    x0, u0, xg = example_inputs(2, 64, np.float64, noise=np.random.default_rng(9).normal(0, 0.001, (64, 4)))
+    ref = o.run_ilqr_cpu(x0, u0, xg)
+    got = run_cpu_twin(2, np.float64, x0, u0, xg, cores=cores, **kw)
+    it = ref["iters"]
+    assert got["iters"] == it and list(got["alphaOut"][: it + 1]) == list(ref["alphaOut"][: it + 1]) and sum(a >= 0 for a in ref["alphaOut"][1: it + 1]) >= 5
+    np.testing.assert_allclose(got["Jout"][: it + 1], ref["Jout"][: it + 1], rtol=1e-8)
+
+
 def test_cpu_entry_point_float32_and_thread_counts():
     kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=8)
     o = Oracle(default_cfg(4, cores=8, spawn_threads=0, **kw), np.float32)

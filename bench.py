@@ -253,6 +253,33 @@ def main():
             "roofline": roof}
 
     s.close()
+    # ---- the same sweeps with the library's DEFAULT options: every knot's cost-to-go written like the reference's d_P / d_p (what allocateMemory_GPU of the facade creates).
+    # `value` above runs with boundary_cost_to_go_only = 1 unless --keep-ctg: the interior slots are no output of runiLQR_GPU and no input of a later phase (same bits in
+    # every output: tests/test_f64_benched_family.py), so both are the same solver -- the line carries both numbers.
+    if not args.keep_ctg:
+        cfg_d = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, boundary_cost_to_go_only=0,
+                                     max_iter=max(100, K + W + 1), device=ctx.device, use_graph=args.graph, _lib_path=args.lib)
+        sd = pyddp.Solver(cfg_d, _lib_path=args.lib)
+        sd.load(x0, u0, xg)
+        sd.iterate(W); sd.sync()
+        shard.barrier(ctx); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sd.iterate(K); sd.sync(); torch.cuda.synchronize()
+        shard.barrier(ctx); torch.cuda.synchronize()
+        td = shard.max_over_ranks(ctx, time.perf_counter() - t0)
+        sd.load(x0, u0, xg); sd.iterate(W); sd.sync()
+        kd = sd.time_kernels(K)
+        line["default_options"] = {"cost_to_go_slots_written": "all (library default, the reference's d_P / d_p)", "value": round(ctx.world * B * K / td, 1), "unit": "DDP iterations/s",
+                                   "ms_per_step": round(1e3 * td / K, 4), "per_kernel_ms": {nm: round(ms, 5) for nm, ms in kd}}
+        sd.close()
+    # ---- what the first run on more than one GPU should show (stated BEFORE it is measured: no node with more than one device has run this yet)
+    line["multi_gpu"] = {
+        "mode": "batch axis sharded round-robin, every step size of a problem on its rank, no data-path collective (SURVEY 8(e) mode R); one all-reduce(max) of the exit flags per poll",
+        "measured_ranks": ctx.world,
+        "expected": {"headline_weak_scaling": "value ~ N x the one-GPU value (fixed 16384 problems per GPU, no exchange inside the timed sweeps; the barrier pair around them costs microseconds against "
+                                              "~0.1 s): efficiency 0.97-1.0 at N = 2, 4, 8, bounded by the box-to-box spread of the pool (~7 %) since the slowest rank sets the time",
+                     "config3_64_rollouts_strong_scaling": "~1.0 x at every N: 64 problems take 0.148 ms per sweep on one GPU and 8 problems 0.13 ms -- the sweep of so few problems is the latency of its "
+                                                           "kernels' dependency chains, not throughput (bench.py --workload config3); sharding it buys nothing and is offered for placement only"}}
     if not args.no_convergence:
         line["convergence"] = batch_convergence(ctx, args, torch, x0, u0, xg, B, N, M, A)
 

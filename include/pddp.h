@@ -234,6 +234,8 @@ int pddp_set_state(pddp_handle h, const pddp_state* in /* [batch] */);
 #define PDDP_PHASE_BP_FUSED  7   /* handles whose production sweep composes the forward sweep's per-segment maps inside the matrix-core backward pass
                                     (KUKA arm, M > 1): that backward pass -- every output of PDDP_PHASE_BP except A - B K / B du, plus the maps */
 #define PDDP_PHASE_SWEEP_FUSED 8 /* ... and the kernel that finishes forwardSweepKern from those maps: every candidate's segment start states -> xs */
+#define PDDP_PHASE_ROLLOUT   9   /* forwardSimKern + costKern + defectKern WITHOUT the sweep: every candidate's segments start from the states that stand in
+                                    "xs" at their first knots (fpHelpers.cuh:225-301 teacher-forced from stored start states, e.g. the reference's own)      */
 int pddp_run_phase(pddp_handle h, int phase);
 
 /* Plant plug-in evaluations on the device, `count` independent (x,u) pairs:

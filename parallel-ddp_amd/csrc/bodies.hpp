@@ -122,7 +122,7 @@ PDDP_HD void nis_body(const Wave& w, NisScratch<P, INTEG, T>& s, const Buffers<T
     P::load_model(w, s.plant, reinterpret_cast<const typename P::Model*>(b.model));
     nis_knot<P, INTEG, T>(w, s, dm, k, xc, uc, b.xGoal + (size_t)pb * NX, cw, dt,
                           b.AB + ((size_t)pb * N + k) * NX * NM, b.H + ((size_t)pb * N + k) * NM * NM, b.g + ((size_t)pb * N + k) * NM,
-                          b.xTarget + (size_t)pb * NX, b.tshift[pb], mode == 1 ? b.costk + (size_t)pb * N + k : nullptr);
+                          b.xTarget + (size_t)pb * NX, b.tshift[pb], mode == 1 ? b.costk + (size_t)pb * N + k : nullptr, mode == 1);
 }
 
 // cost of the loaded trajectory, prevJ = J + 2 TOL_COST, Jout[0], alphaOut[0], fresh solver state

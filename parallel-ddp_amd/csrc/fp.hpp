@@ -76,6 +76,13 @@ PDDP_HD void rollout_seed_segment(const Wave& w, const Dims& dm, const FpArgs<T>
     PDDP_FOR(i, NX) { const T v = a.xcur[NX * bInd * dm.NB + i]; a.segx[NX * bInd + i] = v; a.x[NX * bInd * dm.NB + i] = v; }
 }
 
+// PDDP_PHASE_ROLLOUT (teacher forcing of forwardSimKern alone): no sweep -- segment bInd starts from what the candidate's own x holds at its first knot
+template <typename P, typename T>
+PDDP_HD void rollout_seed_from_candidate(const Wave& w, const Dims& dm, const FpArgs<T>& a, int bInd) {
+    constexpr int NX = P::NX;
+    PDDP_FOR(i, NX) a.segx[NX * bInd + i] = a.x[NX * bInd * dm.NB + i];
+}
+
 // Nonlinear rollout of segment bInd.  Start state: a.segx[bInd] (from the sweep), or xcur[0] for segment 0.
 // Writes x[k+1], u[k] for the segment's knots and the boundary defect.  cost_k (optional, LDS [N]) receives the
 // per-knot cost of every knot this segment owns.

@@ -23,37 +23,44 @@
 
 namespace pddp {
 
-// LDS strides per lane in floats: 4 x odd, so that 16-byte accesses of 8 consecutive lanes cover the 32 banks exactly once
+// LDS strides per lane in ELEMENTS: 4 x odd, so that 16-byte accesses of 8 consecutive lanes cover the 32 banks exactly once (float; the double instantiation is the parity build)
 constexpr int kPipeSX = 20, kPipeSL = 44, kPipeSU = 12;
 constexpr int kPipeXbuf = 2 * 64 * kPipeSX, kPipeLbuf = 2 * 64 * kPipeSL, kPipeUbuf = 2 * 64 * kPipeSU;
 constexpr int kPipeFlags = 8;                                                      // x, u, (spare), cs[2], l[2]
-constexpr int kPipeLdsOpenLoop = (kPipeXbuf + kPipeLbuf + kPipeFlags) * 4;          // bytes: chain + factor waves
-constexpr int kPipeLdsClosedLoop = (kPipeXbuf + kPipeLbuf + kPipeUbuf + kPipeFlags) * 4;
+template <typename T> constexpr int pipe_lds_bytes(bool closed_loop) { return (kPipeXbuf + kPipeLbuf + (closed_loop ? kPipeUbuf : 0)) * (int)sizeof(T) + kPipeFlags * 4; }
+constexpr int kPipeLdsOpenLoop = pipe_lds_bytes<float>(false);                      // bytes: chain + factor waves
+constexpr int kPipeLdsClosedLoop = pipe_lds_bytes<float>(true);
 
 // the step counters are accessed as LDS (address space 3) explicitly: through a generic volatile pointer the compiler emits FLAT loads / stores with system-coherence bits --
 // every poll and post then takes the flat path instead of a ds_read / ds_write (found in the ISA: 73 -> 6x us per 32 steps)
 typedef __attribute__((address_space(3))) volatile int tl_pipe_flag;
-struct TlPipeLds {
-    float* xbuf;            // [2][64][20]   x_k at slot k & 1
-    float* lbuf;            // [2][64][44]   step k's c[7] s[7] (2 pad) L[21] Dinv[7] at slot k & 1
-    float* ubuf;            // [2][64][12]   u_k (closed loop)
+// T = float: the production kernels.  T = double: the same pipeline as a parity instantiation (PDDP_FP=tl4 on a double handle; tests/test_f64_benched_family.py).
+template <typename T>
+struct TlPipeLdsT {
+    T* xbuf;                // [2][64][20]   x_k at slot k & 1
+    T* lbuf;                // [2][64][44]   step k's c[7] s[7] (2 pad) L[21] Dinv[7] at slot k & 1
+    T* ubuf;                // [2][64][12]   u_k (closed loop)
     tl_pipe_flag* flag;     // [0] x: v = x_v is in xbuf   [1] u: v = u_{v-1} is in ubuf   [3 + r] cs, [5 + r] l: v = step v-1's are in lbuf[r]
 };
-__device__ __forceinline__ TlPipeLds tl_pipe_lds(float* base, bool closed_loop) {
-    TlPipeLds p;
+using TlPipeLds = TlPipeLdsT<float>;
+template <typename T>
+__device__ __forceinline__ TlPipeLdsT<T> tl_pipe_lds(T* base, bool closed_loop) {
+    TlPipeLdsT<T> p;
     p.xbuf = base; p.lbuf = p.xbuf + kPipeXbuf; p.ubuf = p.lbuf + kPipeLbuf;
     p.flag = (tl_pipe_flag*)(closed_loop ? p.ubuf + kPipeUbuf : p.ubuf);
     return p;
 }
-typedef float tl_pipe_f4 __attribute__((ext_vector_type(4), aligned(16)));
-// n floats (a multiple of 4 slots are touched) between registers and a 16-byte aligned LDS run
-template <int N4> __device__ __forceinline__ void tl_pipe_ld(float* dst, const float* src) {
+template <typename T> struct TlPipeVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); };
+// n elements (a multiple of 4 slots are touched) between registers and a 16-byte aligned LDS run
+template <int N4, typename T> __device__ __forceinline__ void tl_pipe_ld(T* dst, const T* src) {
+    typedef typename TlPipeVec<T>::v4 V4;
 #pragma unroll
-    for (int i = 0; i < N4; i++) { const tl_pipe_f4 v = reinterpret_cast<const tl_pipe_f4*>(src)[i]; dst[4 * i] = v[0]; dst[4 * i + 1] = v[1]; dst[4 * i + 2] = v[2]; dst[4 * i + 3] = v[3]; }
+    for (int i = 0; i < N4; i++) { const V4 v = reinterpret_cast<const V4*>(src)[i]; dst[4 * i] = v[0]; dst[4 * i + 1] = v[1]; dst[4 * i + 2] = v[2]; dst[4 * i + 3] = v[3]; }
 }
-template <int N4> __device__ __forceinline__ void tl_pipe_st(float* dst, const float* src) {
+template <int N4, typename T> __device__ __forceinline__ void tl_pipe_st(T* dst, const T* src) {
+    typedef typename TlPipeVec<T>::v4 V4;
 #pragma unroll
-    for (int i = 0; i < N4; i++) { tl_pipe_f4 v; v[0] = src[4 * i]; v[1] = src[4 * i + 1]; v[2] = src[4 * i + 2]; v[3] = src[4 * i + 3]; reinterpret_cast<tl_pipe_f4*>(dst)[i] = v; }
+    for (int i = 0; i < N4; i++) { V4 v; v[0] = src[4 * i]; v[1] = src[4 * i + 1]; v[2] = src[4 * i + 2]; v[3] = src[4 * i + 3]; reinterpret_cast<V4*>(dst)[i] = v; }
 }
 __device__ __forceinline__ void tl_pipe_wait(tl_pipe_flag* f, int v) {
     while (*f < v) {}
@@ -64,15 +71,16 @@ __device__ __forceinline__ void tl_pipe_post(tl_pipe_flag* f, int v) {
     *f = v;
 }
 __device__ __forceinline__ float tl_pipe_euler(float a, float b, float dt) { return __builtin_fmaf(dt, b, a); }      // Euler (utils/integrators.cuh:24-36)
+__device__ __forceinline__ double tl_pipe_euler(double a, double b, double dt) { return __builtin_fma(dt, b, a); }
 
 // factor wave r (0 / 1): the sines / cosines and the factors of M(q_j) for the steps j = r, r + 2, ... < njobs.  x0[14]: the rollout's start state.
 // xout != null: lane 0 also stores the states it picks up (x_{j-1}, j >= 2) to xout[14 (j - 1)] -- global stores kept off the chain wave, whose posts would wait for them.
-template <int V>
-__device__ __forceinline__ void tl_pipe_factor_wave(const TlPipeLds& p, int r, int njobs, const float* x0, float dt, int lane, float* xout = nullptr) {
-    constexpr ArmTlModel<float> md = arm_tl_builtin<float>(V);
-    float* o = p.lbuf + (r * 64 + lane) * kPipeSL;
+template <int V, typename T>
+__device__ __forceinline__ void tl_pipe_factor_wave(const TlPipeLdsT<T>& p, int r, int njobs, const T* x0, T dt, int lane, T* xout = nullptr) {
+    constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
+    T* o = p.lbuf + (r * 64 + lane) * kPipeSL;
     for (int j = r; j < njobs; j += 2) {
-        float q[7];
+        T q[7];
         if (j == 0) {
 #pragma unroll
             for (int i = 0; i < 7; i++) q[i] = x0[i];
@@ -81,7 +89,7 @@ __device__ __forceinline__ void tl_pipe_factor_wave(const TlPipeLds& p, int r, i
             for (int i = 0; i < 7; i++) q[i] = tl_pipe_euler(x0[i], x0[7 + i], dt);
         } else {
             tl_pipe_wait(p.flag + 0, j - 1);
-            float xv[16];
+            T xv[16];
             tl_pipe_ld<4>(xv, p.xbuf + ((((j - 1) & 1) * 64) + lane) * kPipeSX);
 #pragma unroll
             for (int i = 0; i < 7; i++) q[i] = tl_pipe_euler(xv[i], xv[7 + i], dt);
@@ -90,15 +98,15 @@ __device__ __forceinline__ void tl_pipe_factor_wave(const TlPipeLds& p, int r, i
                 for (int i = 0; i < 14; i++) xout[14 * (j - 1) + i] = xv[i];
             }
         }
-        ArmTlState<float> st;
-        arm_tl_trig<float>(st, q);
-        float cs[16], ld[28];
+        ArmTlState<T> st;
+        arm_tl_trig<T>(st, q);
+        T cs[16], ld[28];
 #pragma unroll
         for (int i = 0; i < 7; i++) { cs[i] = st.c[i]; cs[7 + i] = st.s[i]; }
-        cs[14] = 0.f; cs[15] = 0.f;
+        cs[14] = T(0); cs[15] = T(0);
         tl_pipe_st<4>(o, cs);
         tl_pipe_post(p.flag + 3 + r, j + 1);
-        arm_tl_factor<float>(md, st);
+        arm_tl_factor<T>(md, st);
 #pragma unroll
         for (int e = 0; e < 21; e++) ld[e] = st.L[e];
 #pragma unroll
@@ -110,25 +118,25 @@ __device__ __forceinline__ void tl_pipe_factor_wave(const TlPipeLds& p, int r, i
 
 // chain wave, step k: x[14] (in: x_k, out: x_{k+1}), u[7] the control of this step.  Posts x_{k+1}.
 // CLOSED: the control of the step is the control wave's (posted through ubuf after it completed the control law on x_k -- while this wave computes the bias); else u[7].
-template <int V, bool CLOSED>
-__device__ __forceinline__ void tl_pipe_chain_step(const TlPipeLds& p, int k, float* x, const float* u, float dt, float grav, int lane) {
-    constexpr ArmTlModel<float> md = arm_tl_builtin<float>(V);
+template <int V, bool CLOSED, typename T>
+__device__ __forceinline__ void tl_pipe_chain_step(const TlPipeLdsT<T>& p, int k, T* x, const T* u, T dt, T grav, int lane) {
+    constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     const int r = k & 1;
-    const float* o = p.lbuf + (r * 64 + lane) * kPipeSL;
-    ArmTlState<float> st;
+    const T* o = p.lbuf + (r * 64 + lane) * kPipeSL;
+    ArmTlState<T> st;
     tl_pipe_wait(p.flag + 3 + r, k + 1);
-    float cs[16], ld[28];
+    T cs[16], ld[28];
     tl_pipe_ld<4>(cs, o);
 #pragma unroll
     for (int i = 0; i < 7; i++) { st.c[i] = cs[i]; st.s[i] = cs[7 + i]; }
-    float bias[7], qdd[7];
-    arm_tl_bias<float>(md, grav, st, x + 7, bias);
+    T bias[7], qdd[7];
+    arm_tl_bias<T>(md, grav, st, x + 7, bias);
     // the waits below are volatile LDS reads, the bias is register arithmetic: without this the compiler sinks the whole recursion BELOW the waits (cycle stamps: the chain
     // then sat at the control wave's post for 1.1 k cycles and at the factors' with its bias still to do -- 6.9 k cycles per step instead of 4.x k)
 #pragma unroll
     for (int i = 0; i < 7; i++) asm volatile("" : "+v"(bias[i]));
     if (CLOSED) {
-        float uv[8];
+        T uv[8];
         tl_pipe_wait(p.flag + 1, k + 1);
         tl_pipe_ld<2>(uv, p.ubuf + (((k & 1) * 64) + lane) * kPipeSU);
 #pragma unroll
@@ -144,13 +152,13 @@ __device__ __forceinline__ void tl_pipe_chain_step(const TlPipeLds& p, int k, fl
 #pragma unroll
     for (int i = 0; i < 7; i++) st.Dinv[i] = ld[21 + i];
     tl_ldl_solve(st, qdd);
-    float xn[16];
+    T xn[16];
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const float qn = tl_pipe_euler(x[i], x[7 + i], dt), vn = tl_pipe_euler(x[7 + i], qdd[i], dt);
+        const T qn = tl_pipe_euler(x[i], x[7 + i], dt), vn = tl_pipe_euler(x[7 + i], qdd[i], dt);
         x[i] = qn; x[7 + i] = vn; xn[i] = qn; xn[7 + i] = vn;
     }
-    xn[14] = 0.f; xn[15] = 0.f;
+    xn[14] = T(0); xn[15] = T(0);
     tl_pipe_st<4>(p.xbuf + ((((k + 1) & 1) * 64) + lane) * kPipeSX, xn);
     tl_pipe_post(p.flag + 0, k + 1);
 }

@@ -42,7 +42,7 @@ inline FpPath select_fp_path(const char* env, bool is_float, bool ee_cost, bool 
     if (env) {
         if (env[0] == 'c') return kFpCoop;
         if (env[0] == 'l') return kFpLg;
-        if (env[0] == 't' && env[1] == 'l' && env[2] == '2') return kFpLg;      // "tl2": the two-wave rollout kernel of a few-problem handle (a lane-group handle otherwise)
+        if (env[0] == 't' && env[1] == 'l' && (env[2] == '2' || env[2] == '4')) return kFpLg;      // "tl2" / "tl4": the split rollout kernels of a few-problem handle (a lane-group handle otherwise; "tl4" also selects them on a double handle)
         if (env[0] == 't' && tl_possible) return kFpTl;
     }
     return (is_float && tl_possible && batch >= kFpTlMinBatch) ? kFpTl : kFpLg;

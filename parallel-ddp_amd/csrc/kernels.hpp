@@ -47,7 +47,7 @@ template <typename P, int INTEG, typename T>
 __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int a_idx = blockIdx.x, pb = blockIdx.y, M = dm.M;
-    if (!init_rollout && !fp_active<T>(b, dm, pb)) return;
+    if (init_rollout != 1 && !fp_active<T>(b, dm, pb)) return;
     using L = FpLds<P, T>;
     unsigned char* ptr = lds_raw;
     SweepScratch<P, T>& sw = *reinterpret_cast<SweepScratch<P, T>*>(ptr); ptr += L::align16(sizeof(SweepScratch<P, T>));
@@ -60,8 +60,11 @@ __global__ void k_fp(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int init_ro
     T* segJ = reinterpret_cast<T*>(ptr);
     const Wave w = this_wave();
     const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm, segJ);
-    if (init_rollout) {
+    if (init_rollout == 1) {
         rollout_seed_segment<P, T>(w, dm, a, wave_id);
+        __syncthreads();
+    } else if (init_rollout == 2) {                      // PDDP_PHASE_ROLLOUT: the candidates' segment start states as they stand in xs, no sweep
+        rollout_seed_from_candidate<P, T>(w, dm, a, wave_id);
         __syncthreads();
     } else if (M > 1) {
         if (wave_id == 0) forward_sweep<P, T>(w, sw, dm, a);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64) void k_bp_ts(Buffers<T> b, Dims dm, int batch) 
 }
 constexpr int kTsMaxN = 256, kTsMaxM = 16;        // longest horizon / most segments the thread-serial forward pass keeps per-knot costs / hand-off states for
 template <typename P, int INTEG, typename T>
-__global__ __launch_bounds__(64) void k_fp_ts(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+__global__ __launch_bounds__(64) void k_fp_ts(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch, int no_sweep = 0) {
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= batch * dm.A) return;
     const int pb = inst / dm.A, a_idx = inst - pb * dm.A;
@@ -231,7 +234,8 @@ __global__ __launch_bounds__(64) void k_fp_ts(Buffers<T> b, Dims dm, CostWeights
     T cost_k[kTsMaxN], segx[kTsMaxM * P::NX], dnorm[kTsMaxM], segJ[kTsMaxM];
     const Wave w = serial_wave();
     const FpArgs<T> a = fp_args<P, T>(b, dm, pb, a_idx, dt, segx, dnorm, segJ);
-    if (dm.M > 1) forward_sweep<P, T>(w, sw, dm, a);
+    if (no_sweep) { for (int bInd = 0; bInd < dm.M; bInd++) rollout_seed_from_candidate<P, T>(w, dm, a, bInd); }
+    else if (dm.M > 1) forward_sweep<P, T>(w, sw, dm, a);
     P::load_model(w, sim.plant, reinterpret_cast<const typename P::Model*>(b.model));
     for (int bInd = 0; bInd < dm.M; bInd++) forward_sim_segment<P, INTEG, T>(w, sim, dm, a, bInd, cw, b.xGoal + (size_t)pb * P::NX, cost_k);
     fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm, nullptr);

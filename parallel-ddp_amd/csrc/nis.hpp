@@ -25,7 +25,7 @@ struct NisScratch {
 // xk/uk: the knot's state and control (global).  Writes ABk (k < N-1), Hk, gk (global).
 template <typename P, int INTEG, typename T>
 PDDP_HD void nis_knot(const Wave& w, NisScratch<P, INTEG, T>& s, const Dims& dm, int k, const T* xk, const T* uk, const T* xg,
-                      const CostWeights<T>& cw, T dt, T* ABk, T* Hk, T* gk, const T* xt = nullptr, int tshift = 0, T* cost_out = nullptr) {
+                      const CostWeights<T>& cw, T dt, T* ABk, T* Hk, T* gk, const T* xt = nullptr, int tshift = 0, T* cost_out = nullptr, bool write_const_H = true) {
     constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
     PDDP_FOR(i, NX) s.x[i] = xk[i];
     PDDP_FOR(i, NU) s.u[i] = uk[i];
@@ -47,7 +47,10 @@ PDDP_HD void nis_knot(const Wave& w, NisScratch<P, INTEG, T>& s, const Dims& dm,
         // nisInitHelpers.cuh:86-92) -- one lane here; H_k may be any matrix the user's costGrad writes, the backward pass reads all of it
         if (w.lane == 0) P::cost_grad(cw, Hk, gk, s.x, s.u, xg, k, dm.N);
     } else {
-    PDDP_FOR(e, NM * NM) { const int i = e / NM, j = e % NM; Hk[e] = (i == j) ? P::weight(cw, i, k, dm.N) : T(0); }
+    // the diagonal joint-space / closed-form cost Hessian does not depend on the trajectory: the reference rewrites it with every setup (costGradientHessianKern), here it is
+    // written when the problem is loaded (init mode) and left alone afterwards -- 1 KB per quadrotor knot and sweep that nobody needs again (the arm's thread-lane setup
+    // kernels have always done so)
+    if (write_const_H) PDDP_FOR(e, NM * NM) { const int i = e / NM, j = e % NM; Hk[e] = (i == j) ? P::weight(cw, i, k, dm.N) : T(0); }
     PDDP_FOR(i, NM) {
         T gv = P::weight(cw, i, k, dm.N) * (i < NX ? (s.x[i] - xg[i]) : s.u[i - NX]);
         if constexpr (P::PLANT == 4) { if (cw.limits && (k < dm.N - 1 || i < NX)) gv += arm_limit_term<T>(s.x, s.u, i, 1); }      // USE_LIMITS_FLAG: the gradient only, H stays (cost_arm.cuh:176-199)

@@ -147,6 +147,8 @@ struct Solver : SolverBase {
         // sweep, line search and setup stay on the lane-group kernels.  PDDP_FP=lg keeps the lane-group rollouts (bit-identity tests), PDDP_FP=tl2 asks for the split.
         const char* fpenv = std::getenv("PDDP_FP");
         fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.use_finite_diff && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
+        // PDDP_FP=tl4 on a DOUBLE handle: the same few-problem selection (k_fp_tl4 pipeline + k_nis_tl7) in its parity instantiation (tests/test_f64_benched_family.py)
+        if (sizeof(T) == 8 && fpenv && std::string(fpenv) == "tl4" && fp_path == kFpLg && !cfg.use_finite_diff && tl_variant >= 0 && !cfg.use_limits && !cfg.use_smooth_abs) fp_split = true;
         // the split's current form is the four-wave pipeline (k_fp_tl4, fp_pipe.hpp; also the end-effector cost family); PDDP_FP=tl2 keeps the two-wave kernel (joint-space cost only)
         fp_two_wave = fp_split && !cfg.ee_cost && fpenv && std::string(fpenv) == "tl2";
     }
@@ -387,7 +389,8 @@ struct Solver : SolverBase {
         return 0;
     }
     // forward pass: the arm runs on lane groups (fp_lg.hpp), the closed-form plants on the wave-cooperative kernel
-    // part: -1 everything; 0 only the linear sweep kernel (when the path has a separate one); 1 only the rollout kernel (per-kernel timing)
+    // part: -1 everything; 0 only the linear sweep kernel (when the path has a separate one); 1 only the rollout kernel (per-kernel timing; kernels that sweep
+    // themselves still do); 2 the rollouts WITHOUT any sweep, from the start states in xs (PDDP_PHASE_ROLLOUT)
     void launch_fp(hipStream_t s, int init_rollout, int store_candidates = 0, int part = -1) {
         const unsigned B = cfg.batch;
         bool lane_groups = false;
@@ -396,9 +399,9 @@ struct Solver : SolverBase {
             if (part == 0) return;
             bool serial = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
-                if (cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+                if (cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B, part == 2 ? 1 : 0); serial = true; }
             }
-            if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout);
+            if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout ? 1 : (part == 2 ? 2 : 0));
             return;
         }
         if constexpr (P::PLANT == 4) {
@@ -406,7 +409,7 @@ struct Solver : SolverBase {
             const unsigned chunks = (A_all > 8 && A_all % 8 == 0) ? A_all / 8 : 1;      // one workgroup per 8 candidates when they tile exactly (see k_fp_lg)
             const int A_eff = A_all / chunks;
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
-            if (!init_rollout && cfg.M > 1 && part != 1) {
+            if (!init_rollout && cfg.M > 1 && part != 1 && part != 2) {
                 bool st = false;
                 if (sweep_fused && (!store_candidates || phase_fused_sweep)) { launch_sweep_maps<T>(s, b, dm, (int)B); st = true; }
                 if constexpr (sizeof(T) == 4) {
@@ -417,11 +420,11 @@ struct Solver : SolverBase {
                 if (!st) hipLaunchKernelGGL((k_sweep_lg<T>), dim3((cfg.A + kLgPerWave - 1) / kLgPerWave, B), dim3(64), 0, s, b, dm, dt);
             }
             if (part == 0) return;
-            if constexpr (sizeof(T) == 4) {
-                if (!init_rollout && fp_split) {
-                    if (fp_two_wave) launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); else launch_fp_tl4(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
-                    return;
-                }
+            if (!init_rollout && fp_split) {
+                bool two = false;
+                if constexpr (sizeof(T) == 4) { if (fp_two_wave) { launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); two = true; } }
+                if (!two) launch_fp_tl4<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
+                return;
             }
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
                 launch_fp_tl<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, store_candidates);
@@ -455,7 +458,7 @@ struct Solver : SolverBase {
             }
             if (!fp_coop && !cfg.use_finite_diff) {
                 if (part == 0) return;
-                if constexpr (sizeof(T) == 4) { if (fp_split && cfg.batch <= kNisTl7MaxBatch) { launch_nis_tl7(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B); return; } }
+                if (fp_split && cfg.batch <= kNisTl7MaxBatch) { launch_nis_tl7<T>(s, tl_variant, b, dm, cw, dt, tl_grav, mode, (int)B); return; }
                 if (cfg.ee_cost) hipLaunchKernelGGL((k_nis_lg<T, true>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 else hipLaunchKernelGGL((k_nis_lg<T>), dim3((cfg.N + 31) / 32, B), dim3(256), 0, s, b, dm, cw, dt, mode);
                 return;
@@ -798,6 +801,10 @@ struct Solver : SolverBase {
             if (phase == PDDP_PHASE_BP_FUSED) launch_sweep(stream, PDDP_PHASE_BP, 1);
             else launch_fp(stream, 0, 1, 0);
             phase_fused_sweep = false;
+        }
+        else if (phase == PDDP_PHASE_ROLLOUT) {
+            launch_fp(stream, 0, 1, 2);
+            hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);
         }
         else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);
         else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);

@@ -295,12 +295,11 @@ void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Di
 // ~650 dependent instructions per step on the chain instead of ~1100 with k_fp_tl2's two barriers per step.  Candidates are stored like the reference's (x, u, d); cost / defect
 // leave as per-segment partial sums.  EE: the end-effector cost family (tl_rollout_step_ee's conditions: every segment runs NB steps, the "final" state of a non-final
 // segment carries no cost, knot N - 1 no dynamics).  Same arithmetic as k_fp_tl: under the float32 bar.
-template <int V, bool EE>
-__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<float> b, Dims dm, CostWeights<float> cw, float dt, float grav, int batch) {
-    using T = float;
+template <typename T, int V, bool EE>
+__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
     constexpr int NX = 14, NU = 7;
-    extern __shared__ __attribute__((aligned(16))) float pipe_lds[];
-    const TlPipeLds p = tl_pipe_lds(pipe_lds, true);
+    extern __shared__ __attribute__((aligned(16))) unsigned char pipe_lds_raw[];
+    const TlPipeLdsT<T> p = tl_pipe_lds(reinterpret_cast<T*>(pipe_lds_raw), true);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < kPipeFlags) p.flag[threadIdx.x] = 0;
     const int A = dm.A, M = dm.M, N = dm.N, NBk = dm.NB, total = batch * M * A;
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<float> b, Dims dm, Co
     if (wave >= 2) { tl_pipe_factor_wave<V>(p, wave - 2, NBk, x, dt, lane); return; }
     if (wave == 0) {
         // ---------------------------------------------------------------- chain
-        for (int k = 0; k < NBk; k++) tl_pipe_chain_step<V, true>(p, k, x, nullptr, dt, grav, lane);
+        for (int k = 0; k < NBk; k++) tl_pipe_chain_step<V, true>(p, k, x, (const T*)nullptr, dt, grav, lane);
         return;
     }
     // -------------------------------------------------------------------- control wave: operands, trajectory out, cost
@@ -407,25 +406,29 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<float> b, Dims dm, Co
         b.parts_fresh[pb] = 1;
     }
 }
-void launch_fp_tl4(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int batch) {
+template <typename T>
+void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch) {
     const unsigned inst = (unsigned)batch * dm.M * dm.A;
+    constexpr int lds = pipe_lds_bytes<T>(true);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLdsClosedLoop);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<T, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<T, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<T, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fp_tl4<T, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const dim3 g((inst + 63) / 64), t(256);
     if (cw.ee) {
-        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<0, true>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
-        else hipLaunchKernelGGL((k_fp_tl4<1, true>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, true>), g, t, lds, s, b, dm, cw, dt, grav, batch);
+        else hipLaunchKernelGGL((k_fp_tl4<T, 1, true>), g, t, lds, s, b, dm, cw, dt, grav, batch);
     } else {
-        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<0, false>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
-        else hipLaunchKernelGGL((k_fp_tl4<1, false>), g, t, kPipeLdsClosedLoop, s, b, dm, cw, dt, grav, batch);
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, false>), g, t, lds, s, b, dm, cw, dt, grav, batch);
+        else hipLaunchKernelGGL((k_fp_tl4<T, 1, false>), g, t, lds, s, b, dm, cw, dt, grav, batch);
     }
 }
+template void launch_fp_tl4<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int);
+template void launch_fp_tl4<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int);      // the parity instantiation (PDDP_FP=tl4)
 
 // k_sweep_st: grid ceil(2 B / 8), block 64.  The linear sweep of forwardSweepKern (fpHelpers.cuh:19-63) for ALL candidates of a problem at once.
 // The sweep is affine in the step size: with e_k = x_k - xcur_k,  e_{k+1} = F_k e_k - alpha (B du)_k + [boundary] d_k,  e_0 = 0,  so
@@ -722,9 +725,8 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
 // Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279), like k_nis_lg.
 // EE: the end-effector cost family -- an eighth row of workgroups (blockIdx.y == 7) evaluates the tool point, its Jacobian, g_k and the position block of H_k
 // (arm_tl_nis_cost_ee_knot), one thread per knot.
-template <int V, bool EE>
-__global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostWeights<float> cw, float dt, float grav, int mode, int batch) {
-    using T = float;
+template <typename T, int V, bool EE>
+__global__ __launch_bounds__(64) void k_nis_tl7(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int mode, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NU = 7, NM = 21;
     const int J = blockIdx.y, g = blockIdx.x * 64 + threadIdx.x, N = dm.N;
@@ -785,14 +787,17 @@ __global__ __launch_bounds__(64) void k_nis_tl7(Buffers<float> b, Dims dm, CostW
         AB[J * NX + r] = tl_AB_const<T>(r, J, dt); AB[(7 + J) * NX + r] = tl_AB_const<T>(r, 7 + J, dt); AB[(14 + J) * NX + r] = tl_AB_const<T>(r, 14 + J, dt);
     }
 }
-void launch_nis_tl7(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int mode, int batch) {
+template <typename T>
+void launch_nis_tl7(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch) {
     const dim3 grid(((unsigned)batch * dm.N + 63) / 64, cw.ee ? 8 : 7);
     if (cw.ee) {
-        if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<0, true>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
-        else hipLaunchKernelGGL((k_nis_tl7<1, true>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
-    } else if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<0, false>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
-    else hipLaunchKernelGGL((k_nis_tl7<1, false>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+        if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<T, 0, true>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+        else hipLaunchKernelGGL((k_nis_tl7<T, 1, true>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+    } else if (variant == 0) hipLaunchKernelGGL((k_nis_tl7<T, 0, false>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
+    else hipLaunchKernelGGL((k_nis_tl7<T, 1, false>), grid, dim3(64), 0, s, b, dm, cw, dt, grav, mode, batch);
 }
+template void launch_nis_tl7<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, int);
+template void launch_nis_tl7<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, int);     // the parity instantiation (PDDP_FP=tl4)
 
 // API view of the compact [A B]: grid ceil(B*N*21 / 256), block 256, thread = (knot, column).  expand: compact -> the reference layout (pddp_get_array("AB"));
 // compact: the reference layout -> compact (pddp_set_array("AB"): teacher-forced tests hand in the oracle's derivatives).

@@ -16,14 +16,15 @@ template <typename T> void launch_fp_tl(hipStream_t s, int variant, const Buffer
 // the rollouts with every step split over two wavefronts (k_fp_tl2: few problems in flight); stores x, u, d of every candidate
 void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int batch);
 // the rollouts as a pipeline over four wavefronts (k_fp_tl4, fp_pipe.hpp: few problems in flight; joint-space and end-effector cost); stores x, u, d of every candidate
-void launch_fp_tl4(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int batch);
+// (T = double: the parity instantiation, selected with PDDP_FP=tl4 on a double handle)
+template <typename T> void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch);
 // the linear sweep of all candidates from two sequences (k_sweep_st, float handles)
 void launch_sweep_st(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch);
 // the same sweep with one workgroup per problem and the chain's operands staged in LDS up front (k_sweep_wg: few problems in flight)
 void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch);
 template <typename T> void launch_nis_tl(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch);
 // next-iteration setup with one thread per (knot, joint) (k_nis_tl7: few problems in flight); adopts the winner from the candidate-major xs / us / ds
-void launch_nis_tl7(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int mode, int batch);
+template <typename T> void launch_nis_tl7(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int mode, int batch);
 // compact [A B] (ab_compact.hpp) <-> the reference layout b.AB, for the API view of a handle that keeps the compact array
 template <typename T> void launch_abc_convert(hipStream_t s, const Buffers<T>& b, int knots, int N, T dt, int to_compact);
 template <typename T> void launch_plant_eval_tl(hipStream_t s, int variant, T grav, int count, const T* x, const T* u, T* out, int grad);

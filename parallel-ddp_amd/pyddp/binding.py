@@ -5,7 +5,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PLANT_DIMS = {1: (1, 2, 1), 2: (2, 4, 1), 3: (6, 12, 4), 4: (7, 14, 7)}  # npos, n, m (config.cuh:24-46)
-PHASE_BP, PHASE_FP, PHASE_LS, PHASE_NIS, PHASE_INIT_NIS, PHASE_INIT_COST, PHASE_BP_COOP, PHASE_BP_FUSED, PHASE_SWEEP_FUSED = range(9)
+PHASE_BP, PHASE_FP, PHASE_LS, PHASE_NIS, PHASE_INIT_NIS, PHASE_INIT_COST, PHASE_BP_COOP, PHASE_BP_FUSED, PHASE_SWEEP_FUSED, PHASE_ROLLOUT = range(10)
 
 
 class PddpError(RuntimeError):

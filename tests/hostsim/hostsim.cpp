@@ -52,7 +52,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
 static bool fp_coop() { const char* v = std::getenv("PDDP_FP"); return v && std::string(v) == "coop"; }   // PDDP_FP=coop: wave-cooperative forward pass / setup (comparison tests)
 
 struct Base {
-    pddp_config cfg; int store_candidates = 0; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
+    pddp_config cfg; int skip_sweep = 0; int store_candidates = 0; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
     virtual ~Base() {}
     virtual int load(const void*, const void*, const void*, const void*, const void*, const void*, const void*, int, int, int) = 0;
     virtual int iterate(int) = 0;
@@ -144,7 +144,7 @@ struct Sim : Base {
                 if (!fp_active<T>(b, dm, pb)) continue;
                 if constexpr (P::PLANT == 4) if (fp_tl()) {          // one "thread" per (candidate, segment): plain scalar code (fp_tl.hpp)
                     using L = LgHost<T>;
-                    for (int a = 0; a < cfg.A; a++) if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data()));
+                    for (int a = 0; a < cfg.A; a++) if (cfg.M > 1 && !skip_sweep) arm_lg_forward_sweep<L, T>(dm, fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data()));
                     const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * cfg.N * NX;
                     for (int sg = 0; sg < cfg.M; sg++) for (int a = 0; a < cfg.A; a++) {
                         if (cfg.ee_cost) {
@@ -163,7 +163,7 @@ struct Sim : Base {
                         using L = LgHost<T>;
                         ArmLgConst<L> c; arm_lg_load_const<L, T>(c, &model);
                         const FpLgArgs<T> la = fp_lg_args<T>(b, dm, pb, a, dt, dnorm.data());
-                        if (cfg.M > 1) arm_lg_forward_sweep<L, T>(dm, la);
+                        if (cfg.M > 1 && !skip_sweep) arm_lg_forward_sweep<L, T>(dm, la);
                         for (int sg = 0; sg < cfg.M; sg++) {
                             if (cfg.ee_cost) arm_lg_rollout_segment_ee<L, T>(c, dm, la, sg, cw, segJ.data(), false);
                             else arm_lg_rollout_segment<L, T>(c, dm, la, sg, cw, cost_k.data(), false);
@@ -171,7 +171,8 @@ struct Sim : Base {
                         fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data(), cfg.ee_cost ? segJ.data() : nullptr);
                         continue;
                     }
-                    if (cfg.M > 1) forward_sweep<P, T>(w, sw, dm, fa);
+                    if (skip_sweep) { for (int sg = 0; sg < cfg.M; sg++) rollout_seed_from_candidate<P, T>(w, dm, fa, sg); }
+                    else if (cfg.M > 1) forward_sweep<P, T>(w, sw, dm, fa);
                     P::load_model(w, sim.plant, &model);
                     for (int sg = 0; sg < cfg.M; sg++) forward_sim_segment<P, INTEG, T>(w, sim, dm, fa, sg, cw, b.xGoal + (size_t)pb * NX, cost_k.data());
                     fp_reduce<T>(w, b, dm, pb, a, cost_k.data(), dnorm.data(), cfg.ee_cost ? segJ.data() : nullptr);
@@ -344,6 +345,7 @@ struct Sim : Base {
     }
     int run_phase(int ph) override {
         if (ph == PDDP_PHASE_BP_COOP) { bp_coop = 1; phase(PDDP_PHASE_BP); bp_coop = 0; return 0; }
+        if (ph == PDDP_PHASE_ROLLOUT) { skip_sweep = 1; const int rc = run_phase(PDDP_PHASE_FP); skip_sweep = 0; return rc; }
         if (ph < 0 || ph > 5) return fail(PDDP_EINVAL, "unknown phase");
         store_candidates = 1; phase(ph); store_candidates = 0;      // teacher-forcing hook: the thread-lane forward pass also stores every candidate
         if (ph == PDDP_PHASE_FP) for (int pb = 0; pb < cfg.batch; pb++) if (b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }

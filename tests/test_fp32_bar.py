@@ -455,3 +455,160 @@ def test_fused_sweep_matches_the_sweep_kernels(B, env):
     assert np.median(same) >= 5 and min(same) >= 2, (np.median(same), min(same))
     rel = np.abs(a["Jout"][:, :3] - k["Jout"][:, :3]) / k["Jout"][:, :3]
     assert rel.max() <= 2e-5, rel.max()
+
+
+# ---------------------------------------------------------------------------------------------------------------- the end-effector cost family under the same bar
+EE_KW = dict(N=64, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=10, ee_cost=1, ignore_max_rho_exit=0)     # BASELINE configs[3]'s shape (examples/WAFR_MPC_examples.cu:4-37)
+
+
+def ee_start(N, dtype):
+    """the MPC example's start (utils/exampleUtils.cuh:40-58) and a tool-point goal some decimetres away"""
+    x0 = np.zeros((N, 14), dtype); x0[:, 1] = 0.7; x0[:, 3] = -0.8; x0[:, 5] = 0.75
+    u0 = np.full((N, 7), 0.01, dtype); xg = np.zeros(14, dtype); xg[:3] = [0.45, 0.15, 0.75]
+    return x0.ravel(), u0.ravel(), xg
+
+
+def run_bar_ee(backend, kw, env, iterations, ensemble):
+    """run_bar for EE_COST 1: every iteration of an oracle64 solve teacher-forced, phase by phase, on ONE handle (slot b = iteration b).  What differs from the joint-space
+    family: H_k moves with the trajectory (the setup kernel's tool-point Jacobian; compact position block on the thread-lane / matrix-core path -- left to the KERNEL's own
+    setup output, like in production, so the HQQ backward pass is what runs), the per-knot costs of the setup (costk), and the candidates' costs come out of the rollouts."""
+    from gpusem_steps import _ee_setup
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
+        o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)
+        o32f = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32, variant="fma") if ensemble else None
+        n, m, N, M, A = 14, 7, kw["N"], kw["M"], kw["A"]
+        nm, NB = n + m, N // M
+        x0, u0, xg = ee_start(N, np.float64)
+        with np.errstate(all="ignore"):
+            recs = list(gpusem_iterations(o64, x0, u0, xg, iterations))
+        B = len(recs)
+        s = make_solver(backend, 4, dtype=0, batch=B, **kw)
+        xg32 = xg.astype(F32)
+        s.load(np.tile(x0.astype(F32), B), np.tile(u0.astype(F32), B), np.tile(xg32, B))
+        with np.errstate(over="ignore"):
+            r32 = [{k: (v.astype(F32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in rec.items()} for rec in recs]
+        stack = lambda key: np.stack([r[key].ravel() for r in r32])
+        rows, ints_ok, n_in_play, bp_ratio = [], True, 0, []
+
+        def check(rec, phase, name, k32, o32v, ref):
+            ek, eo = nrel(k32, ref), nrel(o32v, ref)
+            rows.append((rec.iter, phase, name, ek, eo, bar(ek, eo)))
+
+        st = s.get_state()
+        for b_ in range(B):
+            rec = recs[b_]
+            st[b_].cur = 0; st[b_].cur2 = 1; st[b_].pw = 0; st[b_].rho = rec.rho; st[b_].drho = rec.drho; st[b_].done = 0; st[b_].accepted = 0; st[b_].iter = rec.iter
+        s.set_state(st)
+        s.set("xb", np.concatenate([stack("x").reshape(B, 1, N * n), stack("xp2").reshape(B, 1, N * n)], axis=1))
+        s.set("ucur", stack("u")); s.set("dcur", stack("d"))
+        # ---- setup at every record's trajectory: [A B], g, the cost Hessian (read back through the reference-layout view) and the per-knot costs
+        s.run_phase(pyddp.PHASE_INIT_NIS)
+        ABk, gk, Hk, ck = s.get("AB").reshape(B, -1), s.get("g").reshape(B, -1), s.get("H").reshape(B, N, nm, nm), s.get("costk").reshape(B, N)
+        nAB = (N - 1) * n * nm
+        for i, rec in enumerate(recs):
+            ABo, Ho, go, cko = _ee_setup(o32, r32[i]["x"], r32[i]["u"], xg32[:6])
+            check(rec, "nis", "AB", ABk[i][:nAB], ABo[:nAB], rec.AB[:nAB])
+            check(rec, "nis", "g", gk[i], go, rec.g)
+            Hr, Ho_ = rec.H.reshape(N, nm, nm), Ho.reshape(N, nm, nm)
+            check(rec, "nis", "H", Hk[i][: N - 1], Ho_[: N - 1], Hr[: N - 1])
+            check(rec, "nis", "H_final", Hk[i][N - 1][:n, :n], Ho_[N - 1][:n, :n], Hr[N - 1][:n, :n])
+            check(rec, "nis", "costk", ck[i], cko, rec.costk)
+        # ---- backward pass: [A B], g, boundary cost-to-go from the records; H stays the kernel's own (compact position block where the selection keeps one)
+        for name in ("AB", "g", "Pp", "pp"):
+            s.set(name, stack(name))
+        s.run_phase(pyddp.PHASE_BP)
+        out = {name: s.get(name).reshape(B, -1) for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
+        errk = s.get("err").reshape(B, M)
+        for i, rec in enumerate(recs):
+            q = r32[i]
+            if ensemble:
+                floor, strict_err, strict = bp_noise_floor(o32, o32f, q, rec.rho, rec, i, n, N, M)
+            else:
+                strict = oracle_bp(o32, q, rec.rho)
+                strict_err = {name: nrel(v, r) for name, v, r in bp_quantities(strict, rec, n, N, M)}
+                floor = strict_err
+            ints_ok &= list(errk[i]) == list(rec.err) == list(strict["err"])
+            kern = {name: out[name][i] for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
+            for name, v, ref in bp_quantities(kern, rec, n, N, M):
+                ek = nrel(v, ref)
+                rows.append((rec.iter, "bp", name, ek, strict_err[name], bar(ek, floor[name])))
+                bp_ratio.append(ek / max(floor[name], 1e-4 / 1.5))
+        # ---- forward pass of every step size from the float64 gains: states, controls, boundary defects and the IN-SIM cost
+        for name in ("KT", "du", "ApBK", "Bdu"):
+            s.set(name, stack(name))
+        s.run_phase(pyddp.PHASE_FP)
+        xs, us, ds = s.get("xs").reshape(B, A, N, n), s.get("us").reshape(B, A, N, m), s.get("ds").reshape(B, A, N, n)
+        Jk = s.get("J").reshape(B, A)
+        bnd = [k for k in range(N) if ((k + 1) % NB == 0) and k < N - 1]
+        for i, rec in enumerate(recs):
+            q = r32[i]
+            for a in range(A):
+                xa, ua, da = q["x"].copy(), q["u"].copy(), q["d"].copy()
+                al = rec.alphas[a].astype(F32)
+                with np.errstate(all="ignore"):
+                    if M > 1:
+                        o32.forward_sweep(xa, q["ApBK"], q["Bdu"], q["d"], q["x"], al)
+                    JT = o32.forward_sim_ee(xa, ua, q["KT"], q["du"], da, al, q["x"], xg32[:6])
+                    Jo = F32(0)
+                    for b_ in range(M):
+                        Jo = F32(Jo + JT[b_])
+                ref_x = rec.xs[a]
+                if not (np.isfinite(ref_x).all() and rec.J[a] <= 1.5 * rec.prevJ):
+                    ints_ok &= (not (Jk[i][a] <= rec.prevJ)) and (not (Jo <= rec.prevJ))
+                    continue
+                n_in_play += 1
+                ph = f"fp[a={a}]"
+                check(rec, ph, "x", xs[i][a], xa, ref_x)
+                check(rec, ph, "u", us[i][a][: N - 1], ua.reshape(N, m)[: N - 1], rec.us[a].reshape(N, m)[: N - 1])
+                check(rec, ph, "J", Jk[i][a], Jo, rec.J[a])
+                if bnd:
+                    scale = np.abs(ref_x).max()
+                    dref = rec.ds[a].reshape(N, n)[bnd]
+                    ek = np.abs(ds[i][a][bnd].astype(np.float64) - dref).max() / scale
+                    eo = np.abs(da.reshape(N, n)[bnd].astype(np.float64) - dref).max() / scale
+                    rows.append((rec.iter, ph, "d", ek, eo, bar(ek, eo)))
+        # ---- line search from the float64 cost tables rounded to float32: integers
+        st = s.get_state()
+        for b_ in range(B):
+            st[b_].prevJ = F32(recs[b_].prevJ); st[b_].ignore_defect = recs[b_].ignore_defect; st[b_].alphaIndex = 0
+        s.set_state(st)
+        s.set("J", stack("J")); s.set("dmax", stack("dmax")); s.set("dJexp", stack("dJexp"))
+        s.run_phase(pyddp.PHASE_LS)
+        st = s.get_state()
+        for b_, rec in enumerate(recs):
+            q = r32[b_]
+            ai, ign, dJ, zz = o32.line_search_gpu(q["J"], q["dmax"], q["dJexp_sum"], F32(rec.prevJ), rec.ignore_defect, 0)
+            if dJ < 0:
+                ints_ok &= (st[b_].accepted == 0 and rec.accepted == 0)
+            else:
+                ints_ok &= (st[b_].accepted == 1 and st[b_].alphaIndex == ai == rec.ls_alpha and st[b_].ignore_defect == ign == rec.ls_ignore_defect)
+        assert n_in_play >= B
+        names = dict(s.time_kernels(1))
+        s.close()
+        _run_bar.bp_ratio = np.asarray(bp_ratio)
+        return rows, [r for r in rows if not r[5]], ints_ok, names
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("env,kernels", [pytest.param({}, ("k_bp_mfma", "k_fp_tl4", "k_nis_tl7"), id="few-problem-selection"),
+                                         pytest.param({"PDDP_BP": "mx", "PDDP_FP": "tl"}, ("k_bp_mfma", "k_fp_tl", "k_nis_tl"), id="large-batch-selection")])
+def test_ee_cost_float32_bar_every_iteration(backend, env, kernels):
+    """BASELINE configs[3]'s shape (Kuka N=64, A=8, M=4, MPC_MODE, end-effector cost), float32, every iteration of the solve teacher-forced from oracle64, on both kernel
+    selections the library makes for it: the thread-lane / matrix-core family with the compact position block (HQQ backward pass, in-sim cost in k_fp_tl, k_nis_tl<EE>) and
+    the few-problem kernels (k_fp_tl4's control wave, k_nis_tl7's eighth row)."""
+    iterations = 10 if backend == "hip" else 3
+    ens = backend == "hip"
+    rows, fails, ints_ok, names = run_bar_ee(backend, EE_KW, env, iterations, ens)
+    if backend == "hip":
+        assert all(k in names for k in kernels), names
+    assert ints_ok, "err flags / step-size index / accept-reject / ignore_defect must be identical"
+    assert len({r[0] for r in rows}) == iterations
+    w = summarize(rows)
+    print("end-effector cost, float32: worst err(kernel32, oracle64) | err(oracle32, oracle64) per quantity:", {f"{k[0]}.{k[1]}": f"{v[0]:.1e}|{v[1]:.1e}" for k, v in sorted(w.items())})
+    assert_inside(rows, fails, ens)

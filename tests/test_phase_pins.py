@@ -25,7 +25,11 @@ from oracle_binding import Oracle, default_cfg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MAN = json.load(open(os.path.join(HERE, "golden", "phase_fixtures.json")))
-DATA = np.load(os.path.join(HERE, "golden", "phase_fixtures.npz"))
+DATA = dict(np.load(os.path.join(HERE, "golden", "phase_fixtures.npz")))
+# round 4 (make_phase_fixtures.py --round4): sweeps / rollouts that start from the solver's invariant, and a whole runiLQR_GPU solve at the HEADLINE size N = 128, M = 4, A = 8
+_MAN4 = json.load(open(os.path.join(HERE, "golden", "phase_fixtures_r04.json")))
+DATA.update(np.load(os.path.join(HERE, "golden", "phase_fixtures_r04.npz")))
+MAN["cases"] = MAN["cases"] + _MAN4["cases"]
 CASES = {c["name"]: c for c in MAN["cases"]}
 TOL = 1e-12
 
@@ -298,4 +302,4 @@ def test_fixture_provenance_is_data_only():
     assert set(MAN) == {"_provenance", "cases", "line_search"}
     for c in MAN["cases"]:
         assert set(c) <= {"name", "kind", "cfg", "sem", "inputs", "outputs", "rho", "weights", "inputs_of", "flags"}
-    assert all(DATA[k].dtype.kind in "fi" for k in DATA.files)
+    assert all(DATA[k].dtype.kind in "fi" for k in DATA)

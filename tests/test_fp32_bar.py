@@ -461,14 +461,19 @@ def test_fused_sweep_matches_the_sweep_kernels(B, env):
 EE_KW = dict(N=64, M=4, A=8, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=10, ee_cost=1, ignore_max_rho_exit=0)     # BASELINE configs[3]'s shape (examples/WAFR_MPC_examples.cu:4-37)
 
 
-def ee_start(N, dtype):
-    """the MPC example's start (utils/exampleUtils.cuh:40-58) and a tool-point goal some decimetres away"""
+def ee_start(N, dtype, off_cut=False):
+    """the MPC example's start (utils/exampleUtils.cuh:40-58) and a tool-point goal some decimetres away.  off_cut: the even joints a few hundredths of a radian away from
+    zero -- at the example's own pose the tool's roll and yaw are EXACTLY +-pi, on the cut of atan2 (compute_eePos, dynamics_arm.cuh:1915-1925), where the sign of a rounding
+    error in a rotation entry (or of a zero) decides between +pi and -pi; with roll / pitch / yaw weighted (Q_EE2, QF_EE2 != 0; the reference's example leaves them 0) any two
+    evaluation orders can land on different sides there (measured: profiles/r04_ee_rpy_branch_cut.md)."""
     x0 = np.zeros((N, 14), dtype); x0[:, 1] = 0.7; x0[:, 3] = -0.8; x0[:, 5] = 0.75
+    if off_cut:
+        x0[:, 0] = 0.05; x0[:, 2] = -0.04; x0[:, 4] = 0.03; x0[:, 6] = 0.02
     u0 = np.full((N, 7), 0.01, dtype); xg = np.zeros(14, dtype); xg[:3] = [0.45, 0.15, 0.75]
     return x0.ravel(), u0.ravel(), xg
 
 
-def run_bar_ee(backend, kw, env, iterations, ensemble):
+def run_bar_ee(backend, kw, env, iterations, ensemble, off_cut=False):
     """run_bar for EE_COST 1: every iteration of an oracle64 solve teacher-forced, phase by phase, on ONE handle (slot b = iteration b).  What differs from the joint-space
     family: H_k moves with the trajectory (the setup kernel's tool-point Jacobian; compact position block on the thread-lane / matrix-core path -- left to the KERNEL's own
     setup output, like in production, so the HQQ backward pass is what runs), the per-knot costs of the setup (costk), and the candidates' costs come out of the rollouts."""
@@ -481,7 +486,7 @@ def run_bar_ee(backend, kw, env, iterations, ensemble):
         o32f = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32, variant="fma") if ensemble else None
         n, m, N, M, A = 14, 7, kw["N"], kw["M"], kw["A"]
         nm, NB = n + m, N // M
-        x0, u0, xg = ee_start(N, np.float64)
+        x0, u0, xg = ee_start(N, np.float64, off_cut)
         with np.errstate(all="ignore"):
             recs = list(gpusem_iterations(o64, x0, u0, xg, iterations))
         B = len(recs)
@@ -595,16 +600,20 @@ def run_bar_ee(backend, kw, env, iterations, ensemble):
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
 
+EE_RPY = dict(Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)       # roll / pitch / yaw and nominal-position terms switched on (the reference's example leaves them 0)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("weights", [pytest.param({}, id="example-weights"), pytest.param(EE_RPY, id="rpy-and-nominal-weights")])
 @pytest.mark.parametrize("env,kernels", [pytest.param({}, ("k_bp_mfma", "k_fp_tl4", "k_nis_tl7"), id="few-problem-selection"),
                                          pytest.param({"PDDP_BP": "mx", "PDDP_FP": "tl"}, ("k_bp_mfma", "k_fp_tl", "k_nis_tl"), id="large-batch-selection")])
-def test_ee_cost_float32_bar_every_iteration(backend, env, kernels):
+def test_ee_cost_float32_bar_every_iteration(backend, env, kernels, weights):
     """BASELINE configs[3]'s shape (Kuka N=64, A=8, M=4, MPC_MODE, end-effector cost), float32, every iteration of the solve teacher-forced from oracle64, on both kernel
     selections the library makes for it: the thread-lane / matrix-core family with the compact position block (HQQ backward pass, in-sim cost in k_fp_tl, k_nis_tl<EE>) and
     the few-problem kernels (k_fp_tl4's control wave, k_nis_tl7's eighth row)."""
     iterations = 10 if backend == "hip" else 3
     ens = backend == "hip"
-    rows, fails, ints_ok, names = run_bar_ee(backend, EE_KW, env, iterations, ens)
+    rows, fails, ints_ok, names = run_bar_ee(backend, {**EE_KW, **weights}, env, iterations, ens, off_cut=bool(weights))
     if backend == "hip":
         assert all(k in names for k in kernels), names
     assert ints_ok, "err flags / step-size index / accept-reject / ignore_defect must be identical"
@@ -612,3 +621,30 @@ def test_ee_cost_float32_bar_every_iteration(backend, env, kernels):
     w = summarize(rows)
     print("end-effector cost, float32: worst err(kernel32, oracle64) | err(oracle32, oracle64) per quantity:", {f"{k[0]}.{k[1]}": f"{v[0]:.1e}|{v[1]:.1e}" for k, v in sorted(w.items())})
     assert_inside(rows, fails, ens)
+
+
+
+@pytest.mark.gpu
+def test_ee_cost_float32_whole_solve_with_rpy_weights_follows_the_oracle():
+    """The parity report's end-effector solve with roll / pitch / yaw weighted showed J[1] 5.5e-3 away from both oracles: its start pose sits exactly on atan2's
+    +-pi cut (ee_start).  A few hundredths of a radian away from the cut the float32 solve follows oracle32 and oracle64: identical step sizes over the leading iterations, the
+    first accepted costs within 5 x the float32 oracle's own distance from float64 (floor 2e-4)."""
+    kw = {**EE_KW, **EE_RPY}
+    x0, u0, xg = ee_start(kw["N"], F32, off_cut=True)
+    o32, o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32), Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
+    r32, r64 = o32.run_ilqr_gpusem(x0, u0, xg), o64.run_ilqr_gpusem(x0.astype(np.float64), u0.astype(np.float64), xg.astype(np.float64))
+    for env in ({}, {"PDDP_BP": "mx", "PDDP_FP": "tl"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            s = make_solver("hip", 4, dtype=0, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        out = s.solve(x0, u0, xg)
+        lead = next((i for i in range(9) if not (out["alphaOut"][0][i] == r32["alphaOut"][i] == r64["alphaOut"][i])), 9)
+        assert lead >= 4, (env, out["alphaOut"][0][:9], r32["alphaOut"][:9], r64["alphaOut"][:9])
+        for i in range(min(lead, 4)):
+            ek, eo = abs(float(out["Jout"][0][i]) - r64["Jout"][i]) / r64["Jout"][i], abs(float(r32["Jout"][i]) - r64["Jout"][i]) / r64["Jout"][i]
+            assert ek <= max(2e-4, 5 * eo), (env, i, ek, eo)
+        s.close()

@@ -212,8 +212,8 @@ class Ptr:
         self.buf, self.off = buf, off
 
     @staticmethod
-    def alloc(n, fill=0.0):
-        return Ptr([fill] * int(n), 0)
+    def alloc(n, fill=None):
+        return Ptr([REAL(0.0) if fill is None else fill] * int(n), 0)
 
     def __add__(self, i):
         return Ptr(self.buf, self.off + int(i))
@@ -235,10 +235,131 @@ class Ptr:
         j = self.off + int(i)
         if j < 0:
             raise IndexError("negative offset %d" % j)
+        if type(v) is not F32 and type(self.buf[j]) is F32:      # a store into a float array converts (float32 mode)
+            v = F32(v)
         self.buf[j] = v
 
     def __bool__(self):
         return True
+
+
+# ------------------------------------------------------------------------------------------------------------------ float32 mode (round 4)
+# REAL = float (the default): every T is a Python float, i.e. the reference's statements in double precision -- what phase_fixtures.npz was generated with.
+# set_real("f32"): T = F32, a float32 VALUE TYPE with C's usual arithmetic conversions, so that the translated statements evaluate like the reference compiled with
+# algType = float, strict IEEE, no contraction:  F32 op F32 -> F32 (one float32 rounding per operation);  F32 op int -> F32 (the int converts to float);  F32 op double
+# (a Python float: an unsuffixed literal, a (double) cast, a double variable) -> double;  the result is rounded to float32 where C converts it: on assignment to a T
+# variable or array element, as a T argument or return value, in a (T) cast.  sin / cos / atan2 / pow of a float32 are libm's float functions (the overloads C++ picks).
+import ctypes
+import numpy as _np
+
+_f32 = _np.float32
+_np.seterr(all="ignore")
+
+
+def _mk(v):
+    r = F32.__new__(F32)
+    r.v = v
+    return r
+
+
+class F32:
+    __slots__ = ("v",)
+
+    def __init__(self, x=0.0):
+        self.v = x.v if type(x) is F32 else _f32(x)
+
+    def __add__(self, o):
+        t = type(o)
+        if t is F32: return _mk(self.v + o.v)
+        if t is float: return float(self.v) + o
+        return _mk(self.v + _f32(o))
+
+    def __radd__(self, o):
+        return (o + float(self.v)) if type(o) is float else _mk(_f32(o) + self.v)
+
+    def __sub__(self, o):
+        t = type(o)
+        if t is F32: return _mk(self.v - o.v)
+        if t is float: return float(self.v) - o
+        return _mk(self.v - _f32(o))
+
+    def __rsub__(self, o):
+        return (o - float(self.v)) if type(o) is float else _mk(_f32(o) - self.v)
+
+    def __mul__(self, o):
+        t = type(o)
+        if t is F32: return _mk(self.v * o.v)
+        if t is float: return float(self.v) * o
+        return _mk(self.v * _f32(o))
+
+    def __rmul__(self, o):
+        return (o * float(self.v)) if type(o) is float else _mk(_f32(o) * self.v)
+
+    def __truediv__(self, o):
+        t = type(o)
+        if t is F32: return _mk(self.v / o.v)
+        if t is float: return float(_np.float64(self.v) / _np.float64(o))
+        return _mk(self.v / _f32(o))
+
+    def __rtruediv__(self, o):
+        return float(_np.float64(o) / _np.float64(self.v)) if type(o) is float else _mk(_f32(o) / self.v)
+
+    def __neg__(self): return _mk(-self.v)
+    def __pos__(self): return self
+    def __abs__(self): return _mk(abs(self.v))
+    def __float__(self): return float(self.v)
+    def __int__(self): return int(self.v)
+    def __bool__(self): return bool(self.v != 0)
+    def __repr__(self): return "F32(%r)" % float(self.v)
+    def _o(self, o): return float(o.v) if type(o) is F32 else o
+    def __eq__(self, o): return float(self.v) == self._o(o)
+    def __ne__(self, o): return float(self.v) != self._o(o)
+    def __lt__(self, o): return float(self.v) < self._o(o)
+    def __le__(self, o): return float(self.v) <= self._o(o)
+    def __gt__(self, o): return float(self.v) > self._o(o)
+    def __ge__(self, o): return float(self.v) >= self._o(o)
+    __hash__ = None
+
+
+REAL = float
+
+
+def set_real(kind):
+    """"f64" (default) or "f32": the element type T of everything translated and executed from here on"""
+    global REAL
+    REAL = F32 if kind == "f32" else float
+    return REAL
+
+
+def typed():
+    return REAL is F32
+
+
+_libm = ctypes.CDLL("libm.so.6")
+for _n in ("sinf", "cosf", "tanf", "expf", "logf"):
+    getattr(_libm, _n).restype = ctypes.c_float; getattr(_libm, _n).argtypes = [ctypes.c_float]
+for _n in ("atan2f", "powf"):
+    getattr(_libm, _n).restype = ctypes.c_float; getattr(_libm, _n).argtypes = [ctypes.c_float, ctypes.c_float]
+
+
+def _m1(fname, dbl):
+    cf = getattr(_libm, fname)
+    def f(x):
+        return _mk(_f32(cf(float(x.v)))) if type(x) is F32 else dbl(x)
+    return f
+
+
+t_sin, t_cos, t_tan, t_exp, t_log = _m1("sinf", math.sin), _m1("cosf", math.cos), _m1("tanf", math.tan), _m1("expf", math.exp), _m1("logf", math.log)
+
+
+def t_sqrt(x):
+    return _mk(_np.sqrt(x.v)) if type(x) is F32 else math.sqrt(x)
+
+
+def t_atan2(y, x):
+    if type(y) is F32 and type(x) is F32:
+        return _mk(_f32(_libm.atan2f(float(y.v), float(x.v))))
+    return math.atan2(float(y), float(x))
 
 
 def c_div(a, b):
@@ -255,7 +376,9 @@ def c_mod(a, b):
 
 
 def c_pow(a, b):
-    return math.pow(a, b)
+    if type(a) is F32 and type(b) is F32:                        # pow(float, float) -> powf; pow(float, int) and pow(float, double) are double (C++11 promotion)
+        return _mk(_f32(_libm.powf(float(a.v), float(b.v))))
+    return math.pow(float(a), float(b))
 
 
 SIZEOF = 8        # sizeof(T), in the unit memset / memcpy byte counts are given in: element counts = bytes / SIZEOF (every buffer here holds one Python number per element)
@@ -304,7 +427,7 @@ class Block:
         self.mem = {}
         self.extern = Ptr.alloc(extern_elems) if extern_elems else None
 
-    def shared(self, key, n, fill=0.0):
+    def shared(self, key, n, fill=None):
         if key not in self.mem:
             self.mem[key] = Ptr.alloc(n, fill)
         return self.mem[key]
@@ -347,8 +470,8 @@ def tpl(given, names, defaults):
 TYPE_WORDS = {"T", "int", "int64_t", "unsigned", "bool", "float", "double", "auto", "const", "char", "long", "size_t", "threadDesc_t", "dim3", "void", "half", "algType", "struct", "timeval"}
 QUALIFIERS = {"__host__", "__device__", "__global__", "__forceinline__", "inline", "static", "extern", "__noinline__", "constexpr"}
 SYNC_NAMES = {"__syncthreads"}
-MATH = {"sin": "math.sin", "cos": "math.cos", "sqrt": "math.sqrt", "abs": "abs", "fabs": "abs", "pow": "c_pow", "atan2": "math.atan2", "max": "max", "min": "min",
-        "exp": "math.exp", "log": "math.log", "tan": "math.tan", "floor": "math.floor", "ceil": "math.ceil", "memset": "c_memset", "memcpy": "c_memcpy"}
+MATH = {"sin": "t_sin", "cos": "t_cos", "sqrt": "t_sqrt", "abs": "abs", "fabs": "abs", "pow": "c_pow", "atan2": "t_atan2", "max": "max", "min": "min",
+        "exp": "t_exp", "log": "t_log", "tan": "t_tan", "floor": "math.floor", "ceil": "math.ceil", "memset": "c_memset", "memcpy": "c_memcpy"}      # t_*: libm's double functions for a Python float, its float functions for an F32
 # host side of the CUDA runtime as far as the reference's host drivers use it: copies and fills act on the emulated buffers (byte counts are multiples of sizeof(T)),
 # synchronisation and error queries are no-ops (the emulation is sequential)
 CUDA_RT = {"cudaMemcpy": "cu_memcpy", "cudaMemcpyAsync": "cu_memcpy", "cudaMemset": "cu_memset", "cudaMemsetAsync": "cu_memset", "cudaStreamSynchronize": "cu_ok",
@@ -356,6 +479,14 @@ CUDA_RT = {"cudaMemcpy": "cu_memcpy", "cudaMemcpyAsync": "cu_memcpy", "cudaMemse
 CUDA_VARS = {("threadIdx", "x"): "_t.tix", ("threadIdx", "y"): "_t.tiy", ("threadIdx", "z"): "_t.tiz", ("blockIdx", "x"): "_t.bix", ("blockIdx", "y"): "_t.biy",
              ("blockIdx", "z"): "_t.biz", ("blockDim", "x"): "_t.bdx", ("blockDim", "y"): "_t.bdy", ("blockDim", "z"): "_t.bdz", ("gridDim", "x"): "_t.gdx",
              ("gridDim", "y"): "_t.gdy", ("gridDim", "z"): "_t.gdz"}
+
+
+class Param(tuple):
+    """(name, stars, default) like before + .words: the parameter's type words (float32 mode converts by-value floating arguments at function entry)"""
+    def __new__(cls, t, words):
+        o = tuple.__new__(cls, t)
+        o.words = words
+        return o
 
 
 class FuncDef:
@@ -469,7 +600,7 @@ def parse_header(h, body):
         ids = [t for t in decl if t[0] == "id"]
         pname = ids[-1][1]
         stars = sum(1 for t in decl if t[1] == "*")
-        params.append((pname, stars, default))
+        params.append(Param((pname, stars, default), [t[1] for t in ids[:-1]]))
     ret = [p for p in pre if p not in QUALIFIERS]
     return FuncDef(name, tparams, params, body, ret, "__global__" in pre)
 
@@ -531,7 +662,7 @@ class Translator:
         for nm in names:
             for fd in self.funcs[nm]:
                 self.require(fd)
-        ns = {"math": math, "Ptr": Ptr, "c_div": c_div, "c_mod": c_mod, "c_pow": c_pow, "tpl": tpl, "Struct": Struct, "HOST": HOST, "UNSET": UNSET, "dflt": dflt, "c_memset": c_memset, "c_memcpy": c_memcpy, "padd": padd, "cu_memcpy": cu_memcpy, "cu_memset": cu_memset, "cu_ok": cu_ok,
+        ns = {"t_sin": t_sin, "t_cos": t_cos, "t_tan": t_tan, "t_exp": t_exp, "t_log": t_log, "t_sqrt": t_sqrt, "t_atan2": t_atan2, "F32": F32, "REAL": REAL, "math": math, "Ptr": Ptr, "c_div": c_div, "c_mod": c_mod, "c_pow": c_pow, "tpl": tpl, "Struct": Struct, "HOST": HOST, "UNSET": UNSET, "dflt": dflt, "c_memset": c_memset, "c_memcpy": c_memcpy, "padd": padd, "cu_memcpy": cu_memcpy, "cu_memset": cu_memset, "cu_ok": cu_ok,
               "Dim3": Dim3, "cudaMemcpyHostToDevice": 1, "cudaMemcpyDeviceToHost": 2, "cudaMemcpyDeviceToDevice": 3, "__FILE__": 0, "__LINE__": 0}
         ns.update(self.extra_ns)
         for py in self.order:
@@ -551,6 +682,21 @@ class FuncTranslator:
         self.scalars = {p[0] for p in fd.params if p[1] == 0}   # scalar parameters and declared scalar locals (for &name out-arguments)
         self.loop_incr = []               # stack of increment statements of the enclosing for-loops (for `continue`)
         self.tnames = {tp[0] for tp in fd.tparams if tp[1]}        # typename parameters only (T): integer template parameters are values
+        self.vtypes = {}                  # float32 mode: scalar name -> the conversion its C type applies on assignment ("T", "F32", "float")
+
+    def caster(self, words):
+        """the Python conversion of a C floating type: a typename parameter -> that (run-time) type, algType / T outside a template -> REAL, float -> F32, double -> float.
+        Outside float32 mode everything is a Python float, as it always was."""
+        if not typed():
+            return "float"
+        for w in words:
+            if w in self.tnames:
+                return w
+        if any(w in ("T", "algType") for w in words):
+            return "REAL"
+        if "float" in words:
+            return "F32"
+        return "float"
 
     # ---------------------------------------------------------------- emit helpers
     def emit(self, ind, s):
@@ -575,8 +721,15 @@ class FuncTranslator:
             self.emit(1, l)
         if fd.tparams:
             names = [tp[0] for tp in fd.tparams]
-            defaults = ["float" if tp[1] else (self.expr(tp[2], 1, pre_ok=False) if tp[2] is not None else "None") for tp in fd.tparams]
+            defaults = ["REAL" if tp[1] else (self.expr(tp[2], 1, pre_ok=False) if tp[2] is not None else "None") for tp in fd.tparams]
             self.emit(1, "%s = tpl(_tp, %r, [%s])" % (", ".join(names) + ("," if len(names) == 1 else ""), names, ", ".join(defaults)))
+        if typed():                                                 # by-value floating parameters convert to their type (T rho, T alpha, T Q1 = _Q1 ...)
+            for prm in fd.params:
+                words = getattr(prm, "words", [])
+                if prm[1] == 0 and any(w in self.tnames or w in ("T", "algType", "float", "double") for w in words):
+                    c = self.caster(words)
+                    self.vtypes[prm[0]] = c
+                    self.emit(1, "if %s is not None: %s = %s(%s)" % (prm[0], prm[0], c, prm[0]))
         n0 = len(self.lines)
         self.block(fd.body, 1)
         if len(self.lines) == n0:
@@ -672,7 +825,10 @@ class FuncTranslator:
         if v == "return":
             j = self._stmt_end(toks, i)
             e = toks[i + 1:j - 1]
-            self.emit(ind, "return %s" % self.expr(e, ind) if e else "return")
+            if e and typed() and any(w in self.tnames or w in ("T", "algType", "float", "double") for w in self.fd.ret):
+                self.emit(ind, "return %s(%s)" % (self.caster(self.fd.ret), self.expr(e, ind)))
+            else:
+                self.emit(ind, "return %s" % self.expr(e, ind) if e else "return")
             return j
         if v == "continue":
             incr = self.loop_incr[-1]
@@ -774,15 +930,17 @@ class FuncTranslator:
             if rest and rest[0][1] == "[":
                 j = self._match(rest, 0, "[", "]")
                 size = self.expr(rest[1:j - 1], ind)
+                fill = ", 0" if is_int else ((", %s(0.0)" % self.caster(base)) if typed() else "")
                 if shared:
-                    self.emit(ind, "%s = _t.blk.shared(%r, %s)" % (name, self.fd.pyname + "." + name, size))
+                    self.emit(ind, "%s = _t.blk.shared(%r, %s%s)" % (name, self.fd.pyname + "." + name, size, fill if typed() else ""))
                 else:
-                    self.emit(ind, "%s = Ptr.alloc(%s%s)" % (name, size, ", 0" if is_int else ""))
+                    self.emit(ind, "%s = Ptr.alloc(%s%s)" % (name, size, fill))
                 continue
             if rest and rest[0][1] == "=":
                 val = self.expr(rest[1:], ind)
                 if stars == 0 and not is_int and base and base[0] != "auto":
-                    val = "float(%s)" % val
+                    val = "%s(%s)" % (self.caster(base), val)
+                    if typed(): self.vtypes[name] = self.caster(base)
                 elif stars == 0 and is_int and "bool" not in base:
                     val = "int(%s)" % val
                 mnull = re.match(r"^\(?([A-Za-z_]\w*) [+-] ", val) if stars else None
@@ -792,7 +950,11 @@ class FuncTranslator:
                     self.emit(ind, "%s = %s" % (name, val))
                 self.lockstep(ind)
             else:
-                self.emit(ind, "%s = %s" % (name, "None" if stars else ("0" if is_int else "0.0")))
+                if typed() and stars == 0 and not is_int and base and base[0] != "auto":
+                    self.vtypes[name] = self.caster(base)
+                    self.emit(ind, "%s = %s(0.0)" % (name, self.caster(base)))
+                else:
+                    self.emit(ind, "%s = %s" % (name, "None" if stars else ("0" if is_int else "0.0")))
             if stars == 0:
                 self.scalars.add(name)
 
@@ -834,6 +996,14 @@ class FuncTranslator:
             rhs = self.assignment(False)
             if not stmt:
                 raise SyntaxError("assignment inside an expression in %s" % self.fd.name)
+            cv = self.vtypes.get(lhs) if typed() else None       # float32 mode: the value converts to the variable's type (array elements convert in Ptr.__setitem__)
+            if cv:
+                if op == "=":
+                    return "%s = %s(%s)" % (lhs, cv, rhs)
+                if op == "/=":
+                    return "%s = %s(c_div(%s, %s))" % (lhs, cv, lhs, rhs)
+                if op in ("+=", "-=", "*="):
+                    return "%s = %s(%s %s (%s))" % (lhs, cv, lhs, op[0], rhs)
             if op == "/=":
                 return "%s = c_div(%s, %s)" % (lhs, lhs, rhs)
             if op == "%=":
@@ -924,7 +1094,7 @@ class FuncTranslator:
                         return inner
                     if any(w in ("int", "unsigned", "long", "size_t") for w in words):
                         return "int(%s)" % inner
-                    return "float(%s)" % inner
+                    return "%s(%s)" % (self.caster(words), inner)
         return self.postfix()
 
     @staticmethod
@@ -954,7 +1124,10 @@ class FuncTranslator:
         if kind == "num":
             s = re.sub(r"[uUlL]+$", "", v)
             if re.search(r"[.eE]", s) and not s.lower().startswith("0x"):
-                s = re.sub(r"[fF]$", "", s)
+                if typed() and re.search(r"[fF]$", s):
+                    s = "F32(%s)" % re.sub(r"[fF]$", "", s)           # a float literal
+                else:
+                    s = re.sub(r"[fF]$", "", s)
             base = s
         elif kind == "id":
             base = self.primary_id(v)
@@ -1018,7 +1191,7 @@ class FuncTranslator:
                 return inner
             if any(w in ("int", "unsigned", "long") for w in words):
                 return "int(%s)" % inner
-            return "float(%s)" % inner
+            return "%s(%s)" % (self.caster(words), inner)
         if v == "sizeof":
             assert self.nxt()[1] == "("
             while self.nxt()[1] != ")":
@@ -1047,7 +1220,7 @@ class FuncTranslator:
             sub = []
             for part in split_template_args(inner):
                 if len(part) == 1 and (part[0][1] in self.tnames and part[0][1] == "T" or part[0][1] in ("float", "double", "T")):
-                    sub.append("float")
+                    sub.append(self.caster([part[0][1]]))
                 else:
                     ft = FuncTranslator(self.tu, self.fd)
                     ft.scalars, ft.tnames = self.scalars, self.tnames

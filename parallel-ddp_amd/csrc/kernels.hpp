@@ -240,6 +240,192 @@ __global__ __launch_bounds__(64) void k_fp_ts(Buffers<T> b, Dims dm, CostWeights
     for (int bInd = 0; bInd < dm.M; bInd++) forward_sim_segment<P, INTEG, T>(w, sim, dm, a, bInd, cw, b.xGoal + (size_t)pb * P::NX, cost_k);
     fp_reduce<T>(w, b, dm, pb, a_idx, cost_k, dnorm, nullptr);
 }
+#define PDDP_UNROLL _Pragma("unroll")
+// Forward pass of the scalar closed-form plants with the device full, second form (BASELINE configs[4], the quadrotor).  k_fp_ts above keeps thread = (problem, step
+// size) and the reference's arithmetic, but (counters in profiles/r04_quad.md: waves spend 55 % of their cycles in s_waitcnt, 22 % issuing)
+//   * every thread fetches its problem's K_k, (A - B K)_k, x_k, u_k, du_k, (B du)_k itself: ~90 vector-memory instructions per step, the same 16 addresses A times over;
+//   * each step's loads are issued right after the previous step's stores, and gfx9's single in-order vmcnt makes the wait for the loads a wait for the store
+//     acknowledgements as well -- one write round trip on every step's critical path.
+// Here the wavefront = 64 / A problems x A step sizes fetches each knot's operands ONCE, coalesced, ONE STEP AHEAD of their use (issued before the step's arithmetic,
+// parked in registers, written to a double-buffered LDS stage after it), and the lanes read them back as broadcasts; the step's stores come last, so that what the
+// next step waits for is a load that was issued a whole step earlier.  Two loops as before: the linear sweep (forward_sweep, fp.hpp) for the segments' start states,
+// which go to the candidate's x like the reference's and are read back from there, then the rollouts (forward_sim_segment).  Per thread the arithmetic is that of
+// those two functions, operation by operation.  No barriers: a one-wave block, LDS operations of a wave retire in order (wsync).
+template <typename P, typename T, int A>
+struct FpCfStage {
+    static constexpr int PW = 64 / A, NX = P::NX, NU = P::NU;
+    union {
+        struct { T M[PW][NX * NX], xp[PW][NX], Bdu[PW][NX], d[PW][NX]; } sw;
+        struct { T K[PW][NX * NU], xp[PW][NX], up[PW][NU], du[PW][NU]; } ro;
+    };
+};
+template <typename T, int PW, int L>
+struct FpCfRegs { static constexpr int R = (PW * L + 63) / 64; T v[R]; };
+// lane's share of the PW problems' L-vectors of knot k: element idx = lane + 64 j  ->  problem idx / L, entry idx % L
+template <typename T, int PW, int L>
+__device__ __forceinline__ void fp_cf_fetch(FpCfRegs<T, PW, L>& r, const T* base, size_t per_problem, int k, int pb0, int batch, int lane) {
+    PDDP_UNROLL for (int j = 0; j < FpCfRegs<T, PW, L>::R; j++) {
+        const int idx = lane + 64 * j, p = idx / L, e = idx - p * L;
+        const int pb = (pb0 + p < batch) ? pb0 + p : batch - 1;
+        r.v[j] = (idx < PW * L) ? base[(size_t)pb * per_problem + (size_t)k * L + e] : T(0);
+    }
+}
+template <typename T, int PW, int L>
+__device__ __forceinline__ void fp_cf_put(const FpCfRegs<T, PW, L>& r, T* dst, int lane) {
+    PDDP_UNROLL for (int j = 0; j < FpCfRegs<T, PW, L>::R; j++) { const int idx = lane + 64 * j; if (idx < PW * L) dst[idx] = r.v[j]; }
+}
+// n consecutive values to a 16-byte aligned address, as 16-byte stores (the compiler cannot see the alignment of base + k * n: the buffers come from hipMalloc and
+// n * sizeof(T) is a multiple of 16 for the plants this kernel serves)
+template <typename T, int n>
+__device__ __forceinline__ void cf_store_vec(T* dst, const T* v) {
+    if constexpr ((n * sizeof(T)) % 16 == 0) {
+        typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int W = 16 / sizeof(T);
+        PDDP_UNROLL for (int j = 0; j < n / W; j++) { V q; PDDP_UNROLL for (int e = 0; e < W; e++) q[e] = v[j * W + e]; reinterpret_cast<V*>(dst)[j] = q; }
+    } else {
+        PDDP_UNROLL for (int j = 0; j < n; j++) dst[j] = v[j];
+    }
+}
+// integrator_step (integrators.hpp) for one thread with everything in registers
+template <typename P, int INTEG, typename T>
+__device__ __forceinline__ void cf_integrator_step(T* xn, const T* x, const T* u, T dt) {
+    constexpr int NP = P::NPOS, NX = P::NX;
+    T q1[NP];
+    P::dynamics_eval(q1, x, u);
+    if constexpr (INTEG == 1) {
+        PDDP_UNROLL for (int i = 0; i < NP; i++) { xn[i] = x[i] + dt * x[i + NP]; xn[i + NP] = x[i + NP] + dt * q1[i]; }
+    } else if constexpr (INTEG == 2) {
+        T x2[NX];
+        PDDP_UNROLL for (int i = 0; i < NP; i++) { x2[i] = x[i] + T(0.5) * dt * x[i + NP]; x2[i + NP] = x[i + NP] + T(0.5) * dt * q1[i]; }
+        P::dynamics_eval(q1, x2, u);
+        PDDP_UNROLL for (int i = 0; i < NP; i++) { xn[i] = x[i] + dt * x[i + NP]; xn[i + NP] = x[i + NP] + dt * q1[i]; }
+    } else {
+        T x2[NX], x3[NX], q2[NP], q3[NP];
+        PDDP_UNROLL for (int i = 0; i < NP; i++) { x2[i] = x[i] + T(0.5) * dt * x[i + NP]; x2[i + NP] = x[i + NP] + T(0.5) * dt * q1[i]; }
+        P::dynamics_eval(q2, x2, u);
+        PDDP_UNROLL for (int i = 0; i < NP; i++) {
+            x3[i] = x[i] + dt * (T(2) * x2[i + NP] - x[i + NP]);
+            x3[i + NP] = x[i + NP] + dt * (T(2) * q2[i] - q1[i]);
+        }
+        P::dynamics_eval(q3, x3, u);
+        PDDP_UNROLL for (int i = 0; i < NP; i++) {
+            xn[i] = x[i] + (dt / T(6)) * (x[i + NP] + T(4) * x2[i + NP] + x3[i + NP]);
+            xn[i + NP] = x[i + NP] + (dt / T(6)) * (q1[i] + T(4) * q2[i] + q3[i]);
+        }
+    }
+}
+template <typename P, int INTEG, typename T, int A>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_fp_cf(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+    constexpr int NX = P::NX, NU = P::NU, PW = 64 / A;
+    static_assert(64 % A == 0 && PW * NX <= 64, "a wavefront holds whole problems; one fetch per lane for the state");
+    __shared__ FpCfStage<P, T, A> stage[2];
+    const int lane = threadIdx.x, grp = lane / A, a_idx = lane - grp * A, pb0 = blockIdx.x * PW, N = dm.N;
+    const int pb_raw = pb0 + grp, pb = pb_raw < batch ? pb_raw : batch - 1;
+    const bool live = pb_raw < batch && fp_active<T>(b, dm, pb);
+    const size_t slot = (size_t)pb * A + a_idx;
+    T* xo = b.xs + slot * N * NX; T* uo = b.us + slot * N * NU; T* dout = b.ds + slot * N * NX;
+    const T* xg = b.xGoal + (size_t)pb * NX;
+    const T alpha = b.alpha[a_idx];
+    // the current trajectory sits in one half of xb per PROBLEM (state.cur): this lane's share of the state fetch is entry e of problem p
+    const T* xcur_lane;
+    { const int p = lane / NX, q = (pb0 + p < batch) ? pb0 + p : batch - 1; xcur_lane = b.xb + ((size_t)q * 2 + b.state[q].cur) * N * NX + (lane - p * NX); }
+    const bool xlane = lane < PW * NX;
+    T xstart[NX];
+    // ---- the linear sweep: x_{k+1} = xcur_{k+1} + (A - B K)_k (x_k - xcur_k) - alpha (B du)_k + [boundary] d_k ----
+    if (dm.M > 1) {
+        FpCfRegs<T, PW, NX * NX> rM; FpCfRegs<T, PW, NX> rBdu, rd; T rxp;
+        auto fetch = [&](int k) {
+            fp_cf_fetch<T, PW, NX * NX>(rM, b.ApBK, (size_t)N * NX * NX, k, pb0, batch, lane);
+            rxp = xlane ? xcur_lane[(size_t)k * NX] : T(0);
+            fp_cf_fetch<T, PW, NX>(rBdu, b.Bdu, (size_t)N * NX, k, pb0, batch, lane);
+            fp_cf_fetch<T, PW, NX>(rd, b.dcur, (size_t)N * NX, k, pb0, batch, lane);
+        };
+        auto put = [&](FpCfStage<P, T, A>& sg) {
+            fp_cf_put<T, PW, NX * NX>(rM, &sg.sw.M[0][0], lane);
+            if (xlane) (&sg.sw.xp[0][0])[lane] = rxp;
+            fp_cf_put<T, PW, NX>(rBdu, &sg.sw.Bdu[0][0], lane); fp_cf_put<T, PW, NX>(rd, &sg.sw.d[0][0], lane);
+        };
+        fetch(0); put(stage[0]); wsync();
+        T xk[NX];
+        PDDP_UNROLL for (int i = 0; i < NX; i++) xk[i] = stage[0].sw.xp[grp][i];
+        for (int k = 0; k < N - 1; k++) {
+            const FpCfStage<P, T, A>& sc = stage[k & 1];
+            FpCfStage<P, T, A>& sn = stage[(k + 1) & 1];
+            fetch(k + 1);
+            T val[NX];
+            PDDP_UNROLL for (int r = 0; r < NX; r++) val[r] = 0;
+            PDDP_UNROLL for (int i = 0; i < NX; i++) {
+                const T dxs = xk[i] - sc.sw.xp[grp][i];
+                PDDP_UNROLL for (int r = 0; r < NX; r++) val[r] += sc.sw.M[grp][r + NX * i] * dxs;
+            }
+            put(sn); wsync();
+            const bool bnd = dm.on_defect_boundary(k);
+            PDDP_UNROLL for (int r = 0; r < NX; r++) {
+                T xv = sn.sw.xp[grp][r];
+                xv += -alpha * sc.sw.Bdu[grp][r] + val[r] + (bnd ? sc.sw.d[grp][r] : T(0));
+                xk[r] = xv;
+            }
+            if (bnd && live) cf_store_vec<T, NX>(xo + (size_t)(k + 1) * NX, xk);
+            wsync();
+        }
+    }
+    // ---- the rollouts ----
+    FpCfRegs<T, PW, NX * NU> rK; FpCfRegs<T, PW, NU> rup, rdu; T rxp;
+    auto fetch = [&](int k) {
+        fp_cf_fetch<T, PW, NX * NU>(rK, b.KT, (size_t)N * NX * NU, k, pb0, batch, lane);
+        rxp = xlane ? xcur_lane[(size_t)k * NX] : T(0);
+        fp_cf_fetch<T, PW, NU>(rup, b.ucur, (size_t)N * NU, k, pb0, batch, lane);
+        fp_cf_fetch<T, PW, NU>(rdu, b.du, (size_t)N * NU, k, pb0, batch, lane);
+    };
+    auto put = [&](FpCfStage<P, T, A>& sg) {
+        fp_cf_put<T, PW, NX * NU>(rK, &sg.ro.K[0][0], lane);
+        if (xlane) (&sg.ro.xp[0][0])[lane] = rxp;
+        fp_cf_put<T, PW, NU>(rup, &sg.ro.up[0][0], lane); fp_cf_put<T, PW, NU>(rdu, &sg.ro.du[0][0], lane);
+    };
+    fetch(0); put(stage[0]); wsync();
+    T cost_k[kTsMaxN];
+    T x[NX], u[NU];
+    PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = stage[0].ro.xp[grp][i];
+    if (live) cf_store_vec<T, NX>(xo, x);
+    T dmx = 0;
+    for (int k = 0; k < N - 1; k++) {
+        const FpCfStage<P, T, A>& sc = stage[k & 1];
+        fetch(k + 1);
+        const bool bnd = dm.on_defect_boundary(k);
+        if (bnd) { PDDP_UNROLL for (int i = 0; i < NX; i++) xstart[i] = live ? xo[(size_t)(k + 1) * NX + i] : T(0); }      // the next segment's start state, from the sweep above
+        T dx[NX], xn[NX];
+        PDDP_UNROLL for (int i = 0; i < NX; i++) dx[i] = x[i] - sc.ro.xp[grp][i];
+        PDDP_UNROLL for (int r = 0; r < NU; r++) {                     // u = ucur - alpha du - K (x - xcur)      (computeControlKT)
+            T Kdx = 0;
+            PDDP_UNROLL for (int c = 0; c < NX; c++) Kdx += sc.ro.K[grp][c + r * NX] * dx[c];
+            T uv = sc.ro.up[grp][r];
+            uv -= alpha * sc.ro.du[grp][r] + Kdx;
+            u[r] = uv;
+        }
+        cost_k[k] = P::cost(cw, x, u, xg, k, N);
+        cf_integrator_step<P, INTEG, T>(xn, x, u, dt);
+        put(stage[(k + 1) & 1]); wsync();
+        if (bnd) {                                          // last step of a non-final segment: defect against the next start state, which the next segment starts from
+            T sdef = 0, dv[NX];
+            PDDP_UNROLL for (int i = 0; i < NX; i++) { dv[i] = xn[i] - xstart[i]; sdef += tabs(dv[i]); x[i] = xstart[i]; }
+            dmx = tmax(dmx, sdef);
+            if (live) { cf_store_vec<T, NU>(uo + (size_t)k * NU, u); cf_store_vec<T, NX>(dout + (size_t)k * NX, dv); }
+        } else {
+            PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = xn[i];
+            if (live) { cf_store_vec<T, NU>(uo + (size_t)k * NU, u); cf_store_vec<T, NX>(xo + (size_t)(k + 1) * NX, xn); }
+        }
+    }
+    {                                                       // final knot: terminal cost, and its (unused) control is carried along
+        const FpCfStage<P, T, A>& sc = stage[(N - 1) & 1];
+        PDDP_UNROLL for (int r = 0; r < NU; r++) u[r] = sc.ro.up[grp][r];
+        if (live) cf_store_vec<T, NU>(uo + (size_t)(N - 1) * NU, u);
+        cost_k[N - 1] = P::cost(cw, x, u, xg, N - 1, N);
+        dmx = tmax(dmx, T(0));
+    }
+    if (!live) return;
+    const T J = tree_sum<T>(serial_wave(), cost_k, N);
+    b.J[slot] = J; b.dmax[slot] = dmx;
+}
 template <typename P, int INTEG, typename T>
 __global__ __launch_bounds__(64) void k_nis_ts(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
     const int inst = blockIdx.x * 64 + threadIdx.x;
@@ -269,6 +455,126 @@ __global__ __launch_bounds__(64) void k_bp_gl(Buffers<T> b, Dims dm, int batch) 
     const int grp = threadIdx.x / G, inst = blockIdx.x * U + grp;
     if (inst >= batch * dm.M) return;
     bp_body<P, T>(Wave{(int)threadIdx.x & (G - 1), G, 0}, s[grp], b, dm, inst % dm.M, inst / dm.M);
+}
+
+// Knot-batched setup for the scalar closed-form plants with the RK3 Jacobian (BASELINE configs[4], the quadrotor).  k_nis_gl above runs the plug-in's scalar code on
+// 3 of every 16 lanes (4.4e9 vector instructions per sweep at 16384 problems, counters in profiles/r04_quad.md: the kernel is instruction-issue bound) and assembles
+// [A B] entry by entry with run-time indices.  Here one wavefront takes KB consecutive knots in two phases:
+//   1  lane = knot: the three stage gradients, one after the other (each call also returns the stage's qdd, from which the next stage's state follows -- the same
+//      functions on the same operands as rk3_stage_chain / rk3_stage_gradient, integrators.hpp); dqdd of the three stages -> LDS, entry-major and knot-minor with
+//      a stride of KB + 1 words (conflict-free for the writes of phase 1 AND for the column reads of phase 2); g_k and the winner's copies by the same lane
+//   2  16 lanes = one knot, lane = COLUMN of [A B], four knots per pass: the column of T1, T2 (rk3_assemble's sums, in its order) stays in registers, every index but
+//      the column is a compile-time constant, the factors (0.5 dt d1 + delta), (2 dt T1 - dt d1 + delta) are formed once per column instead of once per row
+// No barrier inside a phase; one between them (a one-wave block).
+template <typename P, typename T, int KB>
+struct NisKbLds { T d[3][P::NPOS * (P::NX + P::NU)][KB + 1]; };
+template <typename P, typename T, int KB>
+__global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
+    constexpr int NP = P::NPOS, NX = P::NX, NU = P::NU, NM = NX + NU, ND = NP * NM;
+    static_assert(NM <= 16 && KB % 4 == 0 && KB <= 64, "one column of [A B] per lane of a 16-lane group");
+    __shared__ NisKbLds<P, T, KB> lds;
+    const int lane = threadIdx.x, N = dm.N, total = batch * N;
+    // ---- phase 1: lane = knot ----
+    {
+        const int inst = blockIdx.x * KB + lane;
+        if (lane < KB && inst < total) {
+            const int pb = inst / N, k = inst - pb * N;
+            const SolverState<T>& st = b.state[pb];
+            const bool moved = mode == 1 || st.accepted == 1;
+            if (moved) {
+                T* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX + (size_t)k * NX;
+                T* uc = b.ucur + ((size_t)pb * N + k) * NU;
+                T x[NX], u[NU];
+                if (mode == 0) {
+                    const size_t slot = (size_t)pb * dm.A + st.alphaIndex;
+                    const T* xw = b.xs + (slot * N + k) * NX; const T* uw = b.us + (slot * N + k) * NU;
+                    PDDP_UNROLL for (int i = 0; i < NX; i++) { x[i] = xw[i]; xc[i] = x[i]; }
+                    PDDP_UNROLL for (int i = 0; i < NU; i++) { u[i] = uw[i]; uc[i] = u[i]; }
+                    if (dm.M > 1 && dm.on_defect_boundary(k)) {
+                        const T* dw = b.ds + (slot * N + k) * NX; T* dc = b.dcur + ((size_t)pb * N + k) * NX;
+                        PDDP_UNROLL for (int i = 0; i < NX; i++) dc[i] = dw[i];
+                    }
+                } else {
+                    PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = xc[i];
+                    PDDP_UNROLL for (int i = 0; i < NU; i++) u[i] = uc[i];
+                }
+                if (mode == 1 || !st.done) {
+                    const T* xg = b.xGoal + (size_t)pb * NX;
+                    T* gk = b.g + ((size_t)pb * N + k) * NM;
+                    if constexpr (P::kPluginCost) P::cost_grad(cw, b.H + ((size_t)pb * N + k) * NM * NM, gk, x, u, xg, k, N);
+                    else for (int i = 0; i < NM; i++) gk[i] = P::weight(cw, i, k, N) * (i < NX ? (x[i] - xg[i]) : u[i - NX]);
+                    if (k < N - 1) {
+                        T dd[ND], q1[NP], q2[NP], q3[NP], xm[NX];
+                        P::gradient_eval(dd, q1, x, u);
+                        PDDP_UNROLL for (int e = 0; e < ND; e++) lds.d[0][e][lane] = dd[e];
+                        PDDP_UNROLL for (int i = 0; i < NP; i++) { xm[i] = x[i] + T(0.5) * dt * x[i + NP]; xm[i + NP] = x[i] + T(0.5) * dt * q1[i]; }
+                        P::gradient_eval(dd, q2, xm, u);
+                        PDDP_UNROLL for (int e = 0; e < ND; e++) lds.d[1][e][lane] = dd[e];
+                        PDDP_UNROLL for (int i = 0; i < NP; i++) {                                  // xm2 from xm1's velocity half BEFORE it is overwritten (rk3_stage_chain)
+                            const T v1 = xm[i + NP];
+                            xm[i + NP] = x[i] + dt * q1[i] + T(2) * dt * q2[i];
+                            xm[i] = x[i] + dt * x[i + NP] + T(2) * dt * v1;
+                        }
+                        P::gradient_eval(dd, q3, xm, u);
+                        PDDP_UNROLL for (int e = 0; e < ND; e++) lds.d[2][e][lane] = dd[e];
+                    }
+                }
+            }
+        }
+    }
+    wsync();
+    // ---- phase 2: 16 lanes = knot, lane = column ----
+    const int grp = lane >> 4, ky = lane & 15;
+    for (int rnd = 0; rnd < KB / 4; rnd++) {
+        const int j = rnd * 4 + grp, inst = blockIdx.x * KB + j;
+        if (inst >= total || ky >= NM) continue;
+        const int pb = inst / N, k = inst - pb * N;
+        const SolverState<T>& st = b.state[pb];
+        if (!(mode == 1 || (st.accepted == 1 && !st.done))) continue;
+        if constexpr (!P::kPluginCost) {
+            if (mode == 1) {                                                            // the constant Hessian: written when the problem is loaded (nis_knot, nis.hpp)
+                T* Hk = b.H + ((size_t)pb * N + k) * NM * NM + (size_t)ky * NM;
+                PDDP_UNROLL for (int i = 0; i < NM; i++) Hk[i] = (i == ky) ? P::weight(cw, i, k, N) : T(0);
+            }
+        }
+        if (k >= N - 1) continue;
+        const T hdt = T(0.5) * dt, dt2 = T(2) * dt;
+        T d1c[NP], T1[NX], T2[NX];
+        PDDP_UNROLL for (int r = 0; r < NP; r++) d1c[r] = lds.d[0][ky * NP + r][j];
+        const int c2 = ky < NP ? ky : (ky < NX ? ky - NP : ky);
+        const T lead = ky < NP ? (hdt * T(0) + T(1)) : (hdt * T(1) + T(0));
+        T f[NP];
+        PDDP_UNROLL for (int i = 0; i < NP; i++) f[i] = hdt * d1c[i] + T(ky == i + NP ? 1 : 0);
+        PDDP_UNROLL for (int kx = 0; kx < NP; kx++) T1[kx] = T(1) * (hdt * d1c[kx] + T(ky == kx + NP ? 1 : 0)) + T(0);
+        PDDP_UNROLL for (int r = 0; r < NP; r++) {
+            const T sel = lds.d[1][c2 * NP + r][j];
+            T val = ky < NX ? sel * lead : T(0);
+            PDDP_UNROLL for (int i = 0; i < NP; i++) val += lds.d[1][(i + NP) * NP + r][j] * f[i];
+            T1[r + NP] = val + (ky < NX ? T(0) : sel);
+        }
+        T gq[NX];
+        PDDP_UNROLL for (int i = 0; i < NP; i++) gq[i] = dt2 * T1[i] - dt * T(i + NP == ky ? 1 : 0) + T(ky == i ? 1 : 0);
+        PDDP_UNROLL for (int i = NP; i < NX; i++) gq[i] = dt2 * T1[i] - dt * d1c[i - NP] + T(ky == i ? 1 : 0);
+        PDDP_UNROLL for (int kx = 0; kx < NP; kx++) T2[kx] = T(1) * (dt2 * T1[kx + NP] - dt * d1c[kx] + T(ky == kx + NP ? 1 : 0)) + T(0);
+        PDDP_UNROLL for (int r = 0; r < NP; r++) {
+            T val = 0;
+            PDDP_UNROLL for (int i = 0; i < NX; i++) val += lds.d[2][i * NP + r][j] * gq[i];
+            T2[r + NP] = val + (ky < NX ? T(0) : lds.d[2][ky * NP + r][j]);
+        }
+        T* ABc = b.AB + ((size_t)pb * N + k) * NX * NM + (size_t)ky * NX;
+        PDDP_UNROLL for (int kx = 0; kx < NX; kx++) {
+            const T dx = kx < NP ? T(kx + NP == ky ? 1 : 0) : d1c[kx - NP];
+            ABc[kx] = (dt / T(6)) * dx + (dt2 / T(3)) * T1[kx] + (dt / T(6)) * T2[kx] + T(kx == ky ? 1 : 0);
+        }
+    }
+}
+
+// debugging aid (PDDP_POISON_LDS, run_phase): fill the whole LDS of the compute unit this block lands on with NaNs
+__global__ __launch_bounds__(256) void k_poison_lds(int words) {
+    extern __shared__ unsigned poison_lds[];
+    for (int i = threadIdx.x; i < words; i += 256) poison_lds[i] = 0x7fc00000u;
+    __syncthreads();
+    if (poison_lds[(threadIdx.x * 97) % words] != 0x7fc00000u) __builtin_trap();
 }
 
 // API view of the compact end-effector Hessian block (Buffers::Hc): H_k of every running knot in the reference layout = Jee' Jee (+ Qx on its diagonal, already in the

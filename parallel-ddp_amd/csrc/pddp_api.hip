@@ -186,6 +186,8 @@ struct Solver : SolverBase {
     }
     bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
     bool gl_bp32 = false, gl_nis8 = false;
+    bool cf_fp_staged = false;                           // thread-serial rollouts with the knot's operands staged through LDS once per wavefront (k_fp_cf: 16 step sizes, 12-state plants); PDDP_CF_FP = cf | ts
+    int kb_nis = 0;                                      // knots per wavefront of the knot-batched setup kernel (k_nis_kb: scalar plug-ins, RK3); 0 = k_nis_gl.  PDDP_CF_NIS = kb16 | kb32 | kb64
     bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
     bool cf_serial = false;        // closed-form plants with many problems in flight: thread-serial kernels (k_bp_ts / k_fp_ts / k_nis_ts); PDDP_CF=coop|ts overrides
     bool bp_wide = false;          // cooperative backward pass with a whole workgroup per block of knots (few problems in flight); PDDP_BP=wide
@@ -261,6 +263,10 @@ struct Solver : SolverBase {
         gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !std::getenv("PDDP_CF");
         gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !std::getenv("PDDP_CF"); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
         if (const char* v = std::getenv("PDDP_CF_NIS")) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
+        cf_fp_staged = cf_fp && P::NX >= 12 && c.A == 16 && !std::getenv("PDDP_CF");
+        if (const char* v = std::getenv("PDDP_CF_FP")) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && c.A == 16; } else cf_fp_staged = false; }
+        kb_nis = (gl_nis && c.integrator == 3) ? 16 : 0;      // 16 knots per wavefront: 2.15 ms (32: 2.6, 64: 3.6; the 16-lane-group kernel 5.7-7.1) at 16384 quadrotor problems -- LDS per block sets the occupancy
+        if (const char* v = std::getenv("PDDP_CF_NIS")) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
         if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32") && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
@@ -399,7 +405,10 @@ struct Solver : SolverBase {
             if (part == 0) return;
             bool serial = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
-                if (cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B, part == 2 ? 1 : 0); serial = true; }
+                if constexpr (P::kScalarPlugin && (64 / 16) * P::NX <= 64) {
+                    if (cf_fp && cf_fp_staged && !init_rollout && part != 2 && cfg.A == 16) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+                }
+                if (!serial && cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B, part == 2 ? 1 : 0); serial = true; }
             }
             if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout ? 1 : (part == 2 ? 2 : 0));
             return;
@@ -466,6 +475,15 @@ struct Solver : SolverBase {
         }
         if (part == 0) return;
         if constexpr (P::PLANT != 4) { if (cf_nis) { hipLaunchKernelGGL((k_nis_ts<P, INTEG, T>), dim3((B * cfg.N + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
+        if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16 && INTEG == 3 && P::kScalarPlugin) {
+            if (gl_nis && kb_nis) {
+                const int units = (int)(B * cfg.N);
+                if (kb_nis == 16) hipLaunchKernelGGL((k_nis_kb<P, T, 16>), dim3((units + 15) / 16), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
+                else if (kb_nis == 64 && sizeof(T) == 4) hipLaunchKernelGGL((k_nis_kb<P, T, sizeof(T) == 4 ? 64 : 16>), dim3((units + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
+                else hipLaunchKernelGGL((k_nis_kb<P, T, 32>), dim3((units + 31) / 32), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
+                return;
+            }
+        }
         if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (gl_nis) { if (gl_nis8) hipLaunchKernelGGL((k_nis_gl<P, INTEG, T, 8>), dim3((B * cfg.N + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); else hipLaunchKernelGGL((k_nis_gl<P, INTEG, T, 16>), dim3((B * cfg.N + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B); return; } }
         hipLaunchKernelGGL((k_nis<P, INTEG, T>), dim3(cfg.N, B), dim3(64), 0, s, b, dm, cw, dt, mode);
     }
@@ -507,7 +525,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : cf_fp ? "k_fp_ts" : "k_fp", ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : gl_nis ? "k_nis_gl" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;
@@ -789,6 +807,11 @@ struct Solver : SolverBase {
     }
     int run_phase(int phase) override {
         const unsigned B = cfg.batch;
+        if (std::getenv("PDDP_POISON_LDS")) {                       // debugging aid (tools/determinism_check.py): every CU's LDS holds NaNs when the phase starts -- a kernel that reads LDS it has not written shows
+            static bool attr_set = false;
+            if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+            hipLaunchKernelGGL(k_poison_lds, dim3(4096), dim3(256), 160 * 1024, stream, 160 * 256);
+        }
         if (phase >= 0 && phase <= 3) {
             launch_sweep(stream, phase, 1);                         // teacher-forcing hook: the forward pass also stores every candidate trajectory
             if (phase == PDDP_PHASE_FP) hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);   // J / dmax readable right after the phase

@@ -92,6 +92,32 @@ template <> PDDP_HD float tcos<float>(float v) {
 }
 template <> PDDP_HD double tsin<double>(double v) { return sin(v); }
 template <> PDDP_HD double tcos<double>(double v) { return cos(v); }
+// Sine and cosine of one angle together, for the CLOSED-FORM plants (pendulum, cart-pole, quadrotor: 1 / 2 / 6 angles per dynamics evaluation, three evaluations per RK3
+// step -- with tsin / tcos above, i.e. double-precision sin and cos rounded to float, they were ~3/4 of the quadrotor rollout kernel's instructions).  float on the device:
+// ocml's single-precision sincosf (<= 2 units in the last place -- what the reference's device code gets from CUDA's sinf / cosf); double: sincos.  The host instantiations
+// (CPU entry points, the test tool) keep libm's sinf / cosf / sin / cos.  The arm keeps tsin / tcos: its mass-matrix solve amplifies a last-place difference (above).
+template <typename T> PDDP_HD void cf_sincos(T v, T& s, T& c);
+template <> PDDP_HD void cf_sincos<float>(float v, float& s, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(v, &s, &c);
+#else
+    s = sinf(v); c = cosf(v);
+#endif
+}
+// cos(2 v) for the quadrotor's inertia terms (dynamics_quad.cuh:60): 2 v is exact in either precision, so the float device form is cosf of the same argument
+template <typename T> PDDP_HD T cf_cos2(T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) return cosf(2.0f * v);
+#endif
+    return static_cast<T>(cos(2.0 * v));
+}
+template <> PDDP_HD void cf_sincos<double>(double v, double& s, double& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(v, &s, &c);
+#else
+    s = sin(v); c = cos(v);
+#endif
+}
 // atan2 / sqrt of the end-effector cost family (ee_cost.hpp): atan2 like sin/cos above, sqrt is correctly rounded on both sides
 template <typename T> PDDP_HD T tatan2(T y, T x);
 template <> PDDP_HD float tatan2<float>(float y, float x) {

@@ -534,6 +534,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             const float4* src = reinterpret_cast<const float4*>(gF + (size_t)k0 * SZ); float4* dst = reinterpret_cast<float4*>(F);
             for (int i = threadIdx.x; i < cnt * (SZ / 4); i += 256) dst[i] = src[i];
             for (int i = threadIdx.x; i < cnt * 16; i += 256) { const int kk = i >> 4, e = i & 15; cB[i] = e < NX ? gB[((size_t)k0 + kk) * NX + e] : 0.f; }
+            // rows 14, 15 of the LAST staged knot's contraction read the 28 words behind its block: the head of cB when the pass fills the staging area, otherwise words
+            // nobody has written -- whatever the previous kernel on this compute unit left there, and a NaN or Inf pattern times the zero rows of E is a NaN
+            // (found with PDDP_POISON_LDS: N = 64, M = 4 stages 48 of 96 knots)
+            if (cnt < chunk && threadIdx.x < 2 * NX) F[(size_t)cnt * SZ + threadIdx.x] = 0.f;
         }
         __syncthreads();
         for (int sl = wave; sl < segs; sl += 4) {                       // this wave's segments of the pass, one after the other

@@ -17,25 +17,31 @@ namespace pddp {
 #define QUAD_MASS 0.5
 #define QUAD_INVMASS 2
 template <typename T> PDDP_HD void pend_dynamics_eval(T* qdd, const T* x, const T* u) {
-    qdd[0] = u[0] + -9.81 * tsin<T>(x[0]);
+    T s0, c0; cf_sincos<T>(x[0], s0, c0);
+    qdd[0] = u[0] + -9.81 * s0;
 }
 template <typename T> PDDP_HD void pend_gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) {
-    pend_dynamics_eval<T>(qdd, x, u);
-    dqdd[0] = -9.81 * tcos<T>(x[0]);
+    T s0, c0; cf_sincos<T>(x[0], s0, c0);
+    qdd[0] = u[0] + -9.81 * s0;                                    // = pend_dynamics_eval (the plug-in's dynamics(), dynamics_pend.cuh:46)
+    dqdd[0] = -9.81 * c0;
     dqdd[1] = 0.0;
     dqdd[2] = 1;
 }
-template <typename T> PDDP_HD void cart_dynamics_eval(T* qdd, const T* x, const T* u) {
-    T ct = tcos<T>(x[1]), st = tsin<T>(x[1]), td2 = x[3] * x[3];
+template <typename T> PDDP_HD void cart_dynamics_trig(T* qdd, const T* x, const T* u, T ct, T st) {
+    T td2 = x[3] * x[3];
     T H0 = CART_M_CART + CART_M_POLE, H1 = CART_MLL, Hod = CART_ML * ct;
     T TauM = CART_ML * st, Tau0 = TauM * td2 + u[0], Tau1 = TauM * CART_G;
     T det = 1 / (H0 * H1 - Hod * Hod);
     qdd[0] = det * (H1 * Tau0 - Hod * Tau1);
     qdd[1] = det * (H0 * Tau1 - Hod * Tau0);
 }
+template <typename T> PDDP_HD void cart_dynamics_eval(T* qdd, const T* x, const T* u) {
+    T ct, st; cf_sincos<T>(x[1], st, ct);
+    cart_dynamics_trig<T>(qdd, x, u, ct, st);
+}
 template <typename T> PDDP_HD void cart_gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) {
-    cart_dynamics_eval<T>(qdd, x, u);
-    T ct = tcos<T>(x[1]), st = tsin<T>(x[1]);
+    T ct, st; cf_sincos<T>(x[1], st, ct);
+    cart_dynamics_trig<T>(qdd, x, u, ct, st);                      // the plug-in's dynamics() inside dynamicsGradient (dynamics_cart.cuh:52): the same numbers as cart_dynamics_eval
     T td = x[3], td2 = td * td;
     T H0 = CART_M_CART + CART_M_POLE, H1 = CART_MLL;
     T Hod = CART_ML * ct, TauM = CART_ML * st;
@@ -56,26 +62,29 @@ template <typename T> PDDP_HD void cart_gradient_eval(T* dqdd, T* qdd, const T* 
     dqdd[6] = xdd_dthetad; dqdd[7] = thetadd_dthetad;
     dqdd[8] = xdd_du; dqdd[9] = thetadd_du;
 }
-template <typename T> PDDP_HD void quad_dynamics_eval(T* qdd, const T* x, const T* u) {
-    T cX3 = tcos<T>(x[3]), cX4 = tcos<T>(x[4]), cX5 = tcos<T>(x[5]);
-    T sX3 = tsin<T>(x[3]), sX4 = tsin<T>(x[4]), sX5 = tsin<T>(x[5]);
+template <typename T> PDDP_HD void quad_dynamics_trig(T* qdd, const T* x, const T* u, T sX3, T cX3, T sX4, T cX4, T sX5, T cX5) {
     T X910 = x[9] * x[10], X911 = x[9] * x[11], X1011 = x[10] * x[11], X11_2 = x[11] * x[11];
     T sumU = u[0] + u[1] + u[2] + u[3];
     qdd[0] = QUAD_INVMASS * sumU * (sX3 * sX5 + cX3 * cX5 * sX4);
     qdd[1] = -QUAD_INVMASS * sumU * (cX5 * sX3 - cX3 * sX4 * sX5);
     qdd[2] = QUAD_G + QUAD_INVMASS * sumU * cX3 * cX4;
     T diffU4 = u[0] - u[1] + u[2] - u[3], diffU2 = u[2] - u[0];
-    T invcX4 = 1 / cX4, cX3_2 = cX3 * cX3, cX34 = cX3 * cX4, s2X3 = 2.0 * sX3 * cX3, c2X3 = cos(2.0 * x[3]);
+    T invcX4 = 1 / cX4, cX3_2 = cX3 * cX3, cX34 = cX3 * cX4, s2X3 = 2.0 * sX3 * cX3, c2X3 = cf_cos2<T>(x[3]);
     qdd[3] = invcX4 * (0.0005434782609 * (32000.0 * X1011 + 140000.0 * (u[1] - u[3]) * cX4 - 28320.0 * X910 * sX4 - 30160.0 * X1011 * cX3_2 + 1127.0 * diffU4 * cX3 * sX4 - 140000.0 * diffU2 * sX3 * sX4 + 30160.0 * X910 * cX3_2 * sX4 - 30160.0 * X1011 * cX34 * cX34 + 30160.0 * x[10] * x[10] * cX3 * cX4 * sX3 - 30160.0 * X11_2 * cX3 * cX4 * sX3 + 30160.0 * X911 * cX3 * cX4 * sX3 * sX4));
     qdd[4] = 76.08695652 * diffU2 * cX3 - 0.6125 * diffU4 * sX3 - 1.0 * X911 * cX4 - 8.195652174 * X910 * s2X3 - 16.39130435 * X11_2 * cX3_2 * cX4 * sX4 + 16.39130435 * X911 * cX3_2 * cX4 + 16.39130435 * X1011 * cX3 * sX3 * sX4;
     qdd[5] = -invcX4 * (0.0005434782609 * (13240.0 * X910 - 1127.0 * diffU4 * cX3 - 140000.0 * diffU2 * sX3 - 16920.0 * X1011 * sX4 + 7540.0 * X11_2 * s2X3 * 2.0 * sX4 * cX4 - 15080.0 * X910 * c2X3 - 15080.0 * X911 * s2X3 * cX4 + 15080.0 * X1011 * c2X3 * sX4));
 }
+template <typename T> PDDP_HD void quad_dynamics_eval(T* qdd, const T* x, const T* u) {
+    T sX3, cX3, sX4, cX4, sX5, cX5;
+    cf_sincos<T>(x[3], sX3, cX3); cf_sincos<T>(x[4], sX4, cX4); cf_sincos<T>(x[5], sX5, cX5);
+    quad_dynamics_trig<T>(qdd, x, u, sX3, cX3, sX4, cX4, sX5, cX5);
+}
 template <typename T> PDDP_HD void quad_gradient_eval(T* dqdd, T* qdd, const T* x, const T* u) {
     enum { NP = 6 };
-    quad_dynamics_eval<T>(qdd, x, u);
+    T sX3, cX3, sX4, cX4, sX5, cX5;
+    cf_sincos<T>(x[3], sX3, cX3); cf_sincos<T>(x[4], sX4, cX4); cf_sincos<T>(x[5], sX5, cX5);
+    quad_dynamics_trig<T>(qdd, x, u, sX3, cX3, sX4, cX4, sX5, cX5);      // the plug-in's dynamics() inside dynamicsGradient (dynamics_quad.cuh:95): the same numbers as quad_dynamics_eval
     for (int i = 0; i < NP * 16; i++) dqdd[i] = 0;
-    T sX3 = tsin<T>(x[3]), sX4 = tsin<T>(x[4]), sX5 = tsin<T>(x[5]);
-    T cX3 = tcos<T>(x[3]), cX4 = tcos<T>(x[4]), cX5 = tcos<T>(x[5]);
     T UMTerm = (u[0] + u[1] + u[2] + u[3]) * QUAD_INVMASS;
     T row6Term = (sX3 * sX5 + cX3 * cX5 * sX4) * QUAD_INVMASS;
     dqdd[0 + 3 * NP] = (cX3 * sX5 - cX5 * sX3 * sX4) * UMTerm;

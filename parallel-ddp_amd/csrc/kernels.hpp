@@ -9,6 +9,7 @@
 #include "fp_lg.hpp"
 #include "nis_lg.hpp"
 #include "bp_lg.hpp"
+#include "bp_cl.hpp"
 #include "mpc.hpp"
 #include "sim.hpp"
 
@@ -315,7 +316,7 @@ __device__ __forceinline__ void cf_integrator_step(T* xn, const T* x, const T* u
     }
 }
 template <typename P, int INTEG, typename T, int A>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_fp_cf(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 1))) void k_fp_cf(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
     constexpr int NX = P::NX, NU = P::NU, PW = 64 / A;
     static_assert(64 % A == 0 && PW * NX <= 64, "a wavefront holds whole problems; one fetch per lane for the state");
     __shared__ FpCfStage<P, T, A> stage[2];
@@ -575,6 +576,32 @@ __global__ __launch_bounds__(256) void k_poison_lds(int words) {
     for (int i = threadIdx.x; i < words; i += 256) poison_lds[i] = 0x7fc00000u;
     __syncthreads();
     if (poison_lds[(threadIdx.x * 97) % words] != 0x7fc00000u) __builtin_trap();
+}
+
+// k_bp_cl: 16 lanes = (problem, block of knots), lane = column of [A B] / H (bp_cl.hpp); grid ceil(B M / 4), block 64
+template <typename P, typename T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 1))) void k_bp_cl(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch, int diag_h) {
+    __shared__ BpClLds<T> s[4];
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15, inst = blockIdx.x * 4 + grp;
+    if (inst >= batch * dm.M) return;
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    const int blk = inst % dm.M, pb = inst / dm.M, N = dm.N;
+    const SolverState<T>& st = b.state[pb];
+    if (st.done) return;
+    BpArgs<T> a;                                                         // as bp_body (bodies.hpp)
+    a.AB = b.AB + (size_t)pb * N * NX * NM;
+    a.Pm = (st.pw ? b.Pp : b.P) + (size_t)pb * N * NX * NX;   a.pv = (st.pw ? b.pp : b.p) + (size_t)pb * N * NX;
+    a.Pp = (st.pw ? b.P : b.Pp) + (size_t)pb * N * NX * NX;   a.pp = (st.pw ? b.p : b.pp) + (size_t)pb * N * NX;
+    a.H = b.H + (size_t)pb * N * NM * NM;    a.g = b.g + (size_t)pb * N * NM;
+    a.KT = b.KT + (size_t)pb * N * NX * NU;  a.du = b.du + (size_t)pb * N * NU;
+    a.dcur = b.dcur + (size_t)pb * N * NX;
+    a.ApBK = b.ApBK + (size_t)pb * N * NX * NX;  a.Bdu = b.Bdu + (size_t)pb * N * NX;
+    a.xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX;
+    a.xprev2 = b.xb + ((size_t)pb * 2 + st.cur2) * N * NX;
+    a.dJexp = b.dJexp + (size_t)pb * 2 * dm.M;
+    a.err = b.err + (size_t)pb * dm.M;
+    a.rho = st.rho;
+    if (bp_cl_block<P, T>(s[grp], c, dm, blk, a, diag_h != 0, P::weight(cw, c, 0, N))) { if (c == 0) a.err[blk] = 1; }
 }
 
 // API view of the compact end-effector Hessian block (Buffers::Hc): H_k of every running knot in the reference layout = Jee' Jee (+ Qx on its diagonal, already in the

@@ -186,6 +186,7 @@ struct Solver : SolverBase {
     }
     bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
     bool gl_bp32 = false, gl_nis8 = false;
+    bool cl_bp = false;                                  // 12 states + 4 controls: 16 lanes per block of knots, lane = column (k_bp_cl, bp_cl.hpp) instead of k_bp_gl; PDDP_CF_BP = cl | gl | gl32
     bool cf_fp_staged = false;                           // thread-serial rollouts with the knot's operands staged through LDS once per wavefront (k_fp_cf: 16 step sizes, 12-state plants); PDDP_CF_FP = cf | ts
     int kb_nis = 0;                                      // knots per wavefront of the knot-batched setup kernel (k_nis_kb: scalar plug-ins, RK3); 0 = k_nis_gl.  PDDP_CF_NIS = kb16 | kb32 | kb64
     bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
@@ -263,11 +264,12 @@ struct Solver : SolverBase {
         gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !std::getenv("PDDP_CF");
         gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !std::getenv("PDDP_CF"); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
         if (const char* v = std::getenv("PDDP_CF_NIS")) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
+        cl_bp = gl_bp && P::NX == 12 && P::NU == 4;
         cf_fp_staged = cf_fp && P::NX >= 12 && c.A == 16 && !std::getenv("PDDP_CF");
         if (const char* v = std::getenv("PDDP_CF_FP")) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && c.A == 16; } else cf_fp_staged = false; }
         kb_nis = (gl_nis && c.integrator == 3) ? 16 : 0;      // 16 knots per wavefront: 2.15 ms (32: 2.6, 64: 3.6; the 16-lane-group kernel 5.7-7.1) at 16384 quadrotor problems -- LDS per block sets the occupancy
         if (const char* v = std::getenv("PDDP_CF_NIS")) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
-        if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32") && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; }
+        if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32" || (std::string(v) == "cl" && P::NX == 12 && P::NU == 4)) && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; cl_bp = gl_bp && std::string(v) == "cl"; }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
@@ -506,6 +508,9 @@ struct Solver : SolverBase {
             if (!lane_groups) {
                 bool serial = false;
                 if constexpr (P::PLANT != 4) { if (cf_bp) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
+                if constexpr (P::PLANT != 4 && P::NX == 12 && P::NU == 4) {
+                    if (!serial && gl_bp && cl_bp) { hipLaunchKernelGGL((k_bp_cl<P, T>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, cw, (int)B, (!P::kPluginCost && !h_overridden) ? 1 : 0); serial = true; }
+                }
                 if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (!serial && gl_bp) { if (gl_bp32) hipLaunchKernelGGL((k_bp_gl<P, T, 32>), dim3((B * cfg.M + 1) / 2), dim3(64), 0, s, b, dm, (int)B); else hipLaunchKernelGGL((k_bp_gl<P, T, 16>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
                 if (serial) {}
                 else if (bp_wide) hipLaunchKernelGGL((k_bp_wide<P, T>), dim3(cfg.M, B), dim3(256), 0, s, b, dm);
@@ -524,7 +529,7 @@ struct Solver : SolverBase {
     // for a slot leaves its name empty and its time 0.
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
-        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
+        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
                              (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));

@@ -57,9 +57,10 @@ def test_thread_serial_equals_cooperative_bit_for_bit(plant, kw, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("B", [5, 64])
-def test_staged_rollouts_and_knot_batched_setup_equal_cooperative_bit_for_bit(dtype, B):
+def test_quadrotor_full_device_kernels_equal_cooperative_bit_for_bit(dtype, B):
     """BASELINE configs[4] with the device full runs k_fp_cf (a wavefront = 4 problems x 16 step sizes, each knot's operands fetched once into an LDS stage a step ahead)
-    and k_nis_kb (lane = knot for the three stage gradients, then lane = column of [A B]): per output element the operations of the cooperative kernels in their order.
+    and k_nis_kb (lane = knot for the three stage gradients, then lane = column of [A B]), from 2048 problems also k_bp_cl (16 lanes per block of knots, lane = column; forced
+    here): per output element the operations of the cooperative kernels in their order.
     5 problems: the last wavefront is partly empty; 64: the automatic selection."""
     plant, kw = 3, dict(N=256, M=4, A=16, integrator=3, total_time=4.0, max_iter=5)
     rng = np.random.default_rng(19)
@@ -68,10 +69,10 @@ def test_staged_rollouts_and_knot_batched_setup_equal_cooperative_bit_for_bit(dt
         x0, u0, xg = example_inputs(plant, kw["N"], dtype, noise=rng.normal(0, 0.001 * (b % 7 + 1), (kw["N"], 12)))
         xs.append(x0); us.append(u0); gs.append(xg)
     outs = {}
-    for mode, env in (("new", {"PDDP_CF_FP": "cf", "PDDP_CF_NIS": "kb16"} if B < 64 else {}), ("coop", {"PDDP_CF": "coop"})):
+    for mode, env in (("new", {"PDDP_CF_FP": "cf", "PDDP_CF_NIS": "kb16", "PDDP_CF_BP": "cl"} if B < 64 else {"PDDP_CF_BP": "cl"}), ("coop", {"PDDP_CF": "coop"})):
         s = with_env(env, lambda: make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, **kw))
         names = dict(s.time_kernels(1))
-        assert ("k_fp_cf" in names) == (mode == "new") and ("k_nis_kb" in names) == (mode == "new"), names
+        assert ("k_fp_cf" in names) == (mode == "new") and ("k_nis_kb" in names) == (mode == "new") and ("k_bp_cl" in names) == (mode == "new"), names
         outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
         outs[mode]["P"] = s.get_cost_to_go()[0]
         s.close()

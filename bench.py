@@ -438,6 +438,53 @@ def closed_form_inputs(plant, N, rng, count):
     return x, u, g
 
 
+F64_LANE_PEAK_TFLOPS = 78.6   # double-precision vector FMAs: 4 cycles per wave64 instruction (tools/probes/valu_ops.hip)
+
+
+def row_roofline(per_kernel_ms, plant, dtype):
+    """`roofline` of a row beside the headline, for its kernel with the longest launch: live HIP-event duration from this run, HBM bytes and instruction counts per launch
+    from the committed counter pass over the same command (profiles/rows_traffic.json <- tools/pmc_rows.sh, tools/make_rows_traffic.py).  None of these kernels is bound
+    by HBM or uses the matrix cores except k_bp_mfma: the closed-form plants' kernels are scalar code on the vector ALU, so the top level is the vector-issue roofline
+    (instructions issued x 128 flop, FMA-equivalent: an UPPER bound of the useful flop) and `hbm` carries the measured traffic as a rate."""
+    tfile = os.path.join(ROOT, "profiles", "rows_traffic.json")
+    if not os.path.exists(tfile):
+        return None
+    tab = json.load(open(tfile))
+    per = {}
+    for nm, ms in per_kernel_ms.items():
+        recs = tab["kernels"].get(f"{nm}|{plant}|{dtype}")
+        if not recs or not ms:
+            continue
+        r = max(recs, key=lambda q: q["grid"])                          # the row with the device full is the largest launch of that kernel in the pass
+        e = {"ms": round(ms, 5)}
+        if "hbm_read_bytes" in r:
+            tb = r["hbm_read_bytes"] + r["hbm_write_bytes"]
+            e.update({"hbm_bytes_per_launch": tb, "hbm_GBs": round(tb / (ms * 1e-3) / 1e9, 1), "hbm_frac_of_peak": round(tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        if "SQ_INSTS_VALU" in r:
+            peak = F64_LANE_PEAK_TFLOPS if dtype == "f64" else FP32_LANE_PEAK_TFLOPS
+            e.update({"vector_instructions_per_launch": r["SQ_INSTS_VALU"], "matrix_instructions_per_launch": r.get("SQ_INSTS_MFMA", 0.0),
+                      "issued_TFLOPs": round(r["SQ_INSTS_VALU"] * 128.0 / (ms * 1e-3) / 1e12, 3), "issued_frac_of_vector_peak": round(r["SQ_INSTS_VALU"] * 128.0 / (ms * 1e-3) / 1e12 / peak, 4)})
+        per[nm] = e
+    if not per:
+        return None
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    peak = F64_LANE_PEAK_TFLOPS if dtype == "f64" else FP32_LANE_PEAK_TFLOPS
+    roof = {"kernel": dom, "avg_launch_ms": d["ms"], "traffic": d.get("hbm_bytes_per_launch"), "traffic_source": tab["source"], "per_kernel": per}
+    if d.get("matrix_instructions_per_launch"):
+        issued = d["matrix_instructions_per_launch"] * 2048.0
+        roof.update({"bound": "mfma", "achieved": round(issued / (d["ms"] * 1e-3) / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(issued / (d["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 5), "accounting": "matrix instructions ISSUED (counter pass) x 2048 flop / live launch duration"})
+    elif "issued_TFLOPs" in d:
+        roof.update({"bound": "valu", "achieved": d["issued_TFLOPs"], "peak": peak, "unit": "TFLOP/s", "frac": d["issued_frac_of_vector_peak"],
+                     "accounting": "vector instructions issued (counter pass) x 128 flop / live launch duration against the vector FMA peak of the element type -- an upper bound of the useful flop"})
+    else:
+        roof.update({"bound": "hbm", "achieved": d.get("hbm_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d.get("hbm_frac_of_peak")})
+    if d.get("hbm_GBs") is not None:
+        roof["hbm"] = {"traffic_GBs": d["hbm_GBs"], "frac_of_peak": d["hbm_frac_of_peak"], "peak_GBs": HBM_PEAK_GBS}
+    return roof
+
+
 def other_config_rows(device):
     """BASELINE configs[1] (cart-pole N=128, 8 alphas, M=4) and configs[4] (quadrotor N=256, RK3, 16 alphas, float32 and float64) with the device full: whole-batch sweeps/s,
     per-kernel HIP-event times, and the rate at which the sweep gets through the reference's byte accounting (NOT a bandwidth -- see roofline.reference_equivalent).
@@ -462,6 +509,7 @@ def other_config_rows(device):
                      "per_kernel_ms": {nm: round(ms, 5) for nm, ms in kern}, "accepted_fraction": round(acc, 3),
                      "reference_equivalent": {"bytes_per_sweep_per_problem": sum(alg.values()), "GBs": round(sum(alg.values()) * B / (ms_plain / 10 * 1e-3) / 1e9, 1),
                                               "ratio_to_hbm_peak": round(sum(alg.values()) * B / (ms_plain / 10 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        res[name]["roofline"] = row_roofline({nm: ms for nm, ms in kern if nm}, {2: "cart", 3: "quad"}[plant], "f64" if dtype else "f32")
         s.close()
     return res
 
@@ -515,6 +563,7 @@ def widening_rows(device):
                                               "per_phase_ms": {k: round(v, 5) for k, v in zip(PHASES, per)}, "per_kernel_ms": {nm: round(ms, 5) for nm, ms in kern},
                                               "reference_equivalent": {"bytes_per_sweep_per_problem": sum(alg.values()), "GBs": round(sum(alg.values()) * B2 / (ms_plain / 20 * 1e-3) / 1e9, 1),
                                                                        "ratio_to_hbm_peak": round(sum(alg.values()) * B2 / (ms_plain / 20 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    res["ee_cost_4096_problems_N64_A8_M4"]["roofline"] = row_roofline({nm: ms for nm, ms in kern if nm}, "arm", "f32")
     s.close()
     # (2) the published shape with its own cost (test/WAFR_fig8.py:5-12: Kuka MPC, N=64, A=16, M=4, EE cost, ~1.36 ms per iteration published):
     #     one problem, a warm start to convergence, then control cycles of 4 iterations shifted by one knot (runiLQR_MPC_GPU)

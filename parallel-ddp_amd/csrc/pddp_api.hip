@@ -265,8 +265,9 @@ struct Solver : SolverBase {
         gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !std::getenv("PDDP_CF"); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
         if (const char* v = std::getenv("PDDP_CF_NIS")) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
         cl_bp = gl_bp && P::NX == 12 && P::NU == 4;
-        cf_fp_staged = cf_fp && P::NX >= 12 && c.A == 16 && !std::getenv("PDDP_CF");
-        if (const char* v = std::getenv("PDDP_CF_FP")) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && c.A == 16; } else cf_fp_staged = false; }
+        const bool cf_fits = (c.A == 16 && (64 / 16) * P::NX <= 64) || (c.A == 8 && (64 / 8) * P::NX <= 64);      // whole problems per wavefront, one state fetch per lane
+        cf_fp_staged = cf_fp && cf_fits && !std::getenv("PDDP_CF");      // (cart-pole, 16384 problems: 0.73 -> 0.69 ms; quadrotor: 8.6 -> 5.1 ms)
+        if (const char* v = std::getenv("PDDP_CF_FP")) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && cf_fits; } else cf_fp_staged = false; }
         kb_nis = (gl_nis && c.integrator == 3) ? 16 : 0;      // 16 knots per wavefront: 2.15 ms (32: 2.6, 64: 3.6; the 16-lane-group kernel 5.7-7.1) at 16384 quadrotor problems -- LDS per block sets the occupancy
         if (const char* v = std::getenv("PDDP_CF_NIS")) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
         if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32" || (std::string(v) == "cl" && P::NX == 12 && P::NU == 4)) && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; cl_bp = gl_bp && std::string(v) == "cl"; }
@@ -409,6 +410,9 @@ struct Solver : SolverBase {
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
                 if constexpr (P::kScalarPlugin && (64 / 16) * P::NX <= 64) {
                     if (cf_fp && cf_fp_staged && !init_rollout && part != 2 && cfg.A == 16) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+                }
+                if constexpr (P::kScalarPlugin && (64 / 8) * P::NX <= 64) {
+                    if (!serial && cf_fp && cf_fp_staged && !init_rollout && part != 2 && cfg.A == 8) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
                 }
                 if (!serial && cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B, part == 2 ? 1 : 0); serial = true; }
             }

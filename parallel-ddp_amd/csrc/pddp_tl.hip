@@ -51,7 +51,10 @@ constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | x
 constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
 // EE: the end-effector cost family (fp_tl.hpp tl_rollout_step_ee): every segment runs NB steps, the cost is accumulated in the rollout.
 template <typename T, int V, bool ALL, bool EE = false>
-__global__ __launch_bounds__(256, sizeof(T) == 4 && !EE && !ALL ? 3 : 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
+#ifndef PDDP_FP_TL_MINBLK
+#define PDDP_FP_TL_MINBLK 3
+#endif
+__global__ __launch_bounds__(256, sizeof(T) == 4 && !EE && !ALL ? PDDP_FP_TL_MINBLK : 2) void k_fp_tl(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
     constexpr ArmTlModel<T> md = arm_tl_builtin<T>(V);
     constexpr int NX = 14, NU = 7, PS = kFpTlPS;
     const int A = dm.A, M = dm.M, N = dm.N, NBk = dm.NB, per_pb = M * A, total = batch * per_pb;

@@ -106,7 +106,7 @@ def test_large_batch_selection_is_thread_serial_and_equals_single_problem_solves
         x0, u0, xg = example_inputs(2, 128, np.float32, noise=rng.normal(0, 0.001, (128, 4)))
         xs.append(x0); us.append(u0)
     s = make_solver("hip", 2, dtype=0, batch=B, **kw)
-    assert "k_fp_ts" in dict(s.time_kernels(1))
+    assert "k_fp_cf" in dict(s.time_kernels(1)) and "k_nis_ts" in dict(s.time_kernels(1))      # thread per rollout (operands staged per wavefront: 8 step sizes), thread per knot
     out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
     s1 = make_solver("hip", 2, dtype=0, batch=1, **kw)
     assert "k_fp" in dict(s1.time_kernels(1))

@@ -110,6 +110,9 @@ PDDP_HD void nis_body(const Wave& w, NisScratch<P, INTEG, T>& s, const Buffers<T
         if (st.accepted != 1) return;
         const size_t slot = (size_t)pb * dm.A + st.alphaIndex;
         const T* xw = b.xs + (slot * N + k) * NX; const T* uw = b.us + (slot * N + k) * NU;
+        if constexpr (P::PLANT != 4) {                              // closed-form plants whose production rollouts keep records state | control knot-major (k_fp_cf, kernels.hpp)
+            if (b.xw) { xw = b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * (NX + NU); uw = xw + NX; }
+        }
         PDDP_FOR(i, NX) xc[i] = xw[i];
         PDDP_FOR(i, NU) uc[i] = uw[i];
         if (dm.M > 1 && dm.on_defect_boundary(k)) {

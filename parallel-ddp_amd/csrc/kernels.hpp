@@ -324,7 +324,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     const int pb_raw = pb0 + grp, pb = pb_raw < batch ? pb_raw : batch - 1;
     const bool live = pb_raw < batch && fp_active<T>(b, dm, pb);
     const size_t slot = (size_t)pb * A + a_idx;
-    T* xo = b.xs + slot * N * NX; T* uo = b.us + slot * N * NU; T* dout = b.ds + slot * N * NX;
+    // candidates leave as RECORDS state | control in the knot-major array xw[problem][knot][step size][NX + NU] (solver_state.hpp; the arm's thread-lane rollouts keep theirs
+    // the same way): the A lanes of a problem fill one contiguous run of A records per step -- whole cache lines -- where the candidate-major slots of xs / us got 48- and
+    // 16-byte pieces 12 KB apart (counters: 8.7 GB written per launch for 4.3 GB of candidates).  The setup kernels adopt the accepted candidate from the records; the
+    // phase hook runs k_fp_ts (candidate-major xs / us, the reference's arrays) and copies them into xw (k_cand_to_xw).
+    constexpr int REC = NX + NU;
+    T* rec0 = b.xw + ((size_t)pb * N * A + a_idx) * REC;                 // record of knot k: rec0 + k * A * REC
+    const size_t rstr = (size_t)A * REC;
+    T* dout = b.ds + slot * N * NX;
     const T* xg = b.xGoal + (size_t)pb * NX;
     const T alpha = b.alpha[a_idx];
     // the current trajectory sits in one half of xb per PROBLEM (state.cur): this lane's share of the state fetch is entry e of problem p
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
                 xv += -alpha * sc.sw.Bdu[grp][r] + val[r] + (bnd ? sc.sw.d[grp][r] : T(0));
                 xk[r] = xv;
             }
-            if (bnd && live) cf_store_vec<T, NX>(xo + (size_t)(k + 1) * NX, xk);
+            if (bnd && live) cf_store_vec<T, NX>(rec0 + (size_t)(k + 1) * rstr, xk);
             wsync();
         }
     }
@@ -387,13 +394,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     T cost_k[kTsMaxN];
     T x[NX], u[NU];
     PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = stage[0].ro.xp[grp][i];
-    if (live) cf_store_vec<T, NX>(xo, x);
     T dmx = 0;
     for (int k = 0; k < N - 1; k++) {
         const FpCfStage<P, T, A>& sc = stage[k & 1];
         fetch(k + 1);
         const bool bnd = dm.on_defect_boundary(k);
-        if (bnd) { PDDP_UNROLL for (int i = 0; i < NX; i++) xstart[i] = live ? xo[(size_t)(k + 1) * NX + i] : T(0); }      // the next segment's start state, from the sweep above
+        if (bnd) { PDDP_UNROLL for (int i = 0; i < NX; i++) xstart[i] = live ? rec0[(size_t)(k + 1) * rstr + i] : T(0); }      // the next segment's start state, from the sweep above
         T dx[NX], xn[NX];
         PDDP_UNROLL for (int i = 0; i < NX; i++) dx[i] = x[i] - sc.ro.xp[grp][i];
         PDDP_UNROLL for (int r = 0; r < NU; r++) {                     // u = ucur - alpha du - K (x - xcur)      (computeControlKT)
@@ -406,20 +412,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
         cost_k[k] = P::cost(cw, x, u, xg, k, N);
         cf_integrator_step<P, INTEG, T>(xn, x, u, dt);
         put(stage[(k + 1) & 1]); wsync();
+        T rec[REC];                                         // this knot's record: the state the step started from and its control
+        PDDP_UNROLL for (int i = 0; i < NX; i++) rec[i] = x[i];
+        PDDP_UNROLL for (int r = 0; r < NU; r++) rec[NX + r] = u[r];
+        if (live) cf_store_vec<T, REC>(rec0 + (size_t)k * rstr, rec);
         if (bnd) {                                          // last step of a non-final segment: defect against the next start state, which the next segment starts from
             T sdef = 0, dv[NX];
             PDDP_UNROLL for (int i = 0; i < NX; i++) { dv[i] = xn[i] - xstart[i]; sdef += tabs(dv[i]); x[i] = xstart[i]; }
             dmx = tmax(dmx, sdef);
-            if (live) { cf_store_vec<T, NU>(uo + (size_t)k * NU, u); cf_store_vec<T, NX>(dout + (size_t)k * NX, dv); }
+            if (live) cf_store_vec<T, NX>(dout + (size_t)k * NX, dv);
         } else {
             PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = xn[i];
-            if (live) { cf_store_vec<T, NU>(uo + (size_t)k * NU, u); cf_store_vec<T, NX>(xo + (size_t)(k + 1) * NX, xn); }
         }
     }
     {                                                       // final knot: terminal cost, and its (unused) control is carried along
         const FpCfStage<P, T, A>& sc = stage[(N - 1) & 1];
         PDDP_UNROLL for (int r = 0; r < NU; r++) u[r] = sc.ro.up[grp][r];
-        if (live) cf_store_vec<T, NU>(uo + (size_t)(N - 1) * NU, u);
+        T rec[REC];
+        PDDP_UNROLL for (int i = 0; i < NX; i++) rec[i] = x[i];
+        PDDP_UNROLL for (int r = 0; r < NU; r++) rec[NX + r] = u[r];
+        if (live) cf_store_vec<T, REC>(rec0 + (size_t)(N - 1) * rstr, rec);
         cost_k[N - 1] = P::cost(cw, x, u, xg, N - 1, N);
         dmx = tmax(dmx, T(0));
     }
@@ -488,7 +500,8 @@ __global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeight
                 T x[NX], u[NU];
                 if (mode == 0) {
                     const size_t slot = (size_t)pb * dm.A + st.alphaIndex;
-                    const T* xw = b.xs + (slot * N + k) * NX; const T* uw = b.us + (slot * N + k) * NU;
+                    const T* xw = b.xw ? b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * (NX + NU) : b.xs + (slot * N + k) * NX;      // the accepted candidate's record, or its slots of xs / us
+                    const T* uw = b.xw ? xw + NX : b.us + (slot * N + k) * NU;
                     PDDP_UNROLL for (int i = 0; i < NX; i++) { x[i] = xw[i]; xc[i] = x[i]; }
                     PDDP_UNROLL for (int i = 0; i < NU; i++) { u[i] = uw[i]; uc[i] = u[i]; }
                     if (dm.M > 1 && dm.on_defect_boundary(k)) {
@@ -568,6 +581,19 @@ __global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeight
             ABc[kx] = (dt / T(6)) * dx + (dt2 / T(3)) * T1[kx] + (dt / T(6)) * T2[kx] + T(kx == ky ? 1 : 0);
         }
     }
+}
+
+// phase hook of the handles whose production rollouts keep records (k_fp_cf): the candidate-major xs / us that k_fp_ts just wrote -> xw.  thread = (problem, knot, step size)
+template <typename P, typename T>
+__global__ __launch_bounds__(256) void k_cand_to_xw(Buffers<T> b, Dims dm, int batch) {
+    constexpr int NX = P::NX, NU = P::NU, REC = NX + NU;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)batch * dm.N * dm.A;
+    if (id >= total) return;
+    const int a = (int)(id % dm.A), k = (int)((id / dm.A) % dm.N), pb = (int)(id / ((size_t)dm.A * dm.N));
+    const size_t slot = (size_t)pb * dm.A + a;
+    T* r = b.xw + id * REC;
+    for (int i = 0; i < NX; i++) r[i] = b.xs[(slot * dm.N + k) * NX + i];
+    for (int i = 0; i < NU; i++) r[NX + i] = b.us[(slot * dm.N + k) * NU + i];
 }
 
 // debugging aid (PDDP_POISON_LDS, run_phase): fill the whole LDS of the compute unit this block lands on with NaNs

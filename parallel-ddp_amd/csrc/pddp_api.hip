@@ -322,6 +322,7 @@ struct Solver : SolverBase {
         b.model = dmodel;
         register_model(dmodel, hm);
         derive_tl_model(hm);
+        if constexpr (P::PLANT != 4) { if (cf_fp_staged) { b.xw_rec = P::NX + P::NU; if ((rc = alloc("xw", &b.xw, B * N * A * b.xw_rec))) return rc; } }   // records of the staged closed-form rollouts (k_fp_cf)
         if constexpr (P::PLANT == 4) { if (fp_path == kFpTl) { b.xw_rec = 22; if ((rc = alloc("xw", &b.xw, B * N * A * b.xw_rec))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
         if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
         if constexpr (P::PLANT == 4) {
@@ -406,17 +407,19 @@ struct Solver : SolverBase {
         if constexpr (P::PLANT == 4) lane_groups = !fp_coop && !(init_rollout && (cfg.use_limits || cfg.use_smooth_abs));       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests); the initial rollout of a thread-lane handle with USE_LIMITS_FLAG too
         if (!lane_groups) {
             if (part == 0) return;
-            bool serial = false;
+            bool serial = false, records_ran = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
+                const bool records = cf_fp && cf_fp_staged && !init_rollout && part != 2 && !store_candidates;      // (the phase hook wants the reference's candidate-major arrays: k_fp_ts, then k_cand_to_xw)
                 if constexpr (P::kScalarPlugin && (64 / 16) * P::NX <= 64) {
-                    if (cf_fp && cf_fp_staged && !init_rollout && part != 2 && cfg.A == 16) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+                    if (records && cfg.A == 16) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; records_ran = true; }
                 }
                 if constexpr (P::kScalarPlugin && (64 / 8) * P::NX <= 64) {
-                    if (!serial && cf_fp && cf_fp_staged && !init_rollout && part != 2 && cfg.A == 8) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; }
+                    if (!serial && records && cfg.A == 8) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; records_ran = true; }
                 }
                 if (!serial && cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B, part == 2 ? 1 : 0); serial = true; }
             }
             if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout ? 1 : (part == 2 ? 2 : 0));
+            if constexpr (P::PLANT != 4) { if (b.xw && !records_ran && !init_rollout) hipLaunchKernelGGL((k_cand_to_xw<P, T>), dim3((unsigned)(((size_t)B * cfg.N * cfg.A + 255) / 256)), dim3(256), 0, s, b, dm, (int)B); }
             return;
         }
         if constexpr (P::PLANT == 4) {

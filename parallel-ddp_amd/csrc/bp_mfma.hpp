@@ -42,6 +42,10 @@
 #include "ab_compact.hpp"
 #include "solver_state.hpp"
 
+#ifndef PDDP_MX_EXP
+#define PDDP_MX_EXP 0        // measurement variants (tools/bp_mfma_experiments.sh): 1 no pivots, 2 no loads, 3 no stores, 4 no matrix instructions, 5 no pivot exchanges
+#endif
+
 namespace pddp {
 
 // Element-type traits of the tile algebra.  Both 16x16x4 instructions take one A / B element per lane -- lane (g = lane >> 4, c = lane & 15) supplies
@@ -56,12 +60,24 @@ template <> struct Mx<float> {
     static __host__ __device__ constexpr int q_of(int g, int r) { return 4 * g + r; }
     static __host__ __device__ constexpr int g_of(int q) { return q >> 2; }
     static __host__ __device__ constexpr int r_of(int q) { return q & 3; }
-    static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) {
+        if (PDDP_MX_EXP == 4) { c[0] = __builtin_fmaf(a, b, c[0]); return c; }
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
     // 1 / d to within one unit in the last place: hardware reciprocal + one Newton step (the reference divides, cudaUtils.h:262)
     static __device__ __forceinline__ float recip(float d) { const float x = __builtin_amdgcn_rcpf(d); return __builtin_fmaf(__builtin_fmaf(-d, x, 1.f), x, x); }
     static __device__ __forceinline__ float readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
     static __device__ __forceinline__ float from_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    // ds_bpermute with the source lane split into a lane-dependent register (bytes) and a compile-time byte OFFSET in the instruction's offset field -- the compiler
+    // does not fold constants into that field and would keep one address register per (pivot, role): nine registers in a kernel that has none to spare.  The result
+    // is only valid after lanes_arrived() (the compiler's own wait-count bookkeeping does not see an asm's LDS operation).
+    template <int OFF> static __device__ __forceinline__ float from_lane_off(float v, int base_bytes) {
+        float r;
+        asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(r) : "v"(base_bytes), "v"(v), "n"(OFF));
+        return r;
+    }
+    static __device__ __forceinline__ void lanes_arrived(float& a, float& b, float& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); }
 };
 template <> struct Mx<double> {
     typedef double v4 __attribute__((ext_vector_type(4)));
@@ -82,6 +98,13 @@ template <> struct Mx<double> {
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    template <int OFF> static __device__ __forceinline__ double from_lane_off(double v, int base_bytes) {
+        const long long w = __double_as_longlong(v);
+        unsigned lo, hi;
+        asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%5\n\tds_bpermute_b32 %1, %2, %4 offset:%5" : "=&v"(lo), "=&v"(hi) : "v"(base_bytes), "v"((unsigned)w), "v"((unsigned)(w >> 32)), "n"(OFF));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    static __device__ __forceinline__ void lanes_arrived(double& a, double& b, double& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); }
 };
 template <typename T> using mx4t = typename Mx<T>::v4;
 
@@ -129,6 +152,31 @@ template <class V, typename T>
 __device__ __forceinline__ V mx_ld(const T* base, unsigned elem_off) {
     return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (unsigned)sizeof(T) * elem_off);
 }
+// Buffer form of the hot loop's loads: base = a wave-uniform resource (four scalar registers, set up once per wave), the knot's position a SCALAR byte offset and the
+// lane's share a loop-invariant 32-bit vector offset -- no per-access vector address arithmetic (the flat form costs a 64-bit vector add per access and a register
+// PAIR per lane offset, which is what pushed the kernel over its 96 registers).  Raw buffer, stride 0, no range limit.
+typedef unsigned mx_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mx_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000); }
+template <typename T> __device__ __forceinline__ T mx_bld(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte);
+template <> __device__ __forceinline__ float mx_bld<float>(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vbyte, sbyte, 0));
+}
+template <> __device__ __forceinline__ double mx_bld<double>(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte) {
+    const mx_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, vbyte, sbyte, 0);
+    return __longlong_as_double((long long)(((unsigned long long)w[1] << 32) | w[0]));
+}
+template <typename T> __device__ __forceinline__ typename Mx<T>::v2u mx_bld2(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte);
+template <> __device__ __forceinline__ Mx<float>::v2u mx_bld2<float>(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte) {
+    const mx_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, vbyte, sbyte, 0);
+    Mx<float>::v2u o; o[0] = __uint_as_float(w[0]); o[1] = __uint_as_float(w[1]); return o;
+}
+template <> __device__ __forceinline__ Mx<double>::v2u mx_bld2<double>(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte) {
+    const mx_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, vbyte, sbyte, 0);
+    Mx<double>::v2u o;
+    o[0] = __longlong_as_double((long long)(((unsigned long long)w[1] << 32) | w[0])); o[1] = __longlong_as_double((long long)(((unsigned long long)w[3] << 32) | w[2]));
+    return o;
+}
 // (a loop-invariant lane offset is hoisted with its 64-bit extension and costs one 64-bit vector add per access; forcing it to stay 32-bit inside the loop
 // with an empty asm costs a register copy + shift per access instead -- measured in instructions, no gain)
 template <typename T>
@@ -156,6 +204,30 @@ __device__ __forceinline__ mx4t<T> mx_mfma2(const mx4t<T>& X, const mx4t<T>& Y, 
     return acc;
 }
 template <typename T> __host__ __device__ constexpr int mx_pi(int b) { return Mx<T>::q_of(b >> 1, b & 1); }
+
+// One pivot of the distributed Gauss-Jordan inversion (arm_mx_bp_block): lane group g owns rows 2g, 2g + 1 (R0, R1) of [Huu | I].
+template <typename T, int PV>
+__device__ __forceinline__ void mx_gj_pivot(T& R0, T& R1, int g, int c4, int g64) {
+    using X = Mx<T>;
+    constexpr int go = PV >> 1;                                           // owner group of the pivot row; its register is PV & 1
+    if (PDDP_MX_EXP == 1) return;
+    if (PDDP_MX_EXP == 5) {                                               // the arithmetic of a pivot without readlane / ds_bpermute
+        const T q = R1 * X::recip(R0 + T(PV));
+        const T n0 = X::fma(-R0, q, R0), n1 = X::fma(-R1, q, R1);
+        R0 = (g == go && !(PV & 1)) ? q : n0; R1 = (g == go && (PV & 1)) ? q : n1;
+        return;
+    }
+    const T src = (PV & 1) ? R1 : R0;
+    const T piv = X::readlane(src, 16 * go + mx_pi<T>(PV));
+    T prow = X::template from_lane_off<64 * go>(src, c4);
+    T col0 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R0, g64), col1 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R1, g64);
+    const T rp = X::recip(piv);
+    X::lanes_arrived(prow, col0, col1);
+    const T q = prow * rp;                                                // the scaled pivot row; row a loses (its pivot-column entry) x q
+    const T n0 = X::fma(-col0, q, R0), n1 = X::fma(-col1, q, R1);
+    R0 = (g == go && !(PV & 1)) ? q : n0;
+    R1 = (g == go && (PV & 1)) ? q : n1;
+}
 
 // the read-only operands of one knot as they come from memory
 template <typename T, bool FS, bool DIAGH>
@@ -216,33 +288,99 @@ __device__ __forceinline__ void mx_load_knot(MxKnotIn<T, FS, DIAGH>& k, const T*
 // chA + offA / chB + offB: this lane's column of the knot's share of its piece, + 2g (ch*: wave-uniform, off*: the lane's element offset); offT0 / offT1: B(state of
 // column c, controls 2g, 2g + 1).
 template <typename T, bool FS, bool DIAGH>
-__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, const T* chA, unsigned offA, const T* chB, unsigned offB, unsigned offT0,
-                                                     unsigned offT1, const T* gk, int g, int c, int ub, T dt) {
+__device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, __amdgpu_buffer_rsrc_t rab, unsigned soCh, unsigned voA, unsigned soB, unsigned voB, unsigned voT0,
+                                                     unsigned voT1, __amdgpu_buffer_rsrc_t rg, unsigned soG, int g, int c, int ub, T dt) {
     constexpr int NX = 14, NU = 7;
+    constexpr unsigned E = (unsigned)sizeof(T);
     using V2 = typename Mx<T>::v2u;
     const int u0 = 2 * g, sc = mx_state<T>(c);
     const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX), g3 = g < 3;
-    const V2 ta = mx_ld<V2, T>(chA, offA);
-    const V2 tb = mx_ld<V2, T>(chB, offB);
+    if (PDDP_MX_EXP == 2) {
+        const T f = T(1e-3) * T(c + 1);
+        k.A0[0] = cx ? ((sc == u0) ? T(1) : ((sc == u0 + 7) ? dt : T(0))) : T(0); k.A0[1] = k.A0[0]; k.A0[2] = cx ? f : T(0); k.A0[3] = (cx && g3) ? -f : T(0);
+        k.B1[0] = T(0); k.B1[1] = T(0); k.B1[2] = cu ? f : T(0); k.B1[3] = (cu && g3) ? f : T(0);
+        k.BT0 = f; k.BT1 = f;
+        for (int r = 0; r < 4; r++) k.CXX[r] = c14 ? f : T(0);
+        k.CUX0 = c14 ? f : T(0); k.CUX1 = k.CUX0; k.hx = T(0); k.hu = T(0);
+        return;
+    }
+    const V2 ta = mx_bld2<T>(rab, voA, soCh);
+    const V2 tb = mx_bld2<T>(rab, voB, soB);
     k.A0[0] = cx ? ((sc == u0) ? T(1) : ((sc == u0 + 7) ? dt : T(0))) : T(0);                // position rows 2g, 2g + 1 of A; B has zeros there
     k.A0[1] = (cx && g3) ? ((sc == u0 + 1) ? T(1) : ((sc == u0 + 8) ? dt : T(0))) : T(0);
     k.A0[2] = cx ? ta[0] : T(0); k.A0[3] = (cx && g3) ? ta[1] : T(0);                       // velocity rows 7 + 2g, 8 + 2g
     k.B1[0] = T(0); k.B1[1] = T(0);
     k.B1[2] = cu ? tb[0] : T(0); k.B1[3] = (cu && g3) ? tb[1] : T(0);
     if (FS) {
-        const T t0 = mx_ld<T, T>(chB, offT0), t1 = mx_ld<T, T>(chB, offT1);
+        const T t0 = mx_bld<T>(rab, voT0, soB), t1 = mx_bld<T>(rab, voT1, soB);
         k.BT0 = (cx && sc >= 7) ? t0 : T(0); k.BT1 = (cx && sc >= 7 && u0 + 1 < NU) ? t1 : T(0);
     }
     static_assert(DIAGH, "the compact [A B] is produced by the thread-lane setup kernel, whose cost Hessian is the joint-space diagonal");
-    const mx4t<T> gx = mx_load_col_raw<T>(gk, g);
-    const T gu0 = mx_ld<T, T>(gk, (unsigned)(NX + u0)), gu1 = mx_ld<T, T>(gk, (unsigned)(NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)));
+    const unsigned vg = E * 2u * (unsigned)g;
+    const V2 gl = mx_bld2<T>(rg, vg, soG), gh = mx_bld2<T>(rg, vg + E * 7u, soG);
+    const T gu0 = mx_bld<T>(rg, vg + E * (unsigned)NX, soG), gu1 = mx_bld<T>(rg, E * (unsigned)(NX + (u0 + 1 < NU ? u0 + 1 : NU - 1)), soG);
+    const mx4t<T> gx = {gl[0], gl[1], gh[0], gh[1]};
 #pragma unroll
     for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : T(0);
     k.CUX0 = c14 ? gu0 : T(0); k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : T(0);
     k.hx = T(0); k.hu = T(0);
 }
 
-// One (problem, block of knots).  lds: 96 elements of this wave.  FS: M > 1 (write the forward-sweep operands A - B K, B du).
+// ---- Operand prefetch through LDS (float handles, compact [A B]).  A knot's operands are four contiguous runs -- its share of the three pieces of the compact [A B]
+// (56 / 42 / 49 floats) and its cost gradient (21) -- so four LDS-direct buffer loads (buffer_load_dword ... lds: lane i's dword lands at M0 + 4 i; no registers) bring
+// the NEXT knot's operands into the other half of a double buffer while the current knot computes; the tile operands are then LDS reads (~100 cycles) instead of
+// HBM loads (~2 k cycles) on the wave's serial chain, and -- gfx9's single in-order vmcnt -- the loads are issued BEFORE the knot's stores instead of queueing behind
+// their acknowledgements.  Inline assembly because the compiler's own LDS-DMA bookkeeping waits for EVERY outstanding transfer before any read of the target array
+// (it would wait for the prefetch it just issued); here the wait is explicit: s_waitcnt vmcnt(2) at the top of a knot = everything but the previous knot's two gain
+// stores has landed (the transfers are older than those stores).  Runs are fetched as 64 dwords: the over-read stays inside the arrays (abc_floats' slack; the cost
+// gradient's run is limited to 32 lanes and the loop never reaches the last knot).
+typedef int mx_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mx_i4 mx_desc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    mx_i4 d = {(int)(unsigned)a, (int)(unsigned)(a >> 32), -1, 0x00020000};
+    return d;
+}
+constexpr int kMxDmaRegion = 64, kMxDmaBuf = 4 * kMxDmaRegion;        // dwords: regions piece 0 | piece 1 | piece 2 | cost gradient
+__device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 dg, unsigned lane4, unsigned s0, unsigned s1, unsigned s2, unsigned sg) {
+    const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)buf;
+    asm volatile(
+        "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s0] offen lds\n\t"
+        "s_mov_b32 m0, %[l1]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s1] offen lds\n\t"
+        "s_mov_b32 m0, %[l2]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s2] offen lds\n\t"
+        "s_mov_b32 exec_hi, 0\n\ts_mov_b32 m0, %[l3]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dg], %[sg] offen lds\n\t"
+        "s_mov_b32 exec_hi, -1"
+        :: [l0] "s"(l0), [l1] "s"(l0 + 4u * kMxDmaRegion), [l2] "s"(l0 + 8u * kMxDmaRegion), [l3] "s"(l0 + 12u * kMxDmaRegion), [v] "v"(lane4), [dab] "s"(dab), [dg] "s"(dg),
+           [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [sg] "s"(sg)
+        : "memory");
+}
+// the knot's tile operands from its LDS copy (the selects of mx_load_knot_compact)
+// (aA .. aG: the lane's LDS BYTE addresses inside half 0 of the double buffer, kept opaque so that a knot pays one add per address; half: byte offset of the half)
+template <bool FS>
+__device__ __forceinline__ void mx_lds_knot(MxKnotIn<float, FS, true>& k, unsigned half, unsigned aA, unsigned aB, unsigned aT, unsigned aG, int g, int c, int ub, float dt) {
+    constexpr int NX = 14, NU = 7;
+    typedef const float __attribute__((address_space(3))) * lptr;
+    const int u0 = 2 * g, sc = mx_state<float>(c);
+    const bool cx = sc < NX, cu = ub < NU, c14 = (sc == NX), g3 = g < 3;
+    const lptr pA = (lptr)(size_t)(aA + half), pB = (lptr)(size_t)(aB + half), pT = (lptr)(size_t)(aT + half), pG = (lptr)(size_t)(aG + half);
+    const float ta0 = pA[0], ta1 = pA[1], tb0 = pB[0], tb1 = pB[1];
+    k.A0[0] = cx ? ((sc == u0) ? 1.f : ((sc == u0 + 7) ? dt : 0.f)) : 0.f;
+    k.A0[1] = (cx && g3) ? ((sc == u0 + 1) ? 1.f : ((sc == u0 + 8) ? dt : 0.f)) : 0.f;
+    k.A0[2] = cx ? ta0 : 0.f; k.A0[3] = (cx && g3) ? ta1 : 0.f;
+    k.B1[0] = 0.f; k.B1[1] = 0.f;
+    k.B1[2] = cu ? tb0 : 0.f; k.B1[3] = (cu && g3) ? tb1 : 0.f;
+    if (FS) {
+        const float t0 = pT[0], t1 = pT[7];
+        k.BT0 = (cx && sc >= 7) ? t0 : 0.f; k.BT1 = (cx && sc >= 7 && u0 + 1 < NU) ? t1 : 0.f;
+    }
+    const float gx[4] = {pG[0], pG[1], pG[7], pG[8]};
+    const float gu0 = pG[NX], gu1 = pG[NX + 1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) k.CXX[r] = (c14 && (g3 || !(r & 1))) ? gx[r] : 0.f;
+    k.CUX0 = c14 ? gu0 : 0.f; k.CUX1 = (c14 && u0 + 1 < NU) ? gu1 : 0.f;
+    k.hx = 0.f; k.hu = 0.f;
+}
+
+// One (problem, block of knots).  lds: kMxLds = 400 elements of this wave.  FS: M > 1 (write the forward-sweep operands A - B K, B du).
 // DIAGH: the cost Hessian of every running knot is the joint-space cost's diag(Q1 x 7, Q2 x 7, R x 7) (plants/cost_arm.cuh:158-202, ArmPlant::weight):
 // the setup kernel wrote exactly those numbers into H, so they are taken from the launch arguments (hq1, hq2, hr) and H is not read in the loop.
 // CAB: [A B] comes from the compact array b.ABc (ab_compact.hpp; dt rebuilds the constant rows).  keepP = 0: only the cost-to-go slots a later pass reads are
@@ -256,7 +394,7 @@ __device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, 
 // HQQ (with DIAGH): the end-effector cost -- the running knots' Hessian is diag(hq1 x 7, hq2 x 7, hr x 7) (nominal-state and control weights) plus the dense 7 x 7 position
 // block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
 // knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
-constexpr int kMxKeepP = 1, kMxFuseSweep = 2;
+constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 512;
 template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
     static_assert(!HQQ || DIAGH, "the compact position block rides on the diagonal-Hessian path");
@@ -315,8 +453,16 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
     }
     T dJ00 = T(0), dJ01 = T(0), dJ10 = T(0), dJ11 = T(0);            // per-control partial sums of the expected reduction (lanes of the vector column: controls 2g, 2g+1)
     const mx4 zero = {T(0), T(0), T(0), T(0)};
-    T* ldsI = lds + 16;                                               // Huu^-1, entry (a, b) at [a * 8 + b]
-    lds[16 + lane] = T(0);                                            // slot b = 7 of every row stays 0
+    // Three transposition areas of 8 rows x 16 tile columns, ONE write address and ONE read address per lane (the areas differ by constant offsets):
+    //   a lane group writes its registers 0, 1 (tile rows 2g, 2g + 1; lane group 3's register 1 is the padding row, parked in row 7) at [row][lane & 15];
+    //   a lane reads row pj = the position state / control its column belongs to (pj == ub on the control lanes), tile columns q_of(g, r).
+    T* ldsI = lds + 16;                                               // Huu^-1: entry (a, b) at [a * 16 + mx_pi(b)]
+    T* ldsP = lds + 144;                                              // compact [A B]: the position rows of [P | p] ...
+    T* ldsW = lds + 272;                                              // ... and of W_u
+    lds[16 + lane] = T(0); lds[80 + lane] = T(0);                     // the inverse's tile column of "control 7" (and row 7) stay 0
+    const int pj = cx ? (sc < 7 ? sc : sc - 7) : 0;                   // the position state whose row of A has its nonzero in this lane's column, and that entry
+    const T fpos = cx ? (sc < 7 ? T(1) : dt) : T(0);
+    const int wa = (2 * g) * 16 + c, ra = pj * 16 + X::q_of(g, 0);
     wsync();
     mx4 PsiT = zero;                                                  // Psi'(m, i) = Psi(i, m): starts as the identity of the 15 x 15 augmented map
     if (FUSE) {
@@ -329,6 +475,8 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
     T* Pk = Pw + (size_t)(ks - 1) * SZP; T* pk = pw + (size_t)(ks - 1) * NX;
     // compact [A B]: per-lane element offsets of this lane's columns inside a knot's share of their pieces, and the per-knot strides of those pieces
     unsigned oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
+    const unsigned krel0 = (unsigned)(knot0 & 63);
+    const __amdgpu_buffer_rsrc_t rab = mx_rsrc(CAB ? b.ABc + (knot0 >> 6) * kAbcChunk : nullptr), rgg = mx_rsrc(gg);
     if (CAB) {
         const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1, roff = 2 * g;
         const int pa = abc_piece(cc);
@@ -338,15 +486,43 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         const int tr = cx && sc >= 7 ? sc - 7 : 0, u1 = u0 + 1 < NU ? u0 + 1 : NU - 1;
         oT0 = abc_piece_off(2) + u0 * 7 + tr; oT1 = abc_piece_off(2) + u1 * 7 + tr;
     }
+    constexpr bool DMA = CAB && sizeof(T) == 4 && PDDP_MX_EXP != 2;   // operand prefetch through LDS (above)
+    const float* dmaLds = reinterpret_cast<const float*>(lds) + kMxLds;
+    unsigned aA = 0, aB = 0, aT = 0, aG = 0;
+    int par = 0;
+    mx_i4 dab = {0, 0, 0, 0}, dgg = {0, 0, 0, 0};
+    if constexpr (DMA) {
+        const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1;
+        const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)dmaLds;
+        aA = l0 + 4u * (unsigned)(abc_piece(cc) * kMxDmaRegion + abc_col_in_piece(cc) * 7 + 2 * g);
+        aB = l0 + 4u * (unsigned)(2 * kMxDmaRegion + uc * 7 + 2 * g);
+        aT = l0 + 4u * (unsigned)(2 * kMxDmaRegion + u0 * 7 + (cx && sc >= 7 ? sc - 7 : 0));
+        aG = l0 + 4u * (unsigned)(3 * kMxDmaRegion + 2 * g);
+        asm volatile("" : "+v"(aA), "+v"(aB), "+v"(aT), "+v"(aG));
+        dab = mx_desc(b.ABc + (knot0 >> 6) * kAbcChunk); dgg = mx_desc(gg);
+    }
+    auto dma_issue = [&](int knot, int half) {                        // (wave-uniform byte offsets of the knot's four runs)
+        const unsigned Gr = krel0 + (unsigned)knot, kk = Gr & 63u, soCh = (Gr >> 6) * (unsigned)(kAbcChunk * 4);
+        mx_dma_knot(dmaLds + half * kMxDmaBuf, dab, dgg, 4u * (unsigned)lane, soCh + kk * 224u, soCh + (unsigned)(abc_piece_off(1) * 4) + kk * 168u,
+                    soCh + (unsigned)(abc_piece_off(2) * 4) + kk * 196u, (unsigned)knot * (unsigned)(NM * 4));
+    };
+    if constexpr (DMA) { if (iterCount >= 0) dma_issue(ks, 0); }
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
         // No register prefetch of the next knot: measured on MI355X (profiles/r02_bp_mfma_experiments.md) the 18 registers it costs are worth more
         // as a fifth resident wave per SIMD (95 registers -> 5 waves: 0.53 ms for 4096 problems, against 0.58 ms with prefetch and 4 waves).
-        if constexpr (CAB) {
-            const size_t G = knot0 + (size_t)ks;
-            const T* ch = b.ABc + (G >> 6) * kAbcChunk;
-            const unsigned kk = (unsigned)(G & 63);
-            const T* chB = ch + kk * 49u;                            // (wave-uniform; the lane parts are unsigned 32-bit offsets)
-            mx_load_knot_compact<T, FS, DIAGH>(in, ch, oA + kk * sA, chB, oB, oT0, oT1, gk, g, c, ub, dt);
+        if constexpr (DMA) {
+            if constexpr (sizeof(T) == 4) {
+                if (PDDP_MX_EXP == 3 || iter == iterCount) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                            // all but the previous knot's two gain stores: this knot's operands are in LDS
+                mx_lds_knot<FS>(in, (unsigned)par * (unsigned)(4 * kMxDmaBuf), aA, aB, aT, aG, g, c, ub, dt);
+                if (iter > 0) dma_issue(ks - 1, par ^ 1);
+                par ^= 1;
+            }
+        } else if constexpr (CAB) {
+            const unsigned Gr = krel0 + (unsigned)ks, kk = Gr & 63u;                              // knot index from the start of the problem's first chunk
+            const unsigned soCh = (Gr >> 6) * (unsigned)(kAbcChunk * sizeof(T));                  // (wave-uniform byte offsets; the lane parts are loop-invariant)
+            mx_load_knot_compact<T, FS, DIAGH>(in, rab, soCh, (unsigned)sizeof(T) * (oA + kk * sA), soCh + kk * (unsigned)(49 * sizeof(T)), (unsigned)sizeof(T) * oB,
+                                               (unsigned)sizeof(T) * oT0, (unsigned)sizeof(T) * oT1, rgg, (unsigned)ks * (unsigned)(NM * sizeof(T)), g, c, ub, dt);
         } else mx_load_knot<T, FS, DIAGH>(in, ABk, Hk, gk, g, c, ub);
         const MxKnotIn<T, FS, DIAGH>& k = in;
         ABk -= SZAB; Hk -= SZH; gk -= NM;
@@ -365,7 +541,19 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             CXU[0] = k.CXU0; CXU[1] = k.CXU1; CUU[0] = k.CUU0; CUU[1] = k.CUU1;
         }
         // ---- W = P' [A | B]  (AB2', rows i = column of P); the B columns take rho B (backprop, :39-64)
-        const mx4 W0 = mx_mfma4<T>(Pa, k.A0, zero);
+        // Compact [A B]: the position rows of A are [I  dt I], so their share of P'A is the position ROWS of P read as columns -- W(i, kx) gets P(kx, i) for a position
+        // column kx, dt P(kx - 7, i) for a velocity column: one nonzero term per element, the bits instructions 0, 1 would have produced.  The transposition goes through
+        // the wave's LDS area (one 8-byte-pair write, one 16-byte read per lane: the LDS pipe, not the float32 lanes the matrix instructions occupy).
+        mx4 W0;
+        if constexpr (CAB) {
+            ldsP[wa] = Pa[0]; ldsP[wa + 16] = Pa[1];
+            wsync();
+            mx4 low;
+#pragma unroll
+            for (int r = 0; r < 4; r++) low[r] = fpos * ldsP[ra + X::q_of(0, r)];
+            wsync();
+            W0 = mx_mfma_hi<T>(Pa, k.A0, low);
+        } else W0 = mx_mfma4<T>(Pa, k.A0, zero);
         mx4 W1 = CAB ? mx_mfma_hi<T>(Pa, k.B1, zero) : mx_mfma4<T>(Pa, k.B1, zero);               // (compact [A B] = Euler step: the position rows of B are exact zeros)
         if (CAB) { W1[2] += rho * k.B1[2]; W1[3] += rho * k.B1[3]; } else W1 = W1 + rho * k.B1;
         const mx4 W0a = c14 ? Pa : W0;                                                            // vector column := p
@@ -376,7 +564,14 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         const mx4 HxxLow = {W0a[0], W0a[1], dt * W0a[0], dt * W0a[1]};
         const mx4 Hxx = (CAB ? mx_mfma_hi<T>(k.A0, W0a, HxxLow) : mx_mfma4<T>(k.A0, W0a, zero)) + CXX;
         const mx4 Hux = (CAB ? mx_mfma_hi<T>(k.B1, W0a, zero) : mx_mfma4<T>(k.B1, W0a, zero)) + CUX;                                    // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
-        const mx4 HxuT = mx_mfma4<T>(W1, k.A0, zero) + CXU;                                       // Hxu(kx, b) as [b][kx]   (with rho)
+        mx4 HxuT;                                                                                 // Hxu(kx, b) as [b][kx]   (with rho)
+        if constexpr (CAB) {                                          // the position rows' share of W_u'A: W_u(kx, b) / dt W_u(kx - 7, b), transposed through LDS as above
+            ldsW[wa] = W1[0]; ldsW[wa + 16] = W1[1];                  // (lanes without a control hold zeros)
+            wsync();
+            const mx4 low = {fpos * ldsW[ra], fpos * ldsW[ra + X::q_of(0, 1)], T(0), T(0)};
+            wsync();
+            HxuT = mx_mfma_hi<T>(W1, k.A0, low) + CXU;
+        } else HxuT = mx_mfma4<T>(W1, k.A0, zero) + CXU;
         const mx4 Huu = (CAB ? mx_mfma_hi<T>(k.B1, W1, zero) : mx_mfma4<T>(k.B1, W1, zero)) + CUU;                                     // Huu(a, b)               (with rho)
         // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292).  The rows stay where the matrix core left them:
         //      lane group g owns rows 2g, 2g + 1 (R0, R1); lane mx_pi(j) of a group keeps column j of Huu, the lane two registers further along the column order
@@ -386,36 +581,22 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         //      rows replicated in every lane.  Same operations per element as before: R[a] -= R[a][pv] * (R[pv] / R[pv][pv]).
         T R0, R1;
         const int e = 2 * cg + cr - 2;                                // identity column of this lane (cr >= 2)
+        const int c4 = 4 * c, g64 = 64 * g;                           // ds_bpermute addresses: source lane x 4 bytes = these + a constant per pivot
         {
             const bool left = cr < 2;
             R0 = left ? Huu[0] : (e == u0 ? T(1) : T(0));
             R1 = left ? Huu[1] : ((e == u0 + 1 && u0 + 1 < NU) ? T(1) : T(0));
         }
-#pragma unroll
-        for (int pv = 0; pv < NU; pv++) {
-            const int go = pv >> 1;                                                // owner group of the pivot row; its register is pv & 1
-            const T src = (pv & 1) ? R1 : R0;
-            const T piv = X::readlane(src, 16 * go + mx_pi<T>(pv));
-            const T prow = X::from_lane(src, 16 * go + c);
-            const T col0 = X::from_lane(R0, 16 * g + mx_pi<T>(pv)), col1 = X::from_lane(R1, 16 * g + mx_pi<T>(pv));
-            const T q = prow * X::recip(piv);                                     // the scaled pivot row; row a loses (its pivot-column entry) x q
-            const T n0 = X::fma(-col0, q, R0), n1 = X::fma(-col1, q, R1);
-            R0 = (g == go && !(pv & 1)) ? q : n0;
-            R1 = (g == go && (pv & 1)) ? q : n1;
-        }
-        if (cr >= 2) {
-            if (e < NU) {
-                ldsI[u0 * 8 + e] = R0;
-                if (u0 + 1 < NU) ldsI[(u0 + 1) * 8 + e] = R1;
-            }
-        }
+        mx_gj_pivot<T, 0>(R0, R1, g, c4, g64); mx_gj_pivot<T, 1>(R0, R1, g, c4, g64); mx_gj_pivot<T, 2>(R0, R1, g, c4, g64); mx_gj_pivot<T, 3>(R0, R1, g, c4, g64);
+        mx_gj_pivot<T, 4>(R0, R1, g, c4, g64); mx_gj_pivot<T, 5>(R0, R1, g, c4, g64); mx_gj_pivot<T, 6>(R0, R1, g, c4, g64);
+        if (cr >= 2 && e < NU) { ldsI[wa - X::q_of(0, 2)] = R0; ldsI[wa + 16 - X::q_of(0, 2)] = R1; }   // identity column e sits two registers along: tile column mx_pi(e)
         wsync();
         mx4 InvT = zero;                                                                          // [b = 2g + r][a = control of this lane] = Huu^-1(a, b)
-        if (cu) { InvT[0] = ldsI[ub * 8 + u0]; InvT[1] = ldsI[ub * 8 + u0 + 1]; }
+        if (cu) { InvT[0] = ldsI[ra]; InvT[1] = ldsI[ra + X::q_of(0, 1)]; }
         wsync();
         // ---- gains (computeKTdu :208-220): K(a, kx) | du(a), rows a = 2g + r
         const mx4 Kp = mx_mfma2<T>(InvT, Hux, zero);
-        if (sc <= NX) {                                               // K row a = 2g + r: 14 elements of KT (lane -> state of its column); du(a) from the lane of the vector column
+        if (sc <= NX && PDDP_MX_EXP != 3) {                           // K row a = 2g + r: 14 elements of KT (lane -> state of its column); du(a) from the lane of the vector column
             T* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
             q0[0] = Kp[0];
             if (u0 + 1 < NU) (cx ? q0 + NX : q0 + 1)[0] = Kp[1];
@@ -448,7 +629,7 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             val = mx_mfma2<T>(-Kp, Hux, val);
             mx4 Pn = Hxx + val;
             if (g == 3) { Pn[1] = T(0); Pn[3] = T(0); }               // the padding and vector rows carry by-products of the vector column: keep them clean
-            if (keepP || iter == 0) mx_store_col<T>(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
+            if ((keepP && PDDP_MX_EXP != 3) || iter == 0) mx_store_col<T>(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
             Pa = Pn;
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;

@@ -4,12 +4,20 @@
 #include "bp_mfma.hpp"
 #include "mx_launch.hpp"
 
+// resident waves per SIMD the float kernel is compiled for: six for the compact-[A B] variants without the end-effector block (78-80 registers, no scratch; measured
+// against five: 1.31 -> 1.27 ms at 16384 problems, profiles/r04_bp_mfma.md), five (<= 102 registers) for the others.  -DPDDP_MX_WAVES=n forces one value (measurement variants).
+#ifdef PDDP_MX_WAVES
+#define PDDP_MX_WAVES_OF(CAB, HQQ) PDDP_MX_WAVES
+#else
+#define PDDP_MX_WAVES_OF(CAB, HQQ) ((CAB) && !(HQQ) ? 6 : 5)
+#endif
+
 namespace pddp {
 
-// k_bp_mfma: grid B*M, block 64 -- one wavefront per (problem, block of knots); <= 102 registers so that five waves share a SIMD.  Replaces backPassKern<<<M, (8,7)>>> (bpHelpers.cuh:339-420).
+// k_bp_mfma: grid B*M, block 64 -- one wavefront per (problem, block of knots).  Replaces backPassKern<<<M, (8,7)>>> (bpHelpers.cuh:339-420).
 template <bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bp_mfma(Buffers<float> b, Dims dm, int batch, float hq1, float hq2, float hr, float dt, int flags) {
-    __shared__ __attribute__((aligned(16))) float lds[96];
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PDDP_MX_WAVES_OF(CAB, HQQ), PDDP_MX_WAVES_OF(CAB, HQQ)))) void k_bp_mfma(Buffers<float> b, Dims dm, int batch, float hq1, float hq2, float hr, float dt, int flags) {
+    __shared__ __attribute__((aligned(16))) float lds[kMxLds + kMxDmaFloats];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
     arm_mx_bp_block<float, FS, DIAGH, CAB, FUSE, HQQ>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);
@@ -18,7 +26,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 // against the oracle at a precision where every step-size decision of a 40-iteration solve is reproducible -- tests/test_f64_benched_family.py).
 template <bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __global__ __launch_bounds__(64) void k_bp_mfma_f64(Buffers<double> b, Dims dm, int batch, double hq1, double hq2, double hr, double dt, int flags) {
-    __shared__ __attribute__((aligned(16))) double lds[96];
+    __shared__ __attribute__((aligned(16))) double lds[kMxLds];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
     arm_mx_bp_block<double, FS, DIAGH, CAB, FUSE, HQQ>(lds, b, dm, inst / dm.M, inst % dm.M, hq1, hq2, hr, dt, flags);

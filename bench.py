@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--keep-ctg", action="store_true", help="write every knot's cost-to-go (the library default) instead of the block-boundary slots only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-default-options", action="store_true", help="skip the second handle with the library's default options (profiling runs: kernel statistics and counters of the headline handle only)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the whole-batch time-to-convergence block (profiling runs: keeps the kernel statistics to the timed sweeps)")
     ap.add_argument("--lib", default=None, help="alternative libpddp build (measurement of build variants only)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -256,7 +257,7 @@ def main():
     # ---- the same sweeps with the library's DEFAULT options: every knot's cost-to-go written like the reference's d_P / d_p (what allocateMemory_GPU of the facade creates).
     # `value` above runs with boundary_cost_to_go_only = 1 unless --keep-ctg: the interior slots are no output of runiLQR_GPU and no input of a later phase (same bits in
     # every output: tests/test_f64_benched_family.py), so both are the same solver -- the line carries both numbers.
-    if not args.keep_ctg:
+    if not args.keep_ctg and not args.no_default_options:
         cfg_d = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, boundary_cost_to_go_only=0,
                                      max_iter=max(100, K + W + 1), device=ctx.device, use_graph=args.graph, _lib_path=args.lib)
         sd = pyddp.Solver(cfg_d, _lib_path=args.lib)

@@ -77,7 +77,7 @@ template <> struct Mx<float> {
         asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(r) : "v"(base_bytes), "v"(v), "n"(OFF));
         return r;
     }
-    static __device__ __forceinline__ void lanes_arrived(float& a, float& b, float& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); }
+    static __device__ __forceinline__ void lanes_arrived(float& a, float& b, float& c, float& before) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(before)); }
 };
 template <> struct Mx<double> {
     typedef double v4 __attribute__((ext_vector_type(4)));
@@ -104,7 +104,7 @@ template <> struct Mx<double> {
         asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%5\n\tds_bpermute_b32 %1, %2, %4 offset:%5" : "=&v"(lo), "=&v"(hi) : "v"(base_bytes), "v"((unsigned)w), "v"((unsigned)(w >> 32)), "n"(OFF));
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
-    static __device__ __forceinline__ void lanes_arrived(double& a, double& b, double& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); }
+    static __device__ __forceinline__ void lanes_arrived(double& a, double& b, double& c, double& before) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(before)); }
 };
 template <typename T> using mx4t = typename Mx<T>::v4;
 
@@ -166,6 +166,13 @@ template <> __device__ __forceinline__ double mx_bld<double>(__amdgpu_buffer_rsr
     const mx_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, vbyte, sbyte, 0);
     return __longlong_as_double((long long)(((unsigned long long)w[1] << 32) | w[0]));
 }
+template <typename T> __device__ __forceinline__ void mx_bst(__amdgpu_buffer_rsrc_t r, T v, unsigned vbyte, unsigned sbyte);
+template <> __device__ __forceinline__ void mx_bst<float>(__amdgpu_buffer_rsrc_t r, float v, unsigned vbyte, unsigned sbyte) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, vbyte, sbyte, 0); }
+template <> __device__ __forceinline__ void mx_bst<double>(__amdgpu_buffer_rsrc_t r, double v, unsigned vbyte, unsigned sbyte) {
+    const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+    mx_u2 p; p[0] = (unsigned)w; p[1] = (unsigned)(w >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(p, r, vbyte, sbyte, 0);
+}
 template <typename T> __device__ __forceinline__ typename Mx<T>::v2u mx_bld2(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte);
 template <> __device__ __forceinline__ Mx<float>::v2u mx_bld2<float>(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte) {
     const mx_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, vbyte, sbyte, 0);
@@ -221,8 +228,8 @@ __device__ __forceinline__ void mx_gj_pivot(T& R0, T& R1, int g, int c4, int g64
     const T piv = X::readlane(src, 16 * go + mx_pi<T>(PV));
     T prow = X::template from_lane_off<64 * go>(src, c4);
     T col0 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R0, g64), col1 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R1, g64);
-    const T rp = X::recip(piv);
-    X::lanes_arrived(prow, col0, col1);
+    T rp = X::recip(piv);                                                  // (issued before the wait: the reciprocal runs while the lanes travel)
+    X::lanes_arrived(prow, col0, col1, rp);
     const T q = prow * rp;                                                // the scaled pivot row; row a loses (its pivot-column entry) x q
     const T n0 = X::fma(-col0, q, R0), n1 = X::fma(-col1, q, R1);
     R0 = (g == go && !(PV & 1)) ? q : n0;
@@ -331,7 +338,7 @@ __device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, 
 // the NEXT knot's operands into the other half of a double buffer while the current knot computes; the tile operands are then LDS reads (~100 cycles) instead of
 // HBM loads (~2 k cycles) on the wave's serial chain, and -- gfx9's single in-order vmcnt -- the loads are issued BEFORE the knot's stores instead of queueing behind
 // their acknowledgements.  Inline assembly because the compiler's own LDS-DMA bookkeeping waits for EVERY outstanding transfer before any read of the target array
-// (it would wait for the prefetch it just issued); here the wait is explicit: s_waitcnt vmcnt(2) at the top of a knot = everything but the previous knot's two gain
+// (it would wait for the prefetch it just issued); here the wait is explicit: s_waitcnt vmcnt(4) at the top of a knot = everything but the previous knot's four gain
 // stores has landed (the transfers are older than those stores).  Runs are fetched as 64 dwords: the over-read stays inside the arrays (abc_floats' slack; the cost
 // gradient's run is limited to 32 lanes and the loop never reaches the last knot).
 typedef int mx_i4 __attribute__((ext_vector_type(4)));
@@ -476,7 +483,8 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
     // compact [A B]: per-lane element offsets of this lane's columns inside a knot's share of their pieces, and the per-knot strides of those pieces
     unsigned oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
     const unsigned krel0 = (unsigned)(knot0 & 63);
-    const __amdgpu_buffer_rsrc_t rab = mx_rsrc(CAB ? b.ABc + (knot0 >> 6) * kAbcChunk : nullptr), rgg = mx_rsrc(gg);
+    const __amdgpu_buffer_rsrc_t rab = mx_rsrc(CAB ? b.ABc + (knot0 >> 6) * kAbcChunk : nullptr), rgg = mx_rsrc(gg), rKT = mx_rsrc(KT), rdu = mx_rsrc(du);
+    const unsigned voKT = (unsigned)sizeof(T) * (unsigned)(u0 * NX + (cx ? sc : 0)), vodu = (unsigned)sizeof(T) * (unsigned)u0;
     if (CAB) {
         const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1, roff = 2 * g;
         const int pa = abc_piece(cc);
@@ -513,7 +521,7 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         if constexpr (DMA) {
             if constexpr (sizeof(T) == 4) {
                 if (PDDP_MX_EXP == 3 || iter == iterCount) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                            // all but the previous knot's two gain stores: this knot's operands are in LDS
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            // all but the previous knot's four gain stores: this knot's operands are in LDS
                 mx_lds_knot<FS>(in, (unsigned)par * (unsigned)(4 * kMxDmaBuf), aA, aB, aT, aG, g, c, ub, dt);
                 if (iter > 0) dma_issue(ks - 1, par ^ 1);
                 par ^= 1;
@@ -596,10 +604,18 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         wsync();
         // ---- gains (computeKTdu :208-220): K(a, kx) | du(a), rows a = 2g + r
         const mx4 Kp = mx_mfma2<T>(InvT, Hux, zero);
-        if (sc <= NX && PDDP_MX_EXP != 3) {                           // K row a = 2g + r: 14 elements of KT (lane -> state of its column); du(a) from the lane of the vector column
-            T* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
-            q0[0] = Kp[0];
-            if (u0 + 1 < NU) (cx ? q0 + NX : q0 + 1)[0] = Kp[1];
+        if (PDDP_MX_EXP != 3) {                                       // K row a = 2g + r: 14 elements of KT (lane -> state of its column); du(a) from the lane of the vector column
+            // (buffer stores: the lane's offset is loop-invariant, the knot's a scalar -- FOUR store instructions per knot, which the prefetch's s_waitcnt vmcnt(4) counts on)
+            constexpr unsigned E = (unsigned)sizeof(T);
+            const unsigned soK = (unsigned)ks * (unsigned)(NX * NU) * E, sod = (unsigned)ks * (unsigned)NU * E;
+            if constexpr (CAB) {
+                if (cx) { mx_bst<T>(rKT, Kp[0], voKT, soK); if (u0 + 1 < NU) mx_bst<T>(rKT, Kp[1], voKT + (unsigned)NX * E, soK); }
+                if (c14) { mx_bst<T>(rdu, Kp[0], vodu, sod); if (u0 + 1 < NU) mx_bst<T>(rdu, Kp[1], vodu + E, sod); }
+            } else if (sc <= NX) {                                    // few problems in flight (reference-layout [A B]): two stores from one address select -- the shorter instruction stream
+                T* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
+                q0[0] = Kp[0];
+                if (u0 + 1 < NU) (cx ? q0 + NX : q0 + 1)[0] = Kp[1];
+            }
         }
         const bool do_ctg = (iter != 0 || blk != 0);                  // the cost-to-go in front of knot 0 is never used (:396)
         // T1(kx, b) = sum_a K(a,kx) Huu(a,b) - Hxu(kx,b) as [b][kx]; its column 14 is Huu' du

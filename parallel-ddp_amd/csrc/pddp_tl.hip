@@ -697,9 +697,6 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
                     out[j] = stage[k2 * P + en];
                     ok[j] = whole || ((mask >> k2) & 1ull); all = all && ok[j];
                 }
-#ifdef PDDP_NIS_EXP
-                if (piece == PDDP_NIS_EXP - 1) { if (out[0] == T(123456.5)) dst[e0] = out[1]; } else
-#endif
                 if (all) { typename NisTlVec<T>::v4 v; v[0] = out[0]; v[1] = out[1]; v[2] = out[2]; v[3] = out[3]; *reinterpret_cast<typename NisTlVec<T>::v4*>(dst + e0) = v; }
                 else {
 #pragma unroll

@@ -15,7 +15,7 @@ for f in sorted(glob.glob(src + "/*/run_counter_collection.csv")):
             d[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kern = sorted({k for k, _ in d})
 m = lambda k, c: statistics.mean(d[(k, c)]) if (k, c) in d else None
-out = {"batch": batch, "source": f"profiles/{sub} (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of `python bench.py --no-cpu-baseline --no-latency --no-convergence --steps 20`)", "kernels": {}}
+out = {"batch": batch, "source": f"profiles/{sub} (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of `python bench.py --no-cpu-baseline --no-latency --no-convergence --no-default-options --steps 20`)", "kernels": {}}
 lines = ["# Counter passes (rocprofv3 --pmc, kernel-trace only) of the bench sweep, per kernel, averages per launch", "",
          "| kernel | HBM read MB (2 x FETCH_SIZE) | HBM write MB | VALU instr / wave | MFMA instr / wave | VALU-active share of wave time | waiting on memory (s_waitcnt) | issue stalls | MFMA pipe busy share |",
          "|---|---|---|---|---|---|---|---|---|"]

@@ -688,22 +688,48 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
             T* dst = ABc0 + abc_piece_off(piece);
             int kk = (4 * lane) / per, ent = 4 * lane - kk * per;
             const bool whole = (mask == ~0ull);
-            for (int e0 = 4 * lane; e0 < count; e0 += 256) {
+            // one group of four consecutive elements, every element tested against the mask (ragged waves: knots of several problems, some of them not moving)
+            auto group = [&](int e0, int kk, int ent, int limit) {
                 T out[4]; bool ok[4], all = true;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const bool over = ent + j >= per;
                     const int k2 = over ? kk + 1 : kk, en = over ? ent + j - per : ent + j;
                     out[j] = stage[k2 * P + en];
-                    ok[j] = whole || ((mask >> k2) & 1ull); all = all && ok[j];
+                    ok[j] = e0 + j < limit && (whole || ((mask >> k2) & 1ull)); all = all && ok[j];
                 }
                 if (all) { typename NisTlVec<T>::v4 v; v[0] = out[0]; v[1] = out[1]; v[2] = out[2]; v[3] = out[3]; *reinterpret_cast<typename NisTlVec<T>::v4*>(dst + e0) = v; }
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; j++) if (ok[j]) dst[e0 + j] = out[j];
                 }
-                ent += 256 % per; kk += 256 / per;
-                if (ent >= per) { ent -= per; kk++; }
+            };
+            // The two masks a wave of ONE problem has when it moves: every knot, or every knot but the problem's terminal one (lane 63: it has no [A B]).  Then the wave's
+            // first nk knots are one dense run of nk * per elements and the flush is a copy: staged index of element e = e + (knot of e) * (P - per), so a group of four
+            // is five consecutive staged words with at most one step over a knot's pad (t = elements left in the knot) -- ~20 instructions per group where the tested
+            // form costs ~75 (three 32-bit multiplies and four 64-bit mask shifts per group): a quarter of the kernel's instructions were this loop.
+            const int nk = whole ? 64 : (mask == (~0ull >> 1) ? 63 : 0);
+            if (nk) {
+                const int cnt = nk * per;
+                int e0 = 4 * lane, sb = e0 + kk * (P - per), t = per - ent;
+                for (; e0 + 3 < cnt; e0 += 256) {
+                    typename NisTlVec<T>::v4 v;
+                    if constexpr (P == per) { v[0] = stage[sb]; v[1] = stage[sb + 1]; v[2] = stage[sb + 2]; v[3] = stage[sb + 3]; }
+                    else {
+                        const T r0 = stage[sb], r1 = stage[sb + 1], r2 = stage[sb + 2], r3 = stage[sb + 3], r4 = stage[sb + 4];
+                        v[0] = r0; v[1] = t > 1 ? r1 : r2; v[2] = t > 2 ? r2 : r3; v[3] = t > 3 ? r3 : r4;
+                    }
+                    *reinterpret_cast<typename NisTlVec<T>::v4*>(dst + e0) = v;
+                    sb += 256 + (256 / per) * (P - per); t -= 256 % per; kk += 256 / per;
+                    if (t <= 0) { t += per; sb += P - per; kk++; }
+                }
+                if (e0 < cnt) group(e0, kk, per - t, cnt);                       // the group the run ends in (nk = 63: cnt need not be a multiple of four)
+            } else {
+                for (int e0 = 4 * lane; e0 < count; e0 += 256) {
+                    group(e0, kk, ent, count);
+                    ent += 256 % per; kk += 256 / per;
+                    if (ent >= per) { ent -= per; kk++; }
+                }
             }
         } else {
             for (int it = 0; it * 64 < 64 * ncols; it++) {

@@ -75,3 +75,41 @@ def test_closed_form_plants_switch_to_thread_serial_kernels_with_the_device_full
     assert kernels(3, 2048, **dict(quad, integrator=1)) == ["k_bp_cl", "k_fp_ts", "k_ls_many", "k_nis_gl"]
     assert kernels(3, 2048, {"PDDP_CF_BP": "gl32"}, **quad)[0] == "k_bp_gl"
     assert kernels(3, 2048, {"PDDP_CF_NIS": "gl"}, **quad)[-1] == "k_nis_gl"
+
+
+def _solve_with(env, batch, N, M, iters=6):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = make_solver("hip", 4, dtype=0, batch=batch, use_graph=0, N=N, M=M, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=iters)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    rng = np.random.default_rng(11)
+    xs, us, gs = [], [], []
+    for _ in range(batch):                                            # every problem its own start: a wrong knot / problem offset cannot hide behind identical data
+        x0, u0, xg = example_inputs(4, N, np.float32, noise=rng.normal(0, 0.002, (N, 14)))
+        xs.append(x0); us.append(u0); gs.append(xg)
+    out = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    names = [n for n, _ in s.time_kernels(1)]
+    res = {k: np.array(out[k]) for k in ("x", "u", "KT", "Jout", "alphaOut")}
+    s.close()
+    return names, res
+
+
+@pytest.mark.parametrize("N,M", [(32, 4), (32, 1), (64, 4), (128, 1), (128, 8), (256, 4)])
+def test_compact_operands_through_the_lds_prefetch_follow_the_reference_layout(N, M):
+    """The float matrix-core backward pass reads the compact [A B] and the cost gradient through LDS-direct buffer loads one knot ahead (bp_mfma.hpp mx_dma_knot), with
+    scalar chunk / knot offsets: chunks of 64 knots shared by two problems (N = 32), several chunks per problem (N = 256), blocks of knots of every length, one block (M = 1).
+    The same first iteration with PDDP_AB=full (reference-layout [A B], plain loads, no prefetch) must land on the same trajectory up to float32 rounding -- a wrong knot,
+    chunk or problem offset would be off by the size of the data, not by 1e-6.  (Across BUILDS the compact path is held bit for bit: tools/cmp_compact_vs_full.py builds,
+    profiles/r04_bp_mfma.md.)"""
+    env = {"PDDP_BP": "mx", "PDDP_FP": "tl"}
+    names_c, c = _solve_with(env, 5, N, M, iters=1)
+    names_f, f = _solve_with(dict(env, PDDP_AB="full"), 5, N, M, iters=1)
+    assert names_c[0] == "k_bp_mfma" and names_f[0] == "k_bp_mfma" and "k_nis_tl" in names_c
+    np.testing.assert_array_equal(c["alphaOut"], f["alphaOut"])
+    np.testing.assert_allclose(c["x"], f["x"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(c["u"], f["u"], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(c["KT"], f["KT"], atol=5e-2, rtol=5e-3)            # (the float32 Riccati recursion amplifies a rounding difference of the operands)
+    np.testing.assert_allclose(c["Jout"][:, :2], f["Jout"][:, :2], rtol=1e-5)

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_poison_lds(int words) {
 
 // k_bp_cl: 16 lanes = (problem, block of knots), lane = column of [A B] / H (bp_cl.hpp); grid ceil(B M / 4), block 64
 template <typename P, typename T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 1))) void k_bp_cl(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch, int diag_h) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 1))) void k_bp_cl(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch, int diag_h) {
     __shared__ BpClLds<T> s[4];
     const int grp = threadIdx.x >> 4, c = threadIdx.x & 15, inst = blockIdx.x * 4 + grp;
     if (inst >= batch * dm.M) return;

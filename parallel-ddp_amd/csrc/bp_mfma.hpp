@@ -401,7 +401,7 @@ __device__ __forceinline__ void mx_lds_knot(MxKnotIn<float, FS, true>& k, unsign
 // HQQ (with DIAGH): the end-effector cost -- the running knots' Hessian is diag(hq1 x 7, hq2 x 7, hr x 7) (nominal-state and control weights) plus the dense 7 x 7 position
 // block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
 // knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
-constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 512;
+constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 512 + 256;     // (float handles: two operand buffers + the staging area of [P | p])
 template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
     static_assert(!HQQ || DIAGH, "the compact position block rides on the diagonal-Hessian path");
@@ -484,6 +484,7 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
     unsigned oA = 0, sA = 0, oB = 0, oT0 = 0, oT1 = 0;
     const unsigned krel0 = (unsigned)(knot0 & 63);
     const __amdgpu_buffer_rsrc_t rab = mx_rsrc(CAB ? b.ABc + (knot0 >> 6) * kAbcChunk : nullptr), rgg = mx_rsrc(gg), rKT = mx_rsrc(KT), rdu = mx_rsrc(du);
+    const __amdgpu_buffer_rsrc_t rPw = mx_rsrc(Pw), rpw = mx_rsrc(pw);
     const unsigned voKT = (unsigned)sizeof(T) * (unsigned)(u0 * NX + (cx ? sc : 0)), vodu = (unsigned)sizeof(T) * (unsigned)u0;
     if (CAB) {
         const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1, roff = 2 * g;
@@ -645,7 +646,24 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             val = mx_mfma2<T>(-Kp, Hux, val);
             mx4 Pn = Hxx + val;
             if (g == 3) { Pn[1] = T(0); Pn[3] = T(0); }               // the padding and vector rows carry by-products of the vector column: keep them clean
-            if ((keepP && PDDP_MX_EXP != 3) || iter == 0) mx_store_col<T>(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
+            if ((keepP && PDDP_MX_EXP != 3) || iter == 0) {
+                if constexpr (DMA) {
+                    // [P | p] of a knot are two contiguous blocks (784 + 56 bytes): staged in LDS in memory order (column sc of P at 14 sc, p at 196 = 4 x 49) they leave as
+                    // 16-byte pieces -- lanes 0..48 one piece of P each, lanes 49..52 the pieces of p -- instead of two 8-byte stores per lane 56 bytes apart
+                    float* stgQ = const_cast<float*>(dmaLds) + 2 * kMxDmaBuf;
+                    if (cx || c14) {
+                        float* q = stgQ + (cx ? sc * NX : SZP);
+                        if (g < 3) { q[u0] = Pn[0]; q[u0 + 1] = Pn[1]; q[7 + u0] = Pn[2]; q[8 + u0] = Pn[3]; } else { q[6] = Pn[0]; q[13] = Pn[2]; }
+                    }
+                    wsync();
+                    const unsigned soP = (unsigned)(ks - 1) * (unsigned)(SZP * 4), sop = (unsigned)(ks - 1) * (unsigned)(NX * 4);
+                    const mx_u4 piece = *reinterpret_cast<const mx_u4*>(stgQ + 4 * lane);
+                    if (lane < 49) __builtin_amdgcn_raw_buffer_store_b128(piece, rPw, 16u * (unsigned)lane, soP, 0);
+                    else if (lane < 52) __builtin_amdgcn_raw_buffer_store_b128(piece, rpw, 16u * (unsigned)(lane - 49), sop, 0);
+                    else if (lane == 52) { mx_u2 h; h[0] = piece[0]; h[1] = piece[1]; __builtin_amdgcn_raw_buffer_store_b64(h, rpw, 48u, sop, 0); }
+                    wsync();
+                } else mx_store_col<T>(cx ? Pk + sc * NX : pk, g, cx || c14, Pn);
+            }
             Pa = Pn;
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;

@@ -712,6 +712,7 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
             if (nk) {
                 const int cnt = nk * per;
                 int e0 = 4 * lane, sb = e0 + kk * (P - per), t = per - ent;
+#pragma unroll 2
                 for (; e0 + 3 < cnt; e0 += 256) {
                     typename NisTlVec<T>::v4 v;
                     if constexpr (P == per) { v[0] = stage[sb]; v[1] = stage[sb + 1]; v[2] = stage[sb + 2]; v[3] = stage[sb + 3]; }

@@ -97,8 +97,26 @@ template <> PDDP_HD double tcos<double>(double v) { return cos(v); }
 // ocml's single-precision sincosf (<= 2 units in the last place -- what the reference's device code gets from CUDA's sinf / cosf); double: sincos.  The host instantiations
 // (CPU entry points, the test tool) keep libm's sinf / cosf / sin / cos.  The arm keeps tsin / tcos: its mass-matrix solve amplifies a last-place difference (above).
 template <typename T> PDDP_HD void cf_sincos(T v, T& s, T& c);
+// (round 4, late: ocml's sincosf reduces its argument in DOUBLE on this target -- two conversions and five double-precision operations per call on a chip whose
+// double rate is a quarter of the float rate, plus a Payne-Hanek branch with a 1 KB scratch table that every wave pays for at launch.  The device form is now the
+// branch-free float evaluation the arm's thread-lane kernels use (plant_arm_tl.hpp tl_sincos): two-term Cody-Waite reduction by pi/2 through fused multiply-adds,
+// degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4], ~1 unit in the last place for the few radians an attitude or a pole angle takes.)
+PDDP_HD void cf_sincos_poly(float q, float& s, float& c) {
+    const float k = rintf(q * 0.636619772367581343f);
+    float r = fmaf(k, -1.57079637050628662109375f, q);
+    r = fmaf(k, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+    const int n = static_cast<int>(k) & 3;
+    const float ss = (n & 1) ? cp : sp, cc = (n & 1) ? sp : cp;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
 template <> PDDP_HD void cf_sincos<float>(float v, float& s, float& c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PDDP_CF_TRIG_OCML)
+    cf_sincos_poly(v, s, c);
+#elif defined(__HIP_DEVICE_COMPILE__)
     sincosf(v, &s, &c);
 #else
     s = sinf(v); c = cosf(v);
@@ -107,7 +125,11 @@ template <> PDDP_HD void cf_sincos<float>(float v, float& s, float& c) {
 // cos(2 v) for the quadrotor's inertia terms (dynamics_quad.cuh:60): 2 v is exact in either precision, so the float device form is cosf of the same argument
 template <typename T> PDDP_HD T cf_cos2(T v) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(PDDP_CF_TRIG_OCML)
     if constexpr (sizeof(T) == 4) return cosf(2.0f * v);
+#else
+    if constexpr (sizeof(T) == 4) { float s2, c2; cf_sincos_poly(2.0f * static_cast<float>(v), s2, c2); return c2; }
+#endif
 #endif
     return static_cast<T>(cos(2.0 * v));
 }

@@ -611,7 +611,11 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             const unsigned soK = (unsigned)ks * (unsigned)(NX * NU) * E, sod = (unsigned)ks * (unsigned)NU * E;
             if constexpr (CAB) {
                 if (cx) { mx_bst<T>(rKT, Kp[0], voKT, soK); if (u0 + 1 < NU) mx_bst<T>(rKT, Kp[1], voKT + (unsigned)NX * E, soK); }
-                if (c14) { mx_bst<T>(rdu, Kp[0], vodu, sod); if (u0 + 1 < NU) mx_bst<T>(rdu, Kp[1], vodu + E, sod); }
+                if (c14) {
+                    mx_bst<T>(rdu, Kp[0], vodu, sod);
+                    asm volatile("" ::: "memory");                   // (the two stores of du are adjacent in memory: they must stay TWO instructions, the wait count above counts them)
+                    if (u0 + 1 < NU) mx_bst<T>(rdu, Kp[1], vodu + E, sod);
+                }
             } else if (sc <= NX) {                                    // few problems in flight (reference-layout [A B]): two stores from one address select -- the shorter instruction stream
                 T* q0 = cx ? KTk + u0 * NX + sc : duk + u0;
                 q0[0] = Kp[0];

@@ -347,8 +347,9 @@ __device__ __forceinline__ mx_i4 mx_desc(const void* base) {
     mx_i4 d = {(int)(unsigned)a, (int)(unsigned)(a >> 32), -1, 0x00020000};
     return d;
 }
-constexpr int kMxDmaRegion = 64, kMxDmaBuf = 4 * kMxDmaRegion;        // dwords: regions piece 0 | piece 1 | piece 2 | cost gradient
-__device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 dg, unsigned lane4, unsigned s0, unsigned s1, unsigned s2, unsigned sg) {
+constexpr int kMxDmaRegion = 64, kMxDmaBuf = 5 * kMxDmaRegion;        // dwords: regions piece 0 | piece 1 | piece 2 | cost gradient | (end-effector cost) position block of H
+template <bool HQQ>
+__device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 dg, mx_i4 dh, unsigned lane4, unsigned s0, unsigned s1, unsigned s2, unsigned sg, unsigned sh) {
     const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)buf;
     asm volatile(
         "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s0] offen lds\n\t"
@@ -359,6 +360,8 @@ __device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 d
         :: [l0] "s"(l0), [l1] "s"(l0 + 4u * kMxDmaRegion), [l2] "s"(l0 + 8u * kMxDmaRegion), [l3] "s"(l0 + 12u * kMxDmaRegion), [v] "v"(lane4), [dab] "s"(dab), [dg] "s"(dg),
            [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [sg] "s"(sg)
         : "memory");
+    if constexpr (HQQ)                                                // the knot's 49-float position block (b.Hc; 64 dwords: the over-read stays inside the array's slack)
+        asm volatile("s_mov_b32 m0, %[l4]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dh], %[sh] offen lds" :: [l4] "s"(l0 + 16u * kMxDmaRegion), [v] "v"(lane4), [dh] "s"(dh), [sh] "s"(sh) : "memory");
 }
 // the knot's tile operands from its LDS copy (the selects of mx_load_knot_compact)
 // (aA .. aG: the lane's LDS BYTE addresses inside half 0 of the double buffer, kept opaque so that a knot pays one add per address; half: byte offset of the half)
@@ -401,7 +404,7 @@ __device__ __forceinline__ void mx_lds_knot(MxKnotIn<float, FS, true>& k, unsign
 // HQQ (with DIAGH): the end-effector cost -- the running knots' Hessian is diag(hq1 x 7, hq2 x 7, hr x 7) (nominal-state and control weights) plus the dense 7 x 7 position
 // block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
 // knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
-constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 512 + 256;     // (float handles: two operand buffers + the staging area of [P | p])
+constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 2 * 5 * 64 + 256;     // (float handles: two operand buffers of five 64-dword regions + the staging area of [P | p])
 template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
     static_assert(!HQQ || DIAGH, "the compact position block rides on the diagonal-Hessian path");
@@ -477,6 +480,7 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         for (int r = 0; r < 4; r++) PsiT[r] = (diag[r] && sc <= NX) ? T(1) : T(0);
     }
     MxKnotIn<T, FS, DIAGH> in;
+    T hq0 = T(0), hq1v = T(0);                                        // HQQ: this lane's two entries of the knot's position block
     const T* ABk = AB + (size_t)ks * SZAB; const T* Hk = H + (size_t)ks * SZH; const T* gk = gg + (size_t)ks * NM;   // running block pointers (wave-uniform)
     T* KTk = KT + (size_t)ks * (NX * NU); T* duk = du + (size_t)ks * NU; T* Fk = ApBK + (size_t)ks * SZP; T* Bduk = Bdu + (size_t)ks * NX;
     T* Pk = Pw + (size_t)(ks - 1) * SZP; T* pk = pw + (size_t)(ks - 1) * NX;
@@ -497,9 +501,9 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
     }
     constexpr bool DMA = CAB && sizeof(T) == 4 && PDDP_MX_EXP != 2;   // operand prefetch through LDS (above)
     const float* dmaLds = reinterpret_cast<const float*>(lds) + kMxLds;
-    unsigned aA = 0, aB = 0, aT = 0, aG = 0;
+    unsigned aA = 0, aB = 0, aT = 0, aG = 0, aH = 0;
     int par = 0;
-    mx_i4 dab = {0, 0, 0, 0}, dgg = {0, 0, 0, 0};
+    mx_i4 dab = {0, 0, 0, 0}, dgg = {0, 0, 0, 0}, dhc = {0, 0, 0, 0};
     if constexpr (DMA) {
         const int cc = cx ? sc : NX - 1, uc = cu ? ub : NU - 1;
         const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)dmaLds;
@@ -509,11 +513,16 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         aG = l0 + 4u * (unsigned)(3 * kMxDmaRegion + 2 * g);
         asm volatile("" : "+v"(aA), "+v"(aB), "+v"(aT), "+v"(aG));
         dab = mx_desc(b.ABc + (knot0 >> 6) * kAbcChunk); dgg = mx_desc(gg);
+        if constexpr (HQQ) {
+            aH = l0 + 4u * (unsigned)(4 * kMxDmaRegion + (sc < 7 ? sc : 6) * 7 + (g < 3 ? 2 * g : 5));
+            asm volatile("" : "+v"(aH));
+            dhc = mx_desc(b.Hc + knot0 * 49);
+        }
     }
     auto dma_issue = [&](int knot, int half) {                        // (wave-uniform byte offsets of the knot's four runs)
         const unsigned Gr = krel0 + (unsigned)knot, kk = Gr & 63u, soCh = (Gr >> 6) * (unsigned)(kAbcChunk * 4);
-        mx_dma_knot(dmaLds + half * kMxDmaBuf, dab, dgg, 4u * (unsigned)lane, soCh + kk * 224u, soCh + (unsigned)(abc_piece_off(1) * 4) + kk * 168u,
-                    soCh + (unsigned)(abc_piece_off(2) * 4) + kk * 196u, (unsigned)knot * (unsigned)(NM * 4));
+        mx_dma_knot<HQQ>(dmaLds + half * kMxDmaBuf, dab, dgg, dhc, 4u * (unsigned)lane, soCh + kk * 224u, soCh + (unsigned)(abc_piece_off(1) * 4) + kk * 168u,
+                         soCh + (unsigned)(abc_piece_off(2) * 4) + kk * 196u, (unsigned)knot * (unsigned)(NM * 4), (unsigned)knot * 196u);
     };
     if constexpr (DMA) { if (iterCount >= 0) dma_issue(ks, 0); }
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
@@ -524,6 +533,11 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
                 if (PDDP_MX_EXP == 3 || iter == iterCount) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            // all but the previous knot's four gain stores: this knot's operands are in LDS
                 mx_lds_knot<FS>(in, (unsigned)par * (unsigned)(4 * kMxDmaBuf), aA, aB, aT, aG, g, c, ub, dt);
+                if constexpr (HQQ) {
+                    typedef const float __attribute__((address_space(3))) * lptr;
+                    const lptr pH = (lptr)(size_t)(aH + (unsigned)par * (unsigned)(4 * kMxDmaBuf));
+                    hq0 = pH[0]; hq1v = pH[1];
+                }
                 if (iter > 0) dma_issue(ks - 1, par ^ 1);
                 par ^= 1;
             }
@@ -542,8 +556,12 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             for (int r = 0; r < 4; r++) if (cx) CXX[r] = diag[r] ? (sc < 7 ? hq1 : hq2) : T(0);
             CUU[0] = (cu && u0 == ub) ? hr : T(0); CUU[1] = (cu && u0 + 1 == ub) ? hr : T(0);
             if (HQQ) {                                                // rows 2g, 2g + 1 of column sc of the position block (symmetric: read as column sc, rows 2g..)
-                const T* hk = b.Hc + (knot0 + (size_t)ks) * 49;
-                const typename X::v2u hv = mx_ld<typename X::v2u, T>(hk, (unsigned)((sc < 7 ? sc : 6) * 7 + (g < 3 ? 2 * g : 5)));
+                typename X::v2u hv;
+                if constexpr (DMA) { hv[0] = hq0; hv[1] = hq1v; }     // (prefetched with the knot's other operands)
+                else {
+                    const T* hk = b.Hc + (knot0 + (size_t)ks) * 49;
+                    hv = mx_ld<typename X::v2u, T>(hk, (unsigned)((sc < 7 ? sc : 6) * 7 + (g < 3 ? 2 * g : 5)));
+                }
                 if (sc < 7) { CXX[0] = (g < 3) ? hv[0] : hv[1]; CXX[1] = (g < 3) ? hv[1] : T(0); }
             }
         } else {

@@ -9,7 +9,7 @@
 #ifdef PDDP_MX_WAVES
 #define PDDP_MX_WAVES_OF(CAB, HQQ) PDDP_MX_WAVES
 #else
-#define PDDP_MX_WAVES_OF(CAB, HQQ) ((CAB) && !(HQQ) ? 6 : 5)
+#define PDDP_MX_WAVES_OF(CAB, HQQ) ((CAB) ? 6 : 5)
 #endif
 
 namespace pddp {

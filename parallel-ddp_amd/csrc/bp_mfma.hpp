@@ -16,8 +16,8 @@
 // 4 g + r -- it is at the same time the A operand of X' (.) and the B operand of (.) X.  So for two RB tiles X, Y with a common row index
 //          mfma4(X, Y, C) = C + X' Y        (four instructions, result again an RB tile, rows = columns of X)
 // and the whole knot is written as products of that one form; no operand is ever transposed through LDS or shuffled between lanes:
-//   W_x, W_u = P' [A | B]                                    (= AB2', rows i)                      8 instructions   (6 with the Euler step's compact [A B])
-//   Hxx' = A' W_x + Hxx_cost    Hux = B' W_x + Hux_cost      -Hxu' = (-W_u)' A - Hxu_cost'    Huu = B' W_u + Huu_cost      16       (10)
+//   W_x, W_u = P' [A | B]                                    (= AB2', rows i)                      8 instructions   (4 with the Euler step's compact [A B])
+//   Hxx' = A' W_x + Hxx_cost    Hux = B' W_x + Hux_cost      -Hxu' = (-W_u)' A - Hxu_cost'    Huu = B' W_u + Huu_cost      16       (8)
 //   K    = (Huu^-1')' Hux                                    (rows a)                              2
 //   T1'  = Huu' K - Hxu'                                     (rows b)                              2
 //   P+   = Hxx + T1'' K - K' Hux                             (rows kx: the next knot's P)          4
@@ -25,7 +25,8 @@
 //   Psi' <- G' Psi'   (sweep map of the segment, blocks 0..M-2)                                   4                 (2)
 // Euler step (compact [A B], CAB): the position rows of B are exact zeros and those of A are [I  dt I]; with the positions in registers 0, 1 of every lane a sum
 // over the state rows of B is instructions 2, 3 only, and the position rows' share of A'W and of G'Psi' is W's / Psi''s own registers 0, 1 and dt x them
-// (state 7 + s sits two registers above state s in the same lane): 28-30 matrix instructions per knot instead of 38.  The float32 matrix instruction executes on
+// (state 7 + s sits two registers above state s in the same lane); the position rows' share of P'A and of W_u'A is the position ROWS of P / W_u read as columns, a
+// transposition of two registers per lane through the wave's LDS area (round 4): 24-26 matrix instructions per knot instead of 38.  The float32 matrix instruction executes on
 // the SIMD's float32 lanes -- it excludes the vector instructions of the other resident waves for its 32 cycles (tools/probes/mfma_valu_overlap.hip) -- so every
 // instruction removed, matrix or vector, is launch time removed.
 // The vectors ride along as state index 14 ("column 14" below; tile column 15, mx_state) of the tiles: p is column 14 of P, so g_x = A'p + g_cost, g_u = B'p + g_cost come out as column 14
@@ -43,7 +44,7 @@
 #include "solver_state.hpp"
 
 #ifndef PDDP_MX_EXP
-#define PDDP_MX_EXP 0        // measurement variants (tools/bp_mfma_experiments.sh): 1 no pivots, 2 no loads, 3 no stores, 4 no matrix instructions, 5 no pivot exchanges
+#define PDDP_MX_EXP 0        // measurement variants (tools/bp_exp_times.py, profiles/r04_bp_mfma.md): 1 no pivots, 2 no loads, 3 no stores, 4 no matrix instructions, 5 no pivot exchanges
 #endif
 
 namespace pddp {

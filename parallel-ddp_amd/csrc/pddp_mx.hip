@@ -84,6 +84,28 @@ __global__ __launch_bounds__(64) void k_sweep_maps(Buffers<T> b, Dims dm, int ba
     const int N = dm.N, NBk = dm.NB, l = lane < NX ? lane : NX - 1;
     const T* xcur = b.xb + ((size_t)pb * 2 + st.cur) * N * NX; const T* dcur = b.dcur + (size_t)pb * N * NX;
     T es = T(0), et = T(0);
+    if (dm.M == 4) {                                                             // the usual M: all three segments' operands requested at once (one memory round trip instead of three;
+        constexpr int S = 3;                                                     // the stores between the segments keep the compiler from hoisting the later loads itself); same operations
+        T ph[S][NX + 1], dk[S], base[S];
+#pragma unroll
+        for (int sgm = 0; sgm < S; sgm++) {
+            const T* o = b.segmap + ((size_t)pb * 4 + sgm) * 256;
+            const int k = (sgm + 1) * NBk - 1;
+#pragma unroll
+            for (int cc = 0; cc <= NX; cc++) ph[sgm][cc] = o[cc * 16 + l];
+            dk[sgm] = dcur[(size_t)k * NX + l]; base[sgm] = xcur[(size_t)(k + 1) * NX + l];
+        }
+#pragma unroll
+        for (int sgm = 0; sgm < S; sgm++) {
+            const int k = (sgm + 1) * NBk - 1;
+            T ns = ph[sgm][NX], nt = dk[sgm];
+#pragma unroll
+            for (int cc = 0; cc < NX; cc++) { ns = Mx<T>::fma(ph[sgm][cc], __shfl(es, cc, W), ns); nt = Mx<T>::fma(ph[sgm][cc], __shfl(et, cc, W), nt); }
+            es = ns; et = nt;
+            if (lane < NX) for (int a = 0; a < dm.A; a++) b.xs[(((size_t)pb * dm.A + a) * N + k + 1) * NX + lane] = base[sgm] + (et - b.alpha[a] * es);
+        }
+        return;
+    }
     for (int sgm = 0; sgm < dm.M - 1; sgm++) {
         const T* o = b.segmap + ((size_t)pb * dm.M + sgm) * 256;                   // Psi'(c, l) at [c * 16 + l]
         const int k = (sgm + 1) * NBk - 1;

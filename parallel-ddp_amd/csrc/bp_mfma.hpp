@@ -47,7 +47,26 @@
 #define PDDP_MX_EXP 0        // measurement variants (tools/bp_exp_times.py, profiles/r04_bp_mfma.md): 1 no pivots, 2 no loads, 3 no stores, 4 no matrix instructions, 5 no pivot exchanges
 #endif
 
+#ifndef PDDP_MX_GJ
+#define PDDP_MX_GJ 0         // exchanges of the distributed Gauss-Jordan inversion: 0 = through the LDS crossbar (ds_bpermute, rounds 3-5: the product); measured alternatives of
+#endif                       // round 5 (profiles/r05_bp_exchange.md): 1 = gfx950's v_permlane16_swap / v_permlane32_swap + DPP row_newbcast moves, 2 = the same with the
+                             // pivot-column broadcast folded into v_fmac_f32_dpp, 3 = pivot row through ds_bpermute + v_fmac_f32_dpp.  Same bits in all four (GPU suite green on 1).
+
 namespace pddp {
+
+typedef unsigned mx_w2 __attribute__((ext_vector_type(2)));
+// Cross-lane moves of one 32-bit register that stay on the vector ALU (no LDS round trip, no lgkmcnt wait on the knot's serial chain):
+//   mx_row_of_group<GO>(w): every lane (g, c) receives lane (GO, c)'s value -- the 16-lane row of lane group GO copied over all four rows.  gfx950's
+//     v_permlane16_swap_b32 (vdst's odd rows <-> vsrc's even rows) applied to two copies of w leaves [r0 r0 r2 r2] and [r1 r1 r3 r3]; v_permlane32_swap_b32 (vdst's upper
+//     half <-> vsrc's lower half) on two copies of the one that holds row GO leaves that row everywhere (tools/probes/permlane_swap.hip checks both on the device).
+//   mx_row_bcast<L>(w): every lane receives lane L OF ITS OWN ROW (DPP row_newbcast, gfx90a+).
+template <int GO> __device__ __forceinline__ unsigned mx_row_of_group(unsigned w) {
+    const mx_w2 a = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    const unsigned x = (GO & 1) ? a[1] : a[0];
+    const mx_w2 b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (GO >> 1) ? b[1] : b[0];
+}
+template <int L> __device__ __forceinline__ unsigned mx_row_bcast(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x150 + L, 0xf, 0xf, false); }
 
 // Element-type traits of the tile algebra.  Both 16x16x4 instructions take one A / B element per lane -- lane (g = lane >> 4, c = lane & 15) supplies
 // A[i = c][k = g], B[k = g][j = c] -- and return four accumulator elements per lane in column c; what differs is the ROW of register r:
@@ -79,6 +98,15 @@ template <> struct Mx<float> {
         return r;
     }
     static __device__ __forceinline__ void lanes_arrived(float& a, float& b, float& c, float& before) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(before)); }
+    static __device__ __forceinline__ void lane_arrived(float& a, float& before) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(before)); }
+    template <int GO> static __device__ __forceinline__ float row_of_group(float v) { return __uint_as_float(mx_row_of_group<GO>(__float_as_uint(v))); }
+    template <int L> static __device__ __forceinline__ float row_bcast(float v) { return __uint_as_float(mx_row_bcast<L>(__float_as_uint(v))); }
+    // r - (lane L of r's own 16-lane row) x q as ONE instruction: the broadcast is the DPP control of the fused multiply-add's first operand (VOP2 v_fmac; the same
+    // rounding as fma(-col, q, r)).  s_nop 1: a DPP operand written by the preceding vector instruction needs two wait states (inline asm is not seen by the hazard pass).
+    template <int L> static __device__ __forceinline__ float fnma_row_bcast(float r, float q) {
+        asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(q), "n"(L));
+        return r;
+    }
 };
 template <> struct Mx<double> {
     typedef double v4 __attribute__((ext_vector_type(4)));
@@ -106,6 +134,18 @@ template <> struct Mx<double> {
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
     static __device__ __forceinline__ void lanes_arrived(double& a, double& b, double& c, double& before) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(before)); }
+    static __device__ __forceinline__ void lane_arrived(double& a, double& before) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(before)); }
+    template <int GO> static __device__ __forceinline__ double row_of_group(double v) {
+        const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = mx_row_of_group<GO>((unsigned)w), hi = mx_row_of_group<GO>((unsigned)(w >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    template <int L> static __device__ __forceinline__ double row_bcast(double v) {
+        const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = mx_row_bcast<L>((unsigned)w), hi = mx_row_bcast<L>((unsigned)(w >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    template <int L> static __device__ __forceinline__ double fnma_row_bcast(double r, double q) { return __builtin_fma(-row_bcast<L>(r), q, r); }
 };
 template <typename T> using mx4t = typename Mx<T>::v4;
 
@@ -227,6 +267,30 @@ __device__ __forceinline__ void mx_gj_pivot(T& R0, T& R1, int g, int c4, int g64
     }
     const T src = (PV & 1) ? R1 : R0;
     const T piv = X::readlane(src, 16 * go + mx_pi<T>(PV));
+    if (PDDP_MX_GJ == 1 || PDDP_MX_GJ == 2) {                             // the exchanges on the vector ALU: same values in the same lanes as below, hence the same bits
+        const T rp = X::recip(piv);
+        const T prow = X::template row_of_group<go>(src);                 // the pivot row: lane group go's register, column for column, in every lane group
+        const T q = prow * rp;
+        T n0, n1;
+        if (PDDP_MX_GJ == 2) { n0 = X::template fnma_row_bcast<mx_pi<T>(PV)>(R0, q); n1 = X::template fnma_row_bcast<mx_pi<T>(PV)>(R1, q); }
+        else {
+            const T col0 = X::template row_bcast<mx_pi<T>(PV)>(R0), col1 = X::template row_bcast<mx_pi<T>(PV)>(R1);   // a group's own two pivot-column entries
+            n0 = X::fma(-col0, q, R0); n1 = X::fma(-col1, q, R1);
+        }
+        R0 = (g == go && !(PV & 1)) ? q : n0;
+        R1 = (g == go && (PV & 1)) ? q : n1;
+        return;
+    }
+    if (PDDP_MX_GJ == 3) {                                                // the pivot row through the LDS crossbar, the pivot-column entries as DPP operands of the update
+        T prow = X::template from_lane_off<64 * go>(src, c4);
+        T rp = X::recip(piv);
+        X::lane_arrived(prow, rp);
+        const T q = prow * rp;
+        const T n0 = X::template fnma_row_bcast<mx_pi<T>(PV)>(R0, q), n1 = X::template fnma_row_bcast<mx_pi<T>(PV)>(R1, q);
+        R0 = (g == go && !(PV & 1)) ? q : n0;
+        R1 = (g == go && (PV & 1)) ? q : n1;
+        return;
+    }
     T prow = X::template from_lane_off<64 * go>(src, c4);
     T col0 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R0, g64), col1 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R1, g64);
     T rp = X::recip(piv);                                                  // (issued before the wait: the reciprocal runs while the lanes travel)
@@ -339,8 +403,8 @@ __device__ __forceinline__ void mx_load_knot_compact(MxKnotIn<T, FS, DIAGH>& k, 
 // the NEXT knot's operands into the other half of a double buffer while the current knot computes; the tile operands are then LDS reads (~100 cycles) instead of
 // HBM loads (~2 k cycles) on the wave's serial chain, and -- gfx9's single in-order vmcnt -- the loads are issued BEFORE the knot's stores instead of queueing behind
 // their acknowledgements.  Inline assembly because the compiler's own LDS-DMA bookkeeping waits for EVERY outstanding transfer before any read of the target array
-// (it would wait for the prefetch it just issued); here the wait is explicit: s_waitcnt vmcnt(4) at the top of a knot = everything but the previous knot's four gain
-// stores has landed (the transfers are older than those stores).  Runs are fetched as 64 dwords: the over-read stays inside the arrays (abc_floats' slack; the cost
+// (it would wait for the prefetch it just issued); here the wait is explicit: s_waitcnt vmcnt(n) at the top of a knot, n = the store instructions the previous knot issued
+// behind its prefetch = everything but those stores has landed (the transfers are older than the stores).  Runs are fetched as 64 dwords: the over-read stays inside the arrays (abc_floats' slack; the cost
 // gradient's run is limited to 32 lanes and the loop never reaches the last knot).
 typedef int mx_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mx_i4 mx_desc(const void* base) {
@@ -352,17 +416,19 @@ constexpr int kMxDmaRegion = 64, kMxDmaBuf = 5 * kMxDmaRegion;        // dwords:
 template <bool HQQ>
 __device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 dg, mx_i4 dh, unsigned lane4, unsigned s0, unsigned s1, unsigned s2, unsigned sg, unsigned sh) {
     const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)buf;
+    unsigned keep;                                                    // exec_hi is narrowed for the 21-float cost gradient (32 lanes) and put back as it was
     asm volatile(
         "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s0] offen lds\n\t"
         "s_mov_b32 m0, %[l1]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s1] offen lds\n\t"
         "s_mov_b32 m0, %[l2]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s2] offen lds\n\t"
-        "s_mov_b32 exec_hi, 0\n\ts_mov_b32 m0, %[l3]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dg], %[sg] offen lds\n\t"
-        "s_mov_b32 exec_hi, -1"
-        :: [l0] "s"(l0), [l1] "s"(l0 + 4u * kMxDmaRegion), [l2] "s"(l0 + 8u * kMxDmaRegion), [l3] "s"(l0 + 12u * kMxDmaRegion), [v] "v"(lane4), [dab] "s"(dab), [dg] "s"(dg),
-           [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [sg] "s"(sg)
-        : "memory");
+        "s_mov_b32 %[keep], exec_hi\n\ts_mov_b32 exec_hi, 0\n\ts_mov_b32 m0, %[l3]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dg], %[sg] offen lds\n\t"
+        "s_mov_b32 exec_hi, %[keep]"
+        : [keep] "=&s"(keep)
+        : [l0] "s"(l0), [l1] "s"(l0 + 4u * kMxDmaRegion), [l2] "s"(l0 + 8u * kMxDmaRegion), [l3] "s"(l0 + 12u * kMxDmaRegion), [v] "v"(lane4), [dab] "s"(dab), [dg] "s"(dg),
+          [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [sg] "s"(sg)
+        : "memory", "m0");
     if constexpr (HQQ)                                                // the knot's 49-float position block (b.Hc; 64 dwords: the over-read stays inside the array's slack)
-        asm volatile("s_mov_b32 m0, %[l4]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dh], %[sh] offen lds" :: [l4] "s"(l0 + 16u * kMxDmaRegion), [v] "v"(lane4), [dh] "s"(dh), [sh] "s"(sh) : "memory");
+        asm volatile("s_mov_b32 m0, %[l4]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dh], %[sh] offen lds" :: [l4] "s"(l0 + 16u * kMxDmaRegion), [v] "v"(lane4), [dh] "s"(dh), [sh] "s"(sh) : "memory", "m0");
 }
 // the knot's tile operands from its LDS copy (the selects of mx_load_knot_compact)
 // (aA .. aG: the lane's LDS BYTE addresses inside half 0 of the double buffer, kept opaque so that a knot pays one add per address; half: byte offset of the half)
@@ -405,6 +471,7 @@ __device__ __forceinline__ void mx_lds_knot(MxKnotIn<float, FS, true>& k, unsign
 // HQQ (with DIAGH): the end-effector cost -- the running knots' Hessian is diag(hq1 x 7, hq2 x 7, hr x 7) (nominal-state and control weights) plus the dense 7 x 7 position
 // block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
 // knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
+constexpr int kMxGainStores = 4, kMxCtgStores = 3;                    // store instructions per knot of the prefetching (compact [A B], float) variants: K rows 2g, 2g + 1 and du(2g), du(2g + 1) | [P | p] as 16-byte pieces
 constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 2 * 5 * 64 + 256;     // (float handles: two operand buffers of five 64-dword regions + the staging area of [P | p])
 template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
@@ -531,8 +598,13 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         // as a fifth resident wave per SIMD (95 registers -> 5 waves: 0.53 ms for 4096 problems, against 0.58 ms with prefetch and 4 waves).
         if constexpr (DMA) {
             if constexpr (sizeof(T) == 4) {
+                // This knot's operands are in LDS once everything OLDER than the previous knot's stores has landed: the wait count is the number of store instructions a knot
+                // issues behind its prefetch -- kMxGainStores, plus kMxCtgStores when every knot's cost-to-go is written.  (Until round 5 the count was 4 in both modes: with
+                // every slot written the chain then also sat out the acknowledgements of three gain stores per knot.)  tests/test_isa_invariants.py holds the emitted
+                // loop to these counts: a store merged, split or added by a compiler or an edit fails the CPU suite instead of racing the LDS reads.
                 if (PDDP_MX_EXP == 3 || iter == iterCount) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            // all but the previous knot's four gain stores: this knot's operands are in LDS
+                else if (keepP) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMxGainStores + kMxCtgStores) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMxGainStores) : "memory");
                 mx_lds_knot<FS>(in, (unsigned)par * (unsigned)(4 * kMxDmaBuf), aA, aB, aT, aG, g, c, ub, dt);
                 if constexpr (HQQ) {
                     typedef const float __attribute__((address_space(3))) * lptr;
@@ -625,11 +697,14 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         // ---- gains (computeKTdu :208-220): K(a, kx) | du(a), rows a = 2g + r
         const mx4 Kp = mx_mfma2<T>(InvT, Hux, zero);
         if (PDDP_MX_EXP != 3) {                                       // K row a = 2g + r: 14 elements of KT (lane -> state of its column); du(a) from the lane of the vector column
-            // (buffer stores: the lane's offset is loop-invariant, the knot's a scalar -- FOUR store instructions per knot, which the prefetch's s_waitcnt vmcnt(4) counts on)
+            // (buffer stores: the lane's offset is loop-invariant, the knot's a scalar -- kMxGainStores = FOUR store instructions per knot, which the prefetch's s_waitcnt counts on)
             constexpr unsigned E = (unsigned)sizeof(T);
             const unsigned soK = (unsigned)ks * (unsigned)(NX * NU) * E, sod = (unsigned)ks * (unsigned)NU * E;
             if constexpr (CAB) {
                 if (cx) { mx_bst<T>(rKT, Kp[0], voKT, soK); if (u0 + 1 < NU) mx_bst<T>(rKT, Kp[1], voKT + (unsigned)NX * E, soK); }
+#ifdef PDDP_MX_TEST_EXTRA_STORE                                       // (tests/test_isa_invariants.py: a fifth gain store on purpose must turn the check red)
+                if (c14) mx_bst<T>(rdu, Kp[1], vodu, sod);
+#endif
                 if (c14) {
                     mx_bst<T>(rdu, Kp[0], vodu, sod);
                     asm volatile("" ::: "memory");                   // (the two stores of du are adjacent in memory: they must stay TWO instructions, the wait count above counts them)

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """profiles/roofline_traffic.json and profiles/<name>/summary.md from the counter passes of tools/pmc_pass.sh (gpurun_out/pmc_<tag>).
-usage: tools/make_traffic_json.py <tag> <profiles subdir> <batch>
+usage: tools/make_traffic_json.py <tag> <profiles subdir> <batch> [handle options: "library defaults" | "lean"]
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the factor 2 on FETCH_SIZE is the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md "HBM": rocprofv3 tallies 128-byte read requests as 64 bytes)."""
 import collections, csv, glob, json, os, statistics, sys
 tag, sub, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+handle_options = sys.argv[4] if len(sys.argv) > 4 else "library defaults"     # "lean" for passes taken with bench.py --lean-ctg
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "pmc_" + tag)
 d = collections.defaultdict(list)
@@ -15,7 +16,7 @@ for f in sorted(glob.glob(src + "/*/run_counter_collection.csv")):
             d[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kern = sorted({k for k, _ in d})
 m = lambda k, c: statistics.mean(d[(k, c)]) if (k, c) in d else None
-out = {"batch": batch, "source": f"profiles/{sub} (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of `python bench.py --no-cpu-baseline --no-latency --no-convergence --no-default-options --steps 20`)", "kernels": {}}
+out = {"batch": batch, "handle_options": handle_options, "source": f"profiles/{sub} (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of `python bench.py --no-cpu-baseline --no-latency --no-convergence --no-lean-row --steps 20`)", "kernels": {}}
 lines = ["# Counter passes (rocprofv3 --pmc, kernel-trace only) of the bench sweep, per kernel, averages per launch", "",
          "| kernel | HBM read MB (2 x FETCH_SIZE) | HBM write MB | VALU instr / wave | MFMA instr / wave | VALU-active share of wave time | waiting on memory (s_waitcnt) | issue stalls | MFMA pipe busy share |",
          "|---|---|---|---|---|---|---|---|---|"]

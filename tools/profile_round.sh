@@ -4,7 +4,7 @@
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python $ROOT/bench.py --no-cpu-baseline --no-latency --no-convergence --no-default-options > $OUT/bench_under_rocprof.log 2>&1
+timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python $ROOT/bench.py --no-cpu-baseline --no-latency --no-convergence --no-lean-row > $OUT/bench_under_rocprof.log 2>&1
 cp $OUT/trace/run_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace
 cd $ROOT && python bench.py > $OUT/bench_full.log 2>&1; grep "^{" $OUT/bench_full.log | tail -1 > $OUT/bench_line.json

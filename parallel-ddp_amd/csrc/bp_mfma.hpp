@@ -603,7 +603,11 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
                 // every slot written the chain then also sat out the acknowledgements of three gain stores per knot.)  tests/test_isa_invariants.py holds the emitted
                 // loop to these counts: a store merged, split or added by a compiler or an edit fails the CPU suite instead of racing the LDS reads.
                 if (PDDP_MX_EXP == 3 || iter == iterCount) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PDDP_MX_CTG_WAIT                                               // (measurement variant: -DPDDP_MX_CTG_WAIT=4 is round 4's count)
+                else if (keepP) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PDDP_MX_CTG_WAIT) : "memory");
+#else
                 else if (keepP) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMxGainStores + kMxCtgStores) : "memory");
+#endif
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMxGainStores) : "memory");
                 mx_lds_knot<FS>(in, (unsigned)par * (unsigned)(4 * kMxDmaBuf), aA, aB, aT, aG, g, c, ub, dt);
                 if constexpr (HQQ) {

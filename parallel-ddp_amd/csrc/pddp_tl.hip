@@ -27,13 +27,14 @@ namespace pddp {
 // instruction instead of 8 bytes 88 bytes apart (one memory transaction per LANE and store).  The record of knot k is complete right after the control law of step k
 // (the state is the rollout's current one), when the step's operands in LDS have been consumed: the staging area overlays them (both operand buffers are dead between
 // the control law and the end-of-step park()).  cur: this lane's record of the current knot; a: its candidate index.
+// (every method forced inline: left to the inliner's cost model, a larger caller turns xu() into a CALL, which parks the whole rollout state in scratch -- round 5)
 template <typename T> struct TlStagedSink {
     typedef T v4 __attribute__((ext_vector_type(4)));
     T* ds; mutable T* cur; int stride; T* stg; int lane, a, A;
-    __device__ void x(int, const T*) const {}
-    __device__ void u(int, const T*) const {}
-    __device__ void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
-    __device__ void xu(int, const T* xv, const T* uv) const {
+    __device__ __forceinline__ void x(int, const T*) const {}
+    __device__ __forceinline__ void u(int, const T*) const {}
+    __device__ __forceinline__ void d(int k, const T* v) const { tl_store14(ds + (size_t)k * 14, v); }
+    __device__ __forceinline__ void xu(int, const T* xv, const T* uv) const {
         wsync();
         T* rec = stg + lane * 22;
         tl_store14(rec, xv); tl_store7(rec + 14, uv);
@@ -45,7 +46,7 @@ template <typename T> struct TlStagedSink {
         if (2 * a < A) *reinterpret_cast<v4*>(dst + step * 5) = *reinterpret_cast<const v4*>(src + step * 5);
         cur += stride;
     }
-    __device__ void xu_last(int, const T* xv, const T* uv) const { tl_store14(cur, xv); tl_store7(cur + 14, uv); }
+    __device__ __forceinline__ void xu_last(int, const T* xv, const T* uv) const { tl_store14(cur, xv); tl_store7(cur + 14, uv); }
 };
 constexpr int kFpTlPS = 132;                 // floats per staged pair: K 98 | xr 14 | uc 7 | du 7 | pad 6
 constexpr int kFpTlMaxPairs = 8;             // pairs per wave (A >= 8; smaller A takes the unstaged path)
@@ -612,6 +613,9 @@ void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
 //   !CAB:          the reference layout, whole 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
 // double handles (PDDP_FP=tl: test selection) run the same code with two waves per workgroup.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
 constexpr int kNisTlStage = 64 * 57;
+#ifndef PDDP_NIS_TL_PARK
+#define PDDP_NIS_TL_PARK 0
+#endif
 template <typename T> struct NisTlCfg { static constexpr int kWaves = sizeof(T) == 4 ? 4 : 2, kThreads = 64 * kWaves; };   // double: two waves per workgroup (58 KB of staging)
 template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); typedef T v4p __attribute__((ext_vector_type(16 / sizeof(T)), aligned(16))); };   // v4p: one 16-byte piece
 template <typename T, int V, bool EE, bool CAB>
@@ -621,6 +625,11 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
     const int g = blockIdx.x * NisTlCfg<T>::kThreads + threadIdx.x, total = batch * dm.N;
     const int pb = g / dm.N, k = g - pb * dm.N;
     __shared__ __attribute__((aligned(16))) T stage_all[NisTlCfg<T>::kWaves * kNisTlStage];
+    // float handles: the 21 entries of the mass matrix's unit lower factor are parked in LDS between the groups of solves (entry-major: a wave's 64 lanes read 64 consecutive
+    // words) -- 21.5 KB per workgroup, with the staging 79.9 KB: two workgroups still share a compute unit's 160 KB.  The kernel needs every one of its 256 registers; the
+    // factor is idle between the eight places that solve with it (round 5, profiles/r05_tl_pruning.md).
+    constexpr bool PARK = PDDP_NIS_TL_PARK && sizeof(T) == 4;
+    __shared__ T lpark[PARK ? 21 * NisTlCfg<T>::kThreads : 1];
     T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
     const int lane = threadIdx.x & 63;
     T x[NX], u[7];
@@ -748,7 +757,8 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
         }
         wsync();
     };
-    arm_tl_nis_jac<T>(md, grav, x, u, emit, flush);
+    if constexpr (PARK) arm_tl_nis_jac_parked<T>(md, grav, x, u, emit, flush, lpark + threadIdx.x, NisTlCfg<T>::kThreads);
+    else arm_tl_nis_jac<T>(md, grav, x, u, emit, flush);
 }
 
 // k_nis_tl7: grid (ceil(B*N / 64), 7), block 64.  Next-iteration setup of a handle with FEW problems in flight (one MPC solve: 127 knots on a 256-CU device):

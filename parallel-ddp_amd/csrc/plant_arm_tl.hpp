@@ -34,7 +34,32 @@
 #pragma clang fp contract(fast)
 #endif
 
+// A fence for the instruction scheduler (device code only): nothing is moved across it.  The gradient below is ONE basic block of ~4 k instructions; left alone the
+// scheduler may interleave neighbouring levels of its sweep.  Measured (tools/tl_probe.py, round 5): fencing the levels does NOT lower the pressure -- k_nis_tl spills 39
+// registers with the fences, 30 without: the live state of ONE level is what does not fit -- so the knob is off; it stays for the next compiler.
+#ifndef PDDP_TL_FENCE
+#define PDDP_TL_FENCE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PDDP_TL_FENCE
+#define PDDP_TL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PDDP_TL_SCHED_FENCE() ((void)0)
+#endif
+
+#ifndef PDDP_TL_OPAQUE
+#define PDDP_TL_OPAQUE 1
+#endif
+
 namespace pddp {
+
+// hides a value's provenance from the optimiser (device code; the host build has registers to spare)
+template <typename T> PDDP_HD void tl_opaque(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
 
 // Joint-frame classes of the iiwa14 chain (validated against the loaded model on the host: arm_tl_model_from_tables).
 //   rotation of F_i:  ID = identity;  A = [-x, z, y] (columns -e_x, e_z, e_y);  B = [x, z, -y] (columns e_x, e_z, -e_y)
@@ -107,6 +132,30 @@ inline bool arm_tl_model_from_tables(ArmTlModel<T>& o, const ArmModel<T>& t) {
     return ok;
 }
 
+// ------------------------------------------------------------------------------------------------ exact-zero pruning (round 5)
+// A third of the robot constants are exact zeros (links 0, 2, 3, 5 of both models: first moment h_x, products of inertia I_xy, I_xz; the base does not move, so link 0's
+// inboard velocity and all of its inboard acceleration but gravity are zeros too), and with the model a constant expression they reach the arithmetic as literals -- but
+// IEEE semantics keep `0 * x + y` alive (x might be an infinity or a NaN, y a negative zero): the compiler deletes those terms only under -ffinite-math-only
+// -fno-signed-zeros, which was measured at -12 % / -15 % static vector instructions on the rollout / setup kernels and lost again to the spills the flags' other
+// rewrites caused (profiles/r04*: "finite-math build: not adopted").  TlZ does the deletion in SOURCE instead, for the zeros only: a product with an operand that the
+// optimiser has proven to be the constant zero IS the constant zero, a sum with it is the other operand.  Finite inputs give the same value as the full expression
+// (up to the sign of a zero result); everything else about the arithmetic -- operation order, the fused multiply-adds of this header -- is untouched.
+// __builtin_constant_p is resolved after inlining and scalar replacement (llvm.is.constant), so a zero is seen wherever the literal ends up, also through the
+// callers' arrays; a value that is not a compile-time zero takes the plain operation.
+#ifndef PDDP_TLZ_MASK
+#define PDDP_TLZ_MASK 31       // which groups of routines prune (measurement knob, tools/tlz_variants.sh): 1 frame changes / inertia products, 2 inertia and rotation transports,
+#endif                         // 4 the gradient's composite sweep, 8 the triangular solves, 16 link accelerations
+template <typename T, bool ON = true> struct TlZ {
+    T v;
+    PDDP_HD TlZ() : v(T(0)) {}
+    PDDP_HD TlZ(T x) : v(x) {}
+    PDDP_HD bool zero() const { return ON && __builtin_constant_p(v) && v == T(0); }
+};
+template <typename T, bool ON> PDDP_HD TlZ<T, ON> operator*(TlZ<T, ON> a, TlZ<T, ON> b) { return (a.zero() || b.zero()) ? TlZ<T, ON>(T(0)) : TlZ<T, ON>(a.v * b.v); }
+template <typename T, bool ON> PDDP_HD TlZ<T, ON> operator+(TlZ<T, ON> a, TlZ<T, ON> b) { return a.zero() ? b : b.zero() ? a : TlZ<T, ON>(a.v + b.v); }
+template <typename T, bool ON> PDDP_HD TlZ<T, ON> operator-(TlZ<T, ON> a, TlZ<T, ON> b) { return b.zero() ? a : a.zero() ? TlZ<T, ON>(-b.v) : TlZ<T, ON>(a.v - b.v); }
+template <typename T, bool ON> PDDP_HD TlZ<T, ON> operator-(TlZ<T, ON> a) { return a.zero() ? TlZ<T, ON>(T(0)) : TlZ<T, ON>(-a.v); }
+
 // ------------------------------------------------------------------------------------------------ frame changes (compile-time kind)
 // parent coordinates -> stage-1 child coordinates (before the joint rotation): w1 = R_F' w
 template <int KIND, typename T> PDDP_HD void tl_to_child_axes(T* o, const T* w) {
@@ -122,70 +171,90 @@ template <int KIND, typename T> PDDP_HD void tl_to_parent_axes(T* o, const T* w1
 }
 // motion vector [w; v] of the parent frame -> child frame:  w_c = Rz' R_F' w,  v_c = Rz' R_F' (v + w x r)
 template <int KIND, typename T> PDDP_HD void tl_motion_to_child(T* o, const T* mv, T r, T c, T s) {
-    T vv[3] = {mv[3], mv[4], mv[5]};
-    if (KIND == kTlAY) { vv[0] = vv[0] - mv[2] * r; vv[2] = vv[2] + mv[0] * r; }         // w x (0, r, 0) = (-wz r, 0, wx r)
-    else { vv[0] = vv[0] + mv[1] * r; vv[1] = vv[1] - mv[0] * r; }                       // w x (0, 0, r) = (wy r, -wx r, 0)
-    T w1[3], v1[3];
-    tl_to_child_axes<KIND>(w1, mv); tl_to_child_axes<KIND>(v1, vv);
-    o[0] = c * w1[0] + s * w1[1]; o[1] = c * w1[1] - s * w1[0]; o[2] = w1[2];
-    o[3] = c * v1[0] + s * v1[1]; o[4] = c * v1[1] - s * v1[0]; o[5] = v1[2];
+    typedef TlZ<T, (PDDP_TLZ_MASK & 1) != 0> Z;
+    const Z m0(mv[0]), m1(mv[1]), m2(mv[2]), rz(r), cz(c), sz(s);
+    Z vv[3] = {Z(mv[3]), Z(mv[4]), Z(mv[5])};
+    if (KIND == kTlAY) { vv[0] = vv[0] - m2 * rz; vv[2] = vv[2] + m0 * rz; }             // w x (0, r, 0) = (-wz r, 0, wx r)
+    else { vv[0] = vv[0] + m1 * rz; vv[1] = vv[1] - m0 * rz; }                           // w x (0, 0, r) = (wy r, -wx r, 0)
+    Z w1[3] = {m0, m1, m2}, v1[3] = {vv[0], vv[1], vv[2]};
+    if (KIND == kTlBZ) { w1[1] = m2; w1[2] = -m1; v1[1] = vv[2]; v1[2] = -vv[1]; }
+    else if (KIND != kTlIdZ) { w1[0] = -m0; w1[1] = m2; w1[2] = m1; v1[0] = -vv[0]; v1[1] = vv[2]; v1[2] = vv[1]; }
+    o[0] = (cz * w1[0] + sz * w1[1]).v; o[1] = (cz * w1[1] - sz * w1[0]).v; o[2] = w1[2].v;
+    o[3] = (cz * v1[0] + sz * v1[1]).v; o[4] = (cz * v1[1] - sz * v1[0]).v; o[5] = v1[2].v;
 }
 // force vector [n; f] of the child frame -> parent frame:  f_p = R_F Rz f,  n_p = R_F Rz n + r x f_p
 template <int KIND, typename T> PDDP_HD void tl_force_to_parent(T* o, const T* fv, T r, T c, T s) {
-    const T n1[3] = {c * fv[0] - s * fv[1], s * fv[0] + c * fv[1], fv[2]};
-    const T f1[3] = {c * fv[3] - s * fv[4], s * fv[3] + c * fv[4], fv[5]};
-    tl_to_parent_axes<KIND>(o, n1); tl_to_parent_axes<KIND>(o + 3, f1);
-    if (KIND == kTlAY) { o[0] = o[0] + r * o[5]; o[2] = o[2] - r * o[3]; }                // (0, r, 0) x f = (r fz, 0, -r fx)
-    else { o[0] = o[0] - r * o[4]; o[1] = o[1] + r * o[3]; }                             // (0, 0, r) x f = (-r fy, r fx, 0)
+    typedef TlZ<T, (PDDP_TLZ_MASK & 1) != 0> Z;
+    const Z cz(c), sz(s), rz(r), f0(fv[0]), f1(fv[1]), f3(fv[3]), f4(fv[4]);
+    const Z n1[3] = {cz * f0 - sz * f1, sz * f0 + cz * f1, Z(fv[2])};
+    const Z g1[3] = {cz * f3 - sz * f4, sz * f3 + cz * f4, Z(fv[5])};
+    Z p[6];
+    if (KIND == kTlIdZ) { p[0] = n1[0]; p[1] = n1[1]; p[2] = n1[2]; p[3] = g1[0]; p[4] = g1[1]; p[5] = g1[2]; }
+    else if (KIND == kTlBZ) { p[0] = n1[0]; p[1] = -n1[2]; p[2] = n1[1]; p[3] = g1[0]; p[4] = -g1[2]; p[5] = g1[1]; }
+    else { p[0] = -n1[0]; p[1] = n1[2]; p[2] = n1[1]; p[3] = -g1[0]; p[4] = g1[2]; p[5] = g1[1]; }
+    if (KIND == kTlAY) { p[0] = p[0] + rz * p[5]; p[2] = p[2] - rz * p[3]; }              // (0, r, 0) x f = (r fz, 0, -r fx)
+    else { p[0] = p[0] - rz * p[4]; p[1] = p[1] + rz * p[3]; }                           // (0, 0, r) x f = (-r fy, r fx, 0)
+#pragma unroll
+    for (int e = 0; e < 6; e++) o[e] = p[e].v;
 }
 // rigid-body inertia (m, h, I: xx yy zz xy xz yz) of the child frame, expressed in the parent frame, ADDED to (mp, hp, Ip)
 template <int KIND, typename T> PDDP_HD void tl_inertia_add_to_parent(T& mp, T* hp, T* Ip, T m, const T* h, const T* I, T r, T c, T s) {
+    typedef TlZ<T, (PDDP_TLZ_MASK & 2) != 0> Z;
+    const Z cz(c), sz(s), rz(r), mz(m), h0(h[0]), h1v(h[1]), I0(I[0]), I1(I[1]), I3(I[3]), I4(I[4]), I5(I[5]);
     // rotate about z: h1 = Rz h, I1 = Rz I Rz'
-    const T h1[3] = {c * h[0] - s * h[1], s * h[0] + c * h[1], h[2]};
-    const T cc = c * c, ss = s * s, cs = c * s;
-    const T d = I[0] - I[1];
-    const T xx = cc * I[0] + ss * I[1] - (cs + cs) * I[3];
-    const T yy = ss * I[0] + cc * I[1] + (cs + cs) * I[3];
-    const T xy = cs * d + (cc - ss) * I[3];
-    const T xz = c * I[4] - s * I[5], yz = s * I[4] + c * I[5], zz = I[2];
+    const Z h1[3] = {cz * h0 - sz * h1v, sz * h0 + cz * h1v, Z(h[2])};
+    const Z cc = cz * cz, ss = sz * sz, cs = cz * sz;
+    const Z d = I0 - I1;
+    const Z xx = cc * I0 + ss * I1 - (cs + cs) * I3;
+    const Z yy = ss * I0 + cc * I1 + (cs + cs) * I3;
+    const Z xy = cs * d + (cc - ss) * I3;
+    const Z xz = cz * I4 - sz * I5, yz = sz * I4 + cz * I5, zz(I[2]);
     // axis permutation R_F
-    T h2[3], J[6];
-    tl_to_parent_axes<KIND>(h2, h1);
-    if (KIND == kTlIdZ) { J[0] = xx; J[1] = yy; J[2] = zz; J[3] = xy; J[4] = xz; J[5] = yz; }
-    else if (KIND == kTlBZ) { J[0] = xx; J[1] = zz; J[2] = yy; J[3] = -xz; J[4] = xy; J[5] = -yz; }      // x' = x, y' = -z, z' = y
-    else { J[0] = xx; J[1] = zz; J[2] = yy; J[3] = -xz; J[4] = -xy; J[5] = yz; }                         // x' = -x, y' = z, z' = y
+    Z h2[3], J[6];
+    if (KIND == kTlIdZ) { h2[0] = h1[0]; h2[1] = h1[1]; h2[2] = h1[2]; J[0] = xx; J[1] = yy; J[2] = zz; J[3] = xy; J[4] = xz; J[5] = yz; }
+    else if (KIND == kTlBZ) { h2[0] = h1[0]; h2[1] = -h1[2]; h2[2] = h1[1]; J[0] = xx; J[1] = zz; J[2] = yy; J[3] = -xz; J[4] = xy; J[5] = -yz; }      // x' = x, y' = -z, z' = y
+    else { h2[0] = -h1[0]; h2[1] = h1[2]; h2[2] = h1[1]; J[0] = xx; J[1] = zz; J[2] = yy; J[3] = -xz; J[4] = -xy; J[5] = yz; }                         // x' = -x, y' = z, z' = y
     // shift the reference point by r along y (AY) or z: I_p = I' - (r h' + h r') + 2 (h.r) 1 - m (r r' - r.r 1)
-    const T mr = m * r;
+    const Z mr = mz * rz;
+    Z Q[6] = {Z(Ip[0]), Z(Ip[1]), Z(Ip[2]), Z(Ip[3]), Z(Ip[4]), Z(Ip[5])}, g[3] = {Z(hp[0]), Z(hp[1]), Z(hp[2])};
     if (KIND == kTlAY) {
-        const T t = (h2[1] + h2[1]) * r + mr * r;
-        Ip[0] += J[0] + t; Ip[1] += J[1]; Ip[2] += J[2] + t; Ip[3] += J[3] - r * h2[0]; Ip[4] += J[4]; Ip[5] += J[5] - r * h2[2];
-        hp[0] += h2[0]; hp[1] += h2[1] + mr; hp[2] += h2[2];
+        const Z t = (h2[1] + h2[1]) * rz + mr * rz;
+        Q[0] = Q[0] + (J[0] + t); Q[1] = Q[1] + J[1]; Q[2] = Q[2] + (J[2] + t); Q[3] = Q[3] + (J[3] - rz * h2[0]); Q[4] = Q[4] + J[4]; Q[5] = Q[5] + (J[5] - rz * h2[2]);
+        g[0] = g[0] + h2[0]; g[1] = g[1] + (h2[1] + mr); g[2] = g[2] + h2[2];
     } else {
-        const T t = (h2[2] + h2[2]) * r + mr * r;
-        Ip[0] += J[0] + t; Ip[1] += J[1] + t; Ip[2] += J[2]; Ip[3] += J[3]; Ip[4] += J[4] - r * h2[0]; Ip[5] += J[5] - r * h2[1];
-        hp[0] += h2[0]; hp[1] += h2[1]; hp[2] += h2[2] + mr;
+        const Z t = (h2[2] + h2[2]) * rz + mr * rz;
+        Q[0] = Q[0] + (J[0] + t); Q[1] = Q[1] + (J[1] + t); Q[2] = Q[2] + J[2]; Q[3] = Q[3] + J[3]; Q[4] = Q[4] + (J[4] - rz * h2[0]); Q[5] = Q[5] + (J[5] - rz * h2[1]);
+        g[0] = g[0] + h2[0]; g[1] = g[1] + h2[1]; g[2] = g[2] + (h2[2] + mr);
     }
-    mp += m;
+#pragma unroll
+    for (int e = 0; e < 6; e++) Ip[e] = Q[e].v;
+#pragma unroll
+    for (int e = 0; e < 3; e++) hp[e] = g[e].v;
+    mp = (Z(mp) + mz).v;
 }
 // f = I_spatial [w; v] = [I w + h x v ; m v - h x w]
 template <typename T> PDDP_HD void tl_inertia_mul(T* o, T m, const T* h, const T* I, const T* mv) {
-    const T* w = mv; const T* v = mv + 3;
-    o[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2] + (h[1] * v[2] - h[2] * v[1]);
-    o[1] = I[3] * w[0] + I[1] * w[1] + I[5] * w[2] + (h[2] * v[0] - h[0] * v[2]);
-    o[2] = I[4] * w[0] + I[5] * w[1] + I[2] * w[2] + (h[0] * v[1] - h[1] * v[0]);
-    o[3] = m * v[0] - (h[1] * w[2] - h[2] * w[1]);
-    o[4] = m * v[1] - (h[2] * w[0] - h[0] * w[2]);
-    o[5] = m * v[2] - (h[0] * w[1] - h[1] * w[0]);
+    typedef TlZ<T, (PDDP_TLZ_MASK & 1) != 0> Z;
+    const Z w[3] = {Z(mv[0]), Z(mv[1]), Z(mv[2])}, v[3] = {Z(mv[3]), Z(mv[4]), Z(mv[5])};
+    const Z hz[3] = {Z(h[0]), Z(h[1]), Z(h[2])}, J[6] = {Z(I[0]), Z(I[1]), Z(I[2]), Z(I[3]), Z(I[4]), Z(I[5])}, mz(m);
+    o[0] = (J[0] * w[0] + J[3] * w[1] + J[4] * w[2] + (hz[1] * v[2] - hz[2] * v[1])).v;
+    o[1] = (J[3] * w[0] + J[1] * w[1] + J[5] * w[2] + (hz[2] * v[0] - hz[0] * v[2])).v;
+    o[2] = (J[4] * w[0] + J[5] * w[1] + J[2] * w[2] + (hz[0] * v[1] - hz[1] * v[0])).v;
+    o[3] = (mz * v[0] - (hz[1] * w[2] - hz[2] * w[1])).v;
+    o[4] = (mz * v[1] - (hz[2] * w[0] - hz[0] * w[2])).v;
+    o[5] = (mz * v[2] - (hz[0] * w[1] - hz[1] * w[0])).v;
 }
 // o += v x* f   (spatial force cross product: [w x n + v x f ; w x f])
 template <typename T> PDDP_HD void tl_crf_add(T* o, const T* mv, const T* fv) {
-    const T* w = mv; const T* v = mv + 3; const T* n = fv; const T* f = fv + 3;
-    o[0] += (w[1] * n[2] - w[2] * n[1]) + (v[1] * f[2] - v[2] * f[1]);
-    o[1] += (w[2] * n[0] - w[0] * n[2]) + (v[2] * f[0] - v[0] * f[2]);
-    o[2] += (w[0] * n[1] - w[1] * n[0]) + (v[0] * f[1] - v[1] * f[0]);
-    o[3] += w[1] * f[2] - w[2] * f[1];
-    o[4] += w[2] * f[0] - w[0] * f[2];
-    o[5] += w[0] * f[1] - w[1] * f[0];
+    typedef TlZ<T, (PDDP_TLZ_MASK & 1) != 0> Z;
+    const Z w[3] = {Z(mv[0]), Z(mv[1]), Z(mv[2])}, v[3] = {Z(mv[3]), Z(mv[4]), Z(mv[5])};
+    const Z n[3] = {Z(fv[0]), Z(fv[1]), Z(fv[2])}, f[3] = {Z(fv[3]), Z(fv[4]), Z(fv[5])};
+    o[0] = (Z(o[0]) + ((w[1] * n[2] - w[2] * n[1]) + (v[1] * f[2] - v[2] * f[1]))).v;
+    o[1] = (Z(o[1]) + ((w[2] * n[0] - w[0] * n[2]) + (v[2] * f[0] - v[0] * f[2]))).v;
+    o[2] = (Z(o[2]) + ((w[0] * n[1] - w[1] * n[0]) + (v[0] * f[1] - v[1] * f[0]))).v;
+    o[3] = (Z(o[3]) + (w[1] * f[2] - w[2] * f[1])).v;
+    o[4] = (Z(o[4]) + (w[2] * f[0] - w[0] * f[2])).v;
+    o[5] = (Z(o[5]) + (w[0] * f[1] - w[1] * f[0])).v;
 }
 
 template <typename T> PDDP_HD void tl_sincos(T q, T& s, T& c);
@@ -216,18 +285,28 @@ struct ArmTlState {
 };
 
 // solve M x = b in place with the stored factors
-template <typename T> PDDP_HD void tl_ldl_solve(const ArmTlState<T>& st, T* x) {
+template <typename T> PDDP_HD void tl_ldl_solve(const T* L, const T* Dinv, T* x) {
+    typedef TlZ<T, (PDDP_TLZ_MASK & 8) != 0> Z;                    // (a unit right-hand side -- the control columns, M^-1 e_j -- skips the multiplications by its leading zeros)
 #pragma unroll
     for (int i = 1; i < kArmNB; i++)
 #pragma unroll
-        for (int j = 0; j < i; j++) x[i] -= st.L[i * (i - 1) / 2 + j] * x[j];
+        for (int j = 0; j < i; j++) x[i] = (Z(x[i]) - Z(L[i * (i - 1) / 2 + j]) * Z(x[j])).v;
 #pragma unroll
-    for (int i = 0; i < kArmNB; i++) x[i] *= st.Dinv[i];
+    for (int i = 0; i < kArmNB; i++) x[i] = (Z(x[i]) * Z(Dinv[i])).v;
 #pragma unroll
     for (int i = kArmNB - 2; i >= 0; i--)
 #pragma unroll
-        for (int j = i + 1; j < kArmNB; j++) x[i] -= st.L[j * (j - 1) / 2 + i] * x[j];
+        for (int j = i + 1; j < kArmNB; j++) x[i] = (Z(x[i]) - Z(L[j * (j - 1) / 2 + i]) * Z(x[j])).v;
 }
+template <typename T> PDDP_HD void tl_ldl_solve(const ArmTlState<T>& st, T* x) { tl_ldl_solve<T>(st.L, st.Dinv, x); }
+// Where the gradient takes the unit lower factor from when it solves: TlFactorsInState = the evaluation's own registers (st.L); the setup kernel parks the 21 numbers in
+// LDS after the factorisation and passes an accessor that reads them back for each group of solves (k_nis_tl, pddp_tl.hip) -- they are idle between the eight groups.
+struct TlFactorsInState {
+    template <typename T> PDDP_HD void operator()(const ArmTlState<T>& st, T* L) const {
+#pragma unroll
+        for (int e = 0; e < 21; e++) L[e] = st.L[e];
+    }
+};
 
 // compile-time loop over the links with their frame kind as a template argument
 template <int I, int END, int STEP> struct TlFor {
@@ -256,12 +335,13 @@ PDDP_HD void arm_tl_bias(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st, con
             constexpr int i = decltype(ic)::value;
             constexpr int K = arm_tl_kind(i);
             T* v = st.v[i];
+            typedef TlZ<T, (PDDP_TLZ_MASK & 16) != 0> Z;
             tl_motion_to_child<K>(v, vp, md.r[i], st.c[i], st.s[i]);
-            v[2] += qd[i];
+            v[2] = (Z(v[2]) + Z(qd[i])).v;
             T an[6];
             tl_motion_to_child<K>(an, a, md.r[i], st.c[i], st.s[i]);
-            an[0] += qd[i] * v[1]; an[1] -= qd[i] * v[0];              // v x (e_z qd): [w x e_z; vl x e_z] qd
-            an[3] += qd[i] * v[4]; an[4] -= qd[i] * v[3];
+            an[0] = (Z(an[0]) + Z(qd[i]) * Z(v[1])).v; an[1] = (Z(an[1]) - Z(qd[i]) * Z(v[0])).v;              // v x (e_z qd): [w x e_z; vl x e_z] qd
+            an[3] = (Z(an[3]) + Z(qd[i]) * Z(v[4])).v; an[4] = (Z(an[4]) - Z(qd[i]) * Z(v[3])).v;
             T Iv[6];
             tl_inertia_mul(f[i], md.m[i], md.h[i], md.I[i], an);
             tl_inertia_mul(Iv, md.m[i], md.h[i], md.I[i], v);
@@ -285,26 +365,18 @@ PDDP_HD void arm_tl_bias(const ArmTlModel<T>& md, T grav, ArmTlState<T>& st, con
 template <typename T>
 PDDP_HD void arm_tl_factor(const ArmTlModel<T>& md, ArmTlState<T>& st) {
     constexpr int NB = kArmNB;
-    // ---- composite rigid bodies and the mass matrix (lower triangle, row-major M[i(i+1)/2 + j])
+    // ---- composite rigid bodies and the mass matrix (lower triangle, row-major M[i(i+1)/2 + j]) in ONE inward sweep: when level i is reached the composite of the links
+    //      i..6 is complete in frame i; its column of M is read off (F = Ic_i e_z carried to the frames j < i) and the composite moves into link i - 1's frame on top of that
+    //      link's own inertia.  Only two composites are ever live (until round 5 all seven were kept for a second loop over the columns: 70 numbers at the peak of the
+    //      rollout kernel's register pressure); the operations and their order per element are the same.
     T M[28];
     {
-        T cm[NB], ch[NB][3], cI[NB][6];
-#pragma unroll
-        for (int i = 0; i < NB; i++) {
-            cm[i] = md.m[i];
-#pragma unroll
-            for (int e = 0; e < 3; e++) ch[i][e] = md.h[i][e];
-#pragma unroll
-            for (int e = 0; e < 6; e++) cI[i][e] = md.I[i][e];
-        }
-        TlFor<NB - 1, 0, -1>::run([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            tl_inertia_add_to_parent<arm_tl_kind(i)>(cm[i - 1], ch[i - 1], cI[i - 1], cm[i], ch[i], cI[i], md.r[i], st.c[i], st.s[i]);
-        });
-        TlFor<0, NB, 1>::run([&](auto ic) {
+        T cm = md.m[NB - 1], ch[3] = {md.h[NB - 1][0], md.h[NB - 1][1], md.h[NB - 1][2]};
+        T cI[6] = {md.I[NB - 1][0], md.I[NB - 1][1], md.I[NB - 1][2], md.I[NB - 1][3], md.I[NB - 1][4], md.I[NB - 1][5]};
+        TlFor<NB - 1, -1, -1>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             // F = Ic_i [e_z; 0] = [I e_z ; -h x e_z]
-            T F[6] = {cI[i][4], cI[i][5], cI[i][2], -ch[i][1], ch[i][0], T(0)};
+            T F[6] = {cI[4], cI[5], cI[2], -ch[1], ch[0], T(0)};
             M[i * (i + 1) / 2 + i] = F[2];
             TlFor<i, 0, -1>::run([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -314,6 +386,16 @@ PDDP_HD void arm_tl_factor(const ArmTlModel<T>& md, ArmTlState<T>& st) {
                 for (int e = 0; e < 6; e++) F[e] = Fp[e];
                 M[i * (i + 1) / 2 + (j - 1)] = F[2];
             });
+            if (i > 0) {
+                T pm = md.m[i - 1], ph[3] = {md.h[i - 1][0], md.h[i - 1][1], md.h[i - 1][2]};
+                T pI[6] = {md.I[i - 1][0], md.I[i - 1][1], md.I[i - 1][2], md.I[i - 1][3], md.I[i - 1][4], md.I[i - 1][5]};
+                tl_inertia_add_to_parent<arm_tl_kind(i)>(pm, ph, pI, cm, ch, cI, md.r[i], st.c[i], st.s[i]);
+                cm = pm;
+#pragma unroll
+                for (int e = 0; e < 3; e++) ch[e] = ph[e];
+#pragma unroll
+                for (int e = 0; e < 6; e++) cI[e] = pI[e];
+            }
         });
     }
     // ---- M = L D L'
@@ -491,11 +573,15 @@ PDDP_HD void arm_tl_grad_control(const ArmTlState<T>& st, Emit emit) {
 // every outboard link and the 2 x 7 force recursions of the chain form (arm_tl_grad_joint, kept for the one-joint-per-thread kernel).  Column k of dtau is complete
 // when level k ends: it is solved (d qdd = -M^-1 dtau) and emitted there.  Same function as dynamicsGradient<T> (plants/dynamics_arm.cuh:2167-2289).
 template <int KIND, typename T> PDDP_HD void tl_rot_to_parent(T* o, const T* x, T c, T s) {
-    const T n1[3] = {c * x[0] - s * x[1], s * x[0] + c * x[1], x[2]};
-    tl_to_parent_axes<KIND>(o, n1);
+    typedef TlZ<T, (PDDP_TLZ_MASK & 2) != 0> Z;
+    const Z cz(c), sz(s), x0(x[0]), x1(x[1]);
+    const Z n1[3] = {cz * x0 - sz * x1, sz * x0 + cz * x1, Z(x[2])};
+    if (KIND == kTlIdZ) { o[0] = n1[0].v; o[1] = n1[1].v; o[2] = n1[2].v; }
+    else if (KIND == kTlBZ) { o[0] = n1[0].v; o[1] = (-n1[2]).v; o[2] = n1[1].v; }
+    else { o[0] = (-n1[0]).v; o[1] = n1[2].v; o[2] = n1[1].v; }
 }
-template <typename T, typename Emit, typename Mark>
-PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark) {
+template <typename T, typename Emit, typename Mark, typename Factors = TlFactorsInState>
+PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark, Factors factors = Factors()) {
     constexpr int NB = kArmNB;
     // ---- link accelerations at the actual qdd
     T a[NB][6];
@@ -504,22 +590,32 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
         TlFor<0, NB, 1>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const T* v = st.v[i];
+            typedef TlZ<T, (PDDP_TLZ_MASK & 16) != 0> Z;
             tl_motion_to_child<arm_tl_kind(i)>(a[i], ap, md.r[i], st.c[i], st.s[i]);
-            a[i][0] += qd[i] * v[1]; a[i][1] -= qd[i] * v[0]; a[i][2] += qdd[i];
-            a[i][3] += qd[i] * v[4]; a[i][4] -= qd[i] * v[3];
+            a[i][0] = (Z(a[i][0]) + Z(qd[i]) * Z(v[1])).v; a[i][1] = (Z(a[i][1]) - Z(qd[i]) * Z(v[0])).v; a[i][2] = (Z(a[i][2]) + Z(qdd[i])).v;
+            a[i][3] = (Z(a[i][3]) + Z(qd[i]) * Z(v[4])).v; a[i][4] = (Z(a[i][4]) - Z(qd[i]) * Z(v[3])).v;
 #pragma unroll
             for (int e = 0; e < 6; e++) ap[e] = a[i][e];
         });
     }
     T dtq[NB][NB], dtv[NB][NB];          // [column][row]
+    typedef TlZ<T, (PDDP_TLZ_MASK & 4) != 0> Z;                    // (exact-zero pruning: the composites start as zeros, links 0, 2, 3, 5 have h_x = I_xy = I_xz = 0, link 0 only turns about its axis)
     // composites of the links outboard of the current level, in the current frame
     T cm = T(0), ch[3] = {T(0), T(0), T(0)}, cI[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     T G[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)}, P[3] = {T(0), T(0), T(0)};       // Gc: G11 row-major, summed linear momentum
     T F[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     TlFor<NB - 1, -1, -1>::run([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const T* v = st.v[k];
+        // The link's velocity as an OPAQUE copy: I_k v_k and v_k x* I_k v_k below are the same expressions the bias recursion of the forward dynamics evaluated
+        // (arm_tl_bias), and common-subexpression elimination would keep those 12 numbers per link alive from there to this level -- 60-odd registers across the whole
+        // sweep, which is what the setup kernel spilled (round 5: 30 spilled registers -> PDDP_TL_OPAQUE).  Recomputing them here costs ~25 instructions per link.
+        // (link 0 keeps its constants: v_0 = (0, 0, qd_0, 0, 0, 0) is what the exact-zero pruning feeds on.)
+        T vk[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { vk[e] = st.v[k][e]; if (PDDP_TL_OPAQUE && k > 0) tl_opaque(vk[e]); }
+        const T* v = vk;
         const T* I = md.I[k]; const T* h = md.h[k];
+        PDDP_TL_SCHED_FENCE();
         // ---- this link joins the composites
         {
             T Iv[6], f[6];
@@ -527,49 +623,59 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
             tl_inertia_mul(f, md.m[k], h, I, a[k]);
             tl_crf_add(f, v, Iv);
 #pragma unroll
-            for (int e = 0; e < 6; e++) F[e] += f[e];
-            cm += md.m[k];
+            for (int e = 0; e < 6; e++) F[e] = (Z(F[e]) + Z(f[e])).v;
+            cm = (Z(cm) + Z(md.m[k])).v;
 #pragma unroll
-            for (int e = 0; e < 3; e++) ch[e] += h[e];
+            for (int e = 0; e < 3; e++) ch[e] = (Z(ch[e]) + Z(h[e])).v;
 #pragma unroll
-            for (int e = 0; e < 6; e++) cI[e] += I[e];
-            const T Im[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
-            const T w[3] = {v[0], v[1], v[2]}, u[3] = {v[3], v[4], v[5]};
-            T A[9];                               // w~ I
+            for (int e = 0; e < 6; e++) cI[e] = (Z(cI[e]) + Z(I[e])).v;
+            const Z Im[9] = {Z(I[0]), Z(I[3]), Z(I[4]), Z(I[3]), Z(I[1]), Z(I[5]), Z(I[4]), Z(I[5]), Z(I[2])};
+            const Z w[3] = {Z(v[0]), Z(v[1]), Z(v[2])}, u[3] = {Z(v[3]), Z(v[4]), Z(v[5])}, hz[3] = {Z(h[0]), Z(h[1]), Z(h[2])};
+            Z A[9];                               // w~ I
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 A[0 + c] = w[1] * Im[6 + c] - w[2] * Im[3 + c];
                 A[3 + c] = w[2] * Im[0 + c] - w[0] * Im[6 + c];
                 A[6 + c] = w[0] * Im[3 + c] - w[1] * Im[0 + c];
             }
-            const T uh2 = T(2) * (u[0] * h[0] + u[1] * h[1] + u[2] * h[2]);
+            const Z uh2 = Z(T(2)) * (u[0] * hz[0] + u[1] * hz[1] + u[2] * hz[2]);
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) G[3 * r + c] += A[3 * r + c] + A[3 * c + r] - h[r] * u[c] - u[r] * h[c] + (r == c ? uh2 : T(0));
-            G[1] += Iv[2]; G[2] -= Iv[1]; G[3] -= Iv[2]; G[5] += Iv[0]; G[6] += Iv[1]; G[7] -= Iv[0];      // - n~
-            P[0] += Iv[3]; P[1] += Iv[4]; P[2] += Iv[5];
+                for (int c = 0; c < 3; c++) {
+                    Z t = A[3 * r + c] + A[3 * c + r] - hz[r] * u[c] - u[r] * hz[c];
+                    if (r == c) t = t + uh2;
+                    G[3 * r + c] = (Z(G[3 * r + c]) + t).v;
+                }
+            G[1] = (Z(G[1]) + Z(Iv[2])).v; G[2] = (Z(G[2]) - Z(Iv[1])).v; G[3] = (Z(G[3]) - Z(Iv[2])).v;                 // - n~
+            G[5] = (Z(G[5]) + Z(Iv[0])).v; G[6] = (Z(G[6]) + Z(Iv[1])).v; G[7] = (Z(G[7]) - Z(Iv[0])).v;
+            P[0] = (Z(P[0]) + Z(Iv[3])).v; P[1] = (Z(P[1]) + Z(Iv[4])).v; P[2] = (Z(P[2]) + Z(Iv[5])).v;
         }
         // ---- column k's force vectors, row k's covectors
-        const T dv[6] = {v[1], -v[0], T(0), v[4], -v[3], T(0)};
+        const T dv[6] = {v[1], (-Z(v[0])).v, T(0), v[4], (-Z(v[3])).v, T(0)};
         auto offsets = [&](auto lc, T* cl) {       // c_l of link l in its own frame
             constexpr int l = decltype(lc)::value;
-            const T* vl = st.v[l]; const T* al = a[l];
-            const T s2 = vl[0] * vl[0] + vl[1] * vl[1], su = vl[0] * vl[3] + vl[1] * vl[4];
-            cl[0] = al[1] + vl[0] * vl[2]; cl[1] = -al[0] + vl[1] * vl[2]; cl[2] = -s2;
-            cl[3] = al[4] + vl[0] * vl[5] + vl[3] * vl[2]; cl[4] = -al[3] + vl[1] * vl[5] + vl[4] * vl[2]; cl[5] = -(su + su);
+            const T* al = a[l];
+            const Z v0(st.v[l][0]), v1(st.v[l][1]), v2(st.v[l][2]), v3(st.v[l][3]), v4(st.v[l][4]), v5(st.v[l][5]);
+            const Z s2 = v0 * v0 + v1 * v1, su = v0 * v3 + v1 * v4;
+            cl[0] = (Z(al[1]) + v0 * v2).v; cl[1] = (-Z(al[0]) + v1 * v2).v; cl[2] = (-s2).v;
+            cl[3] = (Z(al[4]) + v0 * v5 + v3 * v2).v; cl[4] = (-Z(al[3]) + v1 * v5 + v4 * v2).v; cl[5] = (-(su + su)).v;
         };
         T ck[6];
         offsets(kc, ck);
         T wq[6], wv[6];
         tl_inertia_mul(wq, cm, ch, cI, ck);
-        wq[0] += -F[1] + G[0] * dv[0] + G[1] * dv[1]; wq[1] += F[0] + G[3] * dv[0] + G[4] * dv[1]; wq[2] += G[6] * dv[0] + G[7] * dv[1];
-        wq[3] += -F[4] - T(2) * (P[2] * v[0]); wq[4] += F[3] - T(2) * (P[2] * v[1]); wq[5] += T(2) * (P[0] * v[0] + P[1] * v[1]);
-        tl_inertia_mul(wv, cm, ch, cI, dv);
+        {
+            const Z d0(dv[0]), d1(dv[1]), two(T(2)), v0(v[0]), v1(v[1]);
+            wq[0] = (Z(wq[0]) + (-Z(F[1]) + Z(G[0]) * d0 + Z(G[1]) * d1)).v; wq[1] = (Z(wq[1]) + (Z(F[0]) + Z(G[3]) * d0 + Z(G[4]) * d1)).v; wq[2] = (Z(wq[2]) + (Z(G[6]) * d0 + Z(G[7]) * d1)).v;
+            wq[3] = (Z(wq[3]) + (-Z(F[4]) - two * (Z(P[2]) * v0))).v; wq[4] = (Z(wq[4]) + (Z(F[3]) - two * (Z(P[2]) * v1))).v; wq[5] = (Z(wq[5]) + two * (Z(P[0]) * v0 + Z(P[1]) * v1)).v;
+            tl_inertia_mul(wv, cm, ch, cI, dv);
 #pragma unroll
-        for (int e = 0; e < 6; e++) wv[e] += wv[e];
-        wv[0] += G[2]; wv[1] += G[5]; wv[2] += G[8]; wv[3] -= T(2) * P[1]; wv[4] += T(2) * P[0];
-        T y[6] = {cI[4], cI[5], cI[2], -ch[1], ch[0], T(0)}, gr[3] = {G[6], G[7], G[8]};
+            for (int e = 0; e < 6; e++) wv[e] = (Z(wv[e]) + Z(wv[e])).v;
+            wv[0] = (Z(wv[0]) + Z(G[2])).v; wv[1] = (Z(wv[1]) + Z(G[5])).v; wv[2] = (Z(wv[2]) + Z(G[8])).v;
+            wv[3] = (Z(wv[3]) - two * Z(P[1])).v; wv[4] = (Z(wv[4]) + two * Z(P[0])).v;
+        }
+        T y[6] = {cI[4], cI[5], cI[2], (-Z(ch[1])).v, ch[0], T(0)}, gr[3] = {G[6], G[7], G[8]};
         dtq[k][k] = wq[2]; dtv[k][k] = wv[2] + T(0.5);
         TlFor<k - 1, -1, -1>::run([&](auto lc) {
             constexpr int l = decltype(lc)::value;
@@ -588,26 +694,30 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
 #pragma unroll
             for (int e = 0; e < 3; e++) gr[e] = t3[e];
             dtq[k][l] = wq[2]; dtv[k][l] = wv[2];
-            const T* vl = st.v[l];
             T cl[6];
             offsets(lc, cl);
-            dtq[l][k] = y[0] * cl[0] + y[1] * cl[1] + y[2] * cl[2] + y[3] * cl[3] + y[4] * cl[4] + y[5] * cl[5] + (gr[0] * vl[1] - gr[1] * vl[0]);
-            const T yd = y[0] * vl[1] - y[1] * vl[0] + y[3] * vl[4] - y[4] * vl[3];
-            dtv[l][k] = yd + yd + gr[2];
+            const Z v0(st.v[l][0]), v1(st.v[l][1]), v3(st.v[l][3]), v4(st.v[l][4]);
+            const Z y0(y[0]), y1(y[1]), y3(y[3]), y4(y[4]);
+            dtq[l][k] = (y0 * Z(cl[0]) + y1 * Z(cl[1]) + Z(y[2]) * Z(cl[2]) + y3 * Z(cl[3]) + y4 * Z(cl[4]) + Z(y[5]) * Z(cl[5]) + (Z(gr[0]) * v1 - Z(gr[1]) * v0)).v;
+            const Z yd = y0 * v1 - y1 * v0 + y3 * v4 - y4 * v3;
+            dtv[l][k] = (yd + yd + Z(gr[2])).v;
         });
         // ---- column k is complete: d qdd / d(q_k, qd_k) = -M^-1 dtau
+        PDDP_TL_SCHED_FENCE();
         {
-            T cq[NB], cv[NB];
+            T cq[NB], cv[NB], Lf[21];
 #pragma unroll
             for (int i = 0; i < NB; i++) { cq[i] = -dtq[k][i]; cv[i] = -dtv[k][i]; }
-            tl_ldl_solve(st, cq);
-            tl_ldl_solve(st, cv);
+            factors(st, Lf);
+            tl_ldl_solve<T>(Lf, st.Dinv, cq);
+            tl_ldl_solve<T>(Lf, st.Dinv, cv);
 #pragma unroll
             for (int i = 0; i < NB; i++) { emit(k, i, cq[i]); emit(NB + k, i, cv[i]); }
         }
         if (k == 4) mark(std::integral_constant<int, 1>());
         if (k == 0) mark(std::integral_constant<int, 0>());
         // ---- the composites move one frame inwards
+        PDDP_TL_SCHED_FENCE();
         if (k > 0) {
             constexpr int K = arm_tl_kind(k);
             const T r = md.r[k], c = st.c[k], s = st.s[k];
@@ -643,7 +753,19 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
             for (int e = 0; e < 3; e++) P[e] = p2[e];
         }
     });
-    TlFor<0, NB, 1>::run([&](auto jc) { arm_tl_grad_control<decltype(jc)::value, T>(st, emit); });
+    {
+        T Lf[21];
+        factors(st, Lf);
+        TlFor<0, NB, 1>::run([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            T e[NB];
+#pragma unroll
+            for (int i = 0; i < NB; i++) e[i] = (i == j) ? T(1) : T(0);
+            tl_ldl_solve<T>(Lf, st.Dinv, e);
+#pragma unroll
+            for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
+        });
+    }
     mark(std::integral_constant<int, 2>());
 }
 template <typename T, typename Emit>

@@ -82,7 +82,7 @@ BP_FLOPS_PER_KNOT = 2 * 16268  # dense products of one backward-pass knot, n = 1
                                # T1 686, P+ 2744, A - B K | B du 1470   (bpHelpers.cuh:39-334)
 
 
-def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, s_per_step):
+def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, s_per_step, keep_ctg=True):
     """`roofline` of the bench line, for the kernel with the longest average launch.
 
     Top level = the roofline that BINDS that kernel.  Every heavy kernel of this sweep is bound by the SIMDs' float32 lanes, not by HBM: the matrix-core
@@ -98,9 +98,25 @@ def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, 
     if dom_name.startswith("k_bp_mfma"):
         knots = B * (N - M)                                                    # every block walks N/M - 1 knots
         useful = BP_FLOPS_PER_KNOT * knots
-        roof.update({"bound": "mfma", "achieved": round(useful / dur / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(useful / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 5), "algorithmic_flop_per_launch": useful,
-                     "accounting": f"{BP_FLOPS_PER_KNOT} flop per knot (the dense products of backPassKern for n=14, m=7) x {N - M} knots x {B} problems"})
+        mfma_rec = {"bound": "mfma", "achieved": round(useful / dur / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(useful / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 5), "algorithmic_flop_per_launch": useful,
+                    "accounting": f"{BP_FLOPS_PER_KNOT} flop per knot (the dense products of backPassKern for n=14, m=7) x {N - M} knots x {B} problems"}
+        # Which roof binds is a question of arithmetic intensity against the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 flop per byte).  THIS design's algorithmic bytes of
+        # a knot: reads compact [A B] 588 + cost gradient 84, writes K 392 + du 28, and -- when every cost-to-go slot is written, the library
+        # default and the reference's output set -- [P | p] 784 + 56.  With those stores the kernel moves more than a byte per 15 flop: the HBM roof is the nearer one.
+        per_knot = 588 + 84 + 392 + 28 + (784 + 56 if keep_ctg else 0)
+        alg_bytes = float(per_knot) * knots
+        hbm_rec = {"bound": "hbm", "achieved": round(alg_bytes / dur / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / dur / 1e9 / HBM_PEAK_GBS, 5),
+                   "algorithmic_bytes_per_launch": alg_bytes,
+                   "accounting": f"{per_knot} bytes per knot of this design's data layout (compact [A B] 588 + g 84 read; K 392 + du 28" + (" + [P | p] 840" if keep_ctg else "") +
+                                 f" written) x {N - M} knots x {B} problems; `traffic` = what the counters saw"}
+        intensity = useful / (traffic if traffic else alg_bytes)
+        roof["arithmetic_intensity_flop_per_byte"] = round(intensity, 2)
+        roof["ridge_flop_per_byte"] = round(MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9), 2)
+        if intensity < roof["ridge_flop_per_byte"]:
+            roof.update(hbm_rec); roof["mfma"] = {k: mfma_rec[k] for k in ("achieved", "peak", "unit", "frac", "accounting")}
+        else:
+            roof.update(mfma_rec); roof["hbm_algorithmic"] = {k: hbm_rec[k] for k in ("achieved", "peak", "unit", "frac", "accounting")}
         if counters and counters.get("SQ_INSTS_MFMA"):
             n_mx = counters["SQ_INSTS_MFMA"]
             issued = n_mx * 2048.0                                             # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-adds
@@ -252,7 +268,7 @@ def main():
             per = [tj["kernels"].get(nm, {}).get("hbm_bytes_per_launch") for nm, _ in kern]
             if per and all(v is not None for v in per):
                 sweep_traffic = float(sum(per))
-    roof = roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, t_local / K)
+    roof = roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, t_local / K, keep_ctg=not lean)
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),
@@ -433,7 +449,7 @@ def latency_single_problem(device):
         x0, u0, xg = example_inputs(Nk, np.random.default_rng(4321), 1)
         pt = s.solve_phase_timed(x0, u0, xg)
         n_it = int(pt["iters"][0])
-        ph = pt["phase_ms"][:, :n_it]
+        ph = pt["phase_ms"][:4, :n_it]                                    # (row 4 = the linear sweep's kernel alone, a part of row 1)
         res[name]["per_phase_median_us"] = {k: round(float(np.median(ph[i]) * 1e3), 1) for i, k in enumerate(PHASES)}
         if name == "to_convergence_tol_1e-4":
             cum = np.cumsum(ph.sum(axis=0))

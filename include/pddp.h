@@ -29,6 +29,23 @@ extern "C" {
 
 typedef struct pddp_solver* pddp_handle;
 
+/* Which kernel family a handle uses for each phase of a sweep.  0 everywhere (what pddp_default_config writes) = the library's own choice: one function of plant,
+ * element type, batch, M, A and the cost family (Solver::init in csrc/pddp_api.hip; the table is asserted by tests/test_kernel_selection.py and reported back by
+ * pddp_time_kernels).  Every family computes the same functions; the other values exist so that comparison tests and measurements can pin a family WITHOUT the
+ * library reading the process environment (until round 4 these were PDDP_BP, PDDP_FP, ... environment variables).  A value that does not apply to the handle's plant is
+ * ignored exactly as the variable was. */
+typedef struct pddp_kernel_selection {
+    int bp;       /* arm, backward pass:        1 mx (matrix cores)  2 lg (8-lane groups)  3 coop (one wave per block)  4 wide (one workgroup per block)             */
+    int fp;       /* arm, rollouts + setup:     1 tl (thread lanes)  2 lg  3 coop  4 tl2 (two-wave split, few problems)  5 tl4 (four-wave pipeline, few problems)   */
+    int sweep;    /* arm, linear forward sweep: 1 alpha (lane group per candidate)  2 st (two sequences)  3 wg (workgroup per problem); any value: no fusion into bp  */
+    int ls;       /* line search:               1 many (thread per problem)  2 wg (wave per problem)                                                                */
+    int ab;       /* arm, layout of [A B]:      1 full (reference layout instead of the compact one)                                                                */
+    int cf;       /* closed-form plants, every phase: 1 ts (thread-serial)  2 coop                                                                                   */
+    int cf_bp;    /* ... backward pass:         1 ts  2 coop  3 gl (16-lane groups)  4 gl32  5 cl (lane = column)                                                    */
+    int cf_fp;    /* ... rollouts:              1 ts  2 coop  3 cf (staged per wavefront)                                                                            */
+    int cf_nis;   /* ... setup:                 1 ts  2 coop  3 gl  4 gl8  5 kb16  6 kb32  7 kb64 (knot-batched)                                                     */
+} pddp_kernel_selection;
+
 /* The reference's compile-time configuration (config.cuh) as a run-time record. */
 typedef struct pddp_config {
     int plant;            /* PLANT 1 pendulum, 2 cart-pole, 3 quadrotor, 4 KUKA iiwa14      config.cuh:21-61   */
@@ -77,6 +94,10 @@ typedef struct pddp_config {
                            * plants/cost_arm.cuh:13-94,136-149,176-199).  With ee_cost = 1: the same penalties in the cost, the gradient AND the diagonal of H
                            * (:289-291,341-343,374-376).  Handles with use_limits / use_smooth_abs run the thread-lane or the wave-cooperative kernels (the lane-group
                            * family does not carry the variants). */
+    int ee_type;          /* EE_TYPE (dynamics_arm.cuh:50-65): 0 no end effector, 1 flange (default), 2 flange + peg.  With wafr_urdf = 0 link 7's inertia is the base
+                           * values x INERTIA_MODIFIER (1 / 3 / 5) and its mass 1.2 + WEIGHT_MODIFIER (0 / 0.03 / 0.5) (:338-347); the tool offset EE_ON_LINK_Z
+                           * (0 / 0.0635 / 0.1524) is ee_on_link_z above -- pddp_default_config writes EE_TYPE 1's, the source-level facade sets both from the macro. */
+    pddp_kernel_selection kernels;   /* all zero: the library chooses */
 } pddp_config;
 
 /* Reference defaults for a plant (the per-plant blocks of config.cuh:24-61 and the #ifndef defaults below them). */
@@ -122,9 +143,10 @@ int pddp_solve(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal,
                int clear_vars, int ignore_first_defect, double* times_ms);
 
 /* The full reference call.  Warm-start arrays / forward_rollout as in pddp_load_ex.  phase_ms, when not NULL, is
- * [4][max_iter+2] doubles (bp, sweep+sim, line search+accept/reject, next-iteration setup): the duration of each kernel of
- * sweep i measured with HIP events on the solver's stream -- what the reference's bpTime[], sweepTime[]+simTime[], nisTime[]
- * report (DDPWrappers.cuh:54-105).  With phase_ms the sweeps are launched kernel by kernel instead of as a graph; in
+ * [5][max_iter+2] doubles (bp, sweep+sim, line search+accept/reject, next-iteration setup, and -- a part of row 1 -- the linear
+ * forward sweep's own kernel): the duration of each kernel of sweep i measured with HIP events on the solver's stream -- what
+ * the reference's bpTime[], sweepTime[]+simTime[], nisTime[] and sweepTime[] report (DDPWrappers.cuh:54-105; row 4 is 0 on
+ * kernel selections whose rollout kernel sweeps itself).  With phase_ms the sweeps are launched kernel by kernel instead of as a graph; in
  * both modes the loop never synchronises with the host except to poll the exit flags every `poll_every` sweeps. */
 int pddp_solve_ex(pddp_handle h, void* x0_inout, void* u0_inout, const void* xGoal, const void* KT0, const void* P0, const void* p0,
                   const void* d0, void* Jout, int* alphaOut, int forward_rollout, int clear_vars, int ignore_first_defect,
@@ -191,6 +213,14 @@ int pddp_get_array(pddp_handle h, const char* name, void* host, size_t bytes);
 /* Device address of a named array (the reference hands its callers the raw device buffers, nisInitHelpers.cuh:768-772);
  * lets the host layer run an RCCL collective on the cost table without staging it through the host. */
 int pddp_array_ptr(pddp_handle h, const char* name, void** device_ptr, size_t* bytes);
+/* Arrays the reference leaves behind as by-products of copies this design does not make, rebuilt on demand from the state the last sweep left:
+ *   "ApBK", "Bdu"    A - B K and B du of every knot (computeFSVars, bpHelpers.cuh:281-312, M > 1): production sweeps compose the forward sweep's segment maps inside
+ *                    the backward pass and never write them; pddp_get_array of either name rebuilds both first;
+ *   "xs" "us" "ds"   the accepted trajectory in EVERY step size's slot (memcpyCurrAKern x 3, nisInitHelpers.cuh:24-32,270-272): here the slots keep the candidates
+ *                    of the last line search.
+ * pddp_refresh_reference_views writes both into the device arrays (the ones pddp_array_ptr names): what a caller that reads the raw device buffers after
+ * runiLQR_GPU -- the source-level facade hands them out as d_ApBK, d_Bdu, d_x / h_d_x ... -- needs to see the reference's contents.  One small launch + a synchronisation. */
+int pddp_refresh_reference_views(pddp_handle h);
 
 /* ---- multi-GPU (mode R): one process per GPU, rank g owns the problems {r : r % world == g} in its own handle; a sweep needs
  * no exchange.  The two exchanges a caller needs -- "has every problem on every rank exited?" and the cost table of all rollouts -- are RCCL

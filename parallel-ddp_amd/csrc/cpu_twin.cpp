@@ -44,6 +44,7 @@ template <typename T> void fill_model(ArmModel<T>& m, const pddp_config& c) {
         for (int i = 0; i < 16; i++) m.F[16 * b + i] = (T)IIWA14_JOINT_FRAME[v][b][i];
     }
     m.grav = (T)(c.mpc_mode ? 0.0 : 9.81);                  // plants/dynamics_arm.cuh:42-46
+    arm_model_apply_ee_type(m, c.wafr_urdf, c.ee_type);
 }
 void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
 

@@ -656,6 +656,38 @@ __global__ __launch_bounds__(64) void k_adopt_slot0(Buffers<T> b, Dims dm) {
     PDDP_FOR(i, NX) b.dcur[((size_t)pb * N + k) * NX + i] = b.ds[(slot * N + k) * NX + i];
 }
 
+// Reference views on demand (pddp_refresh_reference_views): grid (N, B), block 64.  The reference's backward pass leaves A - B K and B du of every knot in d_ApBK / d_Bdu
+// (computeFSVars, bpHelpers.cuh:281-312: M > 1) and its next-iteration setup copies the accepted trajectory into EVERY step size's slot (memcpyCurrAKern x 3,
+// nisInitHelpers.cuh:24-32,270-272).  The production sweeps do neither (the sweep operands are composed into segment maps inside the backward pass, candidates always start
+// from the current trajectory), so the arrays are rebuilt here from what the last sweep left: reference-layout [A B], KT, du -- the operation order of bp_block (bp.hpp) --
+// and the current trajectory.  what bit 0: sweep operands, bit 1: step-size slots.
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_reference_views(Buffers<T> b, Dims dm, int what) {
+    constexpr int NX = P::NX, NU = P::NU, NM = NX + NU;
+    const int k = blockIdx.x, pb = blockIdx.y, N = dm.N;
+    const Wave w = this_wave();
+    const size_t knot = (size_t)pb * N + k;
+    if ((what & 1) && dm.M > 1 && k < N - 1) {
+        const T* AB = b.AB + knot * (NX * NM); const T* KT = b.KT + knot * (NX * NU); const T* du = b.du + knot * NU;
+        T* F = b.ApBK + knot * (NX * NX); T* Bd = b.Bdu + knot * NX;
+        PDDP_FOR(e, NX * NX) {
+            const int ky = e / NX, kx = e % NX;
+            T val = 0;
+            for (int j = 0; j < NU; j++) val += AB[NX * NX + kx + NX * j] * KT[ky + NX * j];
+            F[e] = AB[e] - val;
+        }
+        PDDP_FOR(kx, NX) { T val = 0; for (int j = 0; j < NU; j++) val += AB[NX * NX + kx + NX * j] * du[j]; Bd[kx] = val; }
+    }
+    if (what & 2) {
+        const T* xc = b.xb + (((size_t)pb * 2 + b.state[pb].cur) * N + k) * NX;
+        for (int a = 0; a < dm.A; a++) {
+            const size_t slot = ((size_t)pb * dm.A + a) * N + k;
+            PDDP_FOR(i, NX) { b.xs[slot * NX + i] = xc[i]; b.ds[slot * NX + i] = b.dcur[knot * NX + i]; }
+            PDDP_FOR(i, NU) b.us[slot * NU + i] = b.ucur[knot * NU + i];
+        }
+    }
+}
+
 // MPC warm start / fall-back (mpc.hpp): grid (B), block 256 -- four waves share the shifting of the previous solution, wave 0 rolls out; block 512 for the arm in float with a
 // built-in robot model (V >= 0): the rollout is a three-wave pipeline that starts at once, the other waves shift and copy beside it.
 template <typename P, int INTEG, typename T, int V = -1>

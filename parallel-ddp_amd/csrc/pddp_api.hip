@@ -54,11 +54,25 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;   // config.cuh:68-71
     c->use_limits = 0;                                          // config.cuh:171-173
     c->use_smooth_abs = 0; c->smooth_abs_alpha = 0.2;           // config.cuh:174-176, cost_arm.cuh:116-118
+    c->ee_type = 1;                                             // dynamics_arm.cuh:50-52
+    std::memset(&c->kernels, 0, sizeof(c->kernels));           // the library's own kernel selection
     return 0;
 }
 
 // (problem, block) pairs from which the matrix-core backward pass is the default for float handles of the arm (profiles/r02_path_sweep_mx.txt)
 static constexpr size_t kBpMfmaMinBlocks = 1;
+// pddp_kernel_selection values by name (0 = nullptr: the library's choice).  The selection logic below is written against these names -- they were the values of the
+// PDDP_BP / PDDP_FP / ... environment variables it read until round 4.
+static const char* ksel(int v, std::initializer_list<const char*> names) { return (v > 0 && (size_t)v <= names.size()) ? *(names.begin() + (v - 1)) : nullptr; }
+static const char* ksel_bp(const pddp_config& c) { return ksel(c.kernels.bp, {"mx", "lg", "coop", "wide"}); }
+static const char* ksel_fp(const pddp_config& c) { return ksel(c.kernels.fp, {"tl", "lg", "coop", "tl2", "tl4"}); }
+static const char* ksel_sweep(const pddp_config& c) { return ksel(c.kernels.sweep, {"alpha", "st", "wg"}); }
+static const char* ksel_ls(const pddp_config& c) { return ksel(c.kernels.ls, {"many", "wg"}); }
+static const char* ksel_ab(const pddp_config& c) { return ksel(c.kernels.ab, {"full"}); }
+static const char* ksel_cf(const pddp_config& c) { return ksel(c.kernels.cf, {"ts", "coop"}); }
+static const char* ksel_cf_bp(const pddp_config& c) { return ksel(c.kernels.cf_bp, {"ts", "coop", "gl", "gl32", "cl"}); }
+static const char* ksel_cf_fp(const pddp_config& c) { return ksel(c.kernels.cf_fp, {"ts", "coop", "cf"}); }
+static const char* ksel_cf_nis(const pddp_config& c) { return ksel(c.kernels.cf_nis, {"ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64"}); }
 static double now_ms() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
 
 struct SolverBase {
@@ -91,6 +105,8 @@ struct SolverBase {
     virtual void drop_graph() = 0;
     virtual int ab_view(int to_compact) = 0;       // compact [A B] handles (ab_compact.hpp): refresh the reference-layout array "AB" from the compact one (0) or the reverse (1)
     virtual int h_view() = 0;                      // handles with the compact end-effector Hessian block: refresh the reference-layout array "H"
+    virtual int reference_views(int what) = 0;     // rebuild d_ApBK / d_Bdu (1) and the winner in every step-size slot (2) from the state the last sweep left
+    bool fs_vars_stale = false;                    // fused sweeps ran since A - B K / B du were last written (pddp_get_array materialises them first)
     virtual int ab_keep_reference_layout() = 0;   // leave the compact mode for good (the cost Hessian was overridden: the backward pass reads the reference layout then)
     hipStream_t stream = nullptr;
 };
@@ -103,6 +119,7 @@ template <typename T> static void fill_model(ArmModel<T>& m, const pddp_config& 
         for (int i = 0; i < 16; i++) m.F[16 * b + i] = (T)IIWA14_JOINT_FRAME[v][b][i];
     }
     m.grav = (T)(c.mpc_mode ? 0.0 : 9.81);   // plants/dynamics_arm.cuh:42-46
+    arm_model_apply_ee_type(m, c.wafr_urdf, c.ee_type);
 }
 static void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
 
@@ -140,12 +157,12 @@ struct Solver : SolverBase {
         tl_grav = hm.grav;
         // USE_FINITE_DIFF: the setup runs on the wave-cooperative kernel (k_nis: any plant's `dynamics`), which adopts the winner from the candidate-major
         // xs / us / ds -- so the rollouts stay on lane groups (they write those), not on the thread-lane kernels
-        fp_path = select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0 && !cfg.use_finite_diff, cfg.batch);
+        fp_path = select_fp_path(ksel_fp(cfg), sizeof(T) == 4, cfg.ee_cost != 0, tl_variant >= 0 && !cfg.use_finite_diff, cfg.batch);
         if ((cfg.use_limits || cfg.use_smooth_abs) && fp_path == kFpLg) fp_path = kFpCoop;      // USE_LIMITS_FLAG / USE_SMOOTH_ABS: the lane-group family does not carry the variants
         fp_coop = (fp_path == kFpCoop);
         // few problems in flight, joint-space cost, float, built-in robot model: the rollouts run on k_fp_tl2 (every step split over two wavefronts);
         // sweep, line search and setup stay on the lane-group kernels.  PDDP_FP=lg keeps the lane-group rollouts (bit-identity tests), PDDP_FP=tl2 asks for the split.
-        const char* fpenv = std::getenv("PDDP_FP");
+        const char* fpenv = ksel_fp(cfg);
         fp_split = sizeof(T) == 4 && fp_path == kFpLg && !cfg.use_finite_diff && tl_variant >= 0 && !(fpenv && std::string(fpenv) == "lg");
         // PDDP_FP=tl4 on a DOUBLE handle: the same few-problem selection (k_fp_tl4 pipeline + k_nis_tl7) in its parity instantiation (tests/test_f64_benched_family.py)
         if (sizeof(T) == 8 && fpenv && std::string(fpenv) == "tl4" && fp_path == kFpLg && !cfg.use_finite_diff && tl_variant >= 0 && !cfg.use_limits && !cfg.use_smooth_abs) fp_split = true;
@@ -175,6 +192,13 @@ struct Solver : SolverBase {
                 HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream));
             }
         }
+        return 0;
+    }
+    int reference_views(int what) override {
+        if ((what & 1) && cfg.M > 1) { int rc = ab_view(0); if (rc) return rc; }           // (the reference-layout [A B] from the compact one)
+        hipLaunchKernelGGL((k_reference_views<P, T>), dim3(cfg.N, cfg.batch), dim3(64), 0, stream, b, dm, what);
+        HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream));
+        if (what & 1) fs_vars_stale = false;
         return 0;
     }
     int model_changed() override {
@@ -243,12 +267,12 @@ struct Solver : SolverBase {
         dm.N = c.N; dm.M = c.M; dm.A = c.A; dm.NB = c.N / c.M;
         bp_lane_groups = (size_t)c.batch * c.M >= 4096;     // measured crossovers on MI355X (Kuka N=128): wide <= 256 problems < cooperative < 1024 <= lane groups
         bp_wide = (size_t)c.batch * c.M <= 1024 && P::NX >= 12;
-        if (const char* v = std::getenv("PDDP_FP")) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
+        if (const char* v = ksel_fp(cfg)) fp_coop = (std::string(v) == "coop");       // the arm refines this below (derive_tl_model)
         // closed-form plants (and user plants): one wave per unit while a handful of problems is in flight (the shorter critical path), one thread per unit once
         // the batch fills the device (64 units per wave instead of 1); the horizon has to fit the per-thread cost table of k_fp_ts
-        { const char* e = std::getenv("PDDP_LS"); ls_many = e ? std::string(e) == "many" : c.batch >= 2048; }      // PDDP_LS=many|wg
+        { const char* e = ksel_ls(cfg); ls_many = e ? std::string(e) == "many" : c.batch >= 2048; }      // PDDP_LS=many|wg
         cf_serial = P::PLANT != 4 && (size_t)c.batch * c.M >= 256 && c.N <= kTsMaxN && c.M <= kTsMaxM;
-        if (const char* v = std::getenv("PDDP_CF")) cf_serial = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
+        if (const char* v = ksel_cf(cfg)) cf_serial = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
         // measured on MI355X (tools/cf_variants.py; profiles/r03_closed_form_variants.txt): the rollouts always win thread-serially once the device is full (cart-pole, 16384
         // problems: 0.74 against 15.7 ms; quadrotor, 4096: 3.0 against 57.9 ms); the derivative kernel too for the small plants (0.16 against 2.1 ms) but not for the
         // quadrotor's 12 states, whose per-thread stage scratch spills to memory (6.2 against 5.4 ms); the backward pass thread-serially only for the small plants with the
@@ -256,24 +280,24 @@ struct Solver : SolverBase {
         cf_fp = cf_serial;
         cf_nis = cf_serial && P::NX < 12;
         cf_bp = cf_serial && P::NX < 12 && (size_t)c.batch * c.M >= 8192;
-        if (std::getenv("PDDP_CF")) cf_bp = cf_nis = cf_fp;         // the override forces every phase
+        if (ksel_cf(cfg)) cf_bp = cf_nis = cf_fp;         // the override forces every phase
         // per-phase overrides (measurement): PDDP_CF_BP / PDDP_CF_FP / PDDP_CF_NIS = coop | ts
-        if (const char* v = std::getenv("PDDP_CF_BP")) cf_bp = P::PLANT != 4 && std::string(v) == "ts";
-        if (const char* v = std::getenv("PDDP_CF_FP")) cf_fp = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
-        if (const char* v = std::getenv("PDDP_CF_NIS")) cf_nis = P::PLANT != 4 && std::string(v) == "ts";
-        gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !std::getenv("PDDP_CF");
-        gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !std::getenv("PDDP_CF"); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
-        if (const char* v = std::getenv("PDDP_CF_NIS")) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
+        if (const char* v = ksel_cf_bp(cfg)) cf_bp = P::PLANT != 4 && std::string(v) == "ts";
+        if (const char* v = ksel_cf_fp(cfg)) cf_fp = P::PLANT != 4 && std::string(v) == "ts" && c.N <= kTsMaxN && c.M <= kTsMaxM;
+        if (const char* v = ksel_cf_nis(cfg)) cf_nis = P::PLANT != 4 && std::string(v) == "ts";
+        gl_nis = cf_serial && !cf_nis && P::NX + P::NU <= 16 && !ksel_cf(cfg);
+        gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !ksel_cf(cfg); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
+        if (const char* v = ksel_cf_nis(cfg)) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
         cl_bp = gl_bp && P::NX == 12 && P::NU == 4;
         const bool cf_fits = (c.A == 16 && (64 / 16) * P::NX <= 64) || (c.A == 8 && (64 / 8) * P::NX <= 64);      // whole problems per wavefront, one state fetch per lane
-        cf_fp_staged = cf_fp && cf_fits && !std::getenv("PDDP_CF");      // (cart-pole, 16384 problems: 0.73 -> 0.69 ms; quadrotor: 8.6 -> 5.1 ms)
-        if (const char* v = std::getenv("PDDP_CF_FP")) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && cf_fits; } else cf_fp_staged = false; }
+        cf_fp_staged = cf_fp && cf_fits && !ksel_cf(cfg);      // (cart-pole, 16384 problems: 0.73 -> 0.69 ms; quadrotor: 8.6 -> 5.1 ms)
+        if (const char* v = ksel_cf_fp(cfg)) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && cf_fits; } else cf_fp_staged = false; }
         kb_nis = (gl_nis && c.integrator == 3) ? 16 : 0;      // 16 knots per wavefront: 2.15 ms (32: 2.6, 64: 3.6; the 16-lane-group kernel 5.7-7.1) at 16384 quadrotor problems -- LDS per block sets the occupancy
-        if (const char* v = std::getenv("PDDP_CF_NIS")) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
-        if (const char* v = std::getenv("PDDP_CF_BP")) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32" || (std::string(v) == "cl" && P::NX == 12 && P::NU == 4)) && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; cl_bp = gl_bp && std::string(v) == "cl"; }
+        if (const char* v = ksel_cf_nis(cfg)) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
+        if (const char* v = ksel_cf_bp(cfg)) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32" || (std::string(v) == "cl" && P::NX == 12 && P::NU == 4)) && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; cl_bp = gl_bp && std::string(v) == "cl"; }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
-            if (const char* v = std::getenv("PDDP_SWEEP")) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
+            if (const char* v = ksel_sweep(cfg)) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
             if (sweep_kind == 2 && c.N / c.M > 96) sweep_kind = 1;
             // default with the matrix-core backward pass: that pass composes the segments' sweep maps itself (bp_mfma.hpp kMxFuseSweep) and k_sweep_maps finishes;
             // sweep_kind stays the kernel of the phase hook, whose teacher-forced A - B K / B du must be what the sweep reads.  PDDP_SWEEP=alpha|st|wg: no fusion.
@@ -281,8 +305,8 @@ struct Solver : SolverBase {
         bp_mfma = (P::PLANT == 4 && sizeof(T) == 4 && (size_t)c.batch * c.M >= kBpMfmaMinBlocks);
         // PDDP_BP=mx on a double handle: the same tile algebra on v_mfma_f64_16x16x4_f64 (a test selection: float64 handles default to the lane-group family,
         // whose operation order is the reference's)
-        if (const char* v = std::getenv("PDDP_BP")) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && std::string(v) == "mx"); }
-        sweep_fused = bp_mfma && c.M > 1 && !std::getenv("PDDP_SWEEP");
+        if (const char* v = ksel_bp(cfg)) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && std::string(v) == "mx"); }
+        sweep_fused = bp_mfma && c.M > 1 && !ksel_sweep(cfg);
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
@@ -326,7 +350,7 @@ struct Solver : SolverBase {
         if constexpr (P::PLANT == 4) { if (fp_path == kFpTl) { b.xw_rec = 22; if ((rc = alloc("xw", &b.xw, B * N * A * b.xw_rec))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
         if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
         if constexpr (P::PLANT == 4) {
-            const char* abenv = std::getenv("PDDP_AB");             // PDDP_AB=full: keep the reference layout (comparison runs)
+            const char* abenv = ksel_ab(cfg);             // PDDP_AB=full: keep the reference layout (comparison runs)
             const bool full_h = c.ee_cost && c.use_limits;         // end-effector cost with USE_LIMITS_FLAG: the whole diagonal of H moves with the trajectory -> reference-layout H and [A B]
             if (bp_mfma && fp_path == kFpTl && !(abenv && abenv[0] == 'f') && !full_h) {
                 if ((rc = alloc("ABc", &b.ABc, abc_floats(B * N)))) return rc;
@@ -577,6 +601,7 @@ struct Solver : SolverBase {
     }
     int iterate(int sweeps) override {
         if (bp_mfma && !keep_all_ctg()) lean_ctg_ran = true;
+        if (sweep_fused && sweeps > 0) fs_vars_stale = true;
         if (cfg.use_graph) {
             if (!graph || graph_mode != bench_mode + 2 * sp.max_iter) {
                 if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
@@ -597,22 +622,29 @@ struct Solver : SolverBase {
         HIPCHK(hipGetLastError());
         return 0;
     }
-    // `sweeps` sweeps, kernel by kernel, an event after every launch; phase_ms[ph*stride + first_sweep + i] = duration of kernel ph
+    // `sweeps` sweeps, kernel by kernel, an event after every launch; phase_ms[ph*stride + first_sweep + i] = duration of phase ph of sweep i, FIVE rows:
+    // 0 backward pass, 1 forward pass (linear sweep + rollouts), 2 line search, 3 next-iteration setup, 4 the linear forward sweep's own kernel alone (a part of row 1:
+    // the reference's sweepTime[], DDPWrappers.cuh:77; 0 on paths whose rollout kernel sweeps itself)
     std::vector<hipEvent_t> trace_ev;
     int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) override {
-        const size_t need = 5 * (size_t)sweeps;
+        const size_t need = 6 * (size_t)sweeps;
+        if (sweep_fused && sweeps > 0) fs_vars_stale = true;
         while (trace_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); trace_ev.push_back(e); }
+        static const int phase_of[5] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS}, part_of[5] = {-1, 0, 1, -1, -1};
         for (int i = 0; i < sweeps; i++) {
-            HIPCHK(hipEventRecord(trace_ev[5 * i], stream));
-            for (int ph = 0; ph < 4; ph++) { launch_sweep(stream, ph); HIPCHK(hipEventRecord(trace_ev[5 * i + ph + 1], stream)); }
+            HIPCHK(hipEventRecord(trace_ev[6 * i], stream));
+            for (int k = 0; k < 5; k++) { launch_sweep(stream, phase_of[k], 0, part_of[k]); HIPCHK(hipEventRecord(trace_ev[6 * i + k + 1], stream)); }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
-        for (int i = 0; i < sweeps; i++)
-            for (int ph = 0; ph < 4; ph++) {
-                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, trace_ev[5 * i + ph], trace_ev[5 * i + ph + 1]));
-                if (first_sweep + i < stride) phase_ms[(size_t)ph * stride + first_sweep + i] = ms;
-            }
+        for (int i = 0; i < sweeps; i++) {
+            if (first_sweep + i >= stride) continue;
+            float ms[5];
+            for (int k = 0; k < 5; k++) HIPCHK(hipEventElapsedTime(&ms[k], trace_ev[6 * i + k], trace_ev[6 * i + k + 1]));
+            const size_t o = (size_t)first_sweep + i;
+            phase_ms[0 * (size_t)stride + o] = ms[0]; phase_ms[1 * (size_t)stride + o] = (double)ms[1] + ms[2]; phase_ms[2 * (size_t)stride + o] = ms[3];
+            phase_ms[3 * (size_t)stride + o] = ms[4]; phase_ms[4 * (size_t)stride + o] = ms[1];
+        }
         return 0;
     }
     int sync() override { HIPCHK(hipStreamSynchronize(stream)); return 0; }
@@ -664,7 +696,7 @@ struct Solver : SolverBase {
         }
         bool split_roll = false;
         if constexpr (P::PLANT == 4 && INTEG == 1 && sizeof(T) == 4) {                // float arm with a built-in robot model: the warm-start rollout split over two waves
-            const char* fpenv = std::getenv("PDDP_FP");
+            const char* fpenv = ksel_fp(cfg);
             if (tl_variant >= 0 && !(fpenv && (std::string(fpenv) == "lg" || std::string(fpenv) == "coop"))) {
                 split_roll = true;
                 if (tl_variant == 0) hipLaunchKernelGGL((k_mpc_load<P, INTEG, T, 0>), dim3(B), dim3(512), 0, stream, b, mb, dm, dt, d_xActual, d_shift, clear_vars, full_rollout, d_goal_in, (cfg.ee_cost && cfg.ee_cost_shift) ? 1 : 0);
@@ -781,7 +813,7 @@ struct Solver : SolverBase {
         }
         // per phase: ONE pass, kernel by kernel, an event after every launch (the sweeps are not replayed a second time:
         // the state machine moves on, and later sweeps do different amounts of work)
-        std::vector<double> ph(4 * (size_t)sweeps, 0.0);
+        std::vector<double> ph(5 * (size_t)sweeps, 0.0);
         int rc = iterate_traced(sweeps, ph.data(), 0, sweeps);
         if (rc) return rc;
         double tot = 0;
@@ -825,6 +857,7 @@ struct Solver : SolverBase {
             hipLaunchKernelGGL(k_poison_lds, dim3(4096), dim3(256), 160 * 1024, stream, 160 * 256);
         }
         if (phase >= 0 && phase <= 3) {
+            if (phase == PDDP_PHASE_BP) fs_vars_stale = false;     // (the hook's backward pass writes A - B K / B du itself)
             launch_sweep(stream, phase, 1);                         // teacher-forcing hook: the forward pass also stores every candidate trajectory
             if (phase == PDDP_PHASE_FP) hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);   // J / dmax readable right after the phase
         }
@@ -841,7 +874,7 @@ struct Solver : SolverBase {
             launch_fp(stream, 0, 1, 2);
             hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);
         }
-        else if (phase == PDDP_PHASE_BP_COOP) hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm);
+        else if (phase == PDDP_PHASE_BP_COOP) { fs_vars_stale = false; hipLaunchKernelGGL((k_bp<P, T>), dim3(cfg.M, B), dim3(64), 0, stream, b, dm); }
         else if (phase == PDDP_PHASE_INIT_NIS) launch_nis(stream, 1);
         else if (phase == PDDP_PHASE_INIT_COST) hipLaunchKernelGGL((k_init_cost<P, T>), dim3(B), dim3(64), cfg.N * sizeof(T), stream, b, dm, cw, sp, 1, 0, cfg.ee_cost ? 1 : 0, 0);
         else return fail(PDDP_EINVAL, "unknown phase");
@@ -967,6 +1000,7 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
     if (c.M < 1 || c.N % c.M || c.N / c.M < 2 || c.M > 16) return fail(PDDP_EINVAL, "M must divide N, N/M >= 2, M <= 16");
     if (c.A < 1 || c.A > 64 || c.batch < 1 || c.max_iter < 1) return fail(PDDP_EINVAL, "A in [1,64], batch >= 1, max_iter >= 1");
     if (c.ee_cost && c.plant != 4) return fail(PDDP_EINVAL, "ee_cost: the end-effector cost family belongs to the KUKA arm (plant 4)");
+    if (c.ee_type < 0 || c.ee_type > 2) return fail(PDDP_EINVAL, "ee_type: EE_TYPE is 0 (no end effector), 1 (flange) or 2 (flange + peg) (dynamics_arm.cuh:50-65)");
     if (c.use_limits && c.plant != 4) return fail(PDDP_EINVAL, "use_limits: USE_LIMITS_FLAG belongs to the KUKA arm's cost files (plant 4)");
     if (c.use_smooth_abs && !(c.plant == 4 && c.ee_cost && c.smooth_abs_alpha > 0.0)) return fail(PDDP_EINVAL, "use_smooth_abs: USE_SMOOTH_ABS belongs to the end-effector cost (plant 4, ee_cost = 1, smooth_abs_alpha > 0)");
     if (c.use_finite_diff && (c.integrator != 1 || c.ee_cost || !(c.finite_diff_epsilon > 0.0)))
@@ -1015,6 +1049,7 @@ extern "C" int pddp_set_cost_ee(pddp_handle h, double Q_EE1, double Q_EE2, doubl
 }
 extern "C" int pddp_set_benchmark_mode(pddp_handle h, int on) { IMPL(h); s->bench_mode = on ? 1 : 0; return 0; }
 extern "C" int pddp_array_bytes(pddp_handle h, const char* name, size_t* bytes) { IMPL(h); void* p; return s->array(name, &p, bytes); }
+extern "C" int pddp_refresh_reference_views(pddp_handle h) { IMPL(h); return s->reference_views(3); }
 extern "C" int pddp_array_ptr(pddp_handle h, const char* name, void** ptr, size_t* bytes) { IMPL(h); if (!ptr || !bytes) return fail(PDDP_EINVAL, "null argument"); return s->array(name, ptr, bytes); }
 extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host, size_t bytes) {
     IMPL(h); void* p; size_t cap; int rc = s->array(name, &p, &cap); if (rc) return rc;
@@ -1036,6 +1071,7 @@ extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_
     HIPCHK(hipStreamSynchronize(s->stream));
     if (std::strcmp(name, "AB") == 0 && (rc = s->ab_view(0))) return rc;
     if (std::strcmp(name, "H") == 0 && (rc = s->h_view())) return rc;
+    if ((std::strcmp(name, "ApBK") == 0 || std::strcmp(name, "Bdu") == 0) && s->fs_vars_stale && (rc = s->reference_views(1))) return rc;
     HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost)); return 0;
 }
 extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { IMPL(h); return s->get_state(out); }

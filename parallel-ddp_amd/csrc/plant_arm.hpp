@@ -30,6 +30,18 @@ struct ArmModel {            // read-only robot data (device global memory)
     T grav;                  // 9.81, or 0 when gravity is compensated by the robot (MPC_MODE)
 };
 
+// EE_TYPE 0 / 2 (plants/dynamics_arm.cuh:50-65): with the default URDF link 7's spatial inertia is the base values x INERTIA_MODIFIER (1 / 3 / 5) and its mass
+// 1.2 + WEIGHT_MODIFIER (0 / 0.03 / 0.5) (initI, :338-347); the tables hold EE_TYPE 1.  (The WAFR model's last link is fixed; there EE_TYPE only moves the tool point.)
+template <typename T>
+inline void arm_model_apply_ee_type(ArmModel<T>& m, int wafr_urdf, int ee_type) {
+    if (wafr_urdf || ee_type == 1) return;
+    const double im = ee_type == 0 ? 1.0 : 5.0, wm = ee_type == 0 ? 0.0 : 0.5;
+    T* S = m.I + 36 * 6;
+    S[0] = (T)(0.0055 * im); S[7] = (T)(0.0055 * im); S[14] = (T)(0.005 * im);
+    S[4] = (T)(-0.024 * im); S[24] = (T)(-0.024 * im); S[9] = (T)(0.024 * im); S[19] = (T)(0.024 * im);
+    S[21] = (T)(1.2 + wm); S[28] = (T)(1.2 + wm); S[35] = (T)(1.2 + wm);
+}
+
 template <typename T>
 struct ArmScratch {          // per-wave LDS
     T I[kArmNB * 36];

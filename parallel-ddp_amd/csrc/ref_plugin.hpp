@@ -35,6 +35,8 @@
 
 #include <math.h>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -82,9 +84,13 @@
 // ---- everything of the adapter that mentions the library's own field names comes BEFORE the user's files (cw.Q2, cw.R would be rewritten by a cost file's `#define Q2`, `#define R`)
 namespace pddp {
 template <typename T> PDDP_HD void ref_plugin_weights(const CostWeights<T>& cw, T* five) { five[0] = cw.Q1; five[1] = cw.Q2; five[2] = cw.R; five[3] = cw.QF1; five[4] = cw.QF2; }
-template <typename T> struct RefPluginHost { static RefPluginTables<T> tab; static bool ready; };
+// host copy of the tables (filled once per library and element type) and the set of DEVICES whose copy of the __device__ symbol has been written: a __device__ variable
+// exists once per device, so a handle created on a second device needs its own upload (with one process-wide flag such a handle read all-zero tables)
+template <typename T> struct RefPluginHost { static RefPluginTables<T> tab; static bool filled; static std::set<int> uploaded; static std::mutex lock; };
 template <typename T> RefPluginTables<T> RefPluginHost<T>::tab;
-template <typename T> bool RefPluginHost<T>::ready = false;
+template <typename T> bool RefPluginHost<T>::filled = false;
+template <typename T> std::set<int> RefPluginHost<T>::uploaded;
+template <typename T> std::mutex RefPluginHost<T>::lock;
 #if defined(__HIPCC__)
 template <typename T> __device__ RefPluginTables<T> g_ref_plugin_tables;
 #endif
@@ -96,12 +102,16 @@ template <typename T> PDDP_HD const RefPluginTables<T>& ref_plugin_tables() {
     return RefPluginHost<T>::tab;
 #endif
 }
+// uploads to the CURRENT device (pddp_create has already made the handle's device current) unless that device has its copy; caller holds RefPluginHost<T>::lock
 template <typename T> inline bool ref_plugin_upload_tables() {
 #if defined(__HIPCC__)
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_ref_plugin_tables<T>), &RefPluginHost<T>::tab, sizeof(RefPluginTables<T>)) == hipSuccess;
-#else
-    return true;
+    int pddp_dev_ = -1;
+    if (hipGetDevice(&pddp_dev_) != hipSuccess) return false;
+    if (RefPluginHost<T>::uploaded.count(pddp_dev_)) return true;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ref_plugin_tables<T>), &RefPluginHost<T>::tab, sizeof(RefPluginTables<T>)) != hipSuccess) return false;
+    RefPluginHost<T>::uploaded.insert(pddp_dev_);
 #endif
+    return true;
 }
 inline std::string ref_plugin_horizon_complaint(int pddp_n_) {
     return "plant 5 was compiled from a reference-form cost file with NUM_TIME_STEPS = " + std::to_string(kUserPlantN) + " (a compile-time constant of such files): create the handle with N = " +
@@ -164,13 +174,16 @@ template <typename T> PDDP_HD void ref_plugin_cost_grad(const CostWeights<T>& pd
 // Called when a handle of plant 5 is created (declared in plants.hpp): fills the tables, checks the two requirements of the header comment.  Returns "" or what is wrong.
 template <typename T> std::string ref_plugin_setup(int pddp_n_) {
     if (pddp_n_ != kUserPlantN) return ref_plugin_horizon_complaint(pddp_n_);
-    if (!RefPluginHost<T>::ready) {
-        RefPluginTables<T>& pddp_t_ = RefPluginHost<T>::tab;
-        std::memset(&pddp_t_, 0, sizeof(pddp_t_));
-        pddp_ref_plugin::initI<T>(pddp_t_.pddp_tab_I);
-        pddp_ref_plugin::initT<T>(pddp_t_.pddp_tab_T);
+    {
+        std::lock_guard<std::mutex> pddp_guard_(RefPluginHost<T>::lock);
+        if (!RefPluginHost<T>::filled) {
+            RefPluginTables<T>& pddp_t_ = RefPluginHost<T>::tab;
+            std::memset(&pddp_t_, 0, sizeof(pddp_t_));
+            pddp_ref_plugin::initI<T>(pddp_t_.pddp_tab_I);
+            pddp_ref_plugin::initT<T>(pddp_t_.pddp_tab_T);
+            RefPluginHost<T>::filled = true;
+        }
         if (!ref_plugin_upload_tables<T>()) return "hipMemcpyToSymbol of the plug-in's initI / initT tables failed";
-        RefPluginHost<T>::ready = true;
     }
     // the qdd of dynamicsGradient against dynamics(), on the host instantiation, at a few states spread over the unit box and beyond
     for (int pddp_trial_ = 0; pddp_trial_ < 8; pddp_trial_++) {

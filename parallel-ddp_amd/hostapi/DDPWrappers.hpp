@@ -18,8 +18,9 @@
 //     (pddp_state.pw), so after a solve the last cost-to-go is in d_P or in d_Pp (pddp_get_state tells which);
 //   * d_xp / d_xp2 are the two halves of one double buffer whose roles (current trajectory / trajectory the stored
 //     boundary cost-to-go belongs to) alternate with every accepted iteration instead of being copied;
-//   * the per-alpha slots are pure outputs of the forward pass: after a solve h_d_x[*alphaIndex] holds the winner, the
-//     other slots hold the other candidates of the LAST line search (the reference overwrites them with the winner);
+//   * the per-alpha slots are pure outputs of the forward pass and d_ApBK / d_Bdu are not written by production sweeps (the forward sweep's operands are
+//     composed inside the backward pass): runiLQR_GPU rebuilds all of them before it returns (pddp_refresh_reference_views: the accepted trajectory in every
+//     alpha slot like memcpyCurrAKern leaves it, A - B K / B du of the last backward pass), unless compiled with -DPDDP_REFERENCE_VIEWS=0;
 //   * d_I / d_Tbody point to the library's robot constants (spatial inertias / fixed joint frames), not to the
 //     reference's 36-float-per-link scratch layout; treat them as opaque;
 //   * `streams` has NUM_STREAMS entries that all alias the solver's single stream (one stream is all it needs).
@@ -32,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -44,6 +46,9 @@
 #ifndef PDDP_DEVICE
 #define PDDP_DEVICE 0
 #endif
+#ifndef PDDP_REFERENCE_VIEWS
+#define PDDP_REFERENCE_VIEWS 1   // after every runiLQR_GPU: d_ApBK / d_Bdu rebuilt and the accepted trajectory copied into every alpha slot, like the reference leaves them
+#endif                           // (one small launch per solve; 0 for callers that never read those buffers)
 #ifndef PDDP_EE_INITIAL_COST_FIX
 #define PDDP_EE_INITIAL_COST_FIX 0   // 1: pddp_config.ee_initial_cost_fix (include/pddp.h) -- NOT the reference's behaviour
 #endif
@@ -53,11 +58,14 @@ namespace pddp_hostapi {
 struct Context {
     pddp_handle h;
     double cost[14];              // the weights the handle currently holds: Q1 Q2 R QF1 QF2 | Q_EE1 Q_EE2 QF_EE1 QF_EE2 R_EE Q_xEE QF_xEE Q_xdEE QF_xdEE
-    std::vector<double> phase;    // [4][MAX_ITER+2]
+    std::vector<double> phase;    // [5][MAX_ITER+2]: bp, sweep + rollouts, line search, setup, the linear sweep alone (pddp_solve_ex)
     std::vector<char> Jtmp;       // [MAX_ITER+2] elements of T
     std::vector<int> atmp;
 };
+// handle registry, keyed by the d_P the caller hands back on every call; guarded: allocate / run / free may come from different host threads (the reference's MPC loop
+// solves on one thread while another publishes, MPCHelpers.cuh:62,756-773)
 inline std::map<const void*, Context*>& registry() { static std::map<const void*, Context*> r; return r; }
+inline std::mutex& registry_lock() { static std::mutex m; return m; }
 
 inline void check(int rc, const char* what) {
     if (rc == 0) return;
@@ -82,6 +90,7 @@ void apply_cost(Context* ctx, T Q1, T Q2, T R, T QF1, T QF2, T Q_EE1, T Q_EE2, T
     for (int i = 0; i < 14; i++) ctx->cost[i] = v[i];
 }
 inline Context* find(const void* d_P) {
+    std::lock_guard<std::mutex> guard(registry_lock());
     auto it = registry().find(d_P);
     if (it == registry().end()) { std::fprintf(stderr, "GPUassert: buffers were not obtained from allocateMemory_GPU\n"); std::exit(1); }
     return it->second;
@@ -107,7 +116,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX;
     c.Q1 = _Q1; c.Q2 = _Q2; c.R = _R; c.QF1 = _QF1; c.QF2 = _QF2;
     c.ee_cost = EE_COST; c.Q_EE1 = _Q_EE1; c.Q_EE2 = _Q_EE2; c.QF_EE1 = _QF_EE1; c.QF_EE2 = _QF_EE2; c.R_EE = _R_EE;
-    c.Q_xEE = _Q_xEE; c.QF_xEE = _QF_xEE; c.Q_xdEE = _Q_xdEE; c.QF_xdEE = _QF_xdEE; c.ee_on_link_z = EE_ON_LINK_Z;
+    c.Q_xEE = _Q_xEE; c.QF_xEE = _QF_xEE; c.Q_xdEE = _Q_xdEE; c.QF_xdEE = _QF_xdEE; c.ee_on_link_z = EE_ON_LINK_Z; c.ee_type = EE_TYPE;
     c.ee_initial_cost_fix = PDDP_EE_INITIAL_COST_FIX;
     c.use_finite_diff = USE_FINITE_DIFF; c.finite_diff_epsilon = FINITE_DIFF_EPSILON;   // config.cuh:68-71
     c.use_limits = USE_LIMITS_FLAG; c.use_smooth_abs = USE_SMOOTH_ABS; c.smooth_abs_alpha = SMOOTH_ABS_ALPHA;   // config.cuh:171-176
@@ -116,7 +125,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     pddp_handle h = ctx->h;
     const double w0[14] = {_Q1, _Q2, _R, _QF1, _QF2, _Q_EE1, _Q_EE2, _QF_EE1, _QF_EE2, _R_EE, _Q_xEE, _QF_xEE, _Q_xdEE, _QF_xdEE};
     for (int i = 0; i < 14; i++) ctx->cost[i] = w0[i];
-    ctx->phase.assign(4 * (MAX_ITER + 2), 0.0);
+    ctx->phase.assign(5 * (MAX_ITER + 2), 0.0);
     ctx->Jtmp.assign(sizeof(T) * (MAX_ITER + 2), 0);
     ctx->atmp.assign(MAX_ITER + 2, 0);
 
@@ -150,7 +159,7 @@ void allocateMemory_GPU(T*** d_x, T*** h_d_x, T** d_xp, T** d_xp2, T*** d_u, T**
     for (int i = 0; i < NUM_STREAMS; i++) (*streams)[i] = static_cast<pddpStream_t>(st);
     if (d_I) *d_I = (PLANT == 4) ? dev<T>(h, "model_I") : nullptr;
     if (d_Tbody) *d_Tbody = (PLANT == 4) ? dev<T>(h, "model_F") : nullptr;
-    registry()[*d_P] = ctx;
+    { std::lock_guard<std::mutex> guard(registry_lock()); registry()[*d_P] = ctx; }
 }
 
 template <typename T>
@@ -179,6 +188,9 @@ void runiLQR_GPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, i
                         PDDP_POLL_EVERY, times, PDDP_PHASE_TIMERS ? ctx->phase.data() : nullptr, &sweeps), "runiLQR_GPU");
     std::memcpy(Jout, Jtmp, (MAX_ITER + 1) * sizeof(T));                 // the reference's arrays hold MAX_ITER+1 entries
     std::memcpy(alphaOut, ctx->atmp.data(), (MAX_ITER + 1) * sizeof(int));
+#if PDDP_REFERENCE_VIEWS
+    check(pddp_refresh_reference_views(h), "pddp_refresh_reference_views");      // d_ApBK / d_Bdu and the winner in every alpha slot, as the reference leaves them
+#endif
     pddp_state st;
     check(pddp_get_state(h, &st), "pddp_get_state");
     const int iter = st.iter;
@@ -193,8 +205,8 @@ void runiLQR_GPU(T* x0, T* u0, T* KT0, T* P0, T* p0, T* d0, T* xGoal, T* Jout, i
     for (int k = 0; k < iter && k < MAX_ITER; k++) {                      // bpTime[iter-1] ... (DDPWrappers.cuh:65,78,89,100)
         const double* ph = ctx->phase.data();
         if (bpTime) bpTime[k] = PDDP_PHASE_TIMERS ? ph[0 * stride + k] : 0.0;
-        if (sweepTime) sweepTime[k] = 0.0;                                // the sweep is fused into the forward-pass kernel
-        if (simTime) simTime[k] = PDDP_PHASE_TIMERS ? ph[1 * stride + k] + ph[2 * stride + k] : 0.0;
+        if (sweepTime) sweepTime[k] = PDDP_PHASE_TIMERS ? ph[4 * stride + k] : 0.0;      // forwardSweepKern's part (k_sweep_maps & co.; DDPWrappers.cuh:77)
+        if (simTime) simTime[k] = PDDP_PHASE_TIMERS ? ph[1 * stride + k] - ph[4 * stride + k] + ph[2 * stride + k] : 0.0;   // rollouts + line search (:89)
         if (nisTime) nisTime[k] = PDDP_PHASE_TIMERS ? ph[3 * stride + k] : 0.0;
     }
     std::printf("GPU (MI355X) Parallel blocks:[%d] t:[%f] with FP[%f], FS[%f], BP[%f], NIU[%f] Xf:[%.4f, %.4f] iters:[%d] cost:[%f] max_d[%f]\n",
@@ -213,7 +225,7 @@ void freeMemory_GPU(T** d_x, T** h_d_x, T* d_xp, T* d_xp2, T** d_u, T** h_d_u, T
     (void)d_KT; (void)d_du; (void)d_d; (void)d_dp; (void)d_dM; (void)d_dT; (void)d_ApBK; (void)d_Bdu; (void)d_JT; (void)d_dJexp; (void)d_alpha;
     (void)d_err; (void)d_I; (void)d_Tbody;
     Context* ctx = find(d_P);
-    registry().erase(d_P);
+    { std::lock_guard<std::mutex> guard(registry_lock()); registry().erase(d_P); }
     check(pddp_destroy(ctx->h), "freeMemory_GPU");
     delete ctx;
     std::free(h_d_x); std::free(h_d_u); std::free(h_d_d); std::free(xGoal); std::free(d); std::free(J); std::free(dJexp); std::free(alpha);
@@ -263,7 +275,7 @@ inline pddp_config pddp_cpu_config_from_macros(T Q1, T Q2, T R, T QF1, T QF2) {
     c.N = NUM_TIME_STEPS; c.M = M_BLOCKS; c.A = NUM_ALPHA; c.integrator = INTEGRATOR; c.batch = 1; c.max_iter = MAX_ITER;
     c.wafr_urdf = USE_WAFR_URDF; c.mpc_mode = MPC_MODE; c.ignore_max_rho_exit = IGNORE_MAX_ROX_EXIT;
     c.total_time = TOTAL_TIME; c.alpha_base = ALPHA_BASE; c.rho_init = RHO_INIT; c.max_defect = MAX_DEFECT_SIZE; c.tol_cost = TOL_COST;
-    c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX; c.Q1 = Q1; c.Q2 = Q2; c.R = R; c.QF1 = QF1; c.QF2 = QF2; c.ee_cost = EE_COST;
+    c.exp_red_min = EXP_RED_MIN; c.exp_red_max = EXP_RED_MAX; c.Q1 = Q1; c.Q2 = Q2; c.R = R; c.QF1 = QF1; c.QF2 = QF2; c.ee_cost = EE_COST; c.ee_type = EE_TYPE; c.ee_on_link_z = EE_ON_LINK_Z;
     c.use_finite_diff = USE_FINITE_DIFF; c.finite_diff_epsilon = FINITE_DIFF_EPSILON;
     c.use_limits = USE_LIMITS_FLAG; c.use_smooth_abs = USE_SMOOTH_ABS; c.smooth_abs_alpha = SMOOTH_ABS_ALPHA;
     return c;

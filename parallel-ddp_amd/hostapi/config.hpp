@@ -269,9 +269,9 @@ PDDP_FIXED_SWITCH(RHO_MAX == 10000000.0 && RHO_MIN == 0.01 && RHO_FACTOR == 1.25
 #elif EE_TYPE == 2
 #define EE_ON_LINK_Z 0.1524
 #endif
-#if EE_TYPE != 1
-#error "only EE_TYPE 1 (flange) is provided: the link-7 inertia of the robot tables includes its INERTIA_MODIFIER / WEIGHT_MODIFIER (dynamics_arm.cuh:53-65)"
-#endif
+#if EE_TYPE < 0 || EE_TYPE > 2
+#error "EE_TYPE is 0 (no end effector), 1 (flange) or 2 (flange + peg) (dynamics_arm.cuh:50-65)"
+#endif                                // (link 7's INERTIA_MODIFIER / WEIGHT_MODIFIER of the default URDF follow from pddp_config.ee_type, :53-65,338-347)
 
 // matrix dimensions (config.cuh:195-236), column-major, leading dimension = rows
 #define DIM_x_r STATE_SIZE

@@ -12,6 +12,29 @@ class PddpError(RuntimeError):
     pass
 
 
+# pddp_kernel_selection (include/pddp.h): value names per field, in the order of the header (index + 1 = the C value; 0 / None = the library's choice)
+KERNEL_NAMES = {"bp": ("mx", "lg", "coop", "wide"), "fp": ("tl", "lg", "coop", "tl2", "tl4"), "sweep": ("alpha", "st", "wg"), "ls": ("many", "wg"), "ab": ("full",),
+                "cf": ("ts", "coop"), "cf_bp": ("ts", "coop", "gl", "gl32", "cl"), "cf_fp": ("ts", "coop", "cf"), "cf_nis": ("ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64")}
+
+
+class PddpKernelSelection(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("bp", "fp", "sweep", "ls", "ab", "cf", "cf_bp", "cf_fp", "cf_nis")]
+
+
+def set_kernels(cfg, **names):
+    """cfg.kernels from names: set_kernels(cfg, bp="mx", fp="tl").  None / "" / "auto" leave the library's choice."""
+    for field, name in names.items():
+        if field not in KERNEL_NAMES:
+            raise ValueError(f"unknown kernel-selection field {field!r} (one of {sorted(KERNEL_NAMES)})")
+        if name in (None, "", "auto"):
+            setattr(cfg.kernels, field, 0)
+        elif name in KERNEL_NAMES[field]:
+            setattr(cfg.kernels, field, KERNEL_NAMES[field].index(name) + 1)
+        else:
+            raise ValueError(f"kernel selection {field}={name!r}: one of {KERNEL_NAMES[field]}")
+    return cfg
+
+
 class PddpConfig(C.Structure):
     """pddp_config (include/pddp.h): the reference's config.cuh macros as a run-time record."""
     _fields_ = [
@@ -30,6 +53,8 @@ class PddpConfig(C.Structure):
         ("use_smooth_abs", C.c_int),
         ("smooth_abs_alpha", C.c_double),
         ("use_limits", C.c_int),
+        ("ee_type", C.c_int),
+        ("kernels", PddpKernelSelection),
     ]
 
 
@@ -90,12 +115,15 @@ def _load(path):
     return _LIBS[path]
 
 
-def default_config(plant, _lib_path=None, **kw):
+def default_config(plant, _lib_path=None, kernels=None, **kw):
+    """pddp_default_config + overrides by field name.  kernels: {"bp": "mx", "fp": "tl", ...} pins kernel families (pddp_kernel_selection); default: the library chooses."""
     lib = _load(_lib_path or library_path())
     c = PddpConfig()
     rc = lib.pddp_default_config(C.byref(c), int(plant))
     if rc:
         raise PddpError(lib.pddp_last_error().decode())
+    if kernels:
+        set_kernels(c, **kernels)
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -275,12 +303,12 @@ class Solver:
 
     def solve_phase_timed(self, x0, u0, xGoal, clear_vars=1, ignore_first_defect=1, poll_every=8):
         """pddp_solve_ex with per-iteration phase timers (HIP events per kernel, like the reference's bpTime[] / simTime[] / nisTime[], DDPWrappers.cuh:54-105):
-        phase_ms[4][max_iter + 2] = backward pass, sweep + rollouts, line search, next-iteration setup of every iteration (batch 1)."""
+        phase_ms[5][max_iter + 2] = backward pass, sweep + rollouts, line search, next-iteration setup of every iteration, and the linear sweep's own kernel (a part of row 1) (batch 1)."""
         B, mi = self.cfg.batch, self.cfg.max_iter
         x0, u0, xGoal = self.arr(x0).copy(), self.arr(u0).copy(), self.arr(xGoal)
         Jout, aout = np.zeros((B, mi + 2), self.dtype), np.zeros((B, mi + 2), np.int32)
         times = (C.c_double * 2)()
-        phase = np.zeros((4, mi + 2), np.float64)
+        phase = np.zeros((5, mi + 2), np.float64)
         sweeps = C.c_int(0)
         self.lib.pddp_solve_ex.argtypes = [C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p]
         self._chk(self.lib.pddp_solve_ex(self.h, _p(x0), _p(u0), _p(xGoal), None, None, None, None, _p(Jout), _p(aout), 0, int(clear_vars), int(ignore_first_defect),
@@ -352,6 +380,10 @@ class Solver:
         a = np.zeros(nb.value // np.dtype(self._adtype(name)).itemsize, self._adtype(name))
         self._chk(self.lib.pddp_get_array(self.h, name.encode(), _p(a), C.c_size_t(nb.value)))
         return a
+
+    def refresh_reference_views(self):
+        """pddp_refresh_reference_views: d_ApBK / d_Bdu and the accepted trajectory in every step-size slot, as the reference leaves them after a solve."""
+        self._chk(self.lib.pddp_refresh_reference_views(self.h))
 
     def set(self, name, a):
         a = np.ascontiguousarray(a, dtype=self._adtype(name)).ravel()

@@ -46,6 +46,7 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     c->ee_on_link_z = 0.0635;   // plants/cost_arm.cuh:104-115, dynamics_arm.cuh:57-58 (EE_TYPE 1)
     c->use_finite_diff = 0; c->finite_diff_epsilon = 0.00001;
     c->use_limits = 0; c->use_smooth_abs = 0; c->smooth_abs_alpha = 0.2;
+    c->ee_type = 1;
     return 0;
 }
 
@@ -74,6 +75,7 @@ template <typename T> static void fill_model(ArmModel<T>& m, const pddp_config& 
     for (int b = 0; b < 7; b++) { for (int i = 0; i < 36; i++) m.I[36 * b + i] = (T)IIWA14_SPATIAL_INERTIA[v][b][i];
                                   for (int i = 0; i < 16; i++) m.F[16 * b + i] = (T)IIWA14_JOINT_FRAME[v][b][i]; }
     m.grav = (T)(c.mpc_mode ? 0.0 : 9.81);
+    arm_model_apply_ee_type(m, c.wafr_urdf, c.ee_type);
 }
 static void fill_model(EmptyModel& m, const pddp_config&) { m.unused = 0; }
 

@@ -171,6 +171,34 @@ def test_two_handles_on_two_host_threads_do_not_disturb_each_other():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reference_views_after_a_solve(dtype):
+    """What the reference leaves in d_ApBK / d_Bdu (computeFSVars, bpHelpers.cuh:281-312) and in EVERY alpha slot of d_x / d_u / d_d (memcpyCurrAKern x 3,
+    nisInitHelpers.cuh:24-32,270-272) after runiLQR_GPU -- production sweeps write neither; pddp_refresh_reference_views (called by the facade's runiLQR_GPU)
+    and pddp_get_array("ApBK" / "Bdu") rebuild them.  Checked against the arithmetic itself and against the oracle's backward pass on the solve's final state."""
+    N, M, A, n, m = 32, 4, 8, 14, 7
+    x0, u0, xg = example_inputs(4, N, dtype, noise=np.random.default_rng(3).normal(0, 0.002, (N, 14)))
+    s = pyddp.Solver(pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=12, dtype=1 if dtype == np.float64 else 0))
+    out = s.solve(x0, u0, xg)
+    AB = s.get("AB").reshape(N, n + m, n); KT = s.get("KT").reshape(N, m, n); du = s.get("du").reshape(N, m)        # column-major blocks: [col][row]
+    F = s.get("ApBK").reshape(N, n, n); Bd = s.get("Bdu").reshape(N, n)                                             # materialised by pddp_get_array
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    for k in range(N - 1):
+        Amat, Bmat, K = AB[k, :n, :].T.astype(np.float64), AB[k, n:, :].T.astype(np.float64), KT[k].astype(np.float64)     # A (n x n), B (n x m), K (m x n)
+        ref = Amat - Bmat @ K
+        assert np.abs(F[k].T - ref).max() <= tol * max(1.0, np.abs(ref).max()), k
+        assert np.abs(Bd[k] - Bmat @ du[k]).max() <= tol * max(1.0, np.abs(Bmat @ du[k]).max()), k
+    assert np.abs(F[: N - 1]).max() > 0.5
+    s.refresh_reference_views()
+    xs = s.get("xs").reshape(A, N, n); us = s.get("us").reshape(A, N, m); ds = s.get("ds").reshape(A, N, n)
+    for a in range(A):
+        assert np.array_equal(xs[a], out["x"][0]) and np.array_equal(us[a][: N - 1], out["u"][0][: N - 1]), a
+        assert np.array_equal(ds[a], ds[0])
+    assert np.array_equal(ds[0], s.get("dcur").reshape(N, n))
+    s.close()
+
+
+@pytest.mark.gpu
 def test_set_cost_equals_creating_with_those_weights():
     x0, u0, xg = example_inputs(4, 32, np.float32)
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=15)

@@ -1,8 +1,10 @@
-"""Which kernels a handle's sweep launches (pddp_time_kernels reports them in launch order).  The parity suites run with the library's automatic selection; this file
+"""Which kernels a handle's sweep launches (pddp_time_kernels reports them in launch order), as a function of the configuration alone: the selection is DATA
+(pddp_config.kernels, include/pddp.h; all zero = the library's documented choice) and the library reads no environment variable for it.  The parity suites run with the library's automatic selection; this file
 states what that selection IS for the shapes they use, so that a handle silently falling back to another family (the lane-group kernels compute the same functions) cannot
 pass unnoticed as coverage of the family a test was written for.  DESIGN.md section 4: matrix-core backward pass for the arm in float at every batch size; rollouts / setup on
 thread lanes from 512 problems (k_fp_tl, k_nis_tl), as a four-wave pipeline and one thread per (knot, joint) for few problems in flight (k_fp_tl4, k_nis_tl7), for the
 joint-space AND the end-effector cost; closed-form plants thread-serial from 256 (problem, segment) units."""
+import ctypes
 import os
 
 import numpy as np
@@ -15,15 +17,9 @@ pytestmark = pytest.mark.gpu
 KUKA = dict(N=64, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=20)
 
 
-def kernels(plant, batch, env=None, dtype=0, **kw):
-    env = env or {}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        s = make_solver("hip", plant, dtype=dtype, batch=batch, use_graph=0, **kw)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+def kernels(plant, batch, sel=None, dtype=0, **kw):
+    """names of the kernels one sweep of such a handle launches; sel: pddp_config.kernels by name (pyddp.set_kernels), None = the library's own choice"""
+    s = make_solver("hip", plant, dtype=dtype, batch=batch, use_graph=0, kernels=sel, **kw)
     N = kw["N"]
     x0, u0, xg = example_inputs(plant, N, np.float64 if dtype else np.float32, noise=np.random.default_rng(3).normal(0, 0.001, (N, s.n)))
     if kw.get("ee_cost"):
@@ -42,10 +38,36 @@ def test_few_problems_in_flight_run_the_pipeline_and_the_per_joint_setup(ee):
     assert kernels(4, 3, **kw)[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
 
 
+def test_the_library_does_not_read_the_environment_for_its_selection():
+    """PDDP_BP / PDDP_FP were environment switches of the library until round 4; now only this test suite's own plumbing (tests/backends.py) translates them.  A config
+    built WITHOUT that plumbing must give the default selection whatever the environment says."""
+    import pyddp
+    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP")}
+    os.environ.update({"PDDP_BP": "lg", "PDDP_FP": "lg"})
+    try:
+        lib = ctypes.CDLL(pyddp.library_path())
+        c = pyddp.PddpConfig()
+        assert lib.pddp_default_config(ctypes.byref(c), 4) == 0
+        for k, v in dict(KUKA, batch=1, use_graph=0).items():
+            setattr(c, k, v)
+        assert all(getattr(c.kernels, f) == 0 for f in pyddp.KERNEL_NAMES)
+        s = pyddp.Solver(c)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    x0, u0, xg = example_inputs(4, 64, np.float32)
+    s.load(x0, u0, xg); s.iterate(2); s.sync()
+    assert [n for n, _ in s.time_kernels(2)] == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_ls", "k_nis_tl7"]
+    s.close()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parallel-ddp_amd", "csrc", "pddp_api.hip")).read()
+    import re
+    assert sorted(set(re.findall(r'getenv\("(\w+)"\)', src))) == ["PDDP_EVAL_GRID", "PDDP_POISON_LDS"]      # debugging / micro-benchmark aids only
+
+
 def test_selection_overrides_reach_the_older_kernels():
-    assert kernels(4, 1, {"PDDP_FP": "tl2"}, **KUKA)[2] == "k_fp_tl2"
-    assert kernels(4, 1, {"PDDP_FP": "lg"}, **KUKA)[2:] == ["k_fp_lg", "k_ls", "k_nis_lg"]
-    assert kernels(4, 64, {"PDDP_BP": "lg", "PDDP_FP": "lg"}, **KUKA)[0] != "k_bp_mfma"
+    assert kernels(4, 1, dict(fp="tl2"), **KUKA)[2] == "k_fp_tl2"
+    assert kernels(4, 1, dict(fp="lg"), **KUKA)[2:] == ["k_fp_lg", "k_ls", "k_nis_lg"]
+    assert kernels(4, 64, dict(bp="lg", fp="lg"), **KUKA)[0] != "k_bp_mfma"
 
 
 @pytest.mark.parametrize("ee", [0, 1])
@@ -58,7 +80,7 @@ def test_large_batches_run_one_thread_per_rollout_and_per_knot(ee):
 
 def test_float64_handles_default_to_lane_groups_and_reach_the_benched_family_on_request():
     assert kernels(4, 2, dtype=1, **KUKA)[-3:] == ["k_fp_lg", "k_ls", "k_nis_lg"]
-    got = kernels(4, 2, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, dtype=1, **KUKA)
+    got = kernels(4, 2, dict(bp="mx", fp="tl"), dtype=1, **KUKA)
     assert got[0].startswith("k_bp_mfma") and got[-3:] == ["k_fp_tl", "k_ls", "k_nis_tl"]
 
 
@@ -67,24 +89,18 @@ def test_closed_form_plants_switch_to_thread_serial_kernels_with_the_device_full
     assert kernels(2, 2, **cart) == ["k_bp", "k_fp", "k_ls", "k_nis"]
     assert kernels(2, 4096, **cart) == ["k_bp_ts", "k_fp_cf", "k_ls_many", "k_nis_ts"]      # line search: one thread per problem from 2048 problems in flight; rollouts: thread per rollout with the knot's operands staged per wavefront (8 or 16 step sizes)
     assert kernels(2, 4096, **dict(cart, A=4)) == ["k_bp_ts", "k_fp_ts", "k_ls_many", "k_nis_ts"]
-    assert kernels(2, 4096, {"PDDP_CF_FP": "ts"}, **cart)[1] == "k_fp_ts"
+    assert kernels(2, 4096, dict(cf_fp="ts"), **cart)[1] == "k_fp_ts"
     quad = dict(N=64, M=4, A=8, integrator=3, total_time=4.0, tol_cost=0.0, max_iter=20)      # 12 states: rollouts thread-serial, setup on 16-lane groups, backward pass cooperative (32-lane groups from 8192 blocks of knots)
     assert kernels(3, 1024, **quad) == ["k_bp", "k_fp_ts", "k_ls", "k_nis_kb"]               # RK3: the knot-batched setup (lane = knot for the scalar gradients, lane = column of [A B] after)
     assert kernels(3, 2048, **quad) == ["k_bp_cl", "k_fp_ts", "k_ls_many", "k_nis_kb"]          # backward pass: 16 lanes per block of knots, lane = column (8 step sizes of a 12-state plant: 8 problems x 12 states do not fit one fetch per lane, the staged rollouts take 16)
     assert kernels(3, 2048, **dict(quad, A=16)) == ["k_bp_cl", "k_fp_cf", "k_ls_many", "k_nis_kb"]
     assert kernels(3, 2048, **dict(quad, integrator=1)) == ["k_bp_cl", "k_fp_ts", "k_ls_many", "k_nis_gl"]
-    assert kernels(3, 2048, {"PDDP_CF_BP": "gl32"}, **quad)[0] == "k_bp_gl"
-    assert kernels(3, 2048, {"PDDP_CF_NIS": "gl"}, **quad)[-1] == "k_nis_gl"
+    assert kernels(3, 2048, dict(cf_bp="gl32"), **quad)[0] == "k_bp_gl"
+    assert kernels(3, 2048, dict(cf_nis="gl"), **quad)[-1] == "k_nis_gl"
 
 
-def _solve_with(env, batch, N, M, iters=6):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        s = make_solver("hip", 4, dtype=0, batch=batch, use_graph=0, N=N, M=M, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=iters)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+def _solve_with(sel, batch, N, M, iters=6):
+    s = make_solver("hip", 4, dtype=0, batch=batch, use_graph=0, N=N, M=M, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=iters, kernels=sel)
     rng = np.random.default_rng(11)
     xs, us, gs = [], [], []
     for _ in range(batch):                                            # every problem its own start: a wrong knot / problem offset cannot hide behind identical data
@@ -104,9 +120,9 @@ def test_compact_operands_through_the_lds_prefetch_follow_the_reference_layout(N
     The same first iteration with PDDP_AB=full (reference-layout [A B], plain loads, no prefetch) must land on the same trajectory up to float32 rounding -- a wrong knot,
     chunk or problem offset would be off by the size of the data, not by 1e-6.  (Across BUILDS the compact path is held bit for bit: tools/cmp_compact_vs_full.py builds,
     profiles/r04_bp_mfma.md.)"""
-    env = {"PDDP_BP": "mx", "PDDP_FP": "tl"}
-    names_c, c = _solve_with(env, 5, N, M, iters=1)
-    names_f, f = _solve_with(dict(env, PDDP_AB="full"), 5, N, M, iters=1)
+    sel = dict(bp="mx", fp="tl")
+    names_c, c = _solve_with(sel, 5, N, M, iters=1)
+    names_f, f = _solve_with(dict(sel, ab="full"), 5, N, M, iters=1)
     assert names_c[0] == "k_bp_mfma" and names_f[0] == "k_bp_mfma" and "k_nis_tl" in names_c
     np.testing.assert_array_equal(c["alphaOut"], f["alphaOut"])
     np.testing.assert_allclose(c["x"], f["x"], atol=1e-4, rtol=0)

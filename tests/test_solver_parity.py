@@ -47,6 +47,27 @@ def test_kuka_float64_whole_solve(backend, M):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("ee_type", [0, 2])
+def test_kuka_ee_type_variants_of_the_default_urdf(backend, ee_type):
+    """EE_TYPE 0 (no end effector) and 2 (flange + peg), plants/dynamics_arm.cuh:50-65: with the default URDF link 7's inertia is the base values x INERTIA_MODIFIER
+    (1 / 5) and its mass 1.2 + WEIGHT_MODIFIER (0 / 0.5) (initI, :338-347) -- pddp_config.ee_type.  The handle's robot tables then equal neither built-in model, so the
+    kernels that take the robot as literals step aside; whole float64 solves follow the oracle (which carries the same switch) decision for decision, and differ from
+    EE_TYPE 1's."""
+    kw = dict(N=32, M=4, A=8, wafr_urdf=0, tol_cost=0.0, total_time=0.5, max_iter=8)
+    x0, u0, xg = example_inputs(4, 32, np.float64, noise=np.random.default_rng(5).normal(0, 0.002, (32, 14)), wafr_urdf=0)
+    ref = Oracle(default_cfg(4, cores=1, spawn_threads=0, ee_type=ee_type, **kw), np.float64).run_ilqr_gpusem(x0, u0, xg)
+    ref1 = Oracle(default_cfg(4, cores=1, spawn_threads=0, ee_type=1, **kw), np.float64).run_ilqr_gpusem(x0, u0, xg)
+    s = make_solver(backend, 4, dtype=1, ee_type=ee_type, **kw)
+    out = s.solve(x0, u0, xg)
+    it = ref["iters"]
+    assert list(out["alphaOut"][0][: it + 1]) == list(ref["alphaOut"][: it + 1])
+    np.testing.assert_allclose(out["Jout"][0][: it + 1], ref["Jout"][: it + 1], rtol=1e-8)
+    np.testing.assert_allclose(out["x"][0].ravel(), ref["x"], rtol=0, atol=1e-8 * np.abs(ref["x"]).max())
+    assert abs(ref["Jout"][it] - ref1["Jout"][it]) > 1e-6 * abs(ref1["Jout"][it])      # (the switch does change the robot)
+    s.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_kuka_float32_headline_config(backend):
     """BASELINE config 3: Kuka, N=128, A=8, M=4, Euler, float."""
     out, refs, _ = run_pair(backend, 4, np.float32, N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=20)

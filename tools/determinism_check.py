@@ -10,6 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import pyddp
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tests'))
+import backends as _backends; _backends.install_env_selection()      # PDDP_BP / PDDP_FP / ... -> pddp_config.kernels (the library reads no environment)
 from backends import make_solver
 from oracle_binding import example_inputs
 from test_fp32_bar import EE_KW, KUKA, ee_start

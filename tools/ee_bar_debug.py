@@ -4,6 +4,7 @@ import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
+import backends as _backends; _backends.install_env_selection()
 import test_fp32_bar as t
 env = {"PDDP_BP": "mx", "PDDP_FP": "tl"} if len(sys.argv) > 1 and sys.argv[1] == "large" else {}
 rows, fails, ints_ok, names = t.run_bar_ee("hip", dict(t.EE_KW), env, 10, True)

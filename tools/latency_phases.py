@@ -4,6 +4,8 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, ROOT)
 import numpy as np, pyddp, bench
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tests'))
+import backends as _backends; _backends.install_env_selection()      # PDDP_BP / PDDP_FP / ... -> pddp_config.kernels (the library reads no environment)
 rng = np.random.default_rng(1)
 for N, A, bp in ((128, 8, None), (128, 8, "coop"), (64, 16, None)):
     if bp: os.environ["PDDP_BP"] = bp

@@ -133,3 +133,35 @@ def test_trajectory_runner_command(out):
     got = [float(v) for v in out["runner_err"].split("tau")[1].split("[!]")[0].split()]
     assert out["runner_err"].startswith("0")
     np.testing.assert_allclose(got, tau, rtol=2e-6)
+
+
+@pytest.mark.gpu
+def test_a_trajectory_solved_on_the_gpu_travels_through_the_wire_format_bit_for_bit(tmp_path):
+    """End to end across the N4 boundary: runiLQR_MPC_GPU (struct facade, HIP kernels) -> trajVars -> trajectoryMessage -> LCM bytes (tests/wire/wire_solve.cpp); the bytes
+    are decoded HERE, independently of hostapi/LCMHelpers.hpp (big-endian members in declaration order behind the 8-byte fingerprint), and must carry exactly the plan
+    the solver left -- every float bit for bit, the reference's byte-count sizes, the plan's time stamp (LCM_MPCLoop_Handler::handleStatus, LCMHelpers.cuh:239-262)."""
+    exe = os.path.join(ROOT, "tests", "wire", "wire_solve")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-Wall", os.path.join(ROOT, "tests", "wire", "wire_solve.cpp"), "-L" + os.path.join(PKG, "lib"), "-lpddp",
+                           "-Wl,-rpath," + os.path.join(PKG, "lib"), "-o", exe])
+    wire_file, raw_file = str(tmp_path / "traj.lcm"), str(tmp_path / "traj.raw")
+    text = subprocess.run([exe, wire_file, raw_file], capture_output=True, text=True, check=True).stdout
+    info = dict(l.split(" ", 1) for l in text.splitlines() if l.startswith(("iterations", "wire_len")))
+    its = info["iterations"].split()
+    assert int(its[0]) >= 4 and float(its[4]) < 0.5 * float(its[2])                      # a real solve: J fell
+    N, n, m = 64, 14, 7                                                                     # the arm's default horizon (config.cuh:51-53)
+    raw = open(raw_file, "rb").read()
+    utime = struct.unpack("<q", raw[:8])[0]
+    plan = np.frombuffer(raw[8:], "<f4")
+    assert plan.size == N * (n + m + n * m)
+    x, u, KT = plan[: N * n], plan[N * n: N * (n + m)], plan[N * (n + m):]
+    assert np.abs(KT).max() > 1e-3 and np.abs(np.diff(x.reshape(N, n), axis=0)).max() > 1e-4   # gains and a moving state: not an empty plan
+    wire = open(wire_file, "rb").read()
+    fp, ut, xs, us, ks = struct.unpack(">qqiii", wire[:28])
+    assert fp == lcm_hash(TRAJ("float")) and ut == utime
+    assert (xs, us, ks) == (n * N * 4, m * N * 4, n * m * N * 4)                             # BYTE counts (the quirk that is the contract)
+    assert len(wire) == 28 + 4 * (xs + us + ks)
+    body = np.frombuffer(wire[28:], ">f4")
+    wx, wu, wk = body[:xs], body[xs: xs + us], body[xs + us:]
+    for sent, kept in ((wx, x), (wu, u), (wk, KT)):
+        assert np.array_equal(sent[: kept.size].astype("<f4").view("<u4"), kept.view("<u4"))   # bit for bit
+        assert not sent[kept.size:].any()                                                   # the elements beyond the copied bytes are zeros

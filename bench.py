@@ -193,7 +193,7 @@ def main():
                                                         "(tools/pmc_rows.sh); prints them as one JSON object, not the bench line")
     args = ap.parse_args()
     if args.rows:
-        print(json.dumps({"other_baseline_configs": other_config_rows(0), "widening": widening_rows(0)}))
+        print(json.dumps({"other_baseline_configs": other_config_rows(0), "widening": widening_rows(0), "bit_exact_family": bit_exact_family_row(0)}))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return relaunch_under_torchrun(args.gpus)
@@ -328,6 +328,7 @@ def main():
         line["latency"] = guarded(latency_single_problem, ctx.device)
         line["widening"] = guarded(widening_rows, ctx.device)
         line["other_baseline_configs"] = guarded(other_config_rows, ctx.device)
+        line["bit_exact_family"] = guarded(bit_exact_family_row, ctx.device)
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = guarded(cpu_baseline)
     elif ctx.rank == 0:
@@ -546,6 +547,25 @@ def other_config_rows(device):
         res[name]["roofline"] = row_roofline({nm: ms for nm, ms in kern if nm}, {2: "cart", 3: "quad"}[plant], "f64" if dtype else "f32")
         s.close()
     return res
+
+
+def bit_exact_family_row(device, B=BENCH_BATCH):
+    """The price of bit-identity with the float32 oracle: the headline workload on the kernel family that executes the reference host path's IEEE
+    operations one for one -- lane groups, built with -ffp-contract=off, float32 backward pass BIT-IDENTICAL to oracle32 (tests/test_lanegroup.py) -- selected through
+    pddp_config.kernels (bp = lg, fp = lg).  The headline runs the matrix-core / thread-lane family instead, which lives under the float32 bar (tests/test_fp32_bar.py)."""
+    N, M, A = 128, 4, 8
+    cfg = pyddp.default_config(4, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, batch=B, max_iter=100, device=device, use_graph=1, kernels=dict(bp="lg", fp="lg"))
+    s = pyddp.Solver(cfg)
+    x0, u0, xg = example_inputs(N, np.random.default_rng(1234), B)
+    s.load(x0, u0, xg)
+    s.iterate(3); s.sync()
+    ms_plain, _ = s.time_sweeps(10, phases=False)
+    s.load(x0, u0, xg); s.iterate(3); s.sync()
+    kern = s.time_kernels(10)
+    s.close()
+    return {"problems": B, "kernels": "lane groups, -ffp-contract=off (pddp_config.kernels: bp = lg, fp = lg)", "iterations_per_s": round(B * 10 / (ms_plain * 1e-3), 1),
+            "ms_per_sweep": round(ms_plain / 10, 4), "per_kernel_ms": {nm: round(ms, 5) for nm, ms in kern if nm},
+            "parity": "float32 backward pass bit-identical to the float32 oracle (tests/test_lanegroup.py); rollouts / setup the reference's operation order"}
 
 
 def ee_inputs(N, rng, count):

@@ -242,6 +242,12 @@ int pddp_comm_all_done(pddp_comm_handle c, pddp_handle h, int* all_done);
 int pddp_comm_allgather_costs(pddp_comm_handle c, pddp_handle h, double* costs);
 /* value = max over the ranks of value (a host double; doubles as a barrier: it returns when every rank has entered) */
 int pddp_comm_allreduce_max(pddp_comm_handle c, double* value);
+/* The per-iteration cost table (north_star: "an RCCL all-reduce of the per-alpha cost over xGMI"; SURVEY.md 8(e) mode R): J[batch][A] of the handle's LAST line search
+ * from every rank, on every rank, as [world * batch][A] doubles in global problem order.  Optional -- the ranks' solves are independent, nothing on the data path waits
+ * for it -- and off the sweep's critical path: _begin enqueues the exchange on the communicator's own stream behind an event on the solver's stream (the line search of
+ * the last enqueued sweep) and returns; the solver may iterate on meanwhile; _end waits for it and fills `table`.  One exchange in flight per communicator. */
+int pddp_comm_cost_table_begin(pddp_comm_handle c, pddp_handle h);
+int pddp_comm_cost_table_end(pddp_comm_handle c, double* table /* [world * batch][A] */);
 /* the configuration a handle was created with */
 int pddp_get_config(pddp_handle h, pddp_config* out);
 

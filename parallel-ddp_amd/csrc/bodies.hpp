@@ -70,24 +70,25 @@ PDDP_HD void fp_reduce(const Wave& w, const Buffers<T>& b, const Dims& dm, int p
     }
 }
 
+// Jsrc / dsrc: where the candidates' total cost / defect norm are read from -- the arrays b.J / b.dmax of the problem (null), or a copy the caller holds closer
+// (the rollout kernel that ends with the line search, k_fp_tl4: its wave's LDS)
 template <typename T>
-PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp, int pb, int freeze_exit) {
+PDDP_HD void ls_body(const Buffers<T>& b, const Dims& dm, const SolverParams& sp, int pb, int freeze_exit, const T* Jsrc = nullptr, const T* dsrc = nullptr) {
     SolverState<T> st = b.state[pb];
     if (st.done) { if (st.win_pending) b.state[pb].win_pending = 0; return; }      // the final accepted step was adopted by the previous sweep's winner kernel
     const int* err = b.err + (size_t)pb * dm.M;
     int any = 0;
     for (int i = 0; i < dm.M; i++) any |= err[i];
-    if (b.parts_fresh && b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }   // thread-lane forward pass: add the per-segment partial sums
+    if (!Jsrc && b.parts_fresh && b.parts_fresh[pb]) { tl_reduce_parts<T>(b, dm, pb); b.parts_fresh[pb] = 0; }   // thread-lane forward pass: add the per-segment partial sums
+    const T* Jp = Jsrc ? Jsrc : b.J + (size_t)pb * dm.A; const T* dp = dsrc ? dsrc : b.dmax + (size_t)pb * dm.A;
     const size_t ho = (size_t)pb * sp.out_stride;
     if (freeze_exit) {   // benchmark mode: never exit, keep writing the same Jout slot
         SolverParams sp2 = sp; sp2.tol_cost = -1e300; sp2.ignore_max_rho_exit = 1;
         const int it = st.iter;
-        line_search_accept<T>(st, sp2, dm, any, b.alpha, b.J + (size_t)pb * dm.A, b.dmax + (size_t)pb * dm.A,
-                              b.dJexp + (size_t)pb * 2 * dm.M, b.Jout + ho, b.alphaOut + ho);
+        line_search_accept<T>(st, sp2, dm, any, b.alpha, Jp, dp, b.dJexp + (size_t)pb * 2 * dm.M, b.Jout + ho, b.alphaOut + ho);
         st.done = 0; st.iter = it;
     } else {
-        line_search_accept<T>(st, sp, dm, any, b.alpha, b.J + (size_t)pb * dm.A, b.dmax + (size_t)pb * dm.A,
-                              b.dJexp + (size_t)pb * 2 * dm.M, b.Jout + ho, b.alphaOut + ho);
+        line_search_accept<T>(st, sp, dm, any, b.alpha, Jp, dp, b.dJexp + (size_t)pb * 2 * dm.M, b.Jout + ho, b.alphaOut + ho);
     }
     b.state[pb] = st;
 }

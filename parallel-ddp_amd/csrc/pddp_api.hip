@@ -224,6 +224,8 @@ struct Solver : SolverBase {
     // every knot's P, p written (the reference's d_P / d_p) unless the caller opted out; MPC handles always keep them (MPCHelpers.cuh:602-655 shifts the whole arrays)
     bool keep_all_ctg() const { return !cfg.boundary_cost_to_go_only || cfg.mpc_mode || mpc_used; }
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
+    // few problems in flight on the four-wave rollout pipeline, every problem's M x A rollouts inside one wavefront: the rollout kernel ends with the line search (k_fp_tl4)
+    bool ls_in_rollouts() const { return P::PLANT == 4 && fp_split && !fp_two_wave && !ls_many && cfg.kernels.ls == 0 && 64 % (cfg.M * cfg.A) == 0; }
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
     size_t fp_lds = 0;
@@ -465,7 +467,7 @@ struct Solver : SolverBase {
             if (!init_rollout && fp_split) {
                 bool two = false;
                 if constexpr (sizeof(T) == 4) { if (fp_two_wave) { launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); two = true; } }
-                if (!two) launch_fp_tl4<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B);
+                if (!two) launch_fp_tl4<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, sp, (ls_in_rollouts() && !store_candidates && part != 2) ? bench_mode : -1);
                 return;
             }
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
@@ -549,7 +551,7 @@ struct Solver : SolverBase {
             }
         }
         if (only < 0 || only == PDDP_PHASE_FP) launch_fp(s, 0, store_candidates, part);
-        if (only < 0 || only == PDDP_PHASE_LS) {
+        if ((only < 0 || only == PDDP_PHASE_LS) && !(ls_in_rollouts() && !store_candidates)) {      // (k_fp_tl4 ended with the line search of its problems)
             if (ls_many) hipLaunchKernelGGL((k_ls_many<T>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, b, dm, sp, bench_mode, (int)B);
             else hipLaunchKernelGGL((k_ls<T>), dim3(B), dim3(64), 0, s, b, dm, sp, bench_mode);
         }
@@ -561,7 +563,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
+                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;

@@ -22,6 +22,12 @@ struct pddp_comm {
     int* d_flag = nullptr;            // [1] this rank's "still running", reduced in place
     double* d_costs = nullptr;        // [world][batch][2], grown on demand
     size_t cost_cap = 0;
+    // the per-iteration cost table (pddp_comm_cost_table_begin / _end): its own stream, so that the solver's next sweep does not queue behind the exchange
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ls = nullptr, ev_done = nullptr;
+    double* d_table = nullptr;        // [world + 1][batch][A]: gathered + this rank's send buffer
+    double* h_table = nullptr;        // pinned, [world][batch][A]
+    size_t table_cap = 0; int table_B = 0, table_A = 0; bool table_pending = false;
 };
 
 #define COMM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return pddp_internal_fail(PDDP_ENODEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -46,6 +52,13 @@ __global__ void k_comm_costs(const SolverState<T>* st, const T* Jout, int stride
     // a problem that exited stopped at `iter` (the slot of its last iteration); one that is still running has `iter` pointing at the NEXT, unwritten slot
     const int last = st[b].done ? st[b].iter : (st[b].iter > 0 ? st[b].iter - 1 : 0);
     out[2 * b + 1] = (double)Jout[(size_t)b * stride + last];
+}
+
+// J[B][A] of the last line search as doubles
+template <typename T>
+__global__ void k_comm_table(const T* J, int count, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (double)J[i];
 }
 
 extern "C" int pddp_comm_unique_id(void* id) {
@@ -74,6 +87,11 @@ extern "C" int pddp_comm_destroy(pddp_comm_handle c) {
     if (!c) return 0;
     if (c->d_flag) hipFree(c->d_flag);
     if (c->d_costs) hipFree(c->d_costs);
+    if (c->d_table) hipFree(c->d_table);
+    if (c->h_table) hipHostFree(c->h_table);
+    if (c->ev_ls) hipEventDestroy(c->ev_ls);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->comm) ncclCommDestroy(c->comm);
     delete c;
     return 0;
@@ -154,5 +172,55 @@ extern "C" int pddp_comm_allgather_costs(pddp_comm_handle c, pddp_handle h, doub
             const size_t g = l * c->world + r;
             costs[2 * g] = rank_major[((size_t)r * B + l) * 2]; costs[2 * g + 1] = rank_major[((size_t)r * B + l) * 2 + 1];
         }
+    return 0;
+}
+
+// The per-iteration cost-table exchange north_star names ("an RCCL all-reduce of the per-alpha cost over xGMI"; SURVEY.md section 8(e) mode R: one all-gather of the [B x A]
+// table per iteration so that every rank can report / select globally).  The solves of different ranks are independent, so nothing on the DATA path needs it: it is
+// optional, and it is kept OFF the sweep's critical path -- _begin copies the table out behind what the solver's stream holds (one small kernel after the line search of the last
+// enqueued sweep), records an event, and gathers on the communicator's own stream; the solver's next sweeps run meanwhile.  _end waits for the exchange and returns the table in global problem order.
+extern "C" int pddp_comm_cost_table_begin(pddp_comm_handle c, pddp_handle h) {
+    if (!c || !h) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_cost_table_begin: null argument");
+    if (c->table_pending) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_cost_table_begin: the previous exchange has not been collected (pddp_comm_cost_table_end)");
+    COMM_HIP(hipSetDevice(c->device));
+    pddp_config cfg; hipStream_t s; void *state, *Jout;
+    int rc = solver_views(h, cfg, s, state, Jout);
+    if (rc) return rc;
+    void* J = nullptr; size_t nb = 0;
+    if ((rc = pddp_array_ptr(h, "J", &J, &nb))) return rc;
+    const size_t B = cfg.batch, A = cfg.A, need = (size_t)(c->world + 1) * B * A;
+    if (!c->side) { COMM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); COMM_HIP(hipEventCreateWithFlags(&c->ev_ls, hipEventDisableTiming)); COMM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming)); }
+    if (need > c->table_cap) {
+        if (c->d_table) hipFree(c->d_table);
+        if (c->h_table) hipHostFree(c->h_table);
+        c->d_table = nullptr; c->h_table = nullptr; c->table_cap = 0;
+        if (hipMalloc((void**)&c->d_table, need * sizeof(double)) != hipSuccess || hipHostMalloc((void**)&c->h_table, (size_t)c->world * B * A * sizeof(double)) != hipSuccess)
+            return pddp_internal_fail(PDDP_ENOMEM, "pddp_comm_cost_table_begin: allocation");
+        c->table_cap = need;
+    }
+    c->table_B = (int)B; c->table_A = (int)A;
+    double* send = c->d_table + (size_t)c->world * B * A;
+    // the table is COPIED OUT on the solver's own stream (one small kernel behind the last enqueued sweep's line search: the next sweep overwrites J), ...
+    const unsigned blocks = (unsigned)((B * A + 255) / 256);
+    if (cfg.dtype == 1) hipLaunchKernelGGL((k_comm_table<double>), dim3(blocks), dim3(256), 0, s, (const double*)J, (int)(B * A), send);
+    else hipLaunchKernelGGL((k_comm_table<float>), dim3(blocks), dim3(256), 0, s, (const float*)J, (int)(B * A), send);
+    COMM_HIP(hipGetLastError());
+    COMM_HIP(hipEventRecord(c->ev_ls, s));
+    COMM_HIP(hipStreamWaitEvent(c->side, c->ev_ls, 0));                          // ... the exchange itself runs beside the solver's stream
+    COMM_NCCL(ncclAllGather(send, c->d_table, B * A, ncclDouble, c->comm, c->side));
+    COMM_HIP(hipMemcpyAsync(c->h_table, c->d_table, (size_t)c->world * B * A * sizeof(double), hipMemcpyDeviceToHost, c->side));
+    COMM_HIP(hipEventRecord(c->ev_done, c->side));
+    c->table_pending = true;
+    return 0;
+}
+extern "C" int pddp_comm_cost_table_end(pddp_comm_handle c, double* table) {
+    if (!c || !table) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_cost_table_end: null argument");
+    if (!c->table_pending) return pddp_internal_fail(PDDP_EINVAL, "pddp_comm_cost_table_end: no exchange in flight (pddp_comm_cost_table_begin)");
+    COMM_HIP(hipSetDevice(c->device));
+    COMM_HIP(hipEventSynchronize(c->ev_done));
+    c->table_pending = false;
+    const size_t B = c->table_B, A = c->table_A;
+    for (int r = 0; r < c->world; r++)                                           // [rank][local][A] -> global problem id g = local * world + rank
+        for (size_t l = 0; l < B; l++) std::memcpy(table + ((size_t)l * c->world + r) * A, c->h_table + ((size_t)r * B + l) * A, A * sizeof(double));
     return 0;
 }

@@ -299,9 +299,14 @@ void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Di
 // ~650 dependent instructions per step on the chain instead of ~1100 with k_fp_tl2's two barriers per step.  Candidates are stored like the reference's (x, u, d); cost / defect
 // leave as per-segment partial sums.  EE: the end-effector cost family (tl_rollout_step_ee's conditions: every segment runs NB steps, the "final" state of a non-final
 // segment carries no cost, knot N - 1 no dynamics).  Same arithmetic as k_fp_tl: under the float32 bar.
+// ls_mode >= 0 (few problems in flight, every problem's M x A rollouts inside ONE wavefront: 64 % (M A) == 0): the control wave ENDS WITH THE LINE SEARCH of its problems --
+// forwardSimGPU's host part + acceptRejectTrajGPU (fpHelpers.cuh:395-408, nisInitHelpers.cuh:489-518; line_search_accept) -- instead of leaving it to a k_ls launch behind
+// this kernel: the candidates' totals are formed from the lanes' own partial sums (the order of tl_reduce_parts / k_ls: segments 0..M-1), one kernel boundary and one
+// dependent launch (~7 us of a ~120 us iteration) disappear.  ls_mode = freeze_exit of k_ls (1: benchmark mode); -1: no line search here (phase hooks, per-phase timing).
 template <typename T, int V, bool EE>
-__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch) {
+__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch, SolverParams sp, int ls_mode) {
     constexpr int NX = 14, NU = 7;
+    __shared__ T ls_J[64], ls_d[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char pipe_lds_raw[];
     const TlPipeLdsT<T> p = tl_pipe_lds(reinterpret_cast<T*>(pipe_lds_raw), true);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -403,15 +408,29 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWe
         for (int i = 0; i < NU; i++) { u[i] = uc[(size_t)(N - 1) * NU + i]; us[(size_t)(N - 1) * NU + i] = u[i]; }
         J += arm_tl_cost<T>(cw, x, u, xg, true);
     }
+    if (EE) J = acc7s[0] + acc7s[1] + acc7s[2] + acc7s[3] + acc7s[4] + acc7s[5] + acc7s[6];
+    const T dseg = (seg == M - 1) ? T(0) : sdef;
     if (live) {
-        if (EE) J = acc7s[0] + acc7s[1] + acc7s[2] + acc7s[3] + acc7s[4] + acc7s[5] + acc7s[6];
         b.Jpart[slot * M + seg] = J;
-        b.dpart[slot * M + seg] = (seg == M - 1) ? T(0) : sdef;
-        b.parts_fresh[pb] = 1;
+        b.dpart[slot * M + seg] = dseg;
+        if (ls_mode < 0) b.parts_fresh[pb] = 1;
+    }
+    if (ls_mode >= 0) {                                                   // (wave-uniform) the line search of this wave's problems
+        ls_J[lane] = J; ls_d[lane] = dseg;
+        wsync();
+        const int base = lane - rem;                                      // first lane of this lane's problem
+        if (live && seg == 0) {                                           // lane of candidate a: the segments' parts in order
+            T Jt = T(0), mx = T(0);
+            for (int sgm = 0; sgm < M; sgm++) { Jt += ls_J[base + sgm * A + a_idx]; mx = tmax(mx, ls_d[base + sgm * A + a_idx]); }
+            b.J[slot] = Jt; b.dmax[slot] = mx;
+            ls_J[lane] = Jt; ls_d[lane] = mx;                             // (lanes base .. base + A - 1: read by the deciding lane; a segment-0 lane only overwrites its own slot,
+        }                                                                 //  and every read of the parts above happens before the wave's next instruction)
+        wsync();
+        if (inst_raw < total && rem == 0) ls_body<T>(b, dm, sp, pb, ls_mode, ls_J + lane, ls_d + lane);
     }
 }
 template <typename T>
-void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch) {
+void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, const SolverParams& sp, int ls_mode) {
     const unsigned inst = (unsigned)batch * dm.M * dm.A;
     constexpr int lds = pipe_lds_bytes<T>(true);
     static bool attr_set = false;
@@ -424,15 +443,15 @@ void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& 
     }
     const dim3 g((inst + 63) / 64), t(256);
     if (cw.ee) {
-        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, true>), g, t, lds, s, b, dm, cw, dt, grav, batch);
-        else hipLaunchKernelGGL((k_fp_tl4<T, 1, true>), g, t, lds, s, b, dm, cw, dt, grav, batch);
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, true>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
+        else hipLaunchKernelGGL((k_fp_tl4<T, 1, true>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
     } else {
-        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, false>), g, t, lds, s, b, dm, cw, dt, grav, batch);
-        else hipLaunchKernelGGL((k_fp_tl4<T, 1, false>), g, t, lds, s, b, dm, cw, dt, grav, batch);
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, false>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
+        else hipLaunchKernelGGL((k_fp_tl4<T, 1, false>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
     }
 }
-template void launch_fp_tl4<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int);
-template void launch_fp_tl4<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int);      // the parity instantiation (PDDP_FP=tl4)
+template void launch_fp_tl4<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, const SolverParams&, int);
+template void launch_fp_tl4<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, const SolverParams&, int);      // the parity instantiation (PDDP_FP=tl4)
 
 // k_sweep_st: grid ceil(2 B / 8), block 64.  The linear sweep of forwardSweepKern (fpHelpers.cuh:19-63) for ALL candidates of a problem at once.
 // The sweep is affine in the step size: with e_k = x_k - xcur_k,  e_{k+1} = F_k e_k - alpha (B du)_k + [boundary] d_k,  e_0 = 0,  so

@@ -179,6 +179,16 @@ class Comm:
         self._chk(self.lib.pddp_comm_allgather_costs(self.h, solver.h, _p(out)))
         return out
 
+    def cost_table_begin(self, solver):
+        """pddp_comm_cost_table_begin: enqueue the all-gather of the last line search's J[batch][A] beside the solver's stream (returns at once)."""
+        self._table_shape = (self.world * solver.cfg.batch, solver.cfg.A)
+        self._chk(self.lib.pddp_comm_cost_table_begin(self.h, solver.h))
+
+    def cost_table_end(self):
+        out = np.zeros(self._table_shape, np.float64)
+        self._chk(self.lib.pddp_comm_cost_table_end(self.h, _p(out)))
+        return out
+
     def max_over_ranks(self, value):
         v = C.c_double(float(value))
         self._chk(self.lib.pddp_comm_allreduce_max(self.h, C.byref(v)))

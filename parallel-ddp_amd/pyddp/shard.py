@@ -111,6 +111,23 @@ def allgather_costs(ctx, jout, batch, stride, last_col):
     return gathered.permute(1, 0, 2).reshape(ctx.world * batch, 2).cpu().numpy()
 
 
+def allgather_cost_table(ctx, J_local, batch, A):
+    """The per-iteration cost table (SURVEY.md 8(e) mode R; include/pddp.h pddp_comm_cost_table_begin / _end is the native twin): J[batch][A] of every rank's last line
+    search -> [world * batch][A] in GLOBAL problem order (problem g lives on rank g % world at local index g // world).  J_local: DeviceArray or numpy."""
+    import torch
+    if isinstance(J_local, np.ndarray):
+        local = torch.from_numpy(np.ascontiguousarray(J_local, dtype=np.float64)).reshape(batch, A)
+    else:
+        local = torch.as_tensor(J_local, device=torch.device("cuda", ctx.device)).reshape(batch, A).to(torch.float64)
+    if ctx.world == 1:
+        return local.cpu().numpy()
+    import torch.distributed as dist
+    local = local.contiguous().to(_dev(ctx))
+    gathered = torch.empty((ctx.world * batch, A), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local)
+    return gathered.reshape(ctx.world, batch, A).permute(1, 0, 2).reshape(ctx.world * batch, A).cpu().numpy()
+
+
 def best_rollout(costs_global):
     """Index (global problem id) and cost of the best rollout -- what an MPC caller picks its control from."""
     final = np.asarray(costs_global)[:, -1]

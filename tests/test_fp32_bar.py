@@ -258,6 +258,14 @@ def assert_inside(rows, fails, ensemble):
     if ensemble:
         r = _run_bar.bp_ratio
         assert np.mean(r <= 1.5) >= 0.99 and r.max() <= 4.0, (float(np.mean(r <= 1.5)), float(r.max()), [(it, ph, nm, f"{ek:.2e}", f"{eo:.2e}") for it, ph, nm, ek, eo, ok in fails[:12]])
+        # the DISTRIBUTION of the kernel's error against the float32 noise floor, not only its tail: a kernel that is "inside 1.5 x" everywhere
+        # but sits AT the floor in the typical comparison would be a worse float32 evaluation than the reference's own.  Typical comparisons must be well inside it.
+        stats = (len(r), float(np.median(r)), float(np.percentile(r, 99)), float(r.max()))
+        print("backward pass vs float32 noise floor: n %d median %.3f p99 %.3f max %.3f" % stats)
+        if len(r) >= 40:
+            assert stats[1] <= 0.5, stats
+        if len(r) >= 250:
+            assert stats[2] <= 1.0, stats
 
 
 def summarize(rows):
@@ -344,7 +352,8 @@ def test_bench_batch_every_phase_under_the_bar():
 
 
 @pytest.mark.gpu
-def test_bench_batch_whole_solves_equal_single_problem_solves():
+@pytest.mark.parametrize("lean", [0, 1], ids=["library-defaults-as-bench.py", "boundary-cost-to-go-only"])
+def test_bench_batch_whole_solves_equal_single_problem_solves(lean):
     """10 production sweeps (hipGraph replay) of bench.BENCH_BATCH problems; 16 problems drawn at random must equal, bit for bit, single-problem solves
     run on the same kernels (PDDP_BP=mx, PDDP_FP=tl force the large-batch selection for a batch of one), and follow the float32 oracle's
     step-size decisions over the leading iterations with J inside the bar measured against oracle64."""
@@ -355,7 +364,7 @@ def test_bench_batch_whole_solves_equal_single_problem_solves():
     for b_ in range(B):
         x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
         xs.append(x0); us.append(u0)
-    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, boundary_cost_to_go_only=1, **kw)     # as bench.py creates it (the single-problem handle below keeps every slot)
+    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, boundary_cost_to_go_only=lean, **kw)     # 0: as bench.py creates it since round 5; 1: its side row (the single-problem handle below keeps every slot)
     out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
     assert (out["iters"] == 10).all()
     o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)

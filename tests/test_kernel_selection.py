@@ -34,8 +34,11 @@ def kernels(plant, batch, sel=None, dtype=0, **kw):
 @pytest.mark.parametrize("ee", [0, 1])
 def test_few_problems_in_flight_run_the_pipeline_and_the_per_joint_setup(ee):
     kw = dict(KUKA, ee_cost=ee, **(dict(mpc_mode=1, ignore_max_rho_exit=0) if ee else {}))
-    assert kernels(4, 1, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_ls", "k_nis_tl7"]
-    assert kernels(4, 3, **kw)[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
+    # (no k_ls: with a problem's M x A rollouts inside one wavefront the rollout pipeline ends with the line search itself, round 5; A = 16 x M = 8 does not fit and keeps it)
+    assert kernels(4, 1, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_nis_tl7"]
+    assert kernels(4, 3, **kw)[2:] == ["k_fp_tl4", "k_nis_tl7"]
+    assert kernels(4, 1, dict(ls="wg"), **kw)[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
+    assert kernels(4, 1, **dict(kw, N=128, M=8, A=16))[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
 
 
 def test_the_library_does_not_read_the_environment_for_its_selection():
@@ -57,7 +60,7 @@ def test_the_library_does_not_read_the_environment_for_its_selection():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     x0, u0, xg = example_inputs(4, 64, np.float32)
     s.load(x0, u0, xg); s.iterate(2); s.sync()
-    assert [n for n, _ in s.time_kernels(2)] == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_ls", "k_nis_tl7"]
+    assert [n for n, _ in s.time_kernels(2)] == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_nis_tl7"]
     s.close()
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parallel-ddp_amd", "csrc", "pddp_api.hip")).read()
     import re

@@ -32,9 +32,16 @@ mk = lambda batch: pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=ba
 res = shard.solve_sharded(ctx, mk, xs, us, gs, poll_every=3)
 tmax = shard.max_over_ranks(ctx, 1.0 + ctx.rank)
 assert tmax == 2.0
+# the per-iteration cost table (SURVEY 8(e) mode R): every rank's J[batch][A] of the last line search, on every rank, in global problem order
+sl = mk(total // 2)
+mine = shard.owned_problems(total, ctx.rank, 2)
+sl.load(np.stack([xs[i] for i in mine]), np.stack([us[i] for i in mine]), np.stack([gs[i] for i in mine]))
+sl.iterate(2); sl.sync()
+table = shard.allgather_cost_table(ctx, sl.get("J"), total // 2, kw["A"])
+assert table.shape == (total, kw["A"]) and np.array_equal(table[ctx.rank::2], sl.get("J").reshape(-1, kw["A"]).astype(np.float64))
 assert shard.owned_problems(total, ctx.rank, 2) == list(range(ctx.rank, total, 2))
 if ctx.rank == 0:
-    json.dump(dict(costs=res["costs"].tolist(), best=res["best"], sweeps=res["sweeps"]), open(sys.argv[1], "w"))
+    json.dump(dict(costs=res["costs"].tolist(), best=res["best"], sweeps=res["sweeps"], table=table.tolist()), open(sys.argv[1], "w"))
 shard.finalize(ctx)
 '''
 
@@ -67,6 +74,10 @@ def test_world_size_2_gloo_matches_single_process(tmp_path):
     assert np.array_equal(costs[:, 0].astype(np.float32), J0) and np.array_equal(costs[:, 1].astype(np.float32), Jf)
     assert res["best"][0] == int(np.argmin(Jf))
     assert res["sweeps"] % 3 == 0
+    # the gathered cost table of two sweeps == the single-process handle's J[6][A] after two sweeps, row for row
+    s2 = pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=6, **kw), _lib_path=path)
+    s2.load(np.stack(xs), np.stack(us), np.stack(gs)); s2.iterate(2); s2.sync()
+    assert np.array_equal(np.asarray(res["table"]), s2.get("J").reshape(6, kw["A"]).astype(np.float64))
 
 
 WORKER4 = r'''
@@ -113,6 +124,34 @@ def test_world_size_4_gloo_uneven_batch_is_rejected_and_an_even_one_gathers_in_g
     costs = np.asarray(res["costs"])
     assert costs.shape == (8, 2) and res["best"][0] == int(np.argmin(costs[:, 1]))
     assert len(set(np.round(costs[:, 0], 3))) == 8              # eight different problems, each reported once
+
+
+@pytest.mark.gpu
+def test_native_cost_table_exchange_beside_the_solver_stream_world_of_one():
+    """pddp_comm_cost_table_begin / _end: the [B x A] table of the last line search leaves on the communicator's own stream behind an event; the solver iterates on meanwhile
+    and the table is the one of the sweep it was taken behind (not of a later one)."""
+    import pyddp
+    from oracle_binding import example_inputs
+    kw = dict(N=32, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=20)
+    B = 5
+    s = pyddp.Solver(pyddp.default_config(4, batch=B, **kw))
+    rng = np.random.default_rng(6)
+    xs, us, gs = zip(*[example_inputs(4, 32, np.float32, noise=rng.normal(0, 0.01 * (b + 1), (32, 14))) for b in range(B)])
+    s.load(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+    comm = pyddp.Comm(0, 1, 0)
+    s.iterate(3)
+    comm.cost_table_begin(s)                 # behind sweep 3 ...
+    s.iterate(4)                             # ... while four more sweeps are enqueued
+    table = comm.cost_table_end()
+    s.sync()
+    later = s.get("J").reshape(B, 8).astype(np.float64)
+    s2 = pyddp.Solver(pyddp.default_config(4, batch=B, **kw))
+    s2.load(np.concatenate(xs), np.concatenate(us), np.concatenate(gs)); s2.iterate(3); s2.sync()
+    assert table.shape == (B, 8) and np.array_equal(table, s2.get("J").reshape(B, 8).astype(np.float64))
+    assert not np.array_equal(table, later)
+    with pytest.raises(pyddp.PddpError):
+        comm.cost_table_end()                # nothing in flight
+    comm.close(); s.close(); s2.close()
 
 
 @pytest.mark.gpu

@@ -10,6 +10,7 @@
 #include "nis_lg.hpp"
 #include "bp_lg.hpp"
 #include "bp_cl.hpp"
+#include "bp_mq.hpp"
 #include "mpc.hpp"
 #include "sim.hpp"
 
@@ -628,6 +629,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     a.err = b.err + (size_t)pb * dm.M;
     a.rho = st.rho;
     if (bp_cl_block<P, T>(s[grp], c, dm, blk, a, diag_h != 0, P::weight(cw, c, 0, N))) { if (c == 0) a.err[blk] = 1; }
+}
+
+// k_bp_mq: one wavefront = (problem, block of knots) of a 12-state / 4-control plant on the matrix cores (bp_mq.hpp); grid B M, block 64.  Replaces backPassKern<<<M, ...>>>
+// (bpHelpers.cuh:339-420) like k_bp_cl, which stays for handles whose cost Hessian is not the plant's own diagonal.
+#ifndef PDDP_MQ_WAVES
+#define PDDP_MQ_WAVES 6      // resident waves per SIMD the float kernel is compiled for (measured: tools/quad_bp_ab.py, profiles/r05_quad_mfma.md)
+#endif
+template <typename P, typename T, bool DIAGH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? PDDP_MQ_WAVES : 3, sizeof(T) == 4 ? PDDP_MQ_WAVES : 3))) void k_bp_mq(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch) {
+    __shared__ T lds[kMqLds];
+    const int inst = blockIdx.x;
+    if (inst >= batch * dm.M) return;
+    if (dm.M > 1) mq_bp_block<P, T, true, DIAGH>(lds, b, dm, cw, inst / dm.M, inst % dm.M);
+    else mq_bp_block<P, T, false, DIAGH>(lds, b, dm, cw, inst / dm.M, inst % dm.M);
 }
 
 // API view of the compact end-effector Hessian block (Buffers::Hc): H_k of every running knot in the reference layout = Jee' Jee (+ Qx on its diagonal, already in the

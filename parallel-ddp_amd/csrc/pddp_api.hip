@@ -70,7 +70,7 @@ static const char* ksel_sweep(const pddp_config& c) { return ksel(c.kernels.swee
 static const char* ksel_ls(const pddp_config& c) { return ksel(c.kernels.ls, {"many", "wg"}); }
 static const char* ksel_ab(const pddp_config& c) { return ksel(c.kernels.ab, {"full"}); }
 static const char* ksel_cf(const pddp_config& c) { return ksel(c.kernels.cf, {"ts", "coop"}); }
-static const char* ksel_cf_bp(const pddp_config& c) { return ksel(c.kernels.cf_bp, {"ts", "coop", "gl", "gl32", "cl"}); }
+static const char* ksel_cf_bp(const pddp_config& c) { return ksel(c.kernels.cf_bp, {"ts", "coop", "gl", "gl32", "cl", "mq"}); }
 static const char* ksel_cf_fp(const pddp_config& c) { return ksel(c.kernels.cf_fp, {"ts", "coop", "cf"}); }
 static const char* ksel_cf_nis(const pddp_config& c) { return ksel(c.kernels.cf_nis, {"ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64"}); }
 static double now_ms() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
@@ -211,6 +211,7 @@ struct Solver : SolverBase {
     bool cf_bp = false, cf_fp = false, cf_nis = false;   // ... per phase
     bool gl_bp32 = false, gl_nis8 = false;
     bool cl_bp = false;                                  // 12 states + 4 controls: 16 lanes per block of knots, lane = column (k_bp_cl, bp_cl.hpp) instead of k_bp_gl; PDDP_CF_BP = cl | gl | gl32
+    bool mq_bp = false;                                  // 12 states + 4 controls on the matrix cores (k_bp_mq, bp_mq.hpp): where k_bp_cl was the choice, for the plant's own diagonal cost Hessian; kernels.cf_bp = mq | cl
     bool cf_fp_staged = false;                           // thread-serial rollouts with the knot's operands staged through LDS once per wavefront (k_fp_cf: 16 step sizes, 12-state plants); PDDP_CF_FP = cf | ts
     int kb_nis = 0;                                      // knots per wavefront of the knot-batched setup kernel (k_nis_kb: scalar plug-ins, RK3); 0 = k_nis_gl.  PDDP_CF_NIS = kb16 | kb32 | kb64
     bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
@@ -291,12 +292,17 @@ struct Solver : SolverBase {
         gl_bp = cf_serial && !cf_bp && P::NX + P::NU <= 16 && (size_t)c.batch * c.M >= 8192 && !ksel_cf(cfg); gl_bp32 = true;      // 32 lanes per block of knots: 1.92 -> 1.72 ms (quadrotor, 4096 problems); 16 lanes: 2.5 ms
         if (const char* v = ksel_cf_nis(cfg)) { gl_nis = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl8") && P::NX + P::NU <= 16; gl_nis8 = std::string(v) == "gl8"; }
         cl_bp = gl_bp && P::NX == 12 && P::NU == 4;
+        mq_bp = cl_bp;                                                    // round 5: 4.1 -> ... ms at 16384 quadrotor problems (profiles/r05_quad_mfma.md)
         const bool cf_fits = (c.A == 16 && (64 / 16) * P::NX <= 64) || (c.A == 8 && (64 / 8) * P::NX <= 64);      // whole problems per wavefront, one state fetch per lane
         cf_fp_staged = cf_fp && cf_fits && !ksel_cf(cfg);      // (cart-pole, 16384 problems: 0.73 -> 0.69 ms; quadrotor: 8.6 -> 5.1 ms)
         if (const char* v = ksel_cf_fp(cfg)) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && cf_fits; } else cf_fp_staged = false; }
         kb_nis = (gl_nis && c.integrator == 3) ? 16 : 0;      // 16 knots per wavefront: 2.15 ms (32: 2.6, 64: 3.6; the 16-lane-group kernel 5.7-7.1) at 16384 quadrotor problems -- LDS per block sets the occupancy
         if (const char* v = ksel_cf_nis(cfg)) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
-        if (const char* v = ksel_cf_bp(cfg)) { gl_bp = P::PLANT != 4 && (std::string(v) == "gl" || std::string(v) == "gl32" || (std::string(v) == "cl" && P::NX == 12 && P::NU == 4)) && P::NX + P::NU <= 16; gl_bp32 = std::string(v) == "gl32"; cl_bp = gl_bp && std::string(v) == "cl"; }
+        if (const char* v = ksel_cf_bp(cfg)) {
+            const std::string m(v);
+            const bool col = (m == "cl" || m == "mq") && P::NX == 12 && P::NU == 4;
+            gl_bp = P::PLANT != 4 && (m == "gl" || m == "gl32" || col) && P::NX + P::NU <= 16; gl_bp32 = m == "gl32"; cl_bp = gl_bp && col; mq_bp = cl_bp && m == "mq";
+        }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = ksel_sweep(cfg)) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
@@ -542,6 +548,13 @@ struct Solver : SolverBase {
                 bool serial = false;
                 if constexpr (P::PLANT != 4) { if (cf_bp) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
                 if constexpr (P::PLANT != 4 && P::NX == 12 && P::NU == 4) {
+                    if (!serial && gl_bp && cl_bp && mq_bp) {
+                        if (!P::kPluginCost && !h_overridden) hipLaunchKernelGGL((k_bp_mq<P, T, true>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);      // the plant's own diagonal cost Hessian: not read
+                        else hipLaunchKernelGGL((k_bp_mq<P, T, false>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);
+                        serial = true;
+                    }
+                }
+                if constexpr (P::PLANT != 4 && P::NX == 12 && P::NU == 4) {
                     if (!serial && gl_bp && cl_bp) { hipLaunchKernelGGL((k_bp_cl<P, T>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, cw, (int)B, (!P::kPluginCost && !h_overridden) ? 1 : 0); serial = true; }
                 }
                 if constexpr (P::PLANT != 4 && P::NX + P::NU <= 16) { if (!serial && gl_bp) { if (gl_bp32) hipLaunchKernelGGL((k_bp_gl<P, T, 32>), dim3((B * cfg.M + 1) / 2), dim3(64), 0, s, b, dm, (int)B); else hipLaunchKernelGGL((k_bp_gl<P, T, 16>), dim3((B * cfg.M + 3) / 4), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
@@ -562,7 +575,7 @@ struct Solver : SolverBase {
     // for a slot leaves its name empty and its time 0.
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
-        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
+        const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp && mq_bp) ? "k_bp_mq" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
                              (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
         HIPCHK(hipStreamSynchronize(stream));

@@ -75,6 +75,8 @@ def prime(s, case, x=None, u=None, xg=None):
 
 
 def selections_for(case):
+    if case["cfg"]["plant"] == 3:       # the quadrotor's size: also the matrix-core backward pass (k_bp_mq, bp_mq.hpp; the library's choice with the device full)
+        return [pytest.param({}, id="default"), pytest.param({"PDDP_CF_BP": "mq"}, id="matrix-core")]
     return ARM_SELECTIONS if case["cfg"]["plant"] == 4 else [pytest.param({}, id="default")]
 
 
@@ -88,7 +90,7 @@ def bp_params():
 @pytest.mark.parametrize("name,env", list(bp_params()))
 def test_backward_pass_kernels_on_the_references_inputs(backend, name, env):
     case = CASES[name]
-    if env.get("PDDP_BP") == "mx" and backend != "hip": pytest.skip("the matrix-core backward pass exists on the GPU only")
+    if (env.get("PDDP_BP") == "mx" or env.get("PDDP_CF_BP") == "mq") and backend != "hip": pytest.skip("the matrix-core backward pass exists on the GPU only")
     s = handle(backend, case, env)
     n, m, N = prime(s, case)
     M = case["cfg"]["M"]

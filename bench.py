@@ -72,6 +72,9 @@ def cpu_baseline(budget_s=14.0):
         results[cores] = (iters / (ms * 1e-3), solves)
     best = max(results, key=lambda c: results[c][0])
     return {"value": round(results[best][0], 2), "unit": "DDP iterations/s", "cores": best, "kind": "port",
+            # both settings as structured fields: CPU_CORES = hardware_concurrency() is the reference's own default (config.cuh:148)
+            "by_cpu_cores": {str(c): {"iterations_per_s": round(results[c][0], 2), "solves": results[c][1]} for c in sorted(results)},
+            "reference_default_cpu_cores": hw, "host_hardware_threads": hw,
             "sample": "runiLQR_CPU semantics (first-acceptable serial line search, pthreads created per phase like the reference), Kuka N=128 A=8 M=4, "
                       "30 iterations per solve; " + "; ".join(f"CPU_CORES={c}: {results[c][1]} solves, {results[c][0]:.1f} it/s" for c in sorted(results))
                       + f"; host has {hw} hardware threads"}

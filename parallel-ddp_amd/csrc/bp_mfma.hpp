@@ -47,6 +47,9 @@
 #define PDDP_MX_EXP 0        // measurement variants (tools/bp_exp_times.py, profiles/r04_bp_mfma.md): 1 no pivots, 2 no loads, 3 no stores, 4 no matrix instructions, 5 no pivot exchanges
 #endif
 
+#ifndef PDDP_MX_DMA_MASK
+#define PDDP_MX_DMA_MASK 0   // 1: the operand prefetch requests exactly each run's dwords (exec narrowed per run; measurement knob of round 5)
+#endif
 #ifndef PDDP_MX_GJ
 #define PDDP_MX_GJ 0         // exchanges of the distributed Gauss-Jordan inversion: 0 = through the LDS crossbar (ds_bpermute, rounds 3-5: the product); measured alternatives of
 #endif                       // round 5 (profiles/r05_bp_exchange.md): 1 = gfx950's v_permlane16_swap / v_permlane32_swap + DPP row_newbcast moves, 2 = the same with the
@@ -416,7 +419,22 @@ constexpr int kMxDmaRegion = 64, kMxDmaBuf = 5 * kMxDmaRegion;        // dwords:
 template <bool HQQ>
 __device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 dg, mx_i4 dh, unsigned lane4, unsigned s0, unsigned s1, unsigned s2, unsigned sg, unsigned sh) {
     const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)buf;
-    unsigned keep;                                                    // exec_hi is narrowed for the 21-float cost gradient (32 lanes) and put back as it was
+    unsigned keep, keep_lo;                                           // exec is narrowed to each run's length and put back as it was
+#if PDDP_MX_DMA_MASK
+    // every run fetches exactly its dwords (56 | 42 | 49 of the compact [A B]'s pieces, 21 of the cost gradient) instead of 64 / 64 / 64 / 32: a third fewer bytes requested
+    asm volatile(
+        "s_mov_b32 %[keep], exec_hi\n\ts_mov_b32 %[keep_lo], exec_lo\n\t"
+        "s_mov_b32 exec_hi, 0x00ffffff\n\ts_mov_b32 m0, %[l0]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s0] offen lds\n\t"
+        "s_mov_b32 exec_hi, 0x000003ff\n\ts_mov_b32 m0, %[l1]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s1] offen lds\n\t"
+        "s_mov_b32 exec_hi, 0x0001ffff\n\ts_mov_b32 m0, %[l2]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s2] offen lds\n\t"
+        "s_mov_b32 exec_hi, 0\n\ts_mov_b32 exec_lo, 0x001fffff\n\ts_mov_b32 m0, %[l3]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dg], %[sg] offen lds\n\t"
+        "s_mov_b32 exec_lo, %[keep_lo]\n\ts_mov_b32 exec_hi, %[keep]"
+        : [keep] "=&s"(keep), [keep_lo] "=&s"(keep_lo)
+        : [l0] "s"(l0), [l1] "s"(l0 + 4u * kMxDmaRegion), [l2] "s"(l0 + 8u * kMxDmaRegion), [l3] "s"(l0 + 12u * kMxDmaRegion), [v] "v"(lane4), [dab] "s"(dab), [dg] "s"(dg),
+          [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [sg] "s"(sg)
+        : "memory", "m0");
+#else
+    (void)keep_lo;
     asm volatile(
         "s_mov_b32 m0, %[l0]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s0] offen lds\n\t"
         "s_mov_b32 m0, %[l1]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dab], %[s1] offen lds\n\t"
@@ -427,6 +445,7 @@ __device__ __forceinline__ void mx_dma_knot(const float* buf, mx_i4 dab, mx_i4 d
         : [l0] "s"(l0), [l1] "s"(l0 + 4u * kMxDmaRegion), [l2] "s"(l0 + 8u * kMxDmaRegion), [l3] "s"(l0 + 12u * kMxDmaRegion), [v] "v"(lane4), [dab] "s"(dab), [dg] "s"(dg),
           [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [sg] "s"(sg)
         : "memory", "m0");
+#endif
     if constexpr (HQQ)                                                // the knot's 49-float position block (b.Hc; 64 dwords: the over-read stays inside the array's slack)
         asm volatile("s_mov_b32 m0, %[l4]\n\ts_nop 0\n\tbuffer_load_dword %[v], %[dh], %[sh] offen lds" :: [l4] "s"(l0 + 16u * kMxDmaRegion), [v] "v"(lane4), [dh] "s"(dh), [sh] "s"(sh) : "memory", "m0");
 }

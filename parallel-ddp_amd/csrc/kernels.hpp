@@ -597,6 +597,19 @@ __global__ __launch_bounds__(256) void k_cand_to_xw(Buffers<T> b, Dims dm, int b
     for (int i = 0; i < NU; i++) r[NX + i] = b.us[(slot * dm.N + k) * NU + i];
 }
 
+// API view the other way (pddp_get_array("xs" / "us") on such a handle after production sweeps): the records of the last rollouts -> the candidate-major arrays
+template <typename P, typename T>
+__global__ __launch_bounds__(256) void k_xw_to_cand(Buffers<T> b, Dims dm, int batch) {
+    constexpr int NX = P::NX, NU = P::NU, REC = NX + NU;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)batch * dm.N * dm.A;
+    if (id >= total) return;
+    const int a = (int)(id % dm.A), k = (int)((id / dm.A) % dm.N), pb = (int)(id / ((size_t)dm.A * dm.N));
+    const size_t slot = (size_t)pb * dm.A + a;
+    const T* r = b.xw + id * REC;
+    for (int i = 0; i < NX; i++) b.xs[(slot * dm.N + k) * NX + i] = r[i];
+    for (int i = 0; i < NU; i++) b.us[(slot * dm.N + k) * NU + i] = r[NX + i];
+}
+
 // debugging aid (PDDP_POISON_LDS, run_phase): fill the whole LDS of the compute unit this block lands on with NaNs
 __global__ __launch_bounds__(256) void k_poison_lds(int words) {
     extern __shared__ unsigned poison_lds[];

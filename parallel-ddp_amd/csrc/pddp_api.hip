@@ -105,6 +105,8 @@ struct SolverBase {
     virtual void drop_graph() = 0;
     virtual int ab_view(int to_compact) = 0;       // compact [A B] handles (ab_compact.hpp): refresh the reference-layout array "AB" from the compact one (0) or the reverse (1)
     virtual int h_view() = 0;                      // handles with the compact end-effector Hessian block: refresh the reference-layout array "H"
+    virtual int cand_view(int to_records) = 0;     // closed-form handles whose production rollouts keep knot-major records (k_fp_cf): refresh xs / us from them (0) or the reverse (1)
+    bool cand_stale = false;                       // production rollouts wrote records since xs / us were last written
     virtual int reference_views(int what) = 0;     // rebuild d_ApBK / d_Bdu (1) and the winner in every step-size slot (2) from the state the last sweep left
     bool fs_vars_stale = false;                    // fused sweeps ran since A - B K / B du were last written (pddp_get_array materialises them first)
     virtual int ab_keep_reference_layout() = 0;   // leave the compact mode for good (the cost Hessian was overridden: the backward pass reads the reference layout then)
@@ -192,6 +194,18 @@ struct Solver : SolverBase {
                 HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream));
             }
         }
+        return 0;
+    }
+    int cand_view(int to_records) override {
+        if constexpr (P::PLANT != 4) {
+            if (b.xw && cf_fp_staged) {
+                const dim3 g((unsigned)(((size_t)cfg.batch * cfg.N * cfg.A + 255) / 256));
+                if (to_records) hipLaunchKernelGGL((k_cand_to_xw<P, T>), g, dim3(256), 0, stream, b, dm, (int)cfg.batch);
+                else hipLaunchKernelGGL((k_xw_to_cand<P, T>), g, dim3(256), 0, stream, b, dm, (int)cfg.batch);
+                HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream));
+            }
+        }
+        cand_stale = false;
         return 0;
     }
     int reference_views(int what) override {
@@ -442,6 +456,7 @@ struct Solver : SolverBase {
             bool serial = false, records_ran = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
                 const bool records = cf_fp && cf_fp_staged && !init_rollout && part != 2 && !store_candidates;      // (the phase hook wants the reference's candidate-major arrays: k_fp_ts, then k_cand_to_xw)
+                if (records) cand_stale = true;
                 if constexpr (P::kScalarPlugin && (64 / 16) * P::NX <= 64) {
                     if (records && cfg.A == 16) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; records_ran = true; }
                 }
@@ -1074,7 +1089,10 @@ extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host,
     // the first write into "H" of a handle that keeps the compact end-effector position block: bring the reference-layout array up to date FIRST (a partial write
     // then lands on the current values, and the caller's data is not overwritten by the expansion afterwards)
     if (std::strcmp(name, "H") == 0 && !s->h_overridden && (rc = s->h_view())) return rc;
+    const bool cand = std::strcmp(name, "xs") == 0 || std::strcmp(name, "us") == 0;
+    if (cand && s->cand_stale && (rc = s->cand_view(0))) return rc;                          // (the other of the two arrays must hold the records' values before both go back)
     HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    if (cand) return s->cand_view(1);                                                         // handles whose setup adopts from the knot-major records: keep them in step
     if (std::strncmp(name, "model_", 6) == 0) return s->model_changed();
     if (std::strcmp(name, "AB") == 0) return s->ab_view(1);
     if (std::strcmp(name, "H") == 0 && !s->h_overridden) { s->h_overridden = true; s->drop_graph(); return s->ab_keep_reference_layout(); }
@@ -1087,6 +1105,7 @@ extern "C" int pddp_get_array(pddp_handle h, const char* name, void* host, size_
     if (std::strcmp(name, "AB") == 0 && (rc = s->ab_view(0))) return rc;
     if (std::strcmp(name, "H") == 0 && (rc = s->h_view())) return rc;
     if ((std::strcmp(name, "ApBK") == 0 || std::strcmp(name, "Bdu") == 0) && s->fs_vars_stale && (rc = s->reference_views(1))) return rc;
+    if ((std::strcmp(name, "xs") == 0 || std::strcmp(name, "us") == 0) && s->cand_stale && (rc = s->cand_view(0))) return rc;      // (handles whose rollouts keep records)
     HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost)); return 0;
 }
 extern "C" int pddp_get_state(pddp_handle h, pddp_state* out) { IMPL(h); return s->get_state(out); }

@@ -16,6 +16,12 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+// The device code is written for gfx950 and nothing else: workgroups of up to 160 KB of LDS (k_nis_kb, k_fp_tl4, k_nis_tl, the sweep staging: several exceed the 64 KB of
+// gfx90a / gfx942), v_mfma_f32_16x16x4_f32 / _f64, LDS-direct buffer loads, DPP row_newbcast.  A build for another target fails HERE, with this message, instead of
+// at some kernel's LDS allocation (the Makefile takes ARCH as a parameter).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libpddp's kernels are written for gfx950 (MI355X): build with --offload-arch=gfx950"
+#endif
 #define PDDP_HD __host__ __device__ __forceinline__
 #define PDDP_D __device__ __forceinline__
 #else

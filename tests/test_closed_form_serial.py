@@ -114,3 +114,32 @@ def test_large_batch_selection_is_thread_serial_and_equals_single_problem_solves
         o1 = s1.solve(xs[b], us[b], xg)
         for k in ("alphaOut", "Jout", "x", "u"):
             assert np.array_equal(o1[k][0], out[k][b]), (int(b), k)
+
+
+@pytest.mark.gpu
+def test_candidate_arrays_are_views_of_the_records_on_staged_handles():
+    """Closed-form handles whose production rollouts keep knot-major records (k_fp_cf) adopt from those records: pddp_get_array("xs" / "us") after production sweeps must
+    show the LAST rollouts (not the arrays' stale contents), and pddp_set_array of either must reach the records."""
+    plant, kw = 3, dict(N=64, M=4, A=16, integrator=3, total_time=2.0, max_iter=6, tol_cost=0.0)
+    B = 4
+    rng = np.random.default_rng(23)
+    probs = [example_inputs(plant, kw["N"], np.float32, noise=rng.normal(0, 0.002, (kw["N"], 12))) for _ in range(B)]
+    x0, u0, xg = (np.concatenate([p[i] for p in probs]) for i in range(3))
+    outs = {}
+    for mode, sel in (("records", dict(cf_fp="cf", cf="ts")), ("plain", dict(cf="ts", cf_fp="ts"))):
+        s = make_solver("hip", plant, dtype=0, batch=B, use_graph=0, kernels=sel, **kw)
+        names = [n for n, _ in s.time_kernels(1)]
+        assert ("k_fp_cf" in names) == (mode == "records"), names
+        s.load(x0, u0, xg); s.iterate(3); s.sync()
+        outs[mode] = (s.get("xs").copy(), s.get("us").copy())
+        if mode == "records":
+            xs = outs[mode][0].copy(); xs[:12] += 1.0
+            s.set("xs", xs)
+            assert np.array_equal(s.get("xs"), xs, equal_nan=True)      # (candidates that run away hold NaNs)
+            xw = s.get("xw").reshape(B, kw["N"], 16, 16)
+            assert np.array_equal(xw[0, 0, 0, :12], xs[:12])                 # knot 0, candidate 0 of problem 0 reached its record
+        s.close()
+    N, n, m, A = kw["N"], 12, 4, 16
+    xr, xp = (outs[k][0].reshape(B, A, N, n) for k in ("records", "plain"))
+    ur, up = (outs[k][1].reshape(B, A, N, m) for k in ("records", "plain"))
+    assert np.array_equal(xr, xp, equal_nan=True) and np.array_equal(ur[:, :, : N - 1], up[:, :, : N - 1], equal_nan=True)

@@ -47,6 +47,9 @@
 #define PDDP_MX_EXP 0        // measurement variants (tools/bp_exp_times.py, profiles/r04_bp_mfma.md): 1 no pivots, 2 no loads, 3 no stores, 4 no matrix instructions, 5 no pivot exchanges
 #endif
 
+#ifndef PDDP_MX_STAGE_K
+#define PDDP_MX_STAGE_K 0    // prefetching variants: the gains K | du of a knot leave through LDS as 16-byte pieces (four store instructions of 16 / 8 / 16 / 12 bytes per lane) instead of
+#endif                       // four 4-byte stores per lane 56 bytes apart.  Measured slower (round 5, profiles/r05_bp_exchange.md: +40 ... +65 us -- the extra LDS round trip sits on the knot's chain): off.
 #ifndef PDDP_MX_DMA_MASK
 #define PDDP_MX_DMA_MASK 0   // 1: the operand prefetch requests exactly each run's dwords (exec narrowed per run; measurement knob of round 5)
 #endif
@@ -200,6 +203,7 @@ __device__ __forceinline__ V mx_ld(const T* base, unsigned elem_off) {
 // lane's share a loop-invariant 32-bit vector offset -- no per-access vector address arithmetic (the flat form costs a 64-bit vector add per access and a register
 // PAIR per lane offset, which is what pushed the kernel over its 96 registers).  Raw buffer, stride 0, no range limit.
 typedef unsigned mx_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned mx_u3 __attribute__((ext_vector_type(3)));
 typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mx_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000); }
 template <typename T> __device__ __forceinline__ T mx_bld(__amdgpu_buffer_rsrc_t r, unsigned vbyte, unsigned sbyte);
@@ -491,7 +495,7 @@ __device__ __forceinline__ void mx_lds_knot(MxKnotIn<float, FS, true>& k, unsign
 // block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
 // knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
 constexpr int kMxGainStores = 4, kMxCtgStores = 3;                    // store instructions per knot of the prefetching (compact [A B], float) variants: K rows 2g, 2g + 1 and du(2g), du(2g + 1) | [P | p] as 16-byte pieces
-constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 2 * 5 * 64 + 256;     // (float handles: two operand buffers of five 64-dword regions + the staging area of [P | p])
+constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 2 * 5 * 64 + 256 + 112;     // (float handles: two operand buffers of five 64-dword regions + the staging areas of [P | p] and of [K | du])
 template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
 __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int pb, int blk, T hq1, T hq2, T hr, T dt, int flags) {
     static_assert(!HQQ || DIAGH, "the compact position block rides on the diagonal-Hessian path");
@@ -723,7 +727,22 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             // (buffer stores: the lane's offset is loop-invariant, the knot's a scalar -- kMxGainStores = FOUR store instructions per knot, which the prefetch's s_waitcnt counts on)
             constexpr unsigned E = (unsigned)sizeof(T);
             const unsigned soK = (unsigned)ks * (unsigned)(NX * NU) * E, sod = (unsigned)ks * (unsigned)NU * E;
-            if constexpr (CAB) {
+            if constexpr (DMA && PDDP_MX_STAGE_K) {
+                // K (7 rows of 14: 392 contiguous bytes of KT) and du (28 bytes) staged in memory order -- K(b, kx) at 14 b + kx, du(b) at 100 + b -- and written as 16-byte
+                // pieces: lanes 0..23 one piece of K each, lane 24 its last 8 bytes, lanes 25, 26 the 16 + 12 bytes of du.  FOUR store instructions, like the per-lane form
+                // (kMxGainStores: the prefetch's wait counts them), a quarter of the memory transactions.
+                float* stgK = const_cast<float*>(dmaLds) + 2 * kMxDmaBuf + 256;
+                if (cx) { stgK[u0 * NX + sc] = Kp[0]; if (u0 + 1 < NU) stgK[(u0 + 1) * NX + sc] = Kp[1]; }
+                else if (c14) { stgK[100 + u0] = Kp[0]; if (u0 + 1 < NU) stgK[100 + u0 + 1] = Kp[1]; }
+                wsync();
+                if (lane < 24) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const mx_u4*>(stgK + 4 * lane), rKT, 16u * (unsigned)lane, soK, 0);
+                else if (lane == 24) __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const mx_u2*>(stgK + 96), rKT, 384u, soK, 0);
+                else if (lane == 25) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const mx_u4*>(stgK + 100), rdu, 0u, sod, 0);
+                else if (lane == 26) { const mx_u4 w = *reinterpret_cast<const mx_u4*>(stgK + 104); mx_u3 t; t[0] = w[0]; t[1] = w[1]; t[2] = w[2]; __builtin_amdgcn_raw_buffer_store_b96(t, rdu, 16u, sod, 0); }
+#ifdef PDDP_MX_TEST_EXTRA_STORE                                       // (tests/test_isa_invariants.py: a fifth gain store on purpose must turn the check red)
+                if (c14) mx_bst<T>(rdu, Kp[1], vodu, sod);
+#endif
+            } else if constexpr (CAB) {
                 if (cx) { mx_bst<T>(rKT, Kp[0], voKT, soK); if (u0 + 1 < NU) mx_bst<T>(rKT, Kp[1], voKT + (unsigned)NX * E, soK); }
 #ifdef PDDP_MX_TEST_EXTRA_STORE                                       // (tests/test_isa_invariants.py: a fifth gain store on purpose must turn the check red)
                 if (c14) mx_bst<T>(rdu, Kp[1], vodu, sod);

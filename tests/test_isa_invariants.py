@@ -63,6 +63,6 @@ def test_a_fifth_gain_store_turns_the_check_red():
         m = PREFETCHING.match(name)
         if m:
             bad = mx_isa.check_prefetch_invariant(body, hqq=m.group(1) == "1")
-            assert any("single-dword buffer stores" in b for b in bad), (name, bad)
+            assert any("buffer stores per knot" in b for b in bad), (name, bad)
             flagged += 1
     assert flagged >= 5

@@ -60,7 +60,7 @@ K_GAIN, K_CTG = 4, 3
 
 def prefetch_loop_ops(body):
     """The memory-side instruction sequence of the knot loop of one k_bp_mfma instantiation, in program order:
-    ("dma" | "load" | "gain" | "ctg" | "store" | "wait:<n>" | "cwait:<n>", text).  dma = buffer_load ... lds; gain = buffer_store_dword; ctg = buffer_store_dwordx2/x4;
+    ("dma" | "load" | "gain" | "store" | "wait:<n>" | "cwait:<n>", text).  dma = buffer_load ... lds; gain = a buffer store of any width; store = any other store;
     wait = an s_waitcnt vmcnt(n) of the source's inline assembly, cwait = one the compiler placed; the loop = the cycle around the "Inner Loop Header" label."""
     hdr = next((i for i, l in enumerate(body) if "Inner Loop Header" in l), None)
     if hdr is None:
@@ -90,17 +90,16 @@ def prefetch_loop_ops(body):
             ops.append(("dma", t))
         elif re.match(r"(buffer|global|flat|scratch)_load", op):
             ops.append(("load", t))
-        elif op == "buffer_store_dword":
-            ops.append(("gain", t))
-        elif op in ("buffer_store_dwordx2", "buffer_store_dwordx4"):
-            ops.append(("ctg", t))
+        elif op.startswith("buffer_store_dword"):
+            ops.append(("gain", t))                                       # (any width: the gain stores and the cost-to-go stores are told apart by their position)
         elif re.match(r"(buffer|global|flat|scratch)_store", op):
             ops.append(("store", t))
     return ops
 
 
 def check_prefetch_invariant(body, hqq=False):
-    """Violations (strings) of what `s_waitcnt vmcnt(kMxGainStores [+ kMxCtgStores])` at the top of a knot relies on; [] = the emitted loop is what the source counts on."""
+    """Violations (strings) of what `s_waitcnt vmcnt(kMxGainStores [+ kMxCtgStores])` at the top of a knot relies on; [] = the emitted loop is what the source counts on.
+    Stores in program order behind the prefetch group: K_GAIN gain stores (K | du), then K_CTG cost-to-go stores ([P | p]) -- buffer stores of any width."""
     ops = prefetch_loop_ops(body)
     if ops is None:
         return ["no knot loop found"]
@@ -118,10 +117,9 @@ def check_prefetch_invariant(body, hqq=False):
         bad.append("a load behind the prefetch group: it would be counted as one of the stores")
     if any(k.startswith("cwait:") for k in rest) or any(k.startswith("cwait:") for k in mem[:n_dma]):
         bad.append("a compiler-placed vmcnt wait inside the loop: something other than the counted stores is in flight")
-    if rest.count("gain") != K_GAIN:
-        bad.append(f"{rest.count('gain')} single-dword buffer stores per knot, the wait counts on exactly {K_GAIN} (kMxGainStores)")
-    if rest.count("ctg") != K_CTG:
-        bad.append(f"{rest.count('ctg')} multi-dword buffer stores per knot, the all-slots wait counts on exactly {K_CTG} (kMxCtgStores)")
-    if "ctg" in rest and "gain" in rest and rest.index("ctg") < len(rest) - 1 - rest[::-1].index("gain"):
-        bad.append("a cost-to-go store is issued before the last gain store")
+    stores = [k for k in rest if k in ("gain", "ctg", "store")]
+    if "store" in stores:
+        bad.append("a store that is not a buffer store behind the prefetch group")
+    if len(stores) != K_GAIN + K_CTG:
+        bad.append(f"{len(stores)} buffer stores per knot, the waits count on exactly {K_GAIN} gain stores (kMxGainStores) + {K_CTG} cost-to-go stores (kMxCtgStores)")
     return bad

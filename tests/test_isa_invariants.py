@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import mx_isa  # noqa: E402
 
 # k_bp_mfma<FS, DIAGH, CAB, FUSE, HQQ>(Buffers<float>, ...): the float instantiations with the compact [A B] prefetch their operands
-PREFETCHING = re.compile(r"^_ZN4pddp9k_bp_mfmaILb[01]ELb1ELb1ELb[01]ELb([01])EEEvNS_7BuffersIfEE")
+PREFETCHING = re.compile(r"^_ZN4pddp9k_bp_mfmaILb([01])ELb1ELb1ELb([01])ELb([01])EEEvNS_7BuffersIfEE")      # groups: FS, FUSE, HQQ
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +39,7 @@ def test_every_prefetching_instantiation_issues_exactly_the_counted_stores(produ
         if not m:
             continue
         seen += 1
-        bad = mx_isa.check_prefetch_invariant(body, hqq=m.group(1) == "1")
+        bad = mx_isa.check_prefetch_invariant(body, hqq=m.group(3) == "1", exact=not (m.group(1) == "1" and m.group(2) == "0"))
         assert not bad, f"{name}: " + "; ".join(bad)
     assert seen >= 5, f"only {seen} prefetching instantiations found: the name pattern no longer matches csrc/pddp_mx.hip"
 
@@ -62,7 +62,9 @@ def test_a_fifth_gain_store_turns_the_check_red():
     for name, body in bodies.items():
         m = PREFETCHING.match(name)
         if m:
-            bad = mx_isa.check_prefetch_invariant(body, hqq=m.group(1) == "1")
+            if m.group(1) == "1" and m.group(2) == "0":
+                continue                                                  # (M > 1 without the fused maps: extra stores are allowed there)
+            bad = mx_isa.check_prefetch_invariant(body, hqq=m.group(3) == "1")
             assert any("buffer stores per knot" in b for b in bad), (name, bad)
             flagged += 1
-    assert flagged >= 5
+    assert flagged >= 3

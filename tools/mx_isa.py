@@ -97,7 +97,7 @@ def prefetch_loop_ops(body):
     return ops
 
 
-def check_prefetch_invariant(body, hqq=False):
+def check_prefetch_invariant(body, hqq=False, exact=True):
     """Violations (strings) of what `s_waitcnt vmcnt(kMxGainStores [+ kMxCtgStores])` at the top of a knot relies on; [] = the emitted loop is what the source counts on.
     Stores in program order behind the prefetch group: K_GAIN gain stores (K | du), then K_CTG cost-to-go stores ([P | p]) -- buffer stores of any width."""
     ops = prefetch_loop_ops(body)
@@ -117,9 +117,11 @@ def check_prefetch_invariant(body, hqq=False):
         bad.append("a load behind the prefetch group: it would be counted as one of the stores")
     if any(k.startswith("cwait:") for k in rest) or any(k.startswith("cwait:") for k in mem[:n_dma]):
         bad.append("a compiler-placed vmcnt wait inside the loop: something other than the counted stores is in flight")
-    stores = [k for k in rest if k in ("gain", "ctg", "store")]
-    if "store" in stores:
+    # exact: the instantiation issues nothing but the counted stores (every one but M > 1 without the fused sweep maps, whose A - B K | B du stores come on top: there the
+    # wait is conservative -- it also sits out some stores -- but still right, because what the count needs is AT LEAST that many stores behind the prefetch)
+    stores = [k for k in rest if k in ("gain", "store")]
+    if exact and "store" in stores:
         bad.append("a store that is not a buffer store behind the prefetch group")
-    if len(stores) != K_GAIN + K_CTG:
+    if (len(stores) != K_GAIN + K_CTG) if exact else (len(stores) < K_GAIN + K_CTG):
         bad.append(f"{len(stores)} buffer stores per knot, the waits count on exactly {K_GAIN} gain stores (kMxGainStores) + {K_CTG} cost-to-go stores (kMxCtgStores)")
     return bad

@@ -382,26 +382,6 @@ PDDP_HD void arm_tl_nis_jac(const ArmTlModel<T>& md, T grav, const T* x, const T
     arm_tl_dynamics<T>(md, grav, ts, qdd, x, x + 7, u);
     arm_tl_gradient<T>(md, grav, ts, x + 7, qdd, emit, mark);
 }
-// the same with the unit lower factor of the mass matrix parked in `park` (this thread's 21 slots, `stride` elements apart) between the groups of solves
-template <typename T> struct TlFactorsParked {
-    const T* park; int stride;
-    PDDP_HD void operator()(const ArmTlState<T>&, T* L) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::: "memory");                                    // (every group of solves reads the slots again: a single hoisted read would keep the 21 registers live)
-#endif
-#pragma unroll
-        for (int e = 0; e < 21; e++) L[e] = park[e * stride];
-    }
-};
-template <typename T, typename Emit, typename Mark>
-PDDP_HD void arm_tl_nis_jac_parked(const ArmTlModel<T>& md, T grav, const T* x, const T* u, Emit emit, Mark mark, T* park, int stride) {
-    ArmTlState<T> ts;
-    T qdd[7];
-    arm_tl_dynamics<T>(md, grav, ts, qdd, x, x + 7, u);
-#pragma unroll
-    for (int e = 0; e < 21; e++) park[e * stride] = ts.L[e];
-    arm_tl_gradient<T>(md, grav, ts, x + 7, qdd, emit, mark, TlFactorsParked<T>{park, stride});
-}
 template <typename T, typename Emit>
 PDDP_HD bool arm_tl_nis_knot(const ArmTlModel<T>& md, T grav, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int mode, int k, int pb, Emit emit) {
     T x[14], u[7];

@@ -632,9 +632,7 @@ void launch_sweep_wg(hipStream_t s, const Buffers<float>& b, const Dims& dm, int
 //   !CAB:          the reference layout, whole 56-byte columns, adjacent columns of a knot by adjacent lanes (224 / 168 / 392 contiguous bytes per knot and piece).
 // double handles (PDDP_FP=tl: test selection) run the same code with two waves per workgroup.  Replaces integratorGradientKern + costGradientHessianKern + memcpyCurrAKern x3 (nisInitHelpers.cuh:247-279).
 constexpr int kNisTlStage = 64 * 57;
-#ifndef PDDP_NIS_TL_PARK
-#define PDDP_NIS_TL_PARK 0
-#endif
+
 template <typename T> struct NisTlCfg { static constexpr int kWaves = sizeof(T) == 4 ? 4 : 2, kThreads = 64 * kWaves; };   // double: two waves per workgroup (58 KB of staging)
 template <typename T> struct NisTlVec { typedef T v4 __attribute__((ext_vector_type(4), aligned(16))); typedef T v4p __attribute__((ext_vector_type(16 / sizeof(T)), aligned(16))); };   // v4p: one 16-byte piece
 template <typename T, int V, bool EE, bool CAB>
@@ -644,11 +642,6 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
     const int g = blockIdx.x * NisTlCfg<T>::kThreads + threadIdx.x, total = batch * dm.N;
     const int pb = g / dm.N, k = g - pb * dm.N;
     __shared__ __attribute__((aligned(16))) T stage_all[NisTlCfg<T>::kWaves * kNisTlStage];
-    // float handles: the 21 entries of the mass matrix's unit lower factor are parked in LDS between the groups of solves (entry-major: a wave's 64 lanes read 64 consecutive
-    // words) -- 21.5 KB per workgroup, with the staging 79.9 KB: two workgroups still share a compute unit's 160 KB.  The kernel needs every one of its 256 registers; the
-    // factor is idle between the eight places that solve with it (round 5, profiles/r05_tl_pruning.md).
-    constexpr bool PARK = PDDP_NIS_TL_PARK && sizeof(T) == 4;
-    __shared__ T lpark[PARK ? 21 * NisTlCfg<T>::kThreads : 1];
     T* stage = stage_all + (threadIdx.x >> 6) * kNisTlStage;
     const int lane = threadIdx.x & 63;
     T x[NX], u[7];
@@ -776,8 +769,7 @@ __global__ __launch_bounds__(NisTlCfg<T>::kThreads, sizeof(T) == 4 ? 2 : 1) void
         }
         wsync();
     };
-    if constexpr (PARK) arm_tl_nis_jac_parked<T>(md, grav, x, u, emit, flush, lpark + threadIdx.x, NisTlCfg<T>::kThreads);
-    else arm_tl_nis_jac<T>(md, grav, x, u, emit, flush);
+    arm_tl_nis_jac<T>(md, grav, x, u, emit, flush);
 }
 
 // k_nis_tl7: grid (ceil(B*N / 64), 7), block 64.  Next-iteration setup of a handle with FEW problems in flight (one MPC solve: 127 knots on a 256-CU device):

@@ -299,15 +299,6 @@ template <typename T> PDDP_HD void tl_ldl_solve(const T* L, const T* Dinv, T* x)
         for (int j = i + 1; j < kArmNB; j++) x[i] = (Z(x[i]) - Z(L[j * (j - 1) / 2 + i]) * Z(x[j])).v;
 }
 template <typename T> PDDP_HD void tl_ldl_solve(const ArmTlState<T>& st, T* x) { tl_ldl_solve<T>(st.L, st.Dinv, x); }
-// Where the gradient takes the unit lower factor from when it solves: TlFactorsInState = the evaluation's own registers (st.L); the setup kernel parks the 21 numbers in
-// LDS after the factorisation and passes an accessor that reads them back for each group of solves (k_nis_tl, pddp_tl.hip) -- they are idle between the eight groups.
-struct TlFactorsInState {
-    template <typename T> PDDP_HD void operator()(const ArmTlState<T>& st, T* L) const {
-#pragma unroll
-        for (int e = 0; e < 21; e++) L[e] = st.L[e];
-    }
-};
-
 // compile-time loop over the links with their frame kind as a template argument
 template <int I, int END, int STEP> struct TlFor {
     template <typename F> static PDDP_HD void run(F&& f) { f(std::integral_constant<int, I>()); TlFor<I + STEP, END, STEP>::run(f); }
@@ -580,8 +571,8 @@ template <int KIND, typename T> PDDP_HD void tl_rot_to_parent(T* o, const T* x, 
     else if (KIND == kTlBZ) { o[0] = n1[0].v; o[1] = (-n1[2]).v; o[2] = n1[1].v; }
     else { o[0] = (-n1[0]).v; o[1] = n1[2].v; o[2] = n1[1].v; }
 }
-template <typename T, typename Emit, typename Mark, typename Factors = TlFactorsInState>
-PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark, Factors factors = Factors()) {
+template <typename T, typename Emit, typename Mark>
+PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T>& st, const T* qd, const T* qdd, Emit emit, Mark mark) {
     constexpr int NB = kArmNB;
     // ---- link accelerations at the actual qdd
     T a[NB][6];
@@ -705,12 +696,11 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
         // ---- column k is complete: d qdd / d(q_k, qd_k) = -M^-1 dtau
         PDDP_TL_SCHED_FENCE();
         {
-            T cq[NB], cv[NB], Lf[21];
+            T cq[NB], cv[NB];
 #pragma unroll
             for (int i = 0; i < NB; i++) { cq[i] = -dtq[k][i]; cv[i] = -dtv[k][i]; }
-            factors(st, Lf);
-            tl_ldl_solve<T>(Lf, st.Dinv, cq);
-            tl_ldl_solve<T>(Lf, st.Dinv, cv);
+            tl_ldl_solve(st, cq);
+            tl_ldl_solve(st, cv);
 #pragma unroll
             for (int i = 0; i < NB; i++) { emit(k, i, cq[i]); emit(NB + k, i, cv[i]); }
         }
@@ -753,19 +743,7 @@ PDDP_HD void arm_tl_gradient(const ArmTlModel<T>& md, T grav, const ArmTlState<T
             for (int e = 0; e < 3; e++) P[e] = p2[e];
         }
     });
-    {
-        T Lf[21];
-        factors(st, Lf);
-        TlFor<0, NB, 1>::run([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            T e[NB];
-#pragma unroll
-            for (int i = 0; i < NB; i++) e[i] = (i == j) ? T(1) : T(0);
-            tl_ldl_solve<T>(Lf, st.Dinv, e);
-#pragma unroll
-            for (int i = 0; i < NB; i++) emit(2 * NB + j, i, e[i]);
-        });
-    }
+    TlFor<0, NB, 1>::run([&](auto jc) { arm_tl_grad_control<decltype(jc)::value, T>(st, emit); });
     mark(std::integral_constant<int, 2>());
 }
 template <typename T, typename Emit>

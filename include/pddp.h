@@ -37,7 +37,7 @@ typedef struct pddp_solver* pddp_handle;
 typedef struct pddp_kernel_selection {
     int bp;       /* arm, backward pass:        1 mx (matrix cores)  2 lg (8-lane groups)  3 coop (one wave per block)  4 wide (one workgroup per block)             */
     int fp;       /* arm, rollouts + setup:     1 tl (thread lanes)  2 lg  3 coop  4 tl2 (two-wave split, few problems)  5 tl4 (four-wave pipeline, few problems)   */
-    int sweep;    /* arm, linear forward sweep: 1 alpha (lane group per candidate)  2 st (two sequences)  3 wg (workgroup per problem); any value: no fusion into bp  */
+    int sweep;    /* arm, linear forward sweep: 1 alpha (lane group per candidate)  2 st (two sequences)  3 wg (workgroup per problem): no fusion into bp;  4 maps: fused, applied by k_sweep_maps even where the rollout kernel would apply the maps itself */
     int ls;       /* line search:               1 many (thread per problem)  2 wg (wave per problem)                                                                */
     int ab;       /* arm, layout of [A B]:      1 full (reference layout instead of the compact one)                                                                */
     int cf;       /* closed-form plants, every phase: 1 ts (thread-serial)  2 coop                                                                                   */
@@ -290,7 +290,7 @@ int pddp_run_phase(pddp_handle h, int phase);
  * comparison tests and measurements -- they never change WHAT is computed, only which kernel family computes it:
  *   PDDP_BP=mx|lg|coop|wide   backward pass: matrix cores | lane groups | one wave per block of knots | one workgroup per block
  *   PDDP_FP=tl|tl2|lg|coop    rollouts + next-iteration setup: thread lanes (tl2: the two-wave predecessor of the few-problem pipeline) | lane groups | cooperative
- *   PDDP_SWEEP=alpha|st|wg    a separate linear-sweep kernel instead of the maps composed in the matrix-core backward pass
+ *   PDDP_SWEEP=alpha|st|wg    a separate linear-sweep kernel instead of the maps composed in the matrix-core backward pass (maps: composed, applied by k_sweep_maps everywhere)
  *   PDDP_LS=many|wg           line search one thread per problem (default from 2048 problems in flight) | one workgroup per problem
  *   PDDP_AB=full              keep [A B] in the reference layout only          PDDP_CF=ts|coop (PDDP_CF_BP / _FP / _NIS)  closed-form plants: thread-serial | cooperative */
 int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);

@@ -66,7 +66,7 @@ static constexpr size_t kBpMfmaMinBlocks = 1;
 static const char* ksel(int v, std::initializer_list<const char*> names) { return (v > 0 && (size_t)v <= names.size()) ? *(names.begin() + (v - 1)) : nullptr; }
 static const char* ksel_bp(const pddp_config& c) { return ksel(c.kernels.bp, {"mx", "lg", "coop", "wide"}); }
 static const char* ksel_fp(const pddp_config& c) { return ksel(c.kernels.fp, {"tl", "lg", "coop", "tl2", "tl4"}); }
-static const char* ksel_sweep(const pddp_config& c) { return ksel(c.kernels.sweep, {"alpha", "st", "wg"}); }
+static const char* ksel_sweep(const pddp_config& c) { return ksel(c.kernels.sweep, {"alpha", "st", "wg", "maps"}); }
 static const char* ksel_ls(const pddp_config& c) { return ksel(c.kernels.ls, {"many", "wg"}); }
 static const char* ksel_ab(const pddp_config& c) { return ksel(c.kernels.ab, {"full"}); }
 static const char* ksel_cf(const pddp_config& c) { return ksel(c.kernels.cf, {"ts", "coop"}); }
@@ -241,6 +241,10 @@ struct Solver : SolverBase {
     bool bp_mfma = false;          // matrix-core backward pass, one wavefront per block of knots (bp_mfma.hpp): float handles of the arm; PDDP_BP=mx
     // few problems in flight on the four-wave rollout pipeline, every problem's M x A rollouts inside one wavefront: the rollout kernel ends with the line search (k_fp_tl4)
     bool ls_in_rollouts() const { return P::PLANT == 4 && fp_split && !fp_two_wave && !ls_many && cfg.kernels.ls == 0 && 64 % (cfg.M * cfg.A) == 0; }
+    // ... and BEGINS with the linear forward sweep: the segment maps the backward pass composed are applied in the rollout kernel's prologue (a problem's M x A lanes sit in
+    // one wavefront, 14 of them walk the maps) instead of by a k_sweep_maps launch in front of it -- one more kernel boundary of the ~115 us iteration gone.
+    // kernels.sweep = maps keeps the separate kernel (A/B, tests); so do the phase hooks and the per-phase / per-kernel timing, which launch the sweep on its own.
+    bool maps_in_rollouts() const { return P::PLANT == 4 && sweep_fused && cfg.kernels.sweep == 0 && fp_split && !fp_two_wave && 64 % (cfg.M * cfg.A) == 0 && cfg.M * cfg.A >= 16; }
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
     size_t fp_lds = 0;
@@ -328,7 +332,7 @@ struct Solver : SolverBase {
         // PDDP_BP=mx on a double handle: the same tile algebra on v_mfma_f64_16x16x4_f64 (a test selection: float64 handles default to the lane-group family,
         // whose operation order is the reference's)
         if (const char* v = ksel_bp(cfg)) { bp_lane_groups = (std::string(v) == "lg"); bp_wide = (std::string(v) == "wide"); bp_mfma = (P::PLANT == 4 && std::string(v) == "mx"); }
-        sweep_fused = bp_mfma && c.M > 1 && !ksel_sweep(cfg);
+        sweep_fused = bp_mfma && c.M > 1 && (!ksel_sweep(cfg) || std::string(ksel_sweep(cfg)) == "maps");
         sp.max_iter = c.max_iter; sp.out_stride = c.max_iter + 2; sp.ignore_max_rho_exit = c.ignore_max_rho_exit; sp.tol_cost = c.tol_cost;
         sp.exp_red_min = c.exp_red_min; sp.exp_red_max = c.exp_red_max; sp.max_defect = c.max_defect; sp.rho_init = c.rho_init; sp.ee_initial_cost_fix = c.ee_initial_cost_fix;
         cw.Q1 = (T)c.Q1; cw.Q2 = (T)c.Q2; cw.R = (T)c.R; cw.QF1 = (T)c.QF1; cw.QF2 = (T)c.QF2;
@@ -476,7 +480,9 @@ struct Solver : SolverBase {
             const unsigned waves = (A_eff * cfg.M + kLgPerWave - 1) / kLgPerWave;
             if (!init_rollout && cfg.M > 1 && part != 1 && part != 2) {
                 bool st = false;
-                if (sweep_fused && (!store_candidates || phase_fused_sweep)) { launch_sweep_maps<T>(s, b, dm, (int)B); st = true; }
+                const bool in_rollouts = maps_in_rollouts() && part == -1 && !store_candidates;      // (k_fp_tl4 begins with the sweep)
+                if (in_rollouts) st = true;
+                else if (sweep_fused && (!store_candidates || phase_fused_sweep)) { launch_sweep_maps<T>(s, b, dm, (int)B); st = true; }
                 if constexpr (sizeof(T) == 4) {
                     if (st) {}
                     else if (sweep_kind == 2) { launch_sweep_wg(s, b, dm, (int)B); st = true; }
@@ -488,7 +494,8 @@ struct Solver : SolverBase {
             if (!init_rollout && fp_split) {
                 bool two = false;
                 if constexpr (sizeof(T) == 4) { if (fp_two_wave) { launch_fp_tl2(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B); two = true; } }
-                if (!two) launch_fp_tl4<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, sp, (ls_in_rollouts() && !store_candidates && part != 2) ? bench_mode : -1);
+                if (!two) launch_fp_tl4<T>(s, tl_variant, b, dm, cw, dt, tl_grav, (int)B, sp, (ls_in_rollouts() && !store_candidates && part != 2) ? bench_mode : -1,
+                                           maps_in_rollouts() && part == -1 && !store_candidates);
                 return;
             }
             if (!init_rollout && fp_path == kFpTl) {               // one thread per (candidate, segment) rollout
@@ -591,8 +598,9 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp && mq_bp) ? "k_bp_mq" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
-        static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS}, part_of[6] = {-1, 0, 1, -1, 0, 1};
+                             (lg && cfg.M > 1 && !maps_in_rollouts()) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
+        static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS};
+        const int part_of[6] = {-1, 0, maps_in_rollouts() ? -1 : 1, -1, 0, 1};      // (a rollout kernel that begins with the sweep is timed as it runs in production)
         HIPCHK(hipStreamSynchronize(stream));
         const size_t need = 7 * (size_t)sweeps;
         while (trace_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); trace_ev.push_back(e); }
@@ -660,10 +668,12 @@ struct Solver : SolverBase {
         const size_t need = 6 * (size_t)sweeps;
         if (sweep_fused && sweeps > 0) fs_vars_stale = true;
         while (trace_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); trace_ev.push_back(e); }
-        static const int phase_of[5] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS}, part_of[5] = {-1, 0, 1, -1, -1};
+        static const int phase_of[5] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS};
+        const bool own_sweep = !maps_in_rollouts();                                  // (otherwise the rollout kernel begins with it: row 4 stays 0)
+        const int part_of[5] = {-1, 0, own_sweep ? 1 : -1, -1, -1};
         for (int i = 0; i < sweeps; i++) {
             HIPCHK(hipEventRecord(trace_ev[6 * i], stream));
-            for (int k = 0; k < 5; k++) { launch_sweep(stream, phase_of[k], 0, part_of[k]); HIPCHK(hipEventRecord(trace_ev[6 * i + k + 1], stream)); }
+            for (int k = 0; k < 5; k++) { if (k != 1 || own_sweep) launch_sweep(stream, phase_of[k], 0, part_of[k]); HIPCHK(hipEventRecord(trace_ev[6 * i + k + 1], stream)); }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -671,6 +681,7 @@ struct Solver : SolverBase {
             if (first_sweep + i >= stride) continue;
             float ms[5];
             for (int k = 0; k < 5; k++) HIPCHK(hipEventElapsedTime(&ms[k], trace_ev[6 * i + k], trace_ev[6 * i + k + 1]));
+            if (!own_sweep) ms[1] = 0.f;
             const size_t o = (size_t)first_sweep + i;
             phase_ms[0 * (size_t)stride + o] = ms[0]; phase_ms[1 * (size_t)stride + o] = (double)ms[1] + ms[2]; phase_ms[2 * (size_t)stride + o] = ms[3];
             phase_ms[3 * (size_t)stride + o] = ms[4]; phase_ms[4 * (size_t)stride + o] = ms[1];

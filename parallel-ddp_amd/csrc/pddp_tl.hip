@@ -303,8 +303,14 @@ void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Di
 // forwardSimGPU's host part + acceptRejectTrajGPU (fpHelpers.cuh:395-408, nisInitHelpers.cuh:489-518; line_search_accept) -- instead of leaving it to a k_ls launch behind
 // this kernel: the candidates' totals are formed from the lanes' own partial sums (the order of tl_reduce_parts / k_ls: segments 0..M-1), one kernel boundary and one
 // dependent launch (~7 us of a ~120 us iteration) disappear.  ls_mode = freeze_exit of k_ls (1: benchmark mode); -1: no line search here (phase hooks, per-phase timing).
+// maps (same condition on M A, and M A >= 16): the kernel BEGINS WITH THE LINEAR FORWARD SWEEP -- forwardSweepKern x A (fpHelpers.cuh:19-63) in the form of k_sweep_maps
+// (pddp_mx.hip): the per-segment maps the matrix-core backward pass composed, e <- Phi_s e + gamma_s for the s- and the t-sequence, walked by the first 14 lanes of the
+// problem's M A (every wave walks them: the same operations in the same order, no exchange between the waves); a rollout's start state is xcur + (t - alpha s) at its
+// segment's boundary, the very expression k_sweep_maps stores.  The defect against the next segment's start state then comes from that rollout's lane, not from memory.
+template <typename T> __device__ __forceinline__ T tl4_fma(T a, T b_, T c) { return __builtin_fma(a, b_, c); }
+template <> __device__ __forceinline__ float tl4_fma<float>(float a, float b_, float c) { return __builtin_fmaf(a, b_, c); }
 template <typename T, int V, bool EE>
-__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch, SolverParams sp, int ls_mode) {
+__global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, T grav, int batch, SolverParams sp, int ls_mode, int maps) {
     constexpr int NX = 14, NU = 7;
     __shared__ T ls_J[64], ls_d[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char pipe_lds_raw[];
@@ -319,8 +325,46 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWe
     const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
     const size_t slot = (size_t)pb * A + a_idx;
     T* xs = b.xs + slot * N * NX; T* us = b.us + slot * N * NU; T* ds = b.ds + slot * N * NX;
+    const T alpha = b.alpha[a_idx];
     T x[NX];
-    if (seg == 0) tl_load14(x, xcur); else tl_load14(x, xs + (size_t)kStart * NX);
+    if (!maps) { if (seg == 0) tl_load14(x, xcur); else tl_load14(x, xs + (size_t)kStart * NX); }
+    else {
+        const int W = M * A, l = rem < NX ? rem : NX - 1;                 // W lanes per problem: the shuffles stay inside them
+        const T* dcur = b.dcur + (size_t)pb * N * NX;
+        tl_load14(x, xcur + (size_t)kStart * NX);                         // the nominal state at the segment's first knot
+        T es = T(0), et = T(0);
+        auto advance = [&](int sgm, const T* ph, T gam, T dk) {
+            T ns = gam, nt = dk;
+#pragma unroll
+            for (int cc = 0; cc < NX; cc++) { ns = tl4_fma<T>(ph[cc], __shfl(es, cc, W), ns); nt = tl4_fma<T>(ph[cc], __shfl(et, cc, W), nt); }
+            es = ns; et = nt;
+#pragma unroll
+            for (int i = 0; i < NX; i++) {                                 // (every lane shuffles: the source lanes belong to segment 0)
+                const T si = __shfl(es, i, W), ti = __shfl(et, i, W);
+                if (seg == sgm + 1) x[i] = x[i] + (ti - alpha * si);
+            }
+        };
+        if (M == 4) {                                                    // the usual M: the three maps requested at once (one memory round trip, as in k_sweep_maps)
+            T ph[3][NX + 1], dk[3];
+#pragma unroll
+            for (int sgm = 0; sgm < 3; sgm++) {
+                const T* o = b.segmap + ((size_t)pb * 4 + sgm) * 256;
+#pragma unroll
+                for (int cc = 0; cc <= NX; cc++) ph[sgm][cc] = o[cc * 16 + l];
+                dk[sgm] = dcur[(size_t)((sgm + 1) * NBk - 1) * NX + l];
+            }
+#pragma unroll
+            for (int sgm = 0; sgm < 3; sgm++) advance(sgm, ph[sgm], ph[sgm][NX], dk[sgm]);
+        } else {
+            for (int sgm = 0; sgm < M - 1; sgm++) {
+                const T* o = b.segmap + ((size_t)pb * M + sgm) * 256;
+                T ph[NX + 1];
+#pragma unroll
+                for (int cc = 0; cc <= NX; cc++) ph[cc] = o[cc * 16 + l];
+                advance(sgm, ph, ph[NX], dcur[(size_t)((sgm + 1) * NBk - 1) * NX + l]);
+            }
+        }
+    }
     __syncthreads();                                                    // the counters are zero
     if (wave >= 2) { tl_pipe_factor_wave<V>(p, wave - 2, NBk, x, dt, lane); return; }
     if (wave == 0) {
@@ -329,7 +373,9 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWe
         return;
     }
     // -------------------------------------------------------------------- control wave: operands, trajectory out, cost
-    const T alpha = b.alpha[a_idx];
+    T x0[NX];                                                             // (maps: the rollout's start state, the next-lower segment's defect is taken against it)
+#pragma unroll
+    for (int i = 0; i < NX; i++) x0[i] = x[i];
     const T* KT = b.KT + (size_t)pb * N * NX * NU; const T* uc = b.ucur + (size_t)pb * N * NU; const T* du = b.du + (size_t)pb * N * NU;
     T xg[NX], goal[6], acc7s[NU];
     int tshift = 0;
@@ -351,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWe
         for (int i = 0; i < NU; i++) { nuc[i] = uc[(size_t)kn * NU + i]; ndu[i] = du[(size_t)kn * NU + i]; }
     };
     fetch(kStart);
-    if (live) tl_store14(xs + (size_t)kStart * NX, x);                    // (a candidate slot already holds it for seg > 0)
+    if (live) tl_store14(xs + (size_t)kStart * NX, x);                    // (without maps a candidate slot already holds it for seg > 0)
     const int iters = EE ? NBk : ((seg < M - 1) ? NBk : NBk - 1);
     for (int k = 0; k < NBk; k++) {
         const int kn = kStart + k;
@@ -390,14 +436,19 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWe
             }
         }
     }
+    T xnext[NX];
+    if (maps) {                                                           // (wave-uniform) the start state of the same candidate's next segment: A lanes up
+#pragma unroll
+        for (int i = 0; i < NX; i++) xnext[i] = __shfl(x0[i], (lane + A) & 63);
+    }
     if (seg < M - 1) {                                                    // the step out of the segment's last knot: defect against the next segment's start
         tl_pipe_wait(p.flag + 0, NBk);
         if (live) {
             T xi[16];
             tl_pipe_ld<4>(xi, p.xbuf + ((((NBk) & 1) * 64) + lane) * kPipeSX);
             const int ks = (seg + 1) * NBk;
-            T xnext[NX], e[NX];
-            tl_load14(xnext, xs + (size_t)ks * NX);
+            T e[NX];
+            if (!maps) tl_load14(xnext, xs + (size_t)ks * NX);
 #pragma unroll
             for (int i = 0; i < NX; i++) { e[i] = xi[i] - xnext[i]; sdef += tabs(e[i]); }
             tl_store14(ds + (size_t)(ks - 1) * NX, e);
@@ -430,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void k_fp_tl4(Buffers<T> b, Dims dm, CostWe
     }
 }
 template <typename T>
-void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, const SolverParams& sp, int ls_mode) {
+void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, const SolverParams& sp, int ls_mode, bool maps) {
     const unsigned inst = (unsigned)batch * dm.M * dm.A;
     constexpr int lds = pipe_lds_bytes<T>(true);
     static bool attr_set = false;
@@ -443,15 +494,15 @@ void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& 
     }
     const dim3 g((inst + 63) / 64), t(256);
     if (cw.ee) {
-        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, true>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
-        else hipLaunchKernelGGL((k_fp_tl4<T, 1, true>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, true>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode, maps ? 1 : 0);
+        else hipLaunchKernelGGL((k_fp_tl4<T, 1, true>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode, maps ? 1 : 0);
     } else {
-        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, false>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
-        else hipLaunchKernelGGL((k_fp_tl4<T, 1, false>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode);
+        if (variant == 0) hipLaunchKernelGGL((k_fp_tl4<T, 0, false>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode, maps ? 1 : 0);
+        else hipLaunchKernelGGL((k_fp_tl4<T, 1, false>), g, t, lds, s, b, dm, cw, dt, grav, batch, sp, ls_mode, maps ? 1 : 0);
     }
 }
-template void launch_fp_tl4<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, const SolverParams&, int);
-template void launch_fp_tl4<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, const SolverParams&, int);      // the parity instantiation (PDDP_FP=tl4)
+template void launch_fp_tl4<float>(hipStream_t, int, const Buffers<float>&, const Dims&, const CostWeights<float>&, float, float, int, const SolverParams&, int, bool);
+template void launch_fp_tl4<double>(hipStream_t, int, const Buffers<double>&, const Dims&, const CostWeights<double>&, double, double, int, const SolverParams&, int, bool);      // the parity instantiation (PDDP_FP=tl4)
 
 // k_sweep_st: grid ceil(2 B / 8), block 64.  The linear sweep of forwardSweepKern (fpHelpers.cuh:19-63) for ALL candidates of a problem at once.
 // The sweep is affine in the step size: with e_k = x_k - xcur_k,  e_{k+1} = F_k e_k - alpha (B du)_k + [boundary] d_k,  e_0 = 0,  so

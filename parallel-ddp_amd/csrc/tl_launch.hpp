@@ -17,7 +17,7 @@ template <typename T> void launch_fp_tl(hipStream_t s, int variant, const Buffer
 void launch_fp_tl2(hipStream_t s, int variant, const Buffers<float>& b, const Dims& dm, const CostWeights<float>& cw, float dt, float grav, int batch);
 // the rollouts as a pipeline over four wavefronts (k_fp_tl4, fp_pipe.hpp: few problems in flight; joint-space and end-effector cost); stores x, u, d of every candidate
 // (T = double: the parity instantiation, selected with PDDP_FP=tl4 on a double handle)
-template <typename T> void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, const SolverParams& sp, int ls_mode);
+template <typename T> void launch_fp_tl4(hipStream_t s, int variant, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, T grav, int batch, const SolverParams& sp, int ls_mode, bool maps);
 // the linear sweep of all candidates from two sequences (k_sweep_st, float handles)
 void launch_sweep_st(hipStream_t s, const Buffers<float>& b, const Dims& dm, int batch);
 // the same sweep with one workgroup per problem and the chain's operands staged in LDS up front (k_sweep_wg: few problems in flight)

@@ -13,7 +13,7 @@ class PddpError(RuntimeError):
 
 
 # pddp_kernel_selection (include/pddp.h): value names per field, in the order of the header (index + 1 = the C value; 0 / None = the library's choice)
-KERNEL_NAMES = {"bp": ("mx", "lg", "coop", "wide"), "fp": ("tl", "lg", "coop", "tl2", "tl4"), "sweep": ("alpha", "st", "wg"), "ls": ("many", "wg"), "ab": ("full",),
+KERNEL_NAMES = {"bp": ("mx", "lg", "coop", "wide"), "fp": ("tl", "lg", "coop", "tl2", "tl4"), "sweep": ("alpha", "st", "wg", "maps"), "ls": ("many", "wg"), "ab": ("full",),
                 "cf": ("ts", "coop"), "cf_bp": ("ts", "coop", "gl", "gl32", "cl", "mq"), "cf_fp": ("ts", "coop", "cf"), "cf_nis": ("ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64")}
 
 

@@ -35,10 +35,12 @@ def kernels(plant, batch, sel=None, dtype=0, **kw):
 def test_few_problems_in_flight_run_the_pipeline_and_the_per_joint_setup(ee):
     kw = dict(KUKA, ee_cost=ee, **(dict(mpc_mode=1, ignore_max_rho_exit=0) if ee else {}))
     # (no k_ls: with a problem's M x A rollouts inside one wavefront the rollout pipeline ends with the line search itself, round 5; A = 16 x M = 8 does not fit and keeps it)
-    assert kernels(4, 1, **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_nis_tl7"]
-    assert kernels(4, 3, **kw)[2:] == ["k_fp_tl4", "k_nis_tl7"]
-    assert kernels(4, 1, dict(ls="wg"), **kw)[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
-    assert kernels(4, 1, **dict(kw, N=128, M=8, A=16))[2:] == ["k_fp_tl4", "k_ls", "k_nis_tl7"]
+    # (no k_sweep_maps either: the same rollout kernel begins with the linear forward sweep -- the maps the backward pass composed; kernels.sweep = maps keeps the kernel)
+    assert kernels(4, 1, **kw) == ["k_bp_mfma", "k_fp_tl4", "k_nis_tl7"]
+    assert kernels(4, 3, **kw) == ["k_bp_mfma", "k_fp_tl4", "k_nis_tl7"]
+    assert kernels(4, 1, dict(sweep="maps"), **kw) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_nis_tl7"]
+    assert kernels(4, 1, dict(ls="wg"), **kw) == ["k_bp_mfma", "k_fp_tl4", "k_ls", "k_nis_tl7"]
+    assert kernels(4, 1, **dict(kw, N=128, M=8, A=16)) == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_ls", "k_nis_tl7"]
 
 
 def test_the_library_does_not_read_the_environment_for_its_selection():
@@ -60,7 +62,7 @@ def test_the_library_does_not_read_the_environment_for_its_selection():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     x0, u0, xg = example_inputs(4, 64, np.float32)
     s.load(x0, u0, xg); s.iterate(2); s.sync()
-    assert [n for n, _ in s.time_kernels(2)] == ["k_bp_mfma", "k_sweep_maps", "k_fp_tl4", "k_nis_tl7"]
+    assert [n for n, _ in s.time_kernels(2)] == ["k_bp_mfma", "k_fp_tl4", "k_nis_tl7"]
     s.close()
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parallel-ddp_amd", "csrc", "pddp_api.hip")).read()
     import re
@@ -132,3 +134,33 @@ def test_compact_operands_through_the_lds_prefetch_follow_the_reference_layout(N
     np.testing.assert_allclose(c["u"], f["u"], atol=2e-3, rtol=2e-3)
     np.testing.assert_allclose(c["KT"], f["KT"], atol=5e-2, rtol=5e-3)            # (the float32 Riccati recursion amplifies a rounding difference of the operands)
     np.testing.assert_allclose(c["Jout"][:, :2], f["Jout"][:, :2], rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,ee,M,A,batch", [(0, 0, 4, 8, 1), (0, 0, 4, 8, 3), (0, 0, 4, 16, 2), (0, 0, 2, 8, 5), (0, 0, 8, 8, 2), (0, 1, 4, 8, 3), (1, 0, 4, 8, 3), (1, 0, 2, 16, 1)])
+def test_the_sweep_inside_the_rollout_kernel_is_the_sweep_kernel_bit_for_bit(dtype, ee, M, A, batch):
+    """Few problems in flight: k_fp_tl4 begins with the linear forward sweep (the segment maps of the matrix-core backward pass walked by 14 lanes of the problem's M x A,
+    every rollout's start state formed in its own lane) instead of a k_sweep_maps launch in front of it.  Same operations in the same order: a whole solve -- graph replay,
+    the production path -- ends on the same bits as with kernels.sweep = maps, for 16 / 32 / 64 lanes per problem, partial wavefronts, both cost families, both
+    element types."""
+    kw = dict(N=64, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=12, ee_cost=ee, **(dict(mpc_mode=1, ignore_max_rho_exit=0) if ee else {}))
+    fam = dict(bp="mx", fp="tl4") if dtype else {}
+    res = []
+    for sel in (dict(fam), dict(fam, sweep="maps")):
+        s = make_solver("hip", 4, dtype=dtype, batch=batch, use_graph=1, kernels=sel or None, **kw)
+        rng = np.random.default_rng(5)
+        xs, us, gs = [], [], []
+        for _ in range(batch):
+            x0, u0, xg = example_inputs(4, 64, np.float64 if dtype else np.float32, noise=rng.normal(0, 0.002, (64, 14)))
+            if ee:                                                                  # (the start of tests/test_ee_thread_lanes.py, every problem its own goal)
+                x0 = np.zeros((64, 14), x0.dtype); x0[:, 1] = 0.7; x0[:, 3] = -0.8; x0[:, 5] = 0.75; x0 = x0.ravel()
+                u0 = np.full(64 * 7, 0.01, x0.dtype)
+                xg = np.asarray([0.45, 0.15 + 0.05 * len(xs), 0.75] + [0] * 11, x0.dtype)
+            xs.append(x0); us.append(u0); gs.append(xg)
+        out = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
+        res.append({k: np.array(out[k]) for k in ("x", "u", "KT", "dmax", "Jout", "alphaOut")})
+        names = [n for n, _ in s.time_kernels(1)]
+        assert ("k_sweep_maps" in names) == ("sweep" in sel) and "k_fp_tl4" in names
+        s.close()
+    assert (res[0]["alphaOut"][:, 1:6] >= 0).any()                                  # steps were taken
+    for k in res[0]:
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)

@@ -8,8 +8,10 @@
 //     register r < 3 of lane group g  <->  state 3 g + r          register 3 of lane group g  <->  control g (control-row tiles) / the vector column's row (unused)
 //     column c = (cg, cr) likewise: cr < 3 a state column, cr = 3 the control cg (control-column tiles B, W_u, Huu) or, for (3, 3), the VECTOR column of the state-column
 //     tiles (p next to P, g_x next to Hxx, du next to K ...)
-// so a sum over the 12 states is instructions r = 0, 1, 2 and a sum over the 4 controls is instruction r = 3 ALONE: 23 matrix instructions per knot (six state
-// contractions x 3, K, K'Huu, B K, and two for the new cost-to-go) where the lane-per-column kernel issues ~1250 vector instructions.  Only the 4 x 4 inverse runs on the
+// so a sum over the 12 states is instructions r = 0, 1, 2 and a sum over the 4 controls is instruction r = 3 ALONE: 17 matrix instructions per knot (four state
+// contractions x 3 -- P'[A | B] on ONE tile, then all four blocks of the Hessian from [A B]' W and its transpose, and the vector column; the first cut issued one
+// contraction per block, 23 in all: same sums, same bits, tools/quad_mq_equal.py --, K, K'Huu, B K, and two for the new cost-to-go) where the lane-per-column kernel
+// issues ~1250 vector instructions.  A knot's operands are requested one knot ahead (PDDP_MQ_PREFETCH).  Only the 4 x 4 inverse runs on the
 // vector ALU (16 cofactors, one per lane, through 48 words of LDS -- the operations and their order are bp_cl_block's, i.e. the reference's).
 // Float results agree with the oracle within the float32 bar (tests/test_fp32_bar.py), not bit for bit: sums over the state index run in the matrix core's order.
 // The cost Hessian of the running knots is taken as diag(P::weight) where it is the plant's own (closed-form cost files); a Hessian overridden through the API and plug-in
@@ -27,6 +29,9 @@ template <typename T> __device__ __forceinline__ mx4t<T> mq_states(const mx4t<T>
 }
 template <typename T> __device__ __forceinline__ mx4t<T> mq_controls(const mx4t<T>& X, const mx4t<T>& Y, mx4t<T> acc) { return Mx<T>::mfma(X[3], Y[3], acc); }   // sum over the 4 controls
 
+#ifndef PDDP_MQ_PREFETCH
+#define PDDP_MQ_PREFETCH 1    // a knot's operands requested one knot ahead (measured: tools/quad_bp_ab.py, profiles/r05_quad_mfma.md)
+#endif
 constexpr int kMqLds = 64;                     // elements per wave: Huu 16 | cofactors 16 | inverse 16 | boundary p 16
 
 // Per-knot memory operations of the loop.  float: BUFFER instructions -- a wave-uniform resource per array, the knot's position a scalar byte offset, the lane's share a
@@ -120,39 +125,58 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
         wsync();
     }
     T dJ0 = T(0), dJ1 = T(0);                                                // lanes (g, vector column): control g's partial sums of the expected reduction
-    for (int iter = iterCount; iter >= 0; iter--, ks--) {
-        const unsigned sAB = (unsigned)ks * SZAB, sG = (unsigned)ks * NM;     // (wave-uniform element offsets of the knot)
-        // ---- operands: A(3g + r, sc) | B(3g + r, control cg) | B(sc, control g) | g_x, g_u in the vector column
-        mx4 A0 = zero, B1 = zero, CXX = zero;
-        {
-            T v[3]; mAB.ld3(v, oCol, sAB);
-            if (cx) { A0[0] = v[0]; A0[1] = v[1]; A0[2] = v[2]; } else { B1[0] = v[0]; B1[1] = v[1]; B1[2] = v[2]; }
+    // A knot's operands as they come from memory: this lane's three elements of its column of [A B], B(sc, g), g_x, g_u (and, read from H_k, its column's pieces).
+    // PDDP_MQ_PREFETCH: requested ONE KNOT AHEAD -- the loads of knot k - 1 are in flight while knot k's products run (the compiler cannot hoist them itself past the
+    // knot's stores); without it every knot begins with a round trip to memory that only the other resident waves hide.
+    struct Ops { T v[3], bt, gx[3], gu, hc[3], hu, hxu; };
+    auto fetch = [&](int k, Ops& o) {
+        const unsigned sAB = (unsigned)k * SZAB, sG = (unsigned)k * NM;      // (wave-uniform element offsets of the knot)
+        mAB.ld3(o.v, oCol, sAB);
+        o.bt = FS ? mAB.ld1(oBt, sAB) : T(0);                                // B(sc, g)   (state-column lanes)
+        mG.ld3(o.gx, oG3, sG); o.gu = mG.ld1(oGu, sG);
+        if (!DIAGH) {                                                        // Hcost(kx, ky) | Hcost(12 + b, kx) | Hcost(kx, 12 + b) | Hcost(12 + a, 12 + b): column-major H_k
+            const unsigned sH = (unsigned)k * SZH;
+            mH.ld3(o.hc, oHcol + oG3, sH);                                   // this lane's column of H_k
+            o.hu = mH.ld1(oHcol + oGu, sH); o.hxu = mH.ld1(oHxu, sH);
         }
-        const T bt = FS ? mAB.ld1(oBt, sAB) : T(0);                          // B(sc, g)   (state-column lanes)
-        T gx[3]; mG.ld3(gx, oG3, sG);
-        const T gx0 = gx[0], gx1 = gx[1], gx2 = gx[2], gu = mG.ld1(oGu, sG);
+    };
+    Ops nxt;
+    if (PDDP_MQ_PREFETCH && iterCount >= 0) fetch(ks, nxt);
+    for (int iter = iterCount; iter >= 0; iter--, ks--) {
+        // ---- operands: A(3g + r, sc) | B(3g + r, control cg) | B(sc, control g) | g_x, g_u in the vector column
+        Ops o;
+        if (PDDP_MQ_PREFETCH) { o = nxt; if (iter > 0) fetch(ks - 1, nxt); } else fetch(ks, o);
+        // ONE tile holds [A | B]: A(3g + r, sc) in the state columns, B(3g + r, control cg) in the control columns (column 15 is control 3 here -- the vector
+        // column of the state-column tiles is kept in a tile of its own, V, below)
+        mx4 AB = {o.v[0], o.v[1], o.v[2], T(0)}, CXX = zero;
+        const T bt = o.bt;
+        const T gx0 = o.gx[0], gx1 = o.gx[1], gx2 = o.gx[2], gu = o.gu;
         mx4 CUX = {T(0), T(0), T(0), cv ? gu : T(0)}, CUU = zero, CXU = zero;
         if (DIAGH) {
             if (cx) { CXX[0] = (3 * g == sc) ? wx : T(0); CXX[1] = (3 * g + 1 == sc) ? wx : T(0); CXX[2] = (3 * g + 2 == sc) ? wx : T(0); }
             CUU[3] = (cu && g == cg) ? wu : T(0);
-        } else {                                                             // Hcost(kx, ky) | Hcost(12 + b, kx) | Hcost(kx, 12 + b) | Hcost(12 + a, 12 + b): column-major H_k
-            const unsigned sH = (unsigned)ks * SZH;
-            T hc[3]; mH.ld3(hc, oHcol + oG3, sH);                            // this lane's column of H_k
-            const T h0 = hc[0], h1 = hc[1], h2 = hc[2], hu = mH.ld1(oHcol + oGu, sH), hxu = mH.ld1(oHxu, sH);
-            if (cx) { CXX[0] = h0; CXX[1] = h1; CXX[2] = h2; CUX[3] = hu; CXU[3] = hxu; }
-            else CUU[3] = hu;
+        } else {
+            if (cx) { CXX[0] = o.hc[0]; CXX[1] = o.hc[1]; CXX[2] = o.hc[2]; CUX[3] = o.hu; CXU[3] = o.hxu; }
+            else CUU[3] = o.hu;
         }
         if (cv) { CXX[0] = gx0; CXX[1] = gx1; CXX[2] = gx2; }
         // ---- W = P'[A | B]; the B columns take rho B (backprop :39-64)
-        const mx4 W0 = mq_states<T>(Pa, A0, zero);
-        mx4 W1 = mq_states<T>(Pa, B1, zero);
-        W1[0] += rho * B1[0]; W1[1] += rho * B1[1]; W1[2] += rho * B1[2];
-        const mx4 W0a = cv ? Pa : W0;                                        // vector column := p
-        // ---- H blocks (:66-93)
-        const mx4 Hxx = mq_states<T>(A0, W0a, zero) + CXX;                   // Hxx(kx, ky) | g_x
-        const mx4 Hux = mq_states<T>(B1, W0a, zero) + CUX;                   // Hux(b, kx)  | g_u     (no rho)
-        const mx4 HxuT = mq_states<T>(W1, A0, zero) + CXU;                   // Hxu(kx, b) as [b][kx]  (with rho)
-        const mx4 Huu = mq_states<T>(B1, W1, zero) + CUU;                    // Huu(a, b)              (with rho)
+        mx4 Wr = mq_states<T>(Pa, AB, zero);
+        if (cu) { Wr[0] += rho * AB[0]; Wr[1] += rho * AB[1]; Wr[2] += rho * AB[2]; }
+        const mx4 V = {cv ? Pa[0] : T(0), cv ? Pa[1] : T(0), cv ? Pa[2] : T(0), T(0)};      // p in the vector column
+        // ---- H blocks (:66-93) as THREE products instead of one per block (round 5, second cut: 12 matrix instructions where the first cut issued 18) -- the sums, their
+        // operands and their order are the per-block products' (a matrix instruction sums over the four lane groups' rows only: the other blocks' entries never meet):
+        //   Hm  = [A B]' Wr:  rows = columns of [A B]; state rows: Hxx(kx, ky) in the state columns; control rows: Hux(b, kx) (state columns: no rho) | Huu(b, a) (with rho)
+        //   HmT = Wr' [A B]:  control rows: Hxu(kx, b) as [b][kx] (with rho)
+        //   Hv  = [A B]' V:   vector column: A'p (state rows) and B'p (control rows)
+        const mx4 Hm = mq_states<T>(AB, Wr, zero), HmT = mq_states<T>(Wr, AB, zero), Hv = mq_states<T>(AB, V, zero);
+        mx4 Hxx, Hux = CUX, HxuT = CXU, Huu = CUU;
+#pragma unroll
+        for (int r = 0; r < 3; r++) Hxx[r] = (cx ? Hm[r] : cv ? Hv[r] : T(0)) + CXX[r];          // Hxx(kx, ky) | g_x
+        Hxx[3] = T(0);
+        Hux[3] = (cx ? Hm[3] : cv ? Hv[3] : T(0)) + CUX[3];                                       // Hux(b, kx)  | g_u     (no rho)
+        HxuT[3] = (cx ? HmT[3] : T(0)) + CXU[3];                                                  // Hxu(kx, b) as [b][kx]  (with rho)
+        Huu[3] = (cu ? Hm[3] : T(0)) + CUU[3];                                                    // Huu(a, b)              (with rho)
         // ---- Huu^-1: 4 x 4 adjugate with a det > 0 test (invHuu_dim4 :132-188; the operations of bp_cl_block): A2[row + 4 col]
         if (cu) ldsU[g + 4 * cg] = Huu[3];
         wsync();
@@ -185,7 +209,7 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
         if (FS) {                                                            // A - B K | B du  (computeFSVars :281-312)
             const mx4 BT = {T(0), T(0), T(0), cx ? bt : T(0)};               // [b][kx] = B(kx, b)
             const mx4 BK = mq_controls<T>(BT, Kp, zero);
-            const mx4 Gt = cv ? BK : A0 - BK;
+            const mx4 Gt = cv ? BK : AB - BK;                                 // (stored from the state-column lanes and the vector column only)
             if (cx) mF.st3(Gt[0], Gt[1], Gt[2], oP, (unsigned)ks * SZP);
             else if (cv) mBd.st3(Gt[0], Gt[1], Gt[2], oG3, (unsigned)ks * NX);
         }

@@ -32,7 +32,7 @@ typedef struct pddp_solver* pddp_handle;
 /* Which kernel family a handle uses for each phase of a sweep.  0 everywhere (what pddp_default_config writes) = the library's own choice: one function of plant,
  * element type, batch, M, A and the cost family (Solver::init in csrc/pddp_api.hip; the table is asserted by tests/test_kernel_selection.py and reported back by
  * pddp_time_kernels).  Every family computes the same functions; the other values exist so that comparison tests and measurements can pin a family WITHOUT the
- * library reading the process environment (until round 4 these were PDDP_BP, PDDP_FP, ... environment variables).  A value that does not apply to the handle's plant is
+ * library reading the process environment (until round 4 these were environment variables).  A value that does not apply to the handle's plant is
  * ignored exactly as the variable was. */
 typedef struct pddp_kernel_selection {
     int bp;       /* arm, backward pass:        1 mx (matrix cores)  2 lg (8-lane groups)  3 coop (one wave per block)  4 wide (one workgroup per block)             */
@@ -219,7 +219,11 @@ int pddp_array_ptr(pddp_handle h, const char* name, void** device_ptr, size_t* b
  *   "xs" "us" "ds"   the accepted trajectory in EVERY step size's slot (memcpyCurrAKern x 3, nisInitHelpers.cuh:24-32,270-272): here the slots keep the candidates
  *                    of the last line search.
  * pddp_refresh_reference_views writes both into the device arrays (the ones pddp_array_ptr names): what a caller that reads the raw device buffers after
- * runiLQR_GPU -- the source-level facade hands them out as d_ApBK, d_Bdu, d_x / h_d_x ... -- needs to see the reference's contents.  One small launch + a synchronisation. */
+ * runiLQR_GPU -- the source-level facade hands them out as d_ApBK, d_Bdu, d_x / h_d_x ... -- needs to see the reference's contents.  One small launch + a synchronisation.
+ * VALID AFTER AN EXIT (every problem done: pddp_solve, or pddp_iterate until pddp_status says so): the reference's loop breaks BEFORE nextIterationSetupGPU
+ * (DDPWrappers.cuh:104-113), so its d_ApBK is A - B K of the trajectory the last backward pass linearised about and its slots hold that exit's state.  On a handle
+ * with problems still running, the last sweep's setup has already moved [A B] to the newly accepted trajectory while K / du are the previous backward pass's: the rebuilt
+ * "ApBK" is then A_new - B_new K_old, a mixture the reference never holds -- call it between sweeps only for the slots view ("xs" "us" "ds"). */
 int pddp_refresh_reference_views(pddp_handle h);
 
 /* ---- multi-GPU (mode R): one process per GPU, rank g owns the problems {r : r % world == g} in its own handle; a sweep needs
@@ -245,7 +249,9 @@ int pddp_comm_allreduce_max(pddp_comm_handle c, double* value);
 /* The per-iteration cost table (north_star: "an RCCL all-reduce of the per-alpha cost over xGMI"; SURVEY.md 8(e) mode R): J[batch][A] of the handle's LAST line search
  * from every rank, on every rank, as [world * batch][A] doubles in global problem order.  Optional -- the ranks' solves are independent, nothing on the data path waits
  * for it -- and off the sweep's critical path: _begin enqueues the exchange on the communicator's own stream behind an event on the solver's stream (the line search of
- * the last enqueued sweep) and returns; the solver may iterate on meanwhile; _end waits for it and fills `table`.  One exchange in flight per communicator. */
+ * the last enqueued sweep) and returns; the solver may iterate on meanwhile; _end waits for it and fills `table`.  One exchange in flight per communicator.  The gather
+ * runs on a DUPLICATE of the communicator (ncclCommSplit at the first _begin, which is therefore collective: every rank makes its first _begin at the same point of its
+ * loop), so pddp_comm_all_done / _allgather_costs issued between _begin and _end do not queue behind it. */
 int pddp_comm_cost_table_begin(pddp_comm_handle c, pddp_handle h);
 int pddp_comm_cost_table_end(pddp_comm_handle c, double* table /* [world * batch][A] */);
 /* the configuration a handle was created with */
@@ -286,13 +292,9 @@ int pddp_run_phase(pddp_handle h, int phase);
  *        8 dynamicsGradient, one thread per evaluation (composite form, csrc/plant_arm_tl.hpp) -> dqdd[count][npos*(n+m)]
  *        9 tool point and its Jacobian, one thread per evaluation (compute_eePos, plants/dynamics_arm.cuh:1879-1925) -> [count][6 + 42]
  *
- * Kernel selection is automatic per handle (plant, element type, cost family, problems in flight); environment variables read at pddp_create override it for
- * comparison tests and measurements -- they never change WHAT is computed, only which kernel family computes it:
- *   PDDP_BP=mx|lg|coop|wide   backward pass: matrix cores | lane groups | one wave per block of knots | one workgroup per block
- *   PDDP_FP=tl|tl2|lg|coop    rollouts + next-iteration setup: thread lanes (tl2: the two-wave predecessor of the few-problem pipeline) | lane groups | cooperative
- *   PDDP_SWEEP=alpha|st|wg    a separate linear-sweep kernel instead of the maps composed in the matrix-core backward pass (maps: composed, applied by k_sweep_maps everywhere)
- *   PDDP_LS=many|wg           line search one thread per problem (default from 2048 problems in flight) | one workgroup per problem
- *   PDDP_AB=full              keep [A B] in the reference layout only          PDDP_CF=ts|coop (PDDP_CF_BP / _FP / _NIS)  closed-form plants: thread-serial | cooperative */
+ * Kernel selection is automatic per handle (plant, element type, cost family, problems in flight).  pddp_config.kernels (pddp_kernel_selection above) pins a family per
+ * phase for comparison tests and measurements -- it never changes WHAT is computed, only which kernel family computes it.  The library reads no
+ * environment variable for it. */
 int pddp_plant_eval(pddp_handle h, int what, int count, const void* x, const void* u, void* out);
 
 #ifdef __cplusplus

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void k_xw_to_cand(Buffers<T> b, Dims dm, int b
 }
 
 // debugging aid (PDDP_POISON_LDS, run_phase): fill the whole LDS of the compute unit this block lands on with NaNs
-__global__ __launch_bounds__(256) void k_poison_lds(int words) {
+static __global__ __launch_bounds__(256) void k_poison_lds(int words) {      // (static: one copy per plant translation unit)
     extern __shared__ unsigned poison_lds[];
     for (int i = threadIdx.x; i < words; i += 256) poison_lds[i] = 0x7fc00000u;
     __syncthreads();
@@ -768,13 +768,6 @@ __global__ __launch_bounds__(64) void k_init_cost(Buffers<T> b, Dims dm, CostWei
                                                   int stage, int keep_alpha) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     init_cost_body<P, T>(this_wave(), reinterpret_cast<T*>(lds_raw), b, dm, cw, sp, ignore_first_defect, rollout, blockIdx.x, stage, keep_alpha);
-}
-// ---------------------------------------------------------------------------------------------- HBM counter calibration (profiling tool)
-// Streams `count` floats from src to dst with the access shape the sweep kernels use (one dword per lane, consecutive
-// lanes on consecutive addresses).  Its byte count is known exactly, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE
-// for this access width (MI355X_MICROARCH.md, "HBM": only the 16 B/lane case is documented).
-__global__ __launch_bounds__(256) void k_hbm_calib_dword(const float* __restrict__ src, float* __restrict__ dst, size_t count) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------- plant evaluation (tests / tools)

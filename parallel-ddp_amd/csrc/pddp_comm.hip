@@ -24,6 +24,8 @@ struct pddp_comm {
     size_t cost_cap = 0;
     // the per-iteration cost table (pddp_comm_cost_table_begin / _end): its own stream, so that the solver's next sweep does not queue behind the exchange
     hipStream_t side = nullptr;
+    ncclComm_t side_comm = nullptr;   // a duplicate of `comm` (ncclCommSplit, every rank one colour) for that exchange: RCCL serialises the operations of ONE communicator across streams,
+                                      // so a pddp_comm_all_done poll issued while a table is in flight would otherwise queue behind the gather
     hipEvent_t ev_ls = nullptr, ev_done = nullptr;
     double* d_table = nullptr;        // [world + 1][batch][A]: gathered + this rank's send buffer
     double* h_table = nullptr;        // pinned, [world][batch][A]
@@ -92,6 +94,7 @@ extern "C" int pddp_comm_destroy(pddp_comm_handle c) {
     if (c->ev_ls) hipEventDestroy(c->ev_ls);
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->side) hipStreamDestroy(c->side);
+    if (c->side_comm) ncclCommDestroy(c->side_comm);
     if (c->comm) ncclCommDestroy(c->comm);
     delete c;
     return 0;
@@ -189,6 +192,12 @@ extern "C" int pddp_comm_cost_table_begin(pddp_comm_handle c, pddp_handle h) {
     void* J = nullptr; size_t nb = 0;
     if ((rc = pddp_array_ptr(h, "J", &J, &nb))) return rc;
     const size_t B = cfg.batch, A = cfg.A, need = (size_t)(c->world + 1) * B * A;
+    if (!c->side_comm) {
+        // the FIRST _begin of a communicator is collective beyond the gather itself: every rank duplicates the communicator here (all ranks call _begin once per iteration
+        // anyway).  Should the duplicate not be available the exchange runs on `comm` -- correct, only ordered with the other pddp_comm_* calls instead of beside them.
+        COMM_HIP(hipStreamSynchronize(s));
+        if (ncclCommSplit(c->comm, 0, c->rank, &c->side_comm, nullptr) != ncclSuccess) c->side_comm = nullptr;
+    }
     if (!c->side) { COMM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)); COMM_HIP(hipEventCreateWithFlags(&c->ev_ls, hipEventDisableTiming)); COMM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming)); }
     if (need > c->table_cap) {
         if (c->d_table) hipFree(c->d_table);
@@ -207,7 +216,7 @@ extern "C" int pddp_comm_cost_table_begin(pddp_comm_handle c, pddp_handle h) {
     COMM_HIP(hipGetLastError());
     COMM_HIP(hipEventRecord(c->ev_ls, s));
     COMM_HIP(hipStreamWaitEvent(c->side, c->ev_ls, 0));                          // ... the exchange itself runs beside the solver's stream
-    COMM_NCCL(ncclAllGather(send, c->d_table, B * A, ncclDouble, c->comm, c->side));
+    COMM_NCCL(ncclAllGather(send, c->d_table, B * A, ncclDouble, c->side_comm ? c->side_comm : c->comm, c->side));
     COMM_HIP(hipMemcpyAsync(c->h_table, c->d_table, (size_t)c->world * B * A * sizeof(double), hipMemcpyDeviceToHost, c->side));
     COMM_HIP(hipEventRecord(c->ev_done, c->side));
     c->table_pending = true;

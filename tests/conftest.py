@@ -12,7 +12,3 @@ for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "parallel-ddp_amd"), R
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
-
-import backends  # noqa: E402
-
-backends.install_env_selection()      # PDDP_BP=mx & co. around a handle's creation -> pddp_config.kernels (the library itself reads no environment)

@@ -50,11 +50,13 @@ extern "C" int pddp_default_config(pddp_config* c, int plant) {
     return 0;
 }
 
-static bool fp_coop() { const char* v = std::getenv("PDDP_FP"); return v && std::string(v) == "coop"; }   // PDDP_FP=coop: wave-cooperative forward pass / setup (comparison tests)
+// kernel selection of a handle: pddp_config.kernels (include/pddp.h), like the library -- this emulation reads no environment either
+static const char* fp_family_name(int v) { static const char* nm[] = {nullptr, "tl", "lg", "coop", "tl2", "tl4"}; return (v >= 1 && v <= 5) ? nm[v] : nullptr; }
 
 struct Base {
     pddp_config cfg; int skip_sweep = 0; int store_candidates = 0; int bench = 0; int bp_coop = 0; int bp_default_coop = 0;   // bp_coop: PDDP_PHASE_BP_COOP runs the cooperative backward pass (comparison tests)
     virtual ~Base() {}
+    bool fp_coop() const { return cfg.kernels.fp == 3; }      // kernels.fp = coop: wave-cooperative forward pass / setup (comparison tests)
     virtual int load(const void*, const void*, const void*, const void*, const void*, const void*, const void*, int, int, int) = 0;
     virtual int iterate(int) = 0;
     virtual int status(int*, int*) = 0;
@@ -122,11 +124,11 @@ struct Sim : Base {
         al("Jpart", &b.Jpart, B * A * M); al("dpart", &b.dpart, B * A * M); al("parts_fresh", &b.parts_fresh, B);
         derive_tl(model);
     }
-    // the library's choice of the arm's forward pass / setup implementation (fp_tl.hpp select_fp_path), evaluated per phase like fp_coop()
+    // the library's choice of the arm's forward pass / setup implementation (fp_tl.hpp select_fp_path), like fp_coop()
     ArmTlModel<T> tl_model{}; bool tl_ok = false;
     void derive_tl(const ArmModel<T>& m) { tl_ok = arm_tl_model_from_tables(tl_model, m); }
     void derive_tl(const EmptyModel&) {}
-    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(std::getenv("PDDP_FP"), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok && !cfg.use_finite_diff, cfg.batch) == kFpTl; }
+    bool fp_tl() const { return P::PLANT == 4 && select_fp_path(fp_family_name(cfg.kernels.fp), sizeof(T) == 4, cfg.ee_cost != 0, tl_ok && !cfg.use_finite_diff, cfg.batch) == kFpTl; }
     void phase(int ph) {
         const int B = cfg.batch; const Wave w = this_wave();
         if (ph == PDDP_PHASE_BP) {
@@ -429,7 +431,7 @@ extern "C" int pddp_create(const pddp_config* cfg, pddp_handle* out) {
 #ifdef PDDP_REF_PLANT_FILE
     if (c.plant == 5) { const std::string complaint = c.dtype == 0 ? ref_plugin_setup<float>(c.N) : ref_plugin_setup<double>(c.N); if (!complaint.empty()) { delete s; return fail(PDDP_EINVAL, complaint); } }
 #endif
-    if (const char* v = std::getenv("PDDP_BP")) s->bp_default_coop = (std::string(v) == "coop");     // same override as the library
+    s->bp_default_coop = (c.kernels.bp == 3);     // kernels.bp = coop: same override as the library
     *out = new pddp_solver{s};
     return 0;
 }
@@ -481,7 +483,7 @@ extern "C" int pddp_solve_ex(pddp_handle h, void* x0, void* u0, const void* xGoa
     }
     s->store(x0, u0, nullptr, Jout, alphaOut, nullptr);
     if (times_ms) { times_ms[0] = 0; times_ms[1] = 0; }
-    if (phase_ms) std::memset(phase_ms, 0, sizeof(double) * 4 * (s->cfg.max_iter + 2));
+    if (phase_ms) std::memset(phase_ms, 0, sizeof(double) * 5 * (s->cfg.max_iter + 2));      // [5][max_iter + 2] (include/pddp.h)
     if (sweeps_out) *sweeps_out = sweeps;
     return 0;
 }

@@ -12,12 +12,12 @@ import test_fp32_bar as t  # noqa: E402
 
 backend = sys.argv[1] if len(sys.argv) > 1 else "hostsim"
 np.seterr(all="ignore")
-cases = (("Kuka N=128 A=8 M=4 float32, matrix-core backward pass (diagonal-H path) + thread-lane forward pass / setup", 4, t.KUKA, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, 40, False),
-         ("Kuka N=128 A=8 M=4 float32, matrix-core backward pass (full-H path) + lane-group forward pass / setup", 4, t.KUKA, {"PDDP_BP": "mx", "PDDP_FP": "lg"}, 40, True),
-         ("Kuka N=128 A=8 M=4 float32, lane-group backward pass + thread-lane forward pass / setup", 4, t.KUKA, {"PDDP_BP": "lg", "PDDP_FP": "tl"}, 40, False),
+cases = (("Kuka N=128 A=8 M=4 float32, matrix-core backward pass (diagonal-H path) + thread-lane forward pass / setup", 4, t.KUKA, dict(bp="mx", fp="tl"), 40, False),
+         ("Kuka N=128 A=8 M=4 float32, matrix-core backward pass (full-H path) + lane-group forward pass / setup", 4, t.KUKA, dict(bp="mx", fp="lg"), 40, True),
+         ("Kuka N=128 A=8 M=4 float32, lane-group backward pass + thread-lane forward pass / setup", 4, t.KUKA, dict(bp="lg", fp="tl"), 40, False),
          ("cart-pole N=128 A=8 M=4 RK3 float32", 2, t.CART, {}, 12, False))
 for name, plant, kw, env, its, full_h in cases:
-    ens = env.get("PDDP_BP") == "mx"
+    ens = env.get("bp") == "mx"
     rows, fails, ints = t.run_bar(backend, plant, kw, env, 5, its, full_h=full_h, ensemble=ens)
     if ens:
         r = t._run_bar.bp_ratio

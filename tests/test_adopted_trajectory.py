@@ -15,17 +15,11 @@ from backends import make_solver
 from oracle_binding import example_inputs
 
 pytestmark = pytest.mark.gpu
-ENV = {"PDDP_FP": "tl", "PDDP_BP": "mx", "PDDP_SWEEP": "st"}      # thread lanes at any batch size; the sweep kernel the hook also uses (M > 1)
+ENV = dict(fp="tl", bp="mx", sweep="st")      # thread lanes at any batch size; the sweep kernel the hook also uses (M > 1)
 
 
 def handle(B, **kw):
-    old = {k: os.environ.get(k) for k in ENV}
-    os.environ.update(ENV)
-    try:
-        return make_solver("hip", 4, dtype=0, batch=B, use_graph=0, **kw)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return make_solver("hip", 4, dtype=0, batch=B, use_graph=0, **kw, kernels=dict(ENV))
 
 
 @pytest.mark.parametrize("A,M", [(8, 1), (16, 1), (4, 1), (8, 4), (16, 4)])

@@ -21,16 +21,6 @@ CASES = [pytest.param(2, dict(N=128, M=4, A=8, integrator=3, total_time=4.0, max
          pytest.param(2, dict(N=64, M=1, A=8, integrator=2, total_time=2.0, max_iter=8), id="cartpole-midpoint-single-shooting")]
 
 
-def with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return fn()
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
-
-
 @pytest.mark.parametrize("plant,kw", CASES)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_thread_serial_equals_cooperative_bit_for_bit(plant, kw, dtype):
@@ -43,9 +33,9 @@ def test_thread_serial_equals_cooperative_bit_for_bit(plant, kw, dtype):
         xs.append(x0); us.append(u0); gs.append(xg)
     outs = {}
     for mode in ("ts", "coop"):
-        s = with_env({"PDDP_CF": mode}, lambda: make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, **kw))
+        s = make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, kernels=dict(cf=mode), **kw)
         names = dict(s.time_kernels(1))
-        assert ("k_fp_ts" in names) == (mode == "ts") and ("k_bp_ts" in names) == (mode == "ts") and ("k_nis_ts" in names) == (mode == "ts"), names   # PDDP_CF forces every phase
+        assert ("k_fp_ts" in names) == (mode == "ts") and ("k_bp_ts" in names) == (mode == "ts") and ("k_nis_ts" in names) == (mode == "ts"), names   # kernels.cf forces every phase
         outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
         outs[mode]["P"] = s.get_cost_to_go()[0]
         s.close()
@@ -69,8 +59,8 @@ def test_quadrotor_full_device_kernels_equal_cooperative_bit_for_bit(dtype, B):
         x0, u0, xg = example_inputs(plant, kw["N"], dtype, noise=rng.normal(0, 0.001 * (b % 7 + 1), (kw["N"], 12)))
         xs.append(x0); us.append(u0); gs.append(xg)
     outs = {}
-    for mode, env in (("new", {"PDDP_CF_FP": "cf", "PDDP_CF_NIS": "kb16", "PDDP_CF_BP": "cl"} if B < 64 else {"PDDP_CF_BP": "cl"}), ("coop", {"PDDP_CF": "coop"})):
-        s = with_env(env, lambda: make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, **kw))
+    for mode, env in (("new", dict(cf_fp="cf", cf_nis="kb16", cf_bp="cl") if B < 64 else dict(cf_bp="cl")), ("coop", dict(cf="coop"))):
+        s = make_solver("hip", plant, dtype=0 if dtype == np.float32 else 1, batch=B, tol_cost=0.0, kernels=env, **kw)
         names = dict(s.time_kernels(1))
         assert ("k_fp_cf" in names) == (mode == "new") and ("k_nis_kb" in names) == (mode == "new") and ("k_bp_cl" in names) == (mode == "new"), names
         outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
@@ -87,7 +77,7 @@ def test_thread_serial_float64_solves_follow_the_oracle(plant, kw):
     n = {1: 2, 2: 4, 3: 12}[plant]
     x0, u0, xg = example_inputs(plant, kw["N"], np.float64, noise=np.random.default_rng(23).normal(0, 0.001, (kw["N"], n)))
     r = Oracle(default_cfg(plant, cores=8, spawn_threads=0, tol_cost=0.0, **kw), np.float64).run_ilqr_gpusem(x0, u0, xg)
-    s = with_env({"PDDP_CF": "ts"}, lambda: make_solver("hip", plant, dtype=1, tol_cost=0.0, **kw))
+    s = make_solver("hip", plant, dtype=1, tol_cost=0.0, kernels=dict(cf="ts"), **kw)
     out = s.solve(x0, u0, xg)
     it = r["iters"]
     assert out["iters"][0] == it and list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
@@ -143,3 +133,34 @@ def test_candidate_arrays_are_views_of_the_records_on_staged_handles():
     xr, xp = (outs[k][0].reshape(B, A, N, n) for k in ("records", "plain"))
     ur, up = (outs[k][1].reshape(B, A, N, m) for k in ("records", "plain"))
     assert np.array_equal(xr, xp, equal_nan=True) and np.array_equal(ur[:, :, : N - 1], up[:, :, : N - 1], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_candidate_views_follow_the_records_across_graph_replays():
+    """with use_graph = 1 only the FIRST pddp_iterate passes through the launch functions (capture); later ones replay the hipGraph.  The flag that says
+    "the records are newer than xs / us" must be raised by pddp_iterate itself: iterate, get, iterate, get -- the second get has to show the second rollouts, on the graph
+    handle exactly what a handle without a graph shows.  And after pddp_refresh_reference_views put the winner into every slot, a get must return THAT."""
+    plant, kw = 3, dict(N=64, M=4, A=16, integrator=3, total_time=2.0, max_iter=8, tol_cost=0.0)
+    B = 4
+    rng = np.random.default_rng(29)
+    probs = [example_inputs(plant, kw["N"], np.float32, noise=rng.normal(0, 0.002, (kw["N"], 12))) for _ in range(B)]
+    x0, u0, xg = (np.concatenate([p[i] for p in probs]) for i in range(3))
+    seen = {}
+    for graph in (1, 0):
+        s = make_solver("hip", plant, dtype=0, batch=B, use_graph=graph, kernels=dict(cf_fp="cf", cf="ts"), **kw)
+        assert "k_fp_cf" in [n for n, _ in s.time_kernels(1)]
+        s.load(x0, u0, xg)
+        got = []
+        for _ in range(3):
+            s.iterate(1); s.sync()
+            got.append((s.get("xs").copy(), s.get("us").copy()))
+        seen[graph] = got
+        if graph:
+            s.refresh_reference_views()
+            xs = s.get("xs").reshape(B, 16, kw["N"], 12)
+            assert all(np.array_equal(xs[:, a], xs[:, 0], equal_nan=True) for a in range(16)), "every slot holds the accepted trajectory after the refresh"
+        s.close()
+    for it in range(3):
+        for j, name in enumerate(("xs", "us")):
+            assert np.array_equal(seen[1][it][j], seen[0][it][j], equal_nan=True), (it, name)
+    assert not np.array_equal(seen[1][0][0], seen[1][1][0], equal_nan=True) and not np.array_equal(seen[1][1][0], seen[1][2][0], equal_nan=True), "the sweeps must move the candidates"

@@ -1,5 +1,5 @@
 """End-effector cost family on the THREAD-LANE / matrix-core kernels (k_fp_tl<EE>, k_nis_tl<EE>, k_bp_mfma with the compact position block of the Gauss-Newton Hessian):
-what BASELINE configs[3] (64 concurrent Kuka MPC rollouts, end-effector cost) and large end-effector batches run from 512 problems up (PDDP_FP=tl PDDP_BP=mx forces the
+what BASELINE configs[3] (64 concurrent Kuka MPC rollouts, end-effector cost) and large end-effector batches run from 512 problems up (kernels fp=tl, bp=mx pin the
 selection on small handles).  Checked against the oracle, whose end-effector family is pinned by the reference's own statements (tests/test_phase_pins.py):
 
   * tool point + Jacobian of the thread-lane world chain (plant_arm_tl.hpp) against compute_eePos's restatement, float64 1e-9;
@@ -17,17 +17,11 @@ from oracle_binding import Oracle, default_cfg
 
 RNG = np.random.default_rng(77)
 EE = dict(N=32, M=4, A=8, wafr_urdf=1, mpc_mode=1, ee_cost=1, tol_cost=1e-5, total_time=0.5, max_iter=8, ignore_max_rho_exit=0)
-TL = {"PDDP_FP": "tl", "PDDP_BP": "mx"}
+TL = dict(fp="tl", bp="mx")
 
 
 def tl_solver(backend, **kw):
-    old = {k: os.environ.get(k) for k in TL}
-    os.environ.update(TL)
-    try:
-        return make_solver(backend, 4, **kw)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return make_solver(backend, 4, **kw, kernels=dict(TL))
 
 
 def start(N, dtype):

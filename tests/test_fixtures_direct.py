@@ -47,8 +47,8 @@ def close(got, ref, what, scale=None, tol=TOL):
     assert e <= tol, (what, e)
 
 
-# the float64 kernel selections of the arm: (environment, needs the GPU library)
-ARM_SELECTIONS = [pytest.param({}, id="default"), pytest.param({"PDDP_BP": "coop", "PDDP_FP": "coop"}, id="coop"), pytest.param({"PDDP_BP": "mx", "PDDP_FP": "tl"}, id="mx-tl")]
+# the float64 kernel selections of the arm (pddp_config.kernels)
+ARM_SELECTIONS = [pytest.param({}, id="default"), pytest.param(dict(bp="coop", fp="coop"), id="coop"), pytest.param(dict(bp="mx", fp="tl"), id="mx-tl")]
 
 
 def handle(backend, case, env=None, **kw):
@@ -56,13 +56,7 @@ def handle(backend, case, env=None, **kw):
     w = {k.strip("_"): v for k, v in case.get("weights", {}).items()}
     for k in ("wafr_urdf", "mpc_mode", "ee_cost"):
         if k in c: kw.setdefault(k, c[k])
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
-    try:
-        s = make_solver(backend, c["plant"], dtype=1, N=c["N"], M=c["M"], A=c["A"], integrator=c["integrator"], total_time=c["total_time"], **w, **kw)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    s = make_solver(backend, c["plant"], dtype=1, N=c["N"], M=c["M"], A=c["A"], integrator=c["integrator"], total_time=c["total_time"], **w, **kw, kernels=dict(env or {}))
     return s
 
 
@@ -76,7 +70,7 @@ def prime(s, case, x=None, u=None, xg=None):
 
 def selections_for(case):
     if case["cfg"]["plant"] == 3:       # the quadrotor's size: also the matrix-core backward pass (k_bp_mq, bp_mq.hpp; the library's choice with the device full)
-        return [pytest.param({}, id="default"), pytest.param({"PDDP_CF_BP": "mq"}, id="matrix-core")]
+        return [pytest.param({}, id="default"), pytest.param(dict(cf_bp="mq"), id="matrix-core")]
     return ARM_SELECTIONS if case["cfg"]["plant"] == 4 else [pytest.param({}, id="default")]
 
 
@@ -90,7 +84,7 @@ def bp_params():
 @pytest.mark.parametrize("name,env", list(bp_params()))
 def test_backward_pass_kernels_on_the_references_inputs(backend, name, env):
     case = CASES[name]
-    if (env.get("PDDP_BP") == "mx" or env.get("PDDP_CF_BP") == "mq") and backend != "hip": pytest.skip("the matrix-core backward pass exists on the GPU only")
+    if (env.get("bp") == "mx" or env.get("cf_bp") == "mq") and backend != "hip": pytest.skip("the matrix-core backward pass exists on the GPU only")
     s = handle(backend, case, env)
     n, m, N = prime(s, case)
     M = case["cfg"]["M"]
@@ -122,7 +116,7 @@ def test_forward_sweep_kernels_on_the_references_inputs(backend, name):
     `xkp1 += ...` (fpHelpers.cuh:43) and the library's sweeps from the current trajectory are the same computation; the general in-place form is pinned on the oracle
     (test_phase_pins.py)."""
     case = CASES[name]
-    envs = [{}] if case["cfg"]["plant"] != 4 else [{}, {"PDDP_FP": "coop"}]
+    envs = [{}] if case["cfg"]["plant"] != 4 else [{}, dict(fp="coop")]
     for env in envs:
         s = handle(backend, case, env)
         n, m, N = prime(s, case)
@@ -142,7 +136,7 @@ def test_forward_sweep_kernels_on_the_references_inputs(backend, name):
 def sim_params():
     for name in names("forward_sim"):
         for sel in selections_for(CASES[name]):
-            if sel.values[0].get("PDDP_BP") == "mx": sel = pytest.param({"PDDP_FP": "tl"}, id="tl")
+            if sel.values[0].get("bp") == "mx": sel = pytest.param(dict(fp="tl"), id="tl")
             yield pytest.param(name, sel.values[0], id=name + "-" + sel.id)
 
 
@@ -179,7 +173,7 @@ def test_rollout_kernels_on_the_references_inputs(backend, name, env):
 def nis_params(kind):
     for name in names(kind):
         for sel in selections_for(CASES[name]):
-            if sel.values[0].get("PDDP_BP") == "mx": sel = pytest.param({"PDDP_FP": "tl"}, id="tl")
+            if sel.values[0].get("bp") == "mx": sel = pytest.param(dict(fp="tl"), id="tl")
             yield pytest.param(name, sel.values[0], id=name + "-" + sel.id)
 
 
@@ -259,9 +253,9 @@ def solve_params():
         if c["kind"] != "solve": continue
         for sel in ARM_SELECTIONS:
             env = sel.values[0]
-            if c["cfg"].get("ee_cost") and env.get("PDDP_FP") == "coop": continue
+            if c["cfg"].get("ee_cost") and env.get("fp") == "coop": continue
             yield pytest.param(c["name"], env, id=c["name"] + "-" + sel.id)
-        yield pytest.param(c["name"], {"PDDP_BP": "mx", "PDDP_FP": "tl4"}, id=c["name"] + "-one-problem")
+        yield pytest.param(c["name"], dict(bp="mx", fp="tl4"), id=c["name"] + "-one-problem")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -272,7 +266,7 @@ def test_whole_solves_on_the_references_inputs(backend, name, env):
     (solve_arm_N128_M4_A8: BASELINE configs[2]); every float64 kernel selection of the arm, including the parity instantiations of the benched families."""
     case = CASES[name]
     c = case["cfg"]
-    if backend != "hip" and env.get("PDDP_BP") == "mx": pytest.skip("matrix-core / pipeline kernels: GPU only")
+    if backend != "hip" and env.get("bp") == "mx": pytest.skip("matrix-core / pipeline kernels: GPU only")
     kw = {k: c[k] for k in ("wafr_urdf", "mpc_mode", "ee_cost", "ignore_max_rho_exit", "tol_cost", "max_iter") if k in c}
     s = handle(backend, dict(cfg=c), env, **{k: v for k, v in kw.items() if k not in ("wafr_urdf", "mpc_mode", "ee_cost")})
     fl = case.get("flags", {})

@@ -93,22 +93,12 @@ def bp_noise_floor(o32, o32f, q, rho, ref, seed, n, N, M):
     return {k_: max(e[k_] for e in errs) for k_ in errs[0]}, errs[0], members[0]
 
 
-def run_bar(backend, plant, kw, env, noise_seed, iterations, batch=None, seeds=1, full_h=False, ensemble=False):
-    """env: kernel-selection overrides (PDDP_BP / PDDP_FP) in force while the handle is created and used (the library reads them at
-    pddp_create, the host emulation at every phase)."""
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return _run_bar(backend, plant, kw, noise_seed, iterations, batch, seeds, full_h, ensemble)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def run_bar(backend, plant, kw, sel, noise_seed, iterations, batch=None, seeds=1, full_h=False, ensemble=False):
+    """sel: kernel families pinned for the handle (pddp_config.kernels, e.g. dict(bp="mx", fp="tl")); {} = the library's own choice."""
+    return _run_bar(backend, plant, kw, sel, noise_seed, iterations, batch, seeds, full_h, ensemble)
 
 
-def _run_bar(backend, plant, kw, noise_seed, iterations, batch, seeds, full_h, ensemble):
+def _run_bar(backend, plant, kw, sel, noise_seed, iterations, batch, seeds, full_h, ensemble):
     """One handle of `batch` problems; slot b holds the oracle64 state of record b % R, the R records being every iteration of `seeds`
     solves (batch = None: R slots).  Every phase is ONE launch over the whole batch -- the launch geometry of a production sweep at that
     batch size -- and every slot is compared: the R distinct ones against the oracles under the bar, the replicas bit for bit with them."""
@@ -124,7 +114,7 @@ def _run_bar(backend, plant, kw, noise_seed, iterations, batch, seeds, full_h, e
     R = len(recs)
     B = batch or R
     slot = np.arange(B) % R
-    s = make_solver(backend, plant, dtype=0, batch=B, **kw)
+    s = make_solver(backend, plant, dtype=0, batch=B, kernels=dict(sel), **kw)
     xg32 = xg.astype(F32)
     s.load(np.tile(x0.astype(F32), B), np.tile(u0.astype(F32), B), np.tile(xg32, B))
     with np.errstate(over="ignore"):
@@ -283,8 +273,8 @@ def summarize(rows):
 
 KUKA = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=40)
 CART = dict(N=128, M=4, A=8, integrator=3, total_time=4.0, tol_cost=0.0, max_iter=12)
-SELECTIONS = [pytest.param({}, True, id="automatic-selection"), pytest.param({"PDDP_BP": "mx", "PDDP_FP": "tl"}, True, id="large-batch-kernels"),
-              pytest.param({"PDDP_BP": "lg", "PDDP_FP": "lg"}, False, id="lane-group-kernels")]
+SELECTIONS = [pytest.param({}, True, id="automatic-selection"), pytest.param(dict(bp="mx", fp="tl"), True, id="large-batch-kernels"),
+              pytest.param(dict(bp="lg", fp="lg"), False, id="lane-group-kernels")]
 
 
 def test_stepped_oracle_loop_is_the_oracle_loop():
@@ -317,10 +307,10 @@ def test_kuka_headline_config_float32_bar_every_iteration(backend, env, ensemble
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw,env,full_h", [
-    pytest.param(KUKA, {"PDDP_BP": "mx", "PDDP_FP": "lg"}, True, id="reference-layout-full-hessian"),
-    pytest.param(KUKA, {"PDDP_BP": "mx", "PDDP_FP": "lg"}, False, id="reference-layout-diagonal-hessian"),
-    pytest.param({**KUKA, "M": 1}, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, False, id="single-shooting-compact"),
-    pytest.param({**KUKA, "M": 2}, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, True, id="two-segments-full-hessian")])
+    pytest.param(KUKA, dict(bp="mx", fp="lg"), True, id="reference-layout-full-hessian"),
+    pytest.param(KUKA, dict(bp="mx", fp="lg"), False, id="reference-layout-diagonal-hessian"),
+    pytest.param({**KUKA, "M": 1}, dict(bp="mx", fp="tl"), False, id="single-shooting-compact"),
+    pytest.param({**KUKA, "M": 2}, dict(bp="mx", fp="tl"), True, id="two-segments-full-hessian")])
 def test_matrix_core_backward_pass_other_instantiations(kw, env, full_h):
     """k_bp_mfma's other template instantiations -- [A B] in the reference layout (lane-group setup kernel; every handle whose cost Hessian was overridden or
     is the end-effector cost's), the full cost Hessian, single shooting (no sweep operands) -- share the tile state order (bp_mfma.hpp mx_state) with the
@@ -358,7 +348,7 @@ def test_bench_batch_every_phase_under_the_bar():
 @pytest.mark.parametrize("lean", [0, 1], ids=["library-defaults-as-bench.py", "boundary-cost-to-go-only"])
 def test_bench_batch_whole_solves_equal_single_problem_solves(lean):
     """10 production sweeps (hipGraph replay) of bench.BENCH_BATCH problems; 16 problems drawn at random must equal, bit for bit, single-problem solves
-    run on the same kernels (PDDP_BP=mx, PDDP_FP=tl force the large-batch selection for a batch of one), and follow the float32 oracle's
+    run on the same kernels (kernels bp=mx, fp=tl pin the large-batch selection for a batch of one), and follow the float32 oracle's
     step-size decisions over the leading iterations with J inside the bar measured against oracle64."""
     kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=10)
     B = BENCH_BATCH
@@ -372,13 +362,7 @@ def test_bench_batch_whole_solves_equal_single_problem_solves(lean):
     assert (out["iters"] == 10).all()
     o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)
     o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
-    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP")}
-    os.environ.update({"PDDP_BP": "mx", "PDDP_FP": "tl"})
-    try:
-        s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw, kernels=dict(bp="mx", fp="tl"))
     agree, pairs = [], []
     for b_ in rng.choice(B, 16, replace=False):
         o1 = s1.solve(xs[b_], us[b_], xg)
@@ -404,14 +388,14 @@ def test_bench_batch_whole_solves_equal_single_problem_solves(lean):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,env", [pytest.param(100, {}, id="100-problems-few-problem-kernels"),
-                                   pytest.param(512, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, id="512-problems-thread-lanes"),
-                                   pytest.param(600, {"PDDP_BP": "mx", "PDDP_FP": "tl"}, id="600-problems-large-batch-kernels"),
-                                   pytest.param(100, {"PDDP_SWEEP": "wg"}, id="100-problems-separate-sweep-kernel-wg"),
-                                   pytest.param(512, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "wg"}, id="512-problems-separate-sweep-kernel-wg"),
-                                   pytest.param(600, {"PDDP_BP": "mx", "PDDP_FP": "tl", "PDDP_SWEEP": "st"}, id="600-problems-separate-sweep-kernel-st")])
+                                   pytest.param(512, dict(bp="mx", fp="tl"), id="512-problems-thread-lanes"),
+                                   pytest.param(600, dict(bp="mx", fp="tl"), id="600-problems-large-batch-kernels"),
+                                   pytest.param(100, dict(sweep="wg"), id="100-problems-separate-sweep-kernel-wg"),
+                                   pytest.param(512, dict(bp="mx", fp="tl", sweep="wg"), id="512-problems-separate-sweep-kernel-wg"),
+                                   pytest.param(600, dict(bp="mx", fp="tl", sweep="st"), id="600-problems-separate-sweep-kernel-st")])
 def test_batches_between_one_and_the_bench_equal_single_problem_solves(B, env):
     """The kernel selection changes with the number of problems in flight (one problem ... 128: k_fp_tl2 + k_nis_tl7; from 512: the thread-lane kernels;
-    the forward sweep by default fused into the matrix-core backward pass + k_sweep_maps, or -- PDDP_SWEEP -- a kernel of its own reading A - B K / B du).
+    the forward sweep by default fused into the matrix-core backward pass + k_sweep_maps, or -- kernels.sweep -- a kernel of its own reading A - B K / B du).
     At each of these sizes a batch -- more than one workgroup of every kernel, ragged last workgroups -- must give, bit for bit, what single-problem
     handles on the SAME kernels give (`env` = the selection, in force for both handles); the per-iteration bar of those kernels is
     test_kuka_headline_config_float32_bar_every_iteration's and test_fused_sweep_matches_the_sweep_kernels'."""
@@ -421,14 +405,8 @@ def test_batches_between_one_and_the_bench_equal_single_problem_solves(B, env):
     for b_ in range(B):
         x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
         xs.append(x0); us.append(u0)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
-        s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw, kernels=dict(env))
+    s1 = make_solver("hip", 4, dtype=0, batch=1, use_graph=1, **kw, kernels=dict(env))
     out = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
     assert (out["iters"] == 8).all()
     for b_ in list(rng.choice(B, 6, replace=False)) + [0, B - 1]:
@@ -443,7 +421,7 @@ def test_batches_between_one_and_the_bench_equal_single_problem_solves(B, env):
 def test_fused_sweep_matches_the_sweep_kernels(B, env):
     """Production sweeps compose every shooting segment's sweep map inside the matrix-core backward pass (Psi = G_last ... G_first, G_k = [A - B K, B du; 0, 1]) and
     k_sweep_maps chains the maps -- A - B K / B du never reach HBM.  Phase by phase this path has no teacher-forcing hook (the hook's sweep reads the arrays the test
-    hands in), so it is pinned here: whole solves with the fused sweep against the same solves with the separate sweep kernel (PDDP_SWEEP=st: sequential
+    hands in), so it is pinned here: whole solves with the fused sweep against the same solves with the separate sweep kernel (kernels.sweep = st: sequential
     matrix-vector steps over A - B K in memory).  The two are different float32 evaluations of the same linear recurrence -- identical step-size indices over the
     leading iterations, and the costs of the first iterations (before rounding differences have been amplified by the solve) within 2e-5."""
     kw = dict(N=128, M=4, A=8, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=6)
@@ -453,14 +431,8 @@ def test_fused_sweep_matches_the_sweep_kernels(B, env):
         x0, u0, xg = example_inputs(4, 128, F32, noise=rng.normal(0, 0.001, (128, 14)))
         xs.append(x0); us.append(u0)
     outs = {}
-    for name, e in (("fused", {}), ("kernel", {"PDDP_SWEEP": "st"})):
-        old = {k: os.environ.get(k) for k in e}
-        os.environ.update(e)
-        try:
-            s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw)
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for name, e in (("fused", {}), ("kernel", dict(sweep="st"))):
+        s = make_solver("hip", 4, dtype=0, batch=B, use_graph=1, **kw, kernels=dict(e))
         outs[name] = s.solve(np.concatenate(xs), np.concatenate(us), np.tile(xg, B))
     a, k = outs["fused"], outs["kernel"]
     same = [next((i for i in range(7) if a["alphaOut"][b_][i] != k["alphaOut"][b_][i]), 7) for b_ in range(B)]
@@ -490,126 +462,120 @@ def run_bar_ee(backend, kw, env, iterations, ensemble, off_cut=False):
     family: H_k moves with the trajectory (the setup kernel's tool-point Jacobian; compact position block on the thread-lane / matrix-core path -- left to the KERNEL's own
     setup output, like in production, so the HQQ backward pass is what runs), the per-knot costs of the setup (costk), and the candidates' costs come out of the rollouts."""
     from gpusem_steps import _ee_setup
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
-        o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)
-        o32f = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32, variant="fma") if ensemble else None
-        n, m, N, M, A = 14, 7, kw["N"], kw["M"], kw["A"]
-        nm, NB = n + m, N // M
-        x0, u0, xg = ee_start(N, np.float64, off_cut)
-        with np.errstate(all="ignore"):
-            recs = list(gpusem_iterations(o64, x0, u0, xg, iterations))
-        B = len(recs)
-        s = make_solver(backend, 4, dtype=0, batch=B, **kw)
-        xg32 = xg.astype(F32)
-        s.load(np.tile(x0.astype(F32), B), np.tile(u0.astype(F32), B), np.tile(xg32, B))
-        with np.errstate(over="ignore"):
-            r32 = [{k: (v.astype(F32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in rec.items()} for rec in recs]
-        stack = lambda key: np.stack([r[key].ravel() for r in r32])
-        rows, ints_ok, n_in_play, bp_ratio = [], True, 0, []
+    o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
+    o32 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32)
+    o32f = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32, variant="fma") if ensemble else None
+    n, m, N, M, A = 14, 7, kw["N"], kw["M"], kw["A"]
+    nm, NB = n + m, N // M
+    x0, u0, xg = ee_start(N, np.float64, off_cut)
+    with np.errstate(all="ignore"):
+        recs = list(gpusem_iterations(o64, x0, u0, xg, iterations))
+    B = len(recs)
+    s = make_solver(backend, 4, dtype=0, batch=B, **kw, kernels=dict(env))
+    xg32 = xg.astype(F32)
+    s.load(np.tile(x0.astype(F32), B), np.tile(u0.astype(F32), B), np.tile(xg32, B))
+    with np.errstate(over="ignore"):
+        r32 = [{k: (v.astype(F32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in rec.items()} for rec in recs]
+    stack = lambda key: np.stack([r[key].ravel() for r in r32])
+    rows, ints_ok, n_in_play, bp_ratio = [], True, 0, []
 
-        def check(rec, phase, name, k32, o32v, ref):
-            ek, eo = nrel(k32, ref), nrel(o32v, ref)
-            rows.append((rec.iter, phase, name, ek, eo, bar(ek, eo)))
+    def check(rec, phase, name, k32, o32v, ref):
+        ek, eo = nrel(k32, ref), nrel(o32v, ref)
+        rows.append((rec.iter, phase, name, ek, eo, bar(ek, eo)))
 
-        st = s.get_state()
-        for b_ in range(B):
-            rec = recs[b_]
-            st[b_].cur = 0; st[b_].cur2 = 1; st[b_].pw = 0; st[b_].rho = rec.rho; st[b_].drho = rec.drho; st[b_].done = 0; st[b_].accepted = 0; st[b_].iter = rec.iter
-        s.set_state(st)
-        s.set("xb", np.concatenate([stack("x").reshape(B, 1, N * n), stack("xp2").reshape(B, 1, N * n)], axis=1))
-        s.set("ucur", stack("u")); s.set("dcur", stack("d"))
-        # ---- setup at every record's trajectory: [A B], g, the cost Hessian (read back through the reference-layout view) and the per-knot costs
-        s.run_phase(pyddp.PHASE_INIT_NIS)
-        ABk, gk, Hk, ck = s.get("AB").reshape(B, -1), s.get("g").reshape(B, -1), s.get("H").reshape(B, N, nm, nm), s.get("costk").reshape(B, N)
-        nAB = (N - 1) * n * nm
-        for i, rec in enumerate(recs):
-            ABo, Ho, go, cko = _ee_setup(o32, r32[i]["x"], r32[i]["u"], xg32[:6])
-            check(rec, "nis", "AB", ABk[i][:nAB], ABo[:nAB], rec.AB[:nAB])
-            check(rec, "nis", "g", gk[i], go, rec.g)
-            Hr, Ho_ = rec.H.reshape(N, nm, nm), Ho.reshape(N, nm, nm)
-            check(rec, "nis", "H", Hk[i][: N - 1], Ho_[: N - 1], Hr[: N - 1])
-            check(rec, "nis", "H_final", Hk[i][N - 1][:n, :n], Ho_[N - 1][:n, :n], Hr[N - 1][:n, :n])
-            check(rec, "nis", "costk", ck[i], cko, rec.costk)
-        # ---- backward pass: [A B], g, boundary cost-to-go from the records; H stays the kernel's own (compact position block where the selection keeps one)
-        for name in ("AB", "g", "Pp", "pp"):
-            s.set(name, stack(name))
-        s.run_phase(pyddp.PHASE_BP)
-        out = {name: s.get(name).reshape(B, -1) for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
-        errk = s.get("err").reshape(B, M)
-        for i, rec in enumerate(recs):
-            q = r32[i]
-            if ensemble:
-                floor, strict_err, strict = bp_noise_floor(o32, o32f, q, rec.rho, rec, i, n, N, M)
-            else:
-                strict = oracle_bp(o32, q, rec.rho)
-                strict_err = {name: nrel(v, r) for name, v, r in bp_quantities(strict, rec, n, N, M)}
-                floor = strict_err
-            ints_ok &= list(errk[i]) == list(rec.err) == list(strict["err"])
-            kern = {name: out[name][i] for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
-            for name, v, ref in bp_quantities(kern, rec, n, N, M):
-                ek = nrel(v, ref)
-                rows.append((rec.iter, "bp", name, ek, strict_err[name], bar(ek, floor[name])))
-                bp_ratio.append(ek / max(floor[name], 1e-4 / 1.5))
-        # ---- forward pass of every step size from the float64 gains: states, controls, boundary defects and the IN-SIM cost
-        for name in ("KT", "du", "ApBK", "Bdu"):
-            s.set(name, stack(name))
-        s.run_phase(pyddp.PHASE_FP)
-        xs, us, ds = s.get("xs").reshape(B, A, N, n), s.get("us").reshape(B, A, N, m), s.get("ds").reshape(B, A, N, n)
-        Jk = s.get("J").reshape(B, A)
-        bnd = [k for k in range(N) if ((k + 1) % NB == 0) and k < N - 1]
-        for i, rec in enumerate(recs):
-            q = r32[i]
-            for a in range(A):
-                xa, ua, da = q["x"].copy(), q["u"].copy(), q["d"].copy()
-                al = rec.alphas[a].astype(F32)
-                with np.errstate(all="ignore"):
-                    if M > 1:
-                        o32.forward_sweep(xa, q["ApBK"], q["Bdu"], q["d"], q["x"], al)
-                    JT = o32.forward_sim_ee(xa, ua, q["KT"], q["du"], da, al, q["x"], xg32[:6])
-                    Jo = F32(0)
-                    for b_ in range(M):
-                        Jo = F32(Jo + JT[b_])
-                ref_x = rec.xs[a]
-                if not (np.isfinite(ref_x).all() and rec.J[a] <= 1.5 * rec.prevJ):
-                    ints_ok &= (not (Jk[i][a] <= rec.prevJ)) and (not (Jo <= rec.prevJ))
-                    continue
-                n_in_play += 1
-                ph = f"fp[a={a}]"
-                check(rec, ph, "x", xs[i][a], xa, ref_x)
-                check(rec, ph, "u", us[i][a][: N - 1], ua.reshape(N, m)[: N - 1], rec.us[a].reshape(N, m)[: N - 1])
-                check(rec, ph, "J", Jk[i][a], Jo, rec.J[a])
-                if bnd:
-                    scale = np.abs(ref_x).max()
-                    dref = rec.ds[a].reshape(N, n)[bnd]
-                    ek = np.abs(ds[i][a][bnd].astype(np.float64) - dref).max() / scale
-                    eo = np.abs(da.reshape(N, n)[bnd].astype(np.float64) - dref).max() / scale
-                    rows.append((rec.iter, ph, "d", ek, eo, bar(ek, eo)))
-        # ---- line search from the float64 cost tables rounded to float32: integers
-        st = s.get_state()
-        for b_ in range(B):
-            st[b_].prevJ = F32(recs[b_].prevJ); st[b_].ignore_defect = recs[b_].ignore_defect; st[b_].alphaIndex = 0
-        s.set_state(st)
-        s.set("J", stack("J")); s.set("dmax", stack("dmax")); s.set("dJexp", stack("dJexp"))
-        s.run_phase(pyddp.PHASE_LS)
-        st = s.get_state()
-        for b_, rec in enumerate(recs):
-            q = r32[b_]
-            ai, ign, dJ, zz = o32.line_search_gpu(q["J"], q["dmax"], q["dJexp_sum"], F32(rec.prevJ), rec.ignore_defect, 0)
-            if dJ < 0:
-                ints_ok &= (st[b_].accepted == 0 and rec.accepted == 0)
-            else:
-                ints_ok &= (st[b_].accepted == 1 and st[b_].alphaIndex == ai == rec.ls_alpha and st[b_].ignore_defect == ign == rec.ls_ignore_defect)
-        assert n_in_play >= B
-        names = dict(s.time_kernels(1))
-        s.close()
-        _run_bar.bp_ratio = np.asarray(bp_ratio)
-        return rows, [r for r in rows if not r[5]], ints_ok, names
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    st = s.get_state()
+    for b_ in range(B):
+        rec = recs[b_]
+        st[b_].cur = 0; st[b_].cur2 = 1; st[b_].pw = 0; st[b_].rho = rec.rho; st[b_].drho = rec.drho; st[b_].done = 0; st[b_].accepted = 0; st[b_].iter = rec.iter
+    s.set_state(st)
+    s.set("xb", np.concatenate([stack("x").reshape(B, 1, N * n), stack("xp2").reshape(B, 1, N * n)], axis=1))
+    s.set("ucur", stack("u")); s.set("dcur", stack("d"))
+    # ---- setup at every record's trajectory: [A B], g, the cost Hessian (read back through the reference-layout view) and the per-knot costs
+    s.run_phase(pyddp.PHASE_INIT_NIS)
+    ABk, gk, Hk, ck = s.get("AB").reshape(B, -1), s.get("g").reshape(B, -1), s.get("H").reshape(B, N, nm, nm), s.get("costk").reshape(B, N)
+    nAB = (N - 1) * n * nm
+    for i, rec in enumerate(recs):
+        ABo, Ho, go, cko = _ee_setup(o32, r32[i]["x"], r32[i]["u"], xg32[:6])
+        check(rec, "nis", "AB", ABk[i][:nAB], ABo[:nAB], rec.AB[:nAB])
+        check(rec, "nis", "g", gk[i], go, rec.g)
+        Hr, Ho_ = rec.H.reshape(N, nm, nm), Ho.reshape(N, nm, nm)
+        check(rec, "nis", "H", Hk[i][: N - 1], Ho_[: N - 1], Hr[: N - 1])
+        check(rec, "nis", "H_final", Hk[i][N - 1][:n, :n], Ho_[N - 1][:n, :n], Hr[N - 1][:n, :n])
+        check(rec, "nis", "costk", ck[i], cko, rec.costk)
+    # ---- backward pass: [A B], g, boundary cost-to-go from the records; H stays the kernel's own (compact position block where the selection keeps one)
+    for name in ("AB", "g", "Pp", "pp"):
+        s.set(name, stack(name))
+    s.run_phase(pyddp.PHASE_BP)
+    out = {name: s.get(name).reshape(B, -1) for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
+    errk = s.get("err").reshape(B, M)
+    for i, rec in enumerate(recs):
+        q = r32[i]
+        if ensemble:
+            floor, strict_err, strict = bp_noise_floor(o32, o32f, q, rec.rho, rec, i, n, N, M)
+        else:
+            strict = oracle_bp(o32, q, rec.rho)
+            strict_err = {name: nrel(v, r) for name, v, r in bp_quantities(strict, rec, n, N, M)}
+            floor = strict_err
+        ints_ok &= list(errk[i]) == list(rec.err) == list(strict["err"])
+        kern = {name: out[name][i] for name in ("KT", "du", "P", "p", "dJexp", "ApBK", "Bdu")}
+        for name, v, ref in bp_quantities(kern, rec, n, N, M):
+            ek = nrel(v, ref)
+            rows.append((rec.iter, "bp", name, ek, strict_err[name], bar(ek, floor[name])))
+            bp_ratio.append(ek / max(floor[name], 1e-4 / 1.5))
+    # ---- forward pass of every step size from the float64 gains: states, controls, boundary defects and the IN-SIM cost
+    for name in ("KT", "du", "ApBK", "Bdu"):
+        s.set(name, stack(name))
+    s.run_phase(pyddp.PHASE_FP)
+    xs, us, ds = s.get("xs").reshape(B, A, N, n), s.get("us").reshape(B, A, N, m), s.get("ds").reshape(B, A, N, n)
+    Jk = s.get("J").reshape(B, A)
+    bnd = [k for k in range(N) if ((k + 1) % NB == 0) and k < N - 1]
+    for i, rec in enumerate(recs):
+        q = r32[i]
+        for a in range(A):
+            xa, ua, da = q["x"].copy(), q["u"].copy(), q["d"].copy()
+            al = rec.alphas[a].astype(F32)
+            with np.errstate(all="ignore"):
+                if M > 1:
+                    o32.forward_sweep(xa, q["ApBK"], q["Bdu"], q["d"], q["x"], al)
+                JT = o32.forward_sim_ee(xa, ua, q["KT"], q["du"], da, al, q["x"], xg32[:6])
+                Jo = F32(0)
+                for b_ in range(M):
+                    Jo = F32(Jo + JT[b_])
+            ref_x = rec.xs[a]
+            if not (np.isfinite(ref_x).all() and rec.J[a] <= 1.5 * rec.prevJ):
+                ints_ok &= (not (Jk[i][a] <= rec.prevJ)) and (not (Jo <= rec.prevJ))
+                continue
+            n_in_play += 1
+            ph = f"fp[a={a}]"
+            check(rec, ph, "x", xs[i][a], xa, ref_x)
+            check(rec, ph, "u", us[i][a][: N - 1], ua.reshape(N, m)[: N - 1], rec.us[a].reshape(N, m)[: N - 1])
+            check(rec, ph, "J", Jk[i][a], Jo, rec.J[a])
+            if bnd:
+                scale = np.abs(ref_x).max()
+                dref = rec.ds[a].reshape(N, n)[bnd]
+                ek = np.abs(ds[i][a][bnd].astype(np.float64) - dref).max() / scale
+                eo = np.abs(da.reshape(N, n)[bnd].astype(np.float64) - dref).max() / scale
+                rows.append((rec.iter, ph, "d", ek, eo, bar(ek, eo)))
+    # ---- line search from the float64 cost tables rounded to float32: integers
+    st = s.get_state()
+    for b_ in range(B):
+        st[b_].prevJ = F32(recs[b_].prevJ); st[b_].ignore_defect = recs[b_].ignore_defect; st[b_].alphaIndex = 0
+    s.set_state(st)
+    s.set("J", stack("J")); s.set("dmax", stack("dmax")); s.set("dJexp", stack("dJexp"))
+    s.run_phase(pyddp.PHASE_LS)
+    st = s.get_state()
+    for b_, rec in enumerate(recs):
+        q = r32[b_]
+        ai, ign, dJ, zz = o32.line_search_gpu(q["J"], q["dmax"], q["dJexp_sum"], F32(rec.prevJ), rec.ignore_defect, 0)
+        if dJ < 0:
+            ints_ok &= (st[b_].accepted == 0 and rec.accepted == 0)
+        else:
+            ints_ok &= (st[b_].accepted == 1 and st[b_].alphaIndex == ai == rec.ls_alpha and st[b_].ignore_defect == ign == rec.ls_ignore_defect)
+    assert n_in_play >= B
+    names = dict(s.time_kernels(1))
+    s.close()
+    _run_bar.bp_ratio = np.asarray(bp_ratio)
+    return rows, [r for r in rows if not r[5]], ints_ok, names
 
 
 EE_RPY = dict(Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)       # roll / pitch / yaw and nominal-position terms switched on (the reference's example leaves them 0)
@@ -618,7 +584,7 @@ EE_RPY = dict(Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)       # roll / pitch / yaw and
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("weights", [pytest.param({}, id="example-weights"), pytest.param(EE_RPY, id="rpy-and-nominal-weights")])
 @pytest.mark.parametrize("env,kernels", [pytest.param({}, ("k_bp_mfma", "k_fp_tl4", "k_nis_tl7"), id="few-problem-selection"),
-                                         pytest.param({"PDDP_BP": "mx", "PDDP_FP": "tl"}, ("k_bp_mfma", "k_fp_tl", "k_nis_tl"), id="large-batch-selection")])
+                                         pytest.param(dict(bp="mx", fp="tl"), ("k_bp_mfma", "k_fp_tl", "k_nis_tl"), id="large-batch-selection")])
 def test_ee_cost_float32_bar_every_iteration(backend, env, kernels, weights):
     """BASELINE configs[3]'s shape (Kuka N=64, A=8, M=4, MPC_MODE, end-effector cost), float32, every iteration of the solve teacher-forced from oracle64, on both kernel
     selections the library makes for it: the thread-lane / matrix-core family with the compact position block (HQQ backward pass, in-sim cost in k_fp_tl, k_nis_tl<EE>) and
@@ -645,14 +611,8 @@ def test_ee_cost_float32_whole_solve_with_rpy_weights_follows_the_oracle():
     x0, u0, xg = ee_start(kw["N"], F32, off_cut=True)
     o32, o64 = Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float32), Oracle(default_cfg(4, cores=1, spawn_threads=0, **kw), np.float64)
     r32, r64 = o32.run_ilqr_gpusem(x0, u0, xg), o64.run_ilqr_gpusem(x0.astype(np.float64), u0.astype(np.float64), xg.astype(np.float64))
-    for env in ({}, {"PDDP_BP": "mx", "PDDP_FP": "tl"}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            s = make_solver("hip", 4, dtype=0, **kw)
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for env in ({}, dict(bp="mx", fp="tl")):
+        s = make_solver("hip", 4, dtype=0, **kw, kernels=dict(env))
         out = s.solve(x0, u0, xg)
         lead = next((i for i in range(9) if not (out["alphaOut"][0][i] == r32["alphaOut"][i] == r64["alphaOut"][i])), 9)
         assert lead >= 4, (env, out["alphaOut"][0][:9], r32["alphaOut"][:9], r64["alphaOut"][:9])

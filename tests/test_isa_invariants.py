@@ -20,10 +20,18 @@ import mx_isa  # noqa: E402
 PREFETCHING = re.compile(r"^_ZN4pddp9k_bp_mfmaILb([01])ELb1ELb1ELb([01])ELb([01])EEEvNS_7BuffersIfEE")      # groups: FS, FUSE, HQQ
 
 
+pytestmark = pytest.mark.skipif(not os.path.exists(mx_isa.HIPCC), reason="needs the ROCm compiler (cross-compiles for gfx950; no GPU needed)")
+
+
 @pytest.fixture(scope="module")
-def product_asm():
-    asm, _ = mx_isa.compile_asm(out="/tmp/isa/test_mx.s")
-    return mx_isa.kernel_bodies(asm)
+def product_build():
+    """ONE device compile of the product translation unit shared by the tests below: (assembly, resource remarks)"""
+    return mx_isa.compile_asm(out="/tmp/isa/test_mx.s")
+
+
+@pytest.fixture(scope="module")
+def product_asm(product_build):
+    return mx_isa.kernel_bodies(product_build[0])
 
 
 def test_source_constants_match_the_checker():
@@ -44,9 +52,9 @@ def test_every_prefetching_instantiation_issues_exactly_the_counted_stores(produ
     assert seen >= 5, f"only {seen} prefetching instantiations found: the name pattern no longer matches csrc/pddp_mx.hip"
 
 
-def test_no_scratch_and_six_waves_for_the_benched_instantiation():
+def test_no_scratch_and_six_waves_for_the_benched_instantiation(product_build):
     # (the occupancy the timing of DESIGN.md section 4 was taken at: a spill inside the knot loop would also add vector memory operations the wait does not count)
-    _, rem = mx_isa.compile_asm(out="/tmp/isa/test_mx.s")
+    _, rem = product_build
     res = mx_isa.resources(rem)
     bench = next(v for k, v in res.items() if k.startswith("_ZN4pddp9k_bp_mfmaILb1ELb1ELb1ELb1ELb0EEEvNS_7BuffersIfEE"))
     assert bench["scratch"] == 0 and bench["occ"] >= 6, bench

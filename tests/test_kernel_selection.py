@@ -44,28 +44,24 @@ def test_few_problems_in_flight_run_the_pipeline_and_the_per_joint_setup(ee):
 
 
 def test_the_library_does_not_read_the_environment_for_its_selection():
-    """PDDP_BP / PDDP_FP were environment switches of the library until round 4; now only this test suite's own plumbing (tests/backends.py) translates them.  A config
-    built WITHOUT that plumbing must give the default selection whatever the environment says."""
+    """Kernel families were environment switches of the library until round 4; the selection is data now (pddp_config.kernels, all zero from pddp_default_config = the
+    library's own choice) and the library's source asks the environment for nothing but its two debugging aids."""
     import pyddp
-    old = {k: os.environ.get(k) for k in ("PDDP_BP", "PDDP_FP")}
-    os.environ.update({"PDDP_BP": "lg", "PDDP_FP": "lg"})
-    try:
-        lib = ctypes.CDLL(pyddp.library_path())
-        c = pyddp.PddpConfig()
-        assert lib.pddp_default_config(ctypes.byref(c), 4) == 0
-        for k, v in dict(KUKA, batch=1, use_graph=0).items():
-            setattr(c, k, v)
-        assert all(getattr(c.kernels, f) == 0 for f in pyddp.KERNEL_NAMES)
-        s = pyddp.Solver(c)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    lib = ctypes.CDLL(pyddp.library_path())
+    c = pyddp.PddpConfig()
+    assert lib.pddp_default_config(ctypes.byref(c), 4) == 0
+    for k, v in dict(KUKA, batch=1, use_graph=0).items():
+        setattr(c, k, v)
+    assert all(getattr(c.kernels, f) == 0 for f in pyddp.KERNEL_NAMES)
+    s = pyddp.Solver(c)
     x0, u0, xg = example_inputs(4, 64, np.float32)
     s.load(x0, u0, xg); s.iterate(2); s.sync()
     assert [n for n, _ in s.time_kernels(2)] == ["k_bp_mfma", "k_fp_tl4", "k_nis_tl7"]
     s.close()
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parallel-ddp_amd", "csrc", "pddp_api.hip")).read()
+    import glob
     import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parallel-ddp_amd", "csrc")
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))))     # every translation unit of the library and what they include
     assert sorted(set(re.findall(r'getenv\("(\w+)"\)', src))) == ["PDDP_EVAL_GRID", "PDDP_POISON_LDS"]      # debugging / micro-benchmark aids only
 
 
@@ -122,7 +118,7 @@ def _solve_with(sel, batch, N, M, iters=6):
 def test_compact_operands_through_the_lds_prefetch_follow_the_reference_layout(N, M):
     """The float matrix-core backward pass reads the compact [A B] and the cost gradient through LDS-direct buffer loads one knot ahead (bp_mfma.hpp mx_dma_knot), with
     scalar chunk / knot offsets: chunks of 64 knots shared by two problems (N = 32), several chunks per problem (N = 256), blocks of knots of every length, one block (M = 1).
-    The same first iteration with PDDP_AB=full (reference-layout [A B], plain loads, no prefetch) must land on the same trajectory up to float32 rounding -- a wrong knot,
+    The same first iteration with kernels.ab = full (reference-layout [A B], plain loads, no prefetch) must land on the same trajectory up to float32 rounding -- a wrong knot,
     chunk or problem offset would be off by the size of the data, not by 1e-6.  (Across BUILDS the compact path is held bit for bit: tools/cmp_compact_vs_full.py builds,
     profiles/r04_bp_mfma.md.)"""
     sel = dict(bp="mx", fp="tl")

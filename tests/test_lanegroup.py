@@ -44,11 +44,8 @@ def test_lane_group_backward_pass_bit_identical_to_cooperative(backend, dtype, N
     import pyddp
     from oracle_binding import example_inputs
     n, m, nm = 14, 7, 21
-    os.environ["PDDP_BP"] = "lg"          # small batches default to the cooperative kernel: force the lane-group one for PHASE_BP
-    try:
-        s = make_solver(backend, 4, dtype=0 if dtype == np.float32 else 1, N=N, M=M, A=2, wafr_urdf=1, total_time=0.5, batch=3)
-    finally:
-        del os.environ["PDDP_BP"]
+    # small batches default to the cooperative kernel: pin the lane-group one for PHASE_BP
+    s = make_solver(backend, 4, dtype=0 if dtype == np.float32 else 1, N=N, M=M, A=2, wafr_urdf=1, total_time=0.5, batch=3, kernels=dict(bp="lg"))
     rng = np.random.default_rng(5)
     xs, us, gs = [], [], []
     for b in range(3):
@@ -94,11 +91,7 @@ def test_whole_solve_identical_with_either_backward_pass(backend):
         xs.append(x); us.append(u); gs.append(xg)
     outs = {}
     for mode in ("lg", "coop", "wide"):
-        os.environ["PDDP_BP"] = mode
-        try:
-            s = make_solver(backend, 4, **kw)
-        finally:
-            del os.environ["PDDP_BP"]
+        s = make_solver(backend, 4, kernels=dict(bp=mode), **kw)
         outs[mode] = s.solve(np.concatenate(xs), np.concatenate(us), np.concatenate(gs))
     assert np.array_equal(outs["lg"]["Jout"], outs["coop"]["Jout"]) and np.array_equal(outs["lg"]["alphaOut"], outs["coop"]["alphaOut"])
     assert np.array_equal(outs["lg"]["x"], outs["coop"]["x"]) and np.array_equal(outs["lg"]["KT"], outs["coop"]["KT"])
@@ -110,7 +103,7 @@ def test_whole_solve_identical_with_either_backward_pass(backend):
 @pytest.mark.parametrize("rollout,N,M,A", [(0, 32, 4, 8), (1, 32, 4, 8), (0, 64, 8, 16)])
 def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(backend, rollout, N, M, A):
     """The end-effector cost family (ee_cost_lg.hpp vs ee_cost.hpp): tool point, Jacobian, Gauss-Newton Hessian, in-rollout cost accumulation --
-    whole float32 solves on the lane-group kernels and on the wave-cooperative ones (PDDP_FP=coop) give the same bits."""
+    whole float32 solves on the lane-group kernels and on the wave-cooperative ones (kernels fp=coop) give the same bits."""
     import os
     kw = dict(N=N, M=M, A=A, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, max_iter=8 if N == 32 else 4, ee_cost=1, ignore_max_rho_exit=0, batch=3,
               Q_EE2=0.02, QF_EE2=3.0, Q_xEE=0.05)
@@ -121,15 +114,12 @@ def test_end_effector_cost_identical_on_lane_groups_and_cooperative_kernels(back
     xg = np.zeros((B, 14), np.float32); xg[:, :6] = [0.45, 0.15, 0.75, 0.1, -0.2, 0.3]; xg[:, 1] += np.float32(0.05) * np.arange(B, dtype=np.float32)
     outs, arrs = {}, {}
     for mode in ("lg", "coop"):
-        os.environ["PDDP_FP"] = mode             # "lg": keep the lane-group kernels (few problems in flight default to the thread-lane pipeline, fp_pipe.hpp)
-        os.environ["PDDP_SWEEP"] = "alpha"       # the per-candidate linear sweep (k_sweep_lg): the one whose operation order equals the cooperative kernel's
-        try:
-            s = make_solver(backend, 4, **kw)
-            s.load(x0, u0, xg, forward_rollout=rollout)
-            arrs[mode] = {k: s.get(k).copy() for k in ("H", "g", "AB", "costk")}
-            outs[mode] = s.solve(x0, u0, xg, forward_rollout=rollout)
-        finally:
-            os.environ.pop("PDDP_FP", None); os.environ.pop("PDDP_SWEEP", None)
+        # fp "lg": keep the lane-group kernels (few problems in flight default to the thread-lane pipeline, fp_pipe.hpp);
+        # sweep "alpha": the per-candidate linear sweep (k_sweep_lg), the one whose operation order equals the cooperative kernel's
+        s = make_solver(backend, 4, kernels=dict(fp=mode, sweep="alpha"), **kw)
+        s.load(x0, u0, xg, forward_rollout=rollout)
+        arrs[mode] = {k: s.get(k).copy() for k in ("H", "g", "AB", "costk")}
+        outs[mode] = s.solve(x0, u0, xg, forward_rollout=rollout)
     for k in ("H", "g", "AB"):
         assert np.array_equal(arrs["lg"][k], arrs["coop"][k]), k
     if not rollout:

@@ -86,17 +86,7 @@ def test_oracle_whole_solves_match_the_executed_reference(name):
     assert list(r0["alphaOut"][:7]) != list(r["alphaOut"][:7]) or rel(r0["Jout"][:3], r["Jout"][:3]) > 1e-3     # the penalties matter in these solves
 
 
-SELECTIONS = [pytest.param({"PDDP_FP": "coop"}, id="cooperative"), pytest.param({"PDDP_BP": "mx", "PDDP_FP": "tl"}, id="thread-lanes")]
-
-
-def with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return fn()
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+SELECTIONS = [pytest.param(dict(fp="coop"), id="cooperative"), pytest.param(dict(bp="mx", fp="tl"), id="thread-lanes")]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -108,7 +98,7 @@ def test_kernels_cost_gradient_and_candidate_costs(backend, env):
     o = oracle(cfg)
 
     def run():
-        s = make_solver(backend, 4, dtype=1, N=N, M=2, A=A, total_time=0.5, wafr_urdf=1, use_limits=1, tol_cost=0.0, max_iter=4)
+        s = make_solver(backend, 4, dtype=1, kernels=dict(env), N=N, M=2, A=A, total_time=0.5, wafr_urdf=1, use_limits=1, tol_cost=0.0, max_iter=4)
         s.load(XS[0], US[0], XG)                                   # init mode of the setup kernel: g, H of the loaded trajectory
         g, H = s.get("g").reshape(N, 21), s.get("H").reshape(N, 441)
         x, u = XS[0].reshape(N, 14), US[0].reshape(N, 7)
@@ -120,7 +110,7 @@ def test_kernels_cost_gradient_and_candidate_costs(backend, env):
         J0 = s.store()["Jout"][0][0]
         assert rel(J0, o.total_cost(1, XS[0], US[0], XG)) <= 1e-12   # initAlgGPU's cost of the loaded trajectory
         s.close()
-    with_env(env, run)
+    run()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -132,11 +122,11 @@ def test_kernels_whole_float64_solves_follow_the_oracle(backend, env, name):
     r = oracle(c).run_ilqr_gpusem(x0, u0, xg)
 
     def run():
-        s = make_solver(backend, 4, dtype=1, use_limits=1, **{k: c[k] for k in ("N", "M", "A", "integrator", "total_time", "wafr_urdf", "tol_cost", "max_iter")})
+        s = make_solver(backend, 4, dtype=1, use_limits=1, kernels=dict(env), **{k: c[k] for k in ("N", "M", "A", "integrator", "total_time", "wafr_urdf", "tol_cost", "max_iter")})
         out = s.solve(x0, u0, xg)
         s.close()
         return out
-    out = with_env(env, run)
+    out = run()
     it = r["iters"]
     assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
     assert rel(out["Jout"][0][: it + 1], r["Jout"][: it + 1]) <= 1e-8 and rel(out["x"][0], r["x"]) <= 1e-7 and rel(out["u"][0], r["u"]) <= 1e-7
@@ -206,7 +196,7 @@ def test_kernels_end_effector_variants(backend, env, flags):
     Nk = c["N"]
 
     def run():
-        s = make_solver(backend, 4, dtype=1, ee_cost=1, **{k: c[k] for k in ("N", "M", "A", "integrator", "total_time", "wafr_urdf", "mpc_mode", "tol_cost", "max_iter",
+        s = make_solver(backend, 4, dtype=1, ee_cost=1, kernels=dict(env), **{k: c[k] for k in ("N", "M", "A", "integrator", "total_time", "wafr_urdf", "mpc_mode", "tol_cost", "max_iter",
                                                                               "ignore_max_rho_exit", "use_smooth_abs", "use_limits")})
         s.load(x0, u0, xg)
         g, H = s.get("g").reshape(Nk, 21), s.get("H").reshape(Nk, 441)
@@ -216,7 +206,7 @@ def test_kernels_end_effector_variants(backend, env, flags):
         out = s.solve(x0, u0, xg)
         s.close()
         return out
-    out = with_env(env, run)
+    out = run()
     it = r["iters"]
     assert list(out["alphaOut"][0][: it + 1]) == list(r["alphaOut"][: it + 1])
     assert rel(out["Jout"][0][: it + 1], r["Jout"][: it + 1]) <= 1e-7 and rel(out["x"][0], r["x"]) <= 1e-6

@@ -147,14 +147,8 @@ def test_warm_started_mpc_after_a_plain_solve_shifts_the_whole_cost_to_go():
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, total_time=0.5, tol_cost=0.0, max_iter=6)
     x0, u0, xg = example_inputs(4, 32, np.float64, noise=RNG.normal(0, 0.001, (32, 14)))
     outs = []
-    for env in ({"PDDP_BP": "mx", "PDDP_FP": "tl"}, {}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            s = make_solver("hip", 4, dtype=1, **kw)
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for env in (dict(bp="mx", fp="tl"), {}):
+        s = make_solver("hip", 4, dtype=1, **kw, kernels=dict(env))
         first = s.solve(x0, u0, xg)
         xa = first["x"][0][2] + 1e-3
         outs.append((first, s.mpc_solve(xa, xg, 2, clear_vars=0, max_iter=4)))

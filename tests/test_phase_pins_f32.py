@@ -17,7 +17,10 @@ from oracle_binding import Oracle, default_cfg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MAN = json.load(open(os.path.join(HERE, "golden", "phase_fixtures_f32.json")))
-DATA = np.load(os.path.join(HERE, "golden", "phase_fixtures_f32.npz"))
+DATA = dict(np.load(os.path.join(HERE, "golden", "phase_fixtures_f32.npz")))
+MAN6 = json.load(open(os.path.join(HERE, "golden", "phase_fixtures_f32_r06.json")))            # round 6: float32 sweeps from the solver's invariant
+DATA.update(np.load(os.path.join(HERE, "golden", "phase_fixtures_f32_r06.npz")))
+MAN["cases"] = MAN["cases"] + MAN6["cases"]
 CASES = {c["name"]: c for c in MAN["cases"]}
 F32 = np.float32
 
@@ -53,8 +56,8 @@ def names(kind):
 
 
 def test_fixture_is_float32_data_only():
-    assert all(DATA[k].dtype.kind in "fi" for k in DATA.files)
-    assert all(DATA[k].dtype == np.float32 for k in DATA.files if "/out/" in k and DATA[k].dtype.kind == "f")
+    assert all(DATA[k].dtype.kind in "fi" for k in DATA)
+    assert all(DATA[k].dtype == np.float32 for k in DATA if "/out/" in k and DATA[k].dtype.kind == "f")
     for c in MAN["cases"]:
         assert set(c) <= {"name", "kind", "cfg", "sem", "inputs", "outputs", "rho", "weights", "flags"}
 

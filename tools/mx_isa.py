@@ -6,11 +6,14 @@ pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value", "-fno-slp-vectorize"]
 
 
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
 def compile_asm(src="csrc/pddp_mx.hip", defs=(), out="/tmp/isa/mx.s"):
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + list(defs) + ["--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", "-o", out, src], cwd=pkg, capture_output=True, text=True)
+    r = subprocess.run([HIPCC] + FLAGS + list(defs) + ["--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", "-o", out, src], cwd=pkg, capture_output=True, text=True)
     if r.returncode:
-        raise SystemExit(r.stderr[-3000:])
+        raise RuntimeError("device compile of %s failed:\n%s" % (src, r.stderr[-3000:]))
     return open(out).read(), r.stderr
 
 

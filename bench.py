@@ -85,7 +85,29 @@ BP_FLOPS_PER_KNOT = 2 * 16268  # dense products of one backward-pass knot, n = 1
                                # T1 686, P+ 2744, A - B K | B du 1470   (bpHelpers.cuh:39-334)
 
 
-def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, s_per_step, keep_ctg=True):
+def design_bytes_per_problem(kernel, N, M, A, n, m, keep_ctg=True, elem=4):
+    """THIS design's algorithmic HBM bytes of one launch, per problem: every array the kernel has to read or write ONCE, in the layout it is kept in.
+    (bytes, accounting) or None for a kernel without a statement.  The ratio of the counter traffic to this figure is the kernel's wasted traffic (VERDICT r5 task 5)."""
+    nm = n + m
+    if kernel.startswith("k_bp_mfma"):
+        per_knot = (n // 2) * 2 * nm * elem + nm * elem + n * m * elem + m * elem + ((n * n + n) * elem if keep_ctg else 0)      # compact [A B] 588 + g 84 | K 392 + du 28 | [P | p] 840
+        return per_knot * (N - M), f"{per_knot} B per knot (compact [A B] {n // 2 * 2 * nm * elem} + g {nm * elem} read; K {n * m * elem} + du {m * elem}" + (f" + [P | p] {(n * n + n) * elem}" if keep_ctg else "") + f" written) x {N - M} knots"
+    if kernel.startswith("k_fp_tl"):
+        rd = (N - 1) * (n * m + m + m) * elem + N * n * elem + A * (M - 1) * n * elem + n * elem      # gains, feed-forward, current controls (N - 1 knots), current states, the candidates' segment start states, goal
+        wr = N * A * (nm + 1) * elem + 2 * A * M * elem + A * (M - 1) * n * elem                     # 22-float records of every candidate and knot, partial cost / defect sums, boundary defects
+        return rd + wr, (f"read {rd} B: K {(N - 1) * n * m * elem} + du {(N - 1) * m * elem} + u {(N - 1) * m * elem} + x {N * n * elem} (shared by the {A} candidates) + start states {A * (M - 1) * n * elem} + goal; "
+                         f"written {wr} B: {N} x {A} records of {nm + 1} floats {N * A * (nm + 1) * elem} + partial sums + boundary defects")
+    if kernel.startswith("k_nis_tl"):
+        rd = N * (nm + 1) * elem + (M - 1) * n * elem                                                  # the accepted candidate's records, its boundary defects
+        wr = (N - 1) * (n // 2) * nm * elem + N * nm * elem + N * n * elem + N * m * elem + (M - 1) * n * elem   # compact [A B], g, adopted x, u, d
+        return rd + wr, (f"read {rd} B: the accepted candidate's {N} records + boundary defects; written {wr} B: compact [A B] {(N - 1) * (n // 2) * nm * elem} + g {N * nm * elem} + adopted x {N * n * elem}, u {N * m * elem}, d")
+    if kernel.startswith("k_sweep_maps"):
+        b_ = M * 16 * 16 * elem + A * (M - 1) * n * elem + (M - 1) * n * elem + n * elem
+        return b_, f"{M} segment maps of 16 x 16 read, {A} x {M - 1} start states written"
+    return None
+
+
+def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, s_per_step, keep_ctg=True, per_kernel_traffic=None, A=8, n=14, m=7):
     """`roofline` of the bench line, for the kernel with the longest average launch.
 
     Top level = the roofline that BINDS that kernel.  Every heavy kernel of this sweep is bound by the SIMDs' float32 lanes, not by HBM: the matrix-core
@@ -151,7 +173,24 @@ def roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, 
         "note": "rate at which the launch gets through the bytes the REFERENCE's phase decomposition moves (SURVEY.md 8(d): every array once per phase and per alpha). "
                 "It is not a bandwidth: the design reads shared operands once for all alphas, keeps [A B] compact, never reads the diagonal cost Hessian and never writes "
                 "A - B K -- a ratio above 1 means exactly that."}
-    roof["per_kernel"] = {nm: {"ms": round(ms, 5)} for nm, ms in kern}
+    # every kernel of the sweep: live duration, this design's algorithmic bytes, the counter traffic (when the counter file belongs to this build) and their ratio
+    roof["per_kernel"] = {}
+    for nm_, ms in kern:
+        e = {"ms": round(ms, 5)}
+        db = design_bytes_per_problem(nm_, N, M, A, n, m, keep_ctg)
+        if db:
+            e["algorithmic_bytes_per_launch"] = float(db[0]) * B
+            e["algorithmic_GBs"] = round(db[0] * B / (ms * 1e-3) / 1e9, 1) if ms else None
+            e["accounting"] = db[1] + f" x {B} problems"
+        tr = (per_kernel_traffic or {}).get(nm_)
+        if tr is not None:
+            e["traffic"] = tr
+            e["traffic_GBs"] = round(tr / (ms * 1e-3) / 1e9, 1) if ms else None
+            if db:
+                e["traffic_over_algorithmic"] = round(tr / (db[0] * B), 4)
+        roof["per_kernel"][nm_] = e
+    if traffic and roof.get("algorithmic_bytes_per_launch"):
+        roof["traffic_over_algorithmic"] = round(traffic / roof["algorithmic_bytes_per_launch"], 4)
     return roof
 
 
@@ -260,18 +299,25 @@ def main():
     traffic, counters, tsrc = args.traffic_bytes, None, "command line" if args.traffic_bytes else None
     tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     sweep_traffic = None
+    per_kernel_traffic = {}
     if os.path.exists(tfile):
         tj = json.load(open(tfile))
         # a counter pass says something about THIS launch only if it was taken at the same batch on the same handle options (files written before round 5: lean handles)
-        if tj.get("batch") == B and tj.get("handle_options", "lean") == ("lean" if lean else "library defaults"):
+        # AND on the build that is running (VERDICT r5 task 7): the sources of the tree the pass profiled against the sources of the tree this script runs from
+        built = (tj.get("build") or {})
+        same_build = built.get("sources") is not None and built.get("sources") == pyddp.build_id(args.lib).get("sources") and not args.lib
+        if traffic is None and not same_build:
+            tsrc = f"stale ({built.get('git_head') or 'no build identity'}: profiles/roofline_traffic.json was taken on other sources -- re-run tools/profile_round.sh)"
+        if same_build and tj.get("batch") == B and tj.get("handle_options", "lean") == ("lean" if lean else "library defaults"):
+            per_kernel_traffic = {nm: ent.get("hbm_bytes_per_launch") for nm, ent in tj.get("kernels", {}).items() if ent.get("hbm_bytes_per_launch") is not None}
             ent = tj.get("kernels", {}).get(dom_name)
             if traffic is None and ent:
-                traffic, counters, tsrc = ent.get("hbm_bytes_per_launch"), ent.get("counters"), tj.get("source")
+                traffic, counters, tsrc = ent.get("hbm_bytes_per_launch"), ent.get("counters"), f"{tj.get('source')}; build {built.get('git_head')} sources {built.get('sources')}"
             # whole-sweep HBM traffic (the north-star's "achieved HBM-bandwidth fraction"): the counter traffic of EVERY kernel of one sweep
             per = [tj["kernels"].get(nm, {}).get("hbm_bytes_per_launch") for nm, _ in kern]
             if per and all(v is not None for v in per):
                 sweep_traffic = float(sum(per))
-    roof = roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, t_local / K, keep_ctg=not lean)
+    roof = roofline_record(dom_name, dom_ms, kern, alg_of, B, N, M, traffic, counters, tsrc, sweep_bytes, t_local / K, keep_ctg=not lean, per_kernel_traffic=per_kernel_traffic, A=A, n=n, m=m)
 
     line = {"metric": "DDP iterations/sec (Kuka iiwa14 N=128, 8 alphas, 4 shooting segments)", "value": round(ctx.world * B * K / t, 1),
             "unit": "DDP iterations/s", "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * t / K, 4),
@@ -488,6 +534,10 @@ def row_roofline(per_kernel_ms, plant, dtype):
     if not os.path.exists(tfile):
         return None
     tab = json.load(open(tfile))
+    built = tab.get("build") or {}
+    if built.get("sources") is None or built.get("sources") != pyddp.build_id().get("sources"):      # counters of another build say nothing about these launches (VERDICT r5 task 7)
+        return {"traffic": None, "traffic_source": f"stale ({built.get('git_head') or 'no build identity'}: profiles/rows_traffic.json was taken on other sources -- re-run tools/pmc_rows.sh)",
+                "per_kernel": {nm: {"ms": round(ms, 5)} for nm, ms in per_kernel_ms.items()}}
     per = {}
     for nm, ms in per_kernel_ms.items():
         recs = tab["kernels"].get(f"{nm}|{plant}|{dtype}")
@@ -508,7 +558,7 @@ def row_roofline(per_kernel_ms, plant, dtype):
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
     peak = F64_LANE_PEAK_TFLOPS if dtype == "f64" else FP32_LANE_PEAK_TFLOPS
-    roof = {"kernel": dom, "avg_launch_ms": d["ms"], "traffic": d.get("hbm_bytes_per_launch"), "traffic_source": tab["source"], "per_kernel": per}
+    roof = {"kernel": dom, "avg_launch_ms": d["ms"], "traffic": d.get("hbm_bytes_per_launch"), "traffic_source": f"{tab['source']}; build {built.get('git_head')} sources {built.get('sources')}", "per_kernel": per}
     if d.get("matrix_instructions_per_launch"):
         issued = d["matrix_instructions_per_launch"] * 2048.0
         roof.update({"bound": "mfma", "achieved": round(issued / (d["ms"] * 1e-3) / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

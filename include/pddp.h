@@ -43,7 +43,7 @@ typedef struct pddp_kernel_selection {
     int cf;       /* closed-form plants, every phase: 1 ts (thread-serial)  2 coop                                                                                   */
     int cf_bp;    /* ... backward pass:         1 ts  2 coop  3 gl (16-lane groups)  4 gl32  5 cl (lane = column)  6 mq (matrix cores, 12 states + 4 controls)            */
     int cf_fp;    /* ... rollouts:              1 ts  2 coop  3 cf (staged per wavefront)                                                                            */
-    int cf_nis;   /* ... setup:                 1 ts  2 coop  3 gl  4 gl8  5 kb16  6 kb32  7 kb64 (knot-batched)                                                     */
+    int cf_nis;   /* ... setup:                 1 ts  2 coop  3 gl  4 gl8  5 kb16  6 kb32  7 kb64  8 kb20 (knot-batched: knots per wavefront; 16 / 20: one lane per (RK3 stage, knot)) */
 } pddp_kernel_selection;
 
 /* The reference's compile-time configuration (config.cuh) as a run-time record. */

@@ -32,7 +32,12 @@ template <typename T> __device__ __forceinline__ mx4t<T> mq_controls(const mx4t<
 #ifndef PDDP_MQ_PREFETCH
 #define PDDP_MQ_PREFETCH 1    // a knot's operands requested one knot ahead (measured: tools/quad_bp_ab.py, profiles/r05_quad_mfma.md)
 #endif
-constexpr int kMqLds = 64;                     // elements per wave: Huu 16 | cofactors 16 | inverse 16 | boundary p 16
+#ifndef PDDP_MQ_STAGE
+#define PDDP_MQ_STAGE 0       // 1: float handles send [P | p] and [A - B K | B du] of a knot through LDS in memory order as 16-byte pieces -- built, same bits, measured SLOWER (round 6,
+                              // profiles/r06_quad.md: 2.11 -> 2.24 ms mean of four alternating handles each); the product keeps the dwordx3 stores in tile order
+#endif
+constexpr int kMqStage = 160;                  // one staged pair: a 12 x 12 block (144) + its 12-vector right behind it, padded to whole 16-byte pieces
+constexpr int kMqLds = 64 + 2 * kMqStage;      // elements per wave: Huu 16 | cofactors 16 | inverse 16 | boundary p 16 | staging [P | p] | staging [A - B K | B du]
 
 // Per-knot memory operations of the loop.  float: BUFFER instructions -- a wave-uniform resource per array, the knot's position a scalar byte offset, the lane's share a
 // loop-invariant 32-bit vector offset (no 64-bit vector address arithmetic per access: as in bp_mfma.hpp, that arithmetic was a third of the first cut's vector
@@ -52,6 +57,10 @@ template <> struct MqMem<float> {
         __builtin_amdgcn_raw_buffer_store_b96(w, r, 4u * velem, 4u * selem, 0);
     }
     __device__ __forceinline__ void st1(float a, unsigned velem, unsigned selem) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), r, 4u * velem, 4u * selem, 0); }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ void st4(const float* lds16, unsigned velem, unsigned selem) const {     // 16 bytes from a 16-byte aligned LDS address
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u4*>(lds16), r, 4u * velem, 4u * selem, 0);
+    }
 };
 template <> struct MqMem<double> {
     double* p;
@@ -97,10 +106,25 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
     // loop-invariant element offsets of this lane inside a knot's blocks
     const unsigned oCol = (unsigned)((cx ? sc : NX + cg) * NX + 3 * g), oBt = (unsigned)((NX + g) * NX + sc), oG3 = (unsigned)(3 * g), oGu = (unsigned)(NX + g);
     const unsigned oKT = (unsigned)(sc + NX * g), oP = (unsigned)(sc * NX + 3 * g), oHcol = (unsigned)((cx ? sc : NX + cg) * NM), oHxu = (unsigned)((NX + g) * NM + sc);
-    auto store_ctg = [&](int slot, const mx4& t) {                          // P, p of one knot: three consecutive elements per lane
-        if (cx) mP.st3(t[0], t[1], t[2], oP, (unsigned)slot * SZP);
-        else if (cv) mp.st3(t[0], t[1], t[2], oG3, (unsigned)slot * NX);
+    // A knot's 12 x 12 block + its 12-vector (P | p, A - B K | B du): three consecutive elements per lane in TILE order -- 48 lanes x 12 bytes.  Float handles send them
+    // through LDS instead (the wave's staging area holds the pair in MEMORY order) and store 16-byte pieces in address order: 36 lanes for the block, 3 for the vector
+    // (the step that was worth 18 % on the arm's [P | p], bp_mfma.hpp; LDS operations of one wave retire in order: no barrier, and the next knot's staging writes
+    // cannot overtake these reads).
+    constexpr bool STG = PDDP_MQ_STAGE && sizeof(T) == 4;
+    auto store_pair = [&](T* stg, const MqMem<T>& mBlock, const MqMem<T>& mVec, int slot, const mx4& t) {
+        if constexpr (STG) {
+            if (cx) { stg[oP] = t[0]; stg[oP + 1] = t[1]; stg[oP + 2] = t[2]; }
+            else if (cv) { stg[SZP + oG3] = t[0]; stg[SZP + oG3 + 1] = t[1]; stg[SZP + oG3 + 2] = t[2]; }
+            wsync();
+            if (lane < SZP / 4) mBlock.st4(reinterpret_cast<const float*>(stg) + 4 * lane, 4u * (unsigned)lane, (unsigned)slot * SZP);
+            else if (lane < SZP / 4 + NX / 4) mVec.st4(reinterpret_cast<const float*>(stg) + 4 * lane, 4u * (unsigned)(lane - SZP / 4), (unsigned)slot * NX);
+        } else {
+            if (cx) mBlock.st3(t[0], t[1], t[2], oP, (unsigned)slot * SZP);
+            else if (cv) mVec.st3(t[0], t[1], t[2], oG3, (unsigned)slot * NX);
+        }
     };
+    T* const stgP = lds + 64; T* const stgF = lds + 64 + kMqStage;
+    auto store_ctg = [&](int slot, const mx4& t) { store_pair(stgP, mP, mp, slot, t); };                    // P, p of one knot
     if (ks == N - 1) {                                                       // last block: the final cost (bpHelpers.cuh:362-367)
         const T* Hf = H + (size_t)ks * SZH; const T* gf = gg + (size_t)ks * NM;
         const T* q = cx ? Hf + sc * NM + 3 * g : gf + 3 * g;
@@ -210,8 +234,7 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
             const mx4 BT = {T(0), T(0), T(0), cx ? bt : T(0)};               // [b][kx] = B(kx, b)
             const mx4 BK = mq_controls<T>(BT, Kp, zero);
             const mx4 Gt = cv ? BK : AB - BK;                                 // (stored from the state-column lanes and the vector column only)
-            if (cx) mF.st3(Gt[0], Gt[1], Gt[2], oP, (unsigned)ks * SZP);
-            else if (cv) mBd.st3(Gt[0], Gt[1], Gt[2], oG3, (unsigned)ks * NX);
+            store_pair(stgF, mF, mBd, ks, Gt);
         }
         if (iter != 0 || blk != 0) {                                         // new cost-to-go (computeCTG :225-276): P(kx, ky) | p(kx); the one in front of knot 0 is never used (:396)
             mx4 val = mq_controls<T>(T1t, Kp, zero);

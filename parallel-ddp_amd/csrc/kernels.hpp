@@ -263,13 +263,55 @@ struct FpCfStage {
 };
 template <typename T, int PW, int L>
 struct FpCfRegs { static constexpr int R = (PW * L + 63) / 64; T v[R]; };
-// lane's share of the PW problems' L-vectors of knot k: element idx = lane + 64 j  ->  problem idx / L, entry idx % L
+// lane's share of the PW problems' L-vectors of a knot: element idx = lane + 64 j  ->  problem idx / L, entry idx % L.  The arrays are [problem][knot][L], so relative to the
+// wave's first problem at the knot -- a wave-uniform address the scalar unit forms -- a lane's element sits at a loop-invariant BYTE offset that fits 32 bits: one register per
+// fetch and no 64-bit vector arithmetic in the step (round 6: the per-lane 64-bit pointers of every fetch were what spilled when the kernel was asked to fit three or four waves).
 template <typename T, int PW, int L>
-__device__ __forceinline__ void fp_cf_fetch(FpCfRegs<T, PW, L>& r, const T* base, size_t per_problem, int k, int pb0, int batch, int lane) {
-    PDDP_UNROLL for (int j = 0; j < FpCfRegs<T, PW, L>::R; j++) {
-        const int idx = lane + 64 * j, p = idx / L, e = idx - p * L;
-        const int pb = (pb0 + p < batch) ? pb0 + p : batch - 1;
-        r.v[j] = (idx < PW * L) ? base[(size_t)pb * per_problem + (size_t)k * L + e] : T(0);
+struct FpCfLane {
+    static constexpr int R = (PW * L + 63) / 64;
+    unsigned off[R];
+    __device__ __forceinline__ void init(size_t per_problem, int pb0, int batch, int lane) {
+        PDDP_UNROLL for (int j = 0; j < R; j++) {
+            const int idx = lane + 64 * j, p = idx / L, e = idx - p * L;
+            const int q = ((pb0 + p < batch) ? pb0 + p : batch - 1) - pb0;
+            off[j] = (idx < PW * L) ? (unsigned)(((size_t)q * per_problem + e) * sizeof(T)) : 0u;
+        }
+    }
+};
+// BUFFER instructions (as in bp_mq.hpp / bp_mfma.hpp): a wave-uniform resource on the wave's first problem, the knot's position a scalar byte offset, the lane's share the
+// 32-bit vector offset -- unconditional (a lane without a share reads offset 0 and drops the value: no exec-mask juggling around every load)
+template <typename T, int PW, int L>
+__device__ __forceinline__ void fp_cf_fetch(FpCfRegs<T, PW, L>& r, const FpCfLane<T, PW, L>& ln, __amdgpu_buffer_rsrc_t rs, int k) {
+    const unsigned so = (unsigned)k * (unsigned)(L * sizeof(T));
+    PDDP_UNROLL for (int j = 0; j < FpCfRegs<T, PW, L>::R; j++) r.v[j] = mx_bld<T>(rs, ln.off[j], so);
+}
+// n consecutive values at (resource, lane byte offset, scalar byte offset) as 16-byte pieces
+typedef unsigned cf_u4 __attribute__((ext_vector_type(4)));
+template <typename T, int n>
+__device__ __forceinline__ void cf_bst_vec(__amdgpu_buffer_rsrc_t rs, unsigned vbyte, unsigned sbyte, const T* v) {
+    constexpr int W = 16 / sizeof(T);
+    if constexpr (n % W == 0) {
+        PDDP_UNROLL for (int j = 0; j < n / W; j++) {
+            T q[W];
+            PDDP_UNROLL for (int e = 0; e < W; e++) q[e] = v[j * W + e];
+            cf_u4 w; __builtin_memcpy(&w, q, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, vbyte + 16u * j, sbyte, 0);
+        }
+    } else {                                                                 // (the cart-pole's 5-element records: element by element)
+        PDDP_UNROLL for (int j = 0; j < n; j++) mx_bst<T>(rs, v[j], vbyte + (unsigned)(j * sizeof(T)), sbyte);
+    }
+}
+template <typename T, int n>
+__device__ __forceinline__ void cf_bld_vec(T* v, __amdgpu_buffer_rsrc_t rs, unsigned vbyte, unsigned sbyte) {
+    constexpr int W = 16 / sizeof(T);
+    if constexpr (n % W == 0) {
+        PDDP_UNROLL for (int j = 0; j < n / W; j++) {
+            const cf_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, vbyte + 16u * j, sbyte, 0);
+            T q[W]; __builtin_memcpy(q, &w, 16);
+            PDDP_UNROLL for (int e = 0; e < W; e++) v[j * W + e] = q[e];
+        }
+    } else {
+        PDDP_UNROLL for (int j = 0; j < n; j++) v[j] = mx_bld<T>(rs, vbyte + (unsigned)(j * sizeof(T)), sbyte);
     }
 }
 template <typename T, int PW, int L>
@@ -286,6 +328,16 @@ __device__ __forceinline__ void cf_store_vec(T* dst, const T* v) {
         PDDP_UNROLL for (int j = 0; j < n / W; j++) { V q; PDDP_UNROLL for (int e = 0; e < W; e++) q[e] = v[j * W + e]; reinterpret_cast<V*>(dst)[j] = q; }
     } else {
         PDDP_UNROLL for (int j = 0; j < n; j++) dst[j] = v[j];
+    }
+}
+template <typename T, int n>
+__device__ __forceinline__ void cf_load_vec(T* v, const T* src) {
+    if constexpr ((n * sizeof(T)) % 16 == 0) {
+        typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int W = 16 / sizeof(T);
+        PDDP_UNROLL for (int j = 0; j < n / W; j++) { const V q = reinterpret_cast<const V*>(src)[j]; PDDP_UNROLL for (int e = 0; e < W; e++) v[j * W + e] = q[e]; }
+    } else {
+        PDDP_UNROLL for (int j = 0; j < n; j++) v[j] = src[j];
     }
 }
 // integrator_step (integrators.hpp) for one thread with everything in registers
@@ -316,11 +368,13 @@ __device__ __forceinline__ void cf_integrator_step(T* xn, const T* x, const T* u
         }
     }
 }
-template <typename P, int INTEG, typename T, int A>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 1))) void k_fp_cf(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+// PART 0: the linear sweep alone (k_sweep_cf), PART 1: the rollouts alone (k_fp_cf).  Until round 5 one kernel ran both loops; the register allocation of the two together
+// is what kept it at two waves per SIMD -- asked for three or four, the compiler spilled inside the SWEEP loop (the rollout loop fits 128 registers) -- so they are two
+// launches now, each with its own occupancy; the sweep leaves the segments' start states in the candidates' records, where the rollouts read them as before.
+template <typename P, int INTEG, typename T, int A, int PART>
+__device__ __forceinline__ void fp_cf_body(FpCfStage<P, T, A>* stage, T (*goal_s)[P::NX], Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, T dt, int batch) {
     constexpr int NX = P::NX, NU = P::NU, PW = 64 / A;
     static_assert(64 % A == 0 && PW * NX <= 64, "a wavefront holds whole problems; one fetch per lane for the state");
-    __shared__ FpCfStage<P, T, A> stage[2];
     const int lane = threadIdx.x, grp = lane / A, a_idx = lane - grp * A, pb0 = blockIdx.x * PW, N = dm.N;
     const int pb_raw = pb0 + grp, pb = pb_raw < batch ? pb_raw : batch - 1;
     const bool live = pb_raw < batch && fp_active<T>(b, dm, pb);
@@ -330,24 +384,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     // 16-byte pieces 12 KB apart (counters: 8.7 GB written per launch for 4.3 GB of candidates).  The setup kernels adopt the accepted candidate from the records; the
     // phase hook runs k_fp_ts (candidate-major xs / us, the reference's arrays) and copies them into xw (k_cand_to_xw).
     constexpr int REC = NX + NU;
-    T* rec0 = b.xw + ((size_t)pb * N * A + a_idx) * REC;                 // record of knot k: rec0 + k * A * REC
-    const size_t rstr = (size_t)A * REC;
-    T* dout = b.ds + slot * N * NX;
-    const T* xg = b.xGoal + (size_t)pb * NX;
+    // addresses: a wave-uniform buffer resource on the wave's first problem + the knot's scalar byte offset + this lane's loop-invariant 32-bit byte offset
+    const __amdgpu_buffer_rsrc_t r_rec = mx_rsrc(b.xw + (size_t)pb0 * N * A * REC), r_d = mx_rsrc(b.ds + (size_t)pb0 * A * N * NX);
+    const unsigned rec_off = (unsigned)(((size_t)(pb - pb0) * N * A + a_idx) * REC * sizeof(T));      // record of knot k of this lane: + k * A * REC elements
+    constexpr unsigned rstr = (unsigned)(A * REC * sizeof(T));
+    const unsigned d_off = (unsigned)(((size_t)(pb - pb0) * A + a_idx) * N * NX * sizeof(T));         // boundary defect of knot k: + k * NX elements
+    // the goal of the wave's problems lives in LDS (round 6): the cost of every step read it from memory -- twelve loads per step queued behind the previous step's stores
+    // (one in-order vmcnt), and a dozen registers' worth of addresses and values kept alive across the three dynamics evaluations
+    { const int p = lane / NX, q = (pb0 + p < batch) ? pb0 + p : batch - 1; if (lane < PW * NX) (&goal_s[0][0])[lane] = b.xGoal[(size_t)q * NX + (lane - p * NX)]; }
+    const T* xg = goal_s[grp];
     const T alpha = b.alpha[a_idx];
     // the current trajectory sits in one half of xb per PROBLEM (state.cur): this lane's share of the state fetch is entry e of problem p
-    const T* xcur_lane;
-    { const int p = lane / NX, q = (pb0 + p < batch) ? pb0 + p : batch - 1; xcur_lane = b.xb + ((size_t)q * 2 + b.state[q].cur) * N * NX + (lane - p * NX); }
+    const __amdgpu_buffer_rsrc_t r_xcur = mx_rsrc(b.xb + (size_t)pb0 * 2 * N * NX);
+    unsigned xcur_off;
+    { const int p = lane / NX, q = (pb0 + p < batch) ? pb0 + p : batch - 1; xcur_off = (unsigned)((((size_t)(q - pb0) * 2 + b.state[q].cur) * N * NX + (lane - p * NX)) * sizeof(T)); }
     const bool xlane = lane < PW * NX;
     T xstart[NX];
     // ---- the linear sweep: x_{k+1} = xcur_{k+1} + (A - B K)_k (x_k - xcur_k) - alpha (B du)_k + [boundary] d_k ----
-    if (dm.M > 1) {
+    if constexpr (PART == 0) {
+        if (dm.M <= 1) return;
+        // (tried and measured, round 6 -- profiles/r06_quad.md: the operands requested TWO knots ahead instead of one: 0.86 -> 0.85 ms, nothing; the map kept in registers across
+        // the 16 lanes of a problem's DPP row with v_mul_f32_dpp row_newbcast instead of LDS broadcasts: same bits, 0.86 -> 0.95 ms)
         FpCfRegs<T, PW, NX * NX> rM; FpCfRegs<T, PW, NX> rBdu, rd; T rxp;
+        FpCfLane<T, PW, NX * NX> lM; FpCfLane<T, PW, NX> lV;
+        lM.init((size_t)N * NX * NX, pb0, batch, lane); lV.init((size_t)N * NX, pb0, batch, lane);
+        const __amdgpu_buffer_rsrc_t r_M = mx_rsrc(b.ApBK + (size_t)pb0 * N * NX * NX), r_Bdu = mx_rsrc(b.Bdu + (size_t)pb0 * N * NX), r_dc = mx_rsrc(b.dcur + (size_t)pb0 * N * NX);
         auto fetch = [&](int k) {
-            fp_cf_fetch<T, PW, NX * NX>(rM, b.ApBK, (size_t)N * NX * NX, k, pb0, batch, lane);
-            rxp = xlane ? xcur_lane[(size_t)k * NX] : T(0);
-            fp_cf_fetch<T, PW, NX>(rBdu, b.Bdu, (size_t)N * NX, k, pb0, batch, lane);
-            fp_cf_fetch<T, PW, NX>(rd, b.dcur, (size_t)N * NX, k, pb0, batch, lane);
+            fp_cf_fetch<T, PW, NX * NX>(rM, lM, r_M, k);
+            rxp = mx_bld<T>(r_xcur, xcur_off, (unsigned)k * (unsigned)(NX * sizeof(T)));
+            fp_cf_fetch<T, PW, NX>(rBdu, lV, r_Bdu, k);
+            fp_cf_fetch<T, PW, NX>(rd, lV, r_dc, k);
         };
         auto put = [&](FpCfStage<P, T, A>& sg) {
             fp_cf_put<T, PW, NX * NX>(rM, &sg.sw.M[0][0], lane);
@@ -363,9 +429,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
             fetch(k + 1);
             T val[NX];
             PDDP_UNROLL for (int r = 0; r < NX; r++) val[r] = 0;
+            // column i of the map as explicit 16-byte LDS reads with its products pinned behind them: left to itself the compiler merges the 144 scalar reads into 36 vector
+            // reads and places ALL of them in front of the first product (144 live registers: what kept this loop at two waves per SIMD)
             PDDP_UNROLL for (int i = 0; i < NX; i++) {
                 const T dxs = xk[i] - sc.sw.xp[grp][i];
-                PDDP_UNROLL for (int r = 0; r < NX; r++) val[r] += sc.sw.M[grp][r + NX * i] * dxs;
+                if constexpr ((NX * sizeof(T)) % 16 == 0) {
+                    typedef T MV __attribute__((ext_vector_type(16 / sizeof(T))));
+                    constexpr int W = 16 / sizeof(T);
+                    const MV* col = reinterpret_cast<const MV*>(&sc.sw.M[grp][NX * i]);
+                    PDDP_UNROLL for (int q = 0; q < NX / W; q++) { const MV m = col[q]; PDDP_UNROLL for (int e = 0; e < W; e++) val[q * W + e] += m[e] * dxs; }
+                    // (the sums are only used behind the next LDS stores, in another basic block: the optimiser SINKS all 288 operations there and leaves the reads here --
+                    // an empty statement that "uses" the partial sums keeps every column's products next to its reads)
+                    PDDP_UNROLL for (int r = 0; r < NX; r++) asm volatile("" : "+v"(val[r]));
+                } else {
+                    PDDP_UNROLL for (int r = 0; r < NX; r++) val[r] += sc.sw.M[grp][r + NX * i] * dxs;
+                }
             }
             put(sn); wsync();
             const bool bnd = dm.on_defect_boundary(k);
@@ -374,17 +452,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
                 xv += -alpha * sc.sw.Bdu[grp][r] + val[r] + (bnd ? sc.sw.d[grp][r] : T(0));
                 xk[r] = xv;
             }
-            if (bnd && live) cf_store_vec<T, NX>(rec0 + (size_t)(k + 1) * rstr, xk);
+            if (bnd && live) cf_bst_vec<T, NX>(r_rec, rec_off, (unsigned)(k + 1) * rstr, xk);
             wsync();
         }
     }
     // ---- the rollouts ----
+    if constexpr (PART == 1) {
     FpCfRegs<T, PW, NX * NU> rK; FpCfRegs<T, PW, NU> rup, rdu; T rxp;
+    FpCfLane<T, PW, NX * NU> lK; FpCfLane<T, PW, NU> lU;
+    lK.init((size_t)N * NX * NU, pb0, batch, lane); lU.init((size_t)N * NU, pb0, batch, lane);
+    const __amdgpu_buffer_rsrc_t r_K = mx_rsrc(b.KT + (size_t)pb0 * N * NX * NU), r_up = mx_rsrc(b.ucur + (size_t)pb0 * N * NU), r_du = mx_rsrc(b.du + (size_t)pb0 * N * NU);
     auto fetch = [&](int k) {
-        fp_cf_fetch<T, PW, NX * NU>(rK, b.KT, (size_t)N * NX * NU, k, pb0, batch, lane);
-        rxp = xlane ? xcur_lane[(size_t)k * NX] : T(0);
-        fp_cf_fetch<T, PW, NU>(rup, b.ucur, (size_t)N * NU, k, pb0, batch, lane);
-        fp_cf_fetch<T, PW, NU>(rdu, b.du, (size_t)N * NU, k, pb0, batch, lane);
+        fp_cf_fetch<T, PW, NX * NU>(rK, lK, r_K, k);
+        rxp = mx_bld<T>(r_xcur, xcur_off, (unsigned)k * (unsigned)(NX * sizeof(T)));
+        fp_cf_fetch<T, PW, NU>(rup, lU, r_up, k);
+        fp_cf_fetch<T, PW, NU>(rdu, lU, r_du, k);
     };
     auto put = [&](FpCfStage<P, T, A>& sg) {
         fp_cf_put<T, PW, NX * NU>(rK, &sg.ro.K[0][0], lane);
@@ -400,7 +482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
         const FpCfStage<P, T, A>& sc = stage[k & 1];
         fetch(k + 1);
         const bool bnd = dm.on_defect_boundary(k);
-        if (bnd) { PDDP_UNROLL for (int i = 0; i < NX; i++) xstart[i] = live ? rec0[(size_t)(k + 1) * rstr + i] : T(0); }      // the next segment's start state, from the sweep above
+        if (bnd) cf_bld_vec<T, NX>(xstart, r_rec, rec_off, (unsigned)(k + 1) * rstr);      // the next segment's start state, from the sweep above
         T dx[NX], xn[NX];
         PDDP_UNROLL for (int i = 0; i < NX; i++) dx[i] = x[i] - sc.ro.xp[grp][i];
         PDDP_UNROLL for (int r = 0; r < NU; r++) {                     // u = ucur - alpha du - K (x - xcur)      (computeControlKT)
@@ -416,12 +498,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
         T rec[REC];                                         // this knot's record: the state the step started from and its control
         PDDP_UNROLL for (int i = 0; i < NX; i++) rec[i] = x[i];
         PDDP_UNROLL for (int r = 0; r < NU; r++) rec[NX + r] = u[r];
-        if (live) cf_store_vec<T, REC>(rec0 + (size_t)k * rstr, rec);
+        if (live) cf_bst_vec<T, REC>(r_rec, rec_off, (unsigned)k * rstr, rec);
         if (bnd) {                                          // last step of a non-final segment: defect against the next start state, which the next segment starts from
             T sdef = 0, dv[NX];
             PDDP_UNROLL for (int i = 0; i < NX; i++) { dv[i] = xn[i] - xstart[i]; sdef += tabs(dv[i]); x[i] = xstart[i]; }
             dmx = tmax(dmx, sdef);
-            if (live) cf_store_vec<T, NX>(dout + (size_t)k * NX, dv);
+            if (live) cf_bst_vec<T, NX>(r_d, d_off, (unsigned)k * (unsigned)(NX * sizeof(T)), dv);
         } else {
             PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = xn[i];
         }
@@ -432,13 +514,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
         T rec[REC];
         PDDP_UNROLL for (int i = 0; i < NX; i++) rec[i] = x[i];
         PDDP_UNROLL for (int r = 0; r < NU; r++) rec[NX + r] = u[r];
-        if (live) cf_store_vec<T, REC>(rec0 + (size_t)(N - 1) * rstr, rec);
+        if (live) cf_bst_vec<T, REC>(r_rec, rec_off, (unsigned)(N - 1) * rstr, rec);
         cost_k[N - 1] = P::cost(cw, x, u, xg, N - 1, N);
         dmx = tmax(dmx, T(0));
     }
     if (!live) return;
     const T J = tree_sum<T>(serial_wave(), cost_k, N);
     b.J[slot] = J; b.dmax[slot] = dmx;
+    }
+}
+#ifndef PDDP_FPCF_WAVES
+#define PDDP_FPCF_WAVES 4      // resident waves per SIMD the float rollout kernel is compiled for (128 registers: the step loop holds no spill)
+#endif
+#ifndef PDDP_SWEEPCF_WAVES
+#define PDDP_SWEEPCF_WAVES 2
+#endif
+template <typename P, int INTEG, typename T, int A>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? PDDP_FPCF_WAVES : 1))) void k_fp_cf(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+    __shared__ FpCfStage<P, T, A> stage[2];
+    __shared__ T goal_s[64 / A][P::NX];
+    fp_cf_body<P, INTEG, T, A, 1>(stage, goal_s, b, dm, cw, dt, batch);
+}
+template <typename P, int INTEG, typename T, int A>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? PDDP_SWEEPCF_WAVES : 1))) void k_sweep_cf(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int batch) {
+    __shared__ FpCfStage<P, T, A> stage[2];
+    __shared__ T goal_s[64 / A][P::NX];
+    fp_cf_body<P, INTEG, T, A, 0>(stage, goal_s, b, dm, cw, dt, batch);
 }
 template <typename P, int INTEG, typename T>
 __global__ __launch_bounds__(64) void k_nis_ts(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
@@ -474,64 +575,124 @@ __global__ __launch_bounds__(64) void k_bp_gl(Buffers<T> b, Dims dm, int batch) 
 // Knot-batched setup for the scalar closed-form plants with the RK3 Jacobian (BASELINE configs[4], the quadrotor).  k_nis_gl above runs the plug-in's scalar code on
 // 3 of every 16 lanes (4.4e9 vector instructions per sweep at 16384 problems, counters in profiles/r04_quad.md: the kernel is instruction-issue bound) and assembles
 // [A B] entry by entry with run-time indices.  Here one wavefront takes KB consecutive knots in two phases:
-//   1  lane = knot: the three stage gradients, one after the other (each call also returns the stage's qdd, from which the next stage's state follows -- the same
-//      functions on the same operands as rk3_stage_chain / rk3_stage_gradient, integrators.hpp); dqdd of the three stages -> LDS, entry-major and knot-minor with
-//      a stride of KB + 1 words (conflict-free for the writes of phase 1 AND for the column reads of phase 2); g_k and the winner's copies by the same lane
+//   1  the three stage gradients -> LDS (dqdd of the three stages, entry-major and knot-minor; conflict-free for the writes of phase 1 AND for the column reads of
+//      phase 2); g_k and the winner's copies by the same lanes.
+//      Round 4: lane = knot, the stages one after the other (each call also returns the stage's qdd, from which the next stage's state follows) -- 16 of 64 lanes live, because
+//      3 x 96 words of LDS per knot set the number of resident knots, and with it the occupancy (KB = 16 beat 32 and 64: 2.15 / 2.6 / 3.6 ms).
+//      Round 6: lane = (stage, knot), 3 KB <= 64: stage s's lane first forms ITS stage state with s evaluations of the plug-in's dynamics() -- the same functions on the same
+//      operands as rk3_stage_chain (integrators.hpp), and a scalar plug-in's dynamics() returns the numbers its dynamicsGradient() returns as qdd (plants.hpp
+//      scalar_plugin_qdd_is_dynamics) -- then all three stage gradients run as ONE pass of the gradient code: 2 dynamics + 1 gradient per wavefront instead of 3 gradients,
+//      48 (KB = 16) or 60 (KB = 20) lanes live.  The same bits in every output (tests/test_closed_form_serial.py).
 //   2  16 lanes = one knot, lane = COLUMN of [A B], four knots per pass: the column of T1, T2 (rk3_assemble's sums, in its order) stays in registers, every index but
 //      the column is a compile-time constant, the factors (0.5 dt d1 + delta), (2 dt T1 - dt d1 + delta) are formed once per column instead of once per row
+// Columns of dqdd that are zero for EVERY state of the plant (GradZeroCols: the quadrotor's accelerations do not depend on its position or its linear velocity -- 6 of 16) are
+// neither staged nor multiplied: their products are exact zeros, adding one changes no finite sum (LDS per knot 288 -> 180 words: three resident waves per SIMD instead of two).
 // No barrier inside a phase; one between them (a one-wave block).
+template <typename P> struct GradZeroCols { static constexpr unsigned value = 0u; };                                    // bit c: column c of dynamicsGradient's dqdd is identically zero
+template <typename T> struct GradZeroCols<QuadPlant<T>> { static constexpr unsigned value = 0x1C7u; };                  // x y z and their rates (plants/dynamics_quad.cuh:75-169 never writes them; tests/test_closed_form_pins.py)
+template <typename P> struct GradCols {
+    static constexpr int NM = P::NX + P::NU;
+    static constexpr unsigned zero = GradZeroCols<P>::value;
+    static constexpr bool live(int c) { return !((zero >> c) & 1u); }
+    static constexpr int index(int c) { int n = 0; for (int i = 0; i < c; i++) n += live(i) ? 1 : 0; return n; }     // position of column c among the staged ones
+    static constexpr int count = index(NM);
+};
 template <typename P, typename T, int KB>
-struct NisKbLds { T d[3][P::NPOS * (P::NX + P::NU)][KB + 1]; };
+struct NisKbLds { T d[GradCols<P>::count * P::NPOS][3][KB + 1]; };
 template <typename P, typename T, int KB>
 __global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeights<T> cw, T dt, int mode, int batch) {
     constexpr int NP = P::NPOS, NX = P::NX, NU = P::NU, NM = NX + NU, ND = NP * NM;
+    using GC = GradCols<P>;
+    constexpr bool kStageLanes = 3 * KB <= 64;          // phase 1 with one lane per (stage, knot)
     static_assert(NM <= 16 && KB % 4 == 0 && KB <= 64, "one column of [A B] per lane of a 16-lane group");
     __shared__ NisKbLds<P, T, KB> lds;
     const int lane = threadIdx.x, N = dm.N, total = batch * N;
-    // ---- phase 1: lane = knot ----
+    // ---- phase 1 ----
     {
-        const int inst = blockIdx.x * KB + lane;
-        if (lane < KB && inst < total) {
+        const int stage = kStageLanes ? lane / KB : 0, j = kStageLanes ? lane - stage * KB : lane;
+        const int inst = blockIdx.x * KB + j;
+        if (lane < (kStageLanes ? 3 * KB : KB) && inst < total) {
             const int pb = inst / N, k = inst - pb * N;
             const SolverState<T>& st = b.state[pb];
             const bool moved = mode == 1 || st.accepted == 1;
             if (moved) {
                 T* xc = b.xb + ((size_t)pb * 2 + st.cur) * N * NX + (size_t)k * NX;
                 T* uc = b.ucur + ((size_t)pb * N + k) * NU;
+                // the winner's copies and the cost gradient: the work of ONE lane per knot, spread over the knot's three stage lanes
+                const bool copy_x = stage == 0, copy_u = !kStageLanes || stage == 1, do_g = !kStageLanes || stage == 2;
                 T x[NX], u[NU];
                 if (mode == 0) {
                     const size_t slot = (size_t)pb * dm.A + st.alphaIndex;
                     const T* xw = b.xw ? b.xw + (((size_t)pb * N + k) * dm.A + st.alphaIndex) * (NX + NU) : b.xs + (slot * N + k) * NX;      // the accepted candidate's record, or its slots of xs / us
                     const T* uw = b.xw ? xw + NX : b.us + (slot * N + k) * NU;
-                    PDDP_UNROLL for (int i = 0; i < NX; i++) { x[i] = xw[i]; xc[i] = x[i]; }
-                    PDDP_UNROLL for (int i = 0; i < NU; i++) { u[i] = uw[i]; uc[i] = u[i]; }
-                    if (dm.M > 1 && dm.on_defect_boundary(k)) {
-                        const T* dw = b.ds + (slot * N + k) * NX; T* dc = b.dcur + ((size_t)pb * N + k) * NX;
-                        PDDP_UNROLL for (int i = 0; i < NX; i++) dc[i] = dw[i];
+                    // (16-byte pieces: every knot block of these arrays starts on a 16-byte boundary when its size is a multiple of 16 bytes -- cf_load_vec / cf_store_vec)
+                    cf_load_vec<T, NX>(x, xw); cf_load_vec<T, NU>(u, uw);
+                    if (copy_x) cf_store_vec<T, NX>(xc, x);
+                    if (copy_u) {
+                        cf_store_vec<T, NU>(uc, u);
+                        if (dm.M > 1 && dm.on_defect_boundary(k)) {
+                            const T* dw = b.ds + (slot * N + k) * NX; T* dc = b.dcur + ((size_t)pb * N + k) * NX;
+                            T dv[NX]; cf_load_vec<T, NX>(dv, dw); cf_store_vec<T, NX>(dc, dv);
+                        }
                     }
                 } else {
-                    PDDP_UNROLL for (int i = 0; i < NX; i++) x[i] = xc[i];
-                    PDDP_UNROLL for (int i = 0; i < NU; i++) u[i] = uc[i];
+                    cf_load_vec<T, NX>(x, xc); cf_load_vec<T, NU>(u, uc);
                 }
                 if (mode == 1 || !st.done) {
-                    const T* xg = b.xGoal + (size_t)pb * NX;
-                    T* gk = b.g + ((size_t)pb * N + k) * NM;
-                    if constexpr (P::kPluginCost) P::cost_grad(cw, b.H + ((size_t)pb * N + k) * NM * NM, gk, x, u, xg, k, N);
-                    else for (int i = 0; i < NM; i++) gk[i] = P::weight(cw, i, k, N) * (i < NX ? (x[i] - xg[i]) : u[i - NX]);
-                    if (k < N - 1) {
-                        T dd[ND], q1[NP], q2[NP], q3[NP], xm[NX];
-                        P::gradient_eval(dd, q1, x, u);
-                        PDDP_UNROLL for (int e = 0; e < ND; e++) lds.d[0][e][lane] = dd[e];
-                        PDDP_UNROLL for (int i = 0; i < NP; i++) { xm[i] = x[i] + T(0.5) * dt * x[i + NP]; xm[i + NP] = x[i] + T(0.5) * dt * q1[i]; }
-                        P::gradient_eval(dd, q2, xm, u);
-                        PDDP_UNROLL for (int e = 0; e < ND; e++) lds.d[1][e][lane] = dd[e];
-                        PDDP_UNROLL for (int i = 0; i < NP; i++) {                                  // xm2 from xm1's velocity half BEFORE it is overwritten (rk3_stage_chain)
-                            const T v1 = xm[i + NP];
-                            xm[i + NP] = x[i] + dt * q1[i] + T(2) * dt * q2[i];
-                            xm[i] = x[i] + dt * x[i + NP] + T(2) * dt * v1;
+                    if (do_g) {
+                        const T* xg = b.xGoal + (size_t)pb * NX;
+                        T* gk = b.g + ((size_t)pb * N + k) * NM;
+                        if constexpr (P::kPluginCost) P::cost_grad(cw, b.H + ((size_t)pb * N + k) * NM * NM, gk, x, u, xg, k, N);
+                        else {
+                            T gv[NM], xgv[NX];
+                            cf_load_vec<T, NX>(xgv, xg);
+                            PDDP_UNROLL for (int i = 0; i < NM; i++) gv[i] = P::weight(cw, i, k, N) * (i < NX ? (x[i] - xgv[i]) : u[i - NX]);
+                            cf_store_vec<T, NM>(gk, gv);
                         }
-                        P::gradient_eval(dd, q3, xm, u);
-                        PDDP_UNROLL for (int e = 0; e < ND; e++) lds.d[2][e][lane] = dd[e];
+                    }
+                    if (k < N - 1) {
+                        auto stage_to_lds = [&](int s_, const T* dd) {
+                            PDDP_UNROLL for (int c = 0; c < NM; c++) {
+                                if (!GC::live(c)) continue;
+                                PDDP_UNROLL for (int r = 0; r < NP; r++) lds.d[GC::index(c) * NP + r][s_][j] = dd[c * NP + r];
+                            }
+                        };
+                        T dd[ND], q1[NP], q2[NP], q3[NP], xm[NX];
+                        if constexpr (kStageLanes) {
+                            // this lane's stage state, from the plug-in's dynamics (rk3_stage_chain's expressions, the reference's stage-state quirk included:
+                            // integrators.cuh:182,190-191)
+                            PDDP_UNROLL for (int i = 0; i < NX; i++) xm[i] = x[i];
+                            if (stage >= 1) {
+                                P::dynamics_eval(q1, x, u);
+                                if (stage == 1) {
+                                    PDDP_UNROLL for (int i = 0; i < NP; i++) { xm[i] = x[i] + T(0.5) * dt * x[i + NP]; xm[i + NP] = x[i] + T(0.5) * dt * q1[i]; }
+                                } else {
+                                    T x1[NX];
+                                    PDDP_UNROLL for (int i = 0; i < NP; i++) { x1[i] = x[i] + T(0.5) * dt * x[i + NP]; x1[i + NP] = x[i] + T(0.5) * dt * q1[i]; }
+                                    P::dynamics_eval(q2, x1, u);
+                                    PDDP_UNROLL for (int i = 0; i < NP; i++) {
+                                        const T v1 = x1[i + NP];
+                                        xm[i + NP] = x[i] + dt * q1[i] + T(2) * dt * q2[i];
+                                        xm[i] = x[i] + dt * x[i + NP] + T(2) * dt * v1;
+                                    }
+                                }
+                            }
+                            P::gradient_eval(dd, q3, xm, u);
+                            stage_to_lds(stage, dd);
+                        } else {
+                            P::gradient_eval(dd, q1, x, u);
+                            stage_to_lds(0, dd);
+                            PDDP_UNROLL for (int i = 0; i < NP; i++) { xm[i] = x[i] + T(0.5) * dt * x[i + NP]; xm[i + NP] = x[i] + T(0.5) * dt * q1[i]; }
+                            P::gradient_eval(dd, q2, xm, u);
+                            stage_to_lds(1, dd);
+                            PDDP_UNROLL for (int i = 0; i < NP; i++) {                                  // xm2 from xm1's velocity half BEFORE it is overwritten (rk3_stage_chain)
+                                const T v1 = xm[i + NP];
+                                xm[i + NP] = x[i] + dt * q1[i] + T(2) * dt * q2[i];
+                                xm[i] = x[i] + dt * x[i + NP] + T(2) * dt * v1;
+                            }
+                            P::gradient_eval(dd, q3, xm, u);
+                            stage_to_lds(2, dd);
+                        }
                     }
                 }
             }
@@ -540,6 +701,11 @@ __global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeight
     wsync();
     // ---- phase 2: 16 lanes = knot, lane = column ----
     const int grp = lane >> 4, ky = lane & 15;
+    const int c2 = ky < NP ? ky : (ky < NX ? ky - NP : ky);
+    // where this lane's two columns of dqdd sit among the staged ones (-1: a column that is identically zero)
+    int ci_ky = -1, ci_c2 = -1;
+    PDDP_UNROLL for (int c = 0; c < NM; c++) { if (GC::live(c)) { if (ky == c) ci_ky = GC::index(c); if (c2 == c) ci_c2 = GC::index(c); } }
+    const int ri_ky = (ci_ky < 0 ? 0 : ci_ky) * NP, ri_c2 = (ci_c2 < 0 ? 0 : ci_c2) * NP;
     for (int rnd = 0; rnd < KB / 4; rnd++) {
         const int j = rnd * 4 + grp, inst = blockIdx.x * KB + j;
         if (inst >= total || ky >= NM) continue;
@@ -549,22 +715,24 @@ __global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeight
         if constexpr (!P::kPluginCost) {
             if (mode == 1) {                                                            // the constant Hessian: written when the problem is loaded (nis_knot, nis.hpp)
                 T* Hk = b.H + ((size_t)pb * N + k) * NM * NM + (size_t)ky * NM;
-                PDDP_UNROLL for (int i = 0; i < NM; i++) Hk[i] = (i == ky) ? P::weight(cw, i, k, N) : T(0);
+                T hv[NM];
+                PDDP_UNROLL for (int i = 0; i < NM; i++) hv[i] = (i == ky) ? P::weight(cw, i, k, N) : T(0);
+                cf_store_vec<T, NM>(Hk, hv);
             }
         }
         if (k >= N - 1) continue;
         const T hdt = T(0.5) * dt, dt2 = T(2) * dt;
         T d1c[NP], T1[NX], T2[NX];
-        PDDP_UNROLL for (int r = 0; r < NP; r++) d1c[r] = lds.d[0][ky * NP + r][j];
-        const int c2 = ky < NP ? ky : (ky < NX ? ky - NP : ky);
+        PDDP_UNROLL for (int r = 0; r < NP; r++) { const T v = lds.d[ri_ky + r][0][j]; d1c[r] = ci_ky < 0 ? T(0) : v; }
         const T lead = ky < NP ? (hdt * T(0) + T(1)) : (hdt * T(1) + T(0));
         T f[NP];
         PDDP_UNROLL for (int i = 0; i < NP; i++) f[i] = hdt * d1c[i] + T(ky == i + NP ? 1 : 0);
         PDDP_UNROLL for (int kx = 0; kx < NP; kx++) T1[kx] = T(1) * (hdt * d1c[kx] + T(ky == kx + NP ? 1 : 0)) + T(0);
         PDDP_UNROLL for (int r = 0; r < NP; r++) {
-            const T sel = lds.d[1][c2 * NP + r][j];
+            const T selv = lds.d[ri_c2 + r][1][j];
+            const T sel = ci_c2 < 0 ? T(0) : selv;
             T val = ky < NX ? sel * lead : T(0);
-            PDDP_UNROLL for (int i = 0; i < NP; i++) val += lds.d[1][(i + NP) * NP + r][j] * f[i];
+            PDDP_UNROLL for (int i = 0; i < NP; i++) { if (GC::live(i + NP)) val += lds.d[GC::index(i + NP) * NP + r][1][j] * f[i]; }      // (a zero column adds an exact zero)
             T1[r + NP] = val + (ky < NX ? T(0) : sel);
         }
         T gq[NX];
@@ -573,14 +741,17 @@ __global__ __launch_bounds__(64) void k_nis_kb(Buffers<T> b, Dims dm, CostWeight
         PDDP_UNROLL for (int kx = 0; kx < NP; kx++) T2[kx] = T(1) * (dt2 * T1[kx + NP] - dt * d1c[kx] + T(ky == kx + NP ? 1 : 0)) + T(0);
         PDDP_UNROLL for (int r = 0; r < NP; r++) {
             T val = 0;
-            PDDP_UNROLL for (int i = 0; i < NX; i++) val += lds.d[2][i * NP + r][j] * gq[i];
-            T2[r + NP] = val + (ky < NX ? T(0) : lds.d[2][ky * NP + r][j]);
+            PDDP_UNROLL for (int i = 0; i < NX; i++) { if (GC::live(i)) val += lds.d[GC::index(i) * NP + r][2][j] * gq[i]; }
+            const T own = lds.d[ri_ky + r][2][j];
+            T2[r + NP] = val + (ky < NX ? T(0) : (ci_ky < 0 ? T(0) : own));
         }
         T* ABc = b.AB + ((size_t)pb * N + k) * NX * NM + (size_t)ky * NX;
+        T abv[NX];
         PDDP_UNROLL for (int kx = 0; kx < NX; kx++) {
             const T dx = kx < NP ? T(kx + NP == ky ? 1 : 0) : d1c[kx - NP];
-            ABc[kx] = (dt / T(6)) * dx + (dt2 / T(3)) * T1[kx] + (dt / T(6)) * T2[kx] + T(kx == ky ? 1 : 0);
+            abv[kx] = (dt / T(6)) * dx + (dt2 / T(3)) * T1[kx] + (dt / T(6)) * T2[kx] + T(kx == ky ? 1 : 0);
         }
+        cf_store_vec<T, NX>(ABc, abv);                                       // this lane's column: 16-byte pieces; a knot's 16 lanes fill one contiguous run
     }
 }
 
@@ -651,7 +822,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 #endif
 template <typename P, typename T, bool DIAGH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? PDDP_MQ_WAVES : 3, sizeof(T) == 4 ? PDDP_MQ_WAVES : 3))) void k_bp_mq(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch) {
-    __shared__ T lds[kMqLds];
+    __shared__ __attribute__((aligned(16))) T lds[kMqLds];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
     if (dm.M > 1) mq_bp_block<P, T, true, DIAGH>(lds, b, dm, cw, inst / dm.M, inst % dm.M);

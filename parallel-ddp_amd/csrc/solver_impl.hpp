@@ -22,7 +22,7 @@ static const char* ksel_ab(const pddp_config& c) { return ksel(c.kernels.ab, {"f
 static const char* ksel_cf(const pddp_config& c) { return ksel(c.kernels.cf, {"ts", "coop"}); }
 static const char* ksel_cf_bp(const pddp_config& c) { return ksel(c.kernels.cf_bp, {"ts", "coop", "gl", "gl32", "cl", "mq"}); }
 static const char* ksel_cf_fp(const pddp_config& c) { return ksel(c.kernels.cf_fp, {"ts", "coop", "cf"}); }
-static const char* ksel_cf_nis(const pddp_config& c) { return ksel(c.kernels.cf_nis, {"ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64"}); }
+static const char* ksel_cf_nis(const pddp_config& c) { return ksel(c.kernels.cf_nis, {"ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64", "kb20"}); }
 template <typename T> static void fill_model(ArmModel<T>& m, const pddp_config& c) {
     const int v = c.wafr_urdf ? 1 : 0;
     for (int b = 0; b < 7; b++) {
@@ -154,6 +154,7 @@ struct Solver : SolverBase {
     // ... and BEGINS with the linear forward sweep: the segment maps the backward pass composed are applied in the rollout kernel's prologue (a problem's M x A lanes sit in
     // one wavefront, 14 of them walk the maps) instead of by a k_sweep_maps launch in front of it -- one more kernel boundary of the ~115 us iteration gone.
     // kernels.sweep = maps keeps the separate kernel (A/B, tests); so do the phase hooks and the per-phase / per-kernel timing, which launch the sweep on its own.
+    bool cf_records() const { return P::PLANT != 4 && cf_fp && cf_fp_staged; }      // production rollouts = k_sweep_cf + k_fp_cf (records in xw)
     bool maps_in_rollouts() const { return P::PLANT == 4 && sweep_fused && cfg.kernels.sweep == 0 && fp_split && !fp_two_wave && 64 % (cfg.M * cfg.A) == 0 && cfg.M * cfg.A >= 16; }
     hipGraphExec_t graph = nullptr;
     int graph_mode = -1;
@@ -225,7 +226,7 @@ struct Solver : SolverBase {
         cf_fp_staged = cf_fp && cf_fits && !ksel_cf(cfg);      // (cart-pole, 16384 problems: 0.73 -> 0.69 ms; quadrotor: 8.6 -> 5.1 ms)
         if (const char* v = ksel_cf_fp(cfg)) { if (std::string(v) == "cf") { cf_fp = P::PLANT != 4 && c.N <= kTsMaxN && c.M <= kTsMaxM; cf_fp_staged = cf_fp && cf_fits; } else cf_fp_staged = false; }
         kb_nis = (gl_nis && c.integrator == 3) ? 16 : 0;      // 16 knots per wavefront: 2.15 ms (32: 2.6, 64: 3.6; the 16-lane-group kernel 5.7-7.1) at 16384 quadrotor problems -- LDS per block sets the occupancy
-        if (const char* v = ksel_cf_nis(cfg)) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
+        if (const char* v = ksel_cf_nis(cfg)) { const std::string m(v); kb_nis = (P::PLANT != 4 && P::NX + P::NU <= 16 && c.integrator == 3) ? (m == "kb16" ? 16 : m == "kb20" ? 20 : m == "kb32" ? 32 : m == "kb64" ? 64 : 0) : 0; if (kb_nis) { gl_nis = true; cf_nis = false; } }
         if (const char* v = ksel_cf_bp(cfg)) {
             const std::string m(v);
             const bool col = (m == "cl" || m == "mq") && P::NX == 12 && P::NU == 4;
@@ -366,19 +367,29 @@ struct Solver : SolverBase {
         bool lane_groups = false;
         if constexpr (P::PLANT == 4) lane_groups = !fp_coop && !(init_rollout && (cfg.use_limits || cfg.use_smooth_abs));       // PDDP_FP=coop: the wave-cooperative forward pass / setup kernels (comparison tests); the initial rollout of a thread-lane handle with USE_LIMITS_FLAG too
         if (!lane_groups) {
-            if (part == 0) return;
             bool serial = false, records_ran = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
                 const bool records = cf_fp && cf_fp_staged && !init_rollout && part != 2 && !store_candidates;      // (the phase hook wants the reference's candidate-major arrays: k_fp_ts, then k_cand_to_xw)
                 if (records) cand_stale = true;
+                // two launches: the linear sweep (segment start states -> the candidates' records), then the rollouts (kernels.hpp fp_cf_body); part 0 / 1 = only the one / the other
                 if constexpr (P::kScalarPlugin && (64 / 16) * P::NX <= 64) {
-                    if (records && cfg.A == 16) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; records_ran = true; }
+                    if (records && cfg.A == 16) {
+                        if (part != 1 && cfg.M > 1) hipLaunchKernelGGL((k_sweep_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B);
+                        if (part != 0) hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B);
+                        return;
+                    }
                 }
                 if constexpr (P::kScalarPlugin && (64 / 8) * P::NX <= 64) {
-                    if (!serial && records && cfg.A == 8) { hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B); serial = true; records_ran = true; }
+                    if (records && cfg.A == 8) {
+                        if (part != 1 && cfg.M > 1) hipLaunchKernelGGL((k_sweep_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B);
+                        if (part != 0) hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B);
+                        return;
+                    }
                 }
+                if (part == 0) return;                                  // (the paths below sweep inside their rollout kernel)
                 if (!serial && cf_fp && !init_rollout) { hipLaunchKernelGGL((k_fp_ts<P, INTEG, T>), dim3((B * cfg.A + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, (int)B, part == 2 ? 1 : 0); serial = true; }
             }
+            if (part == 0) return;
             if (!serial) hipLaunchKernelGGL((k_fp<P, INTEG, T>), dim3(init_rollout ? 1 : cfg.A, B), dim3(64 * cfg.M), fp_lds, s, b, dm, cw, dt, init_rollout ? 1 : (part == 2 ? 2 : 0));
             if constexpr (P::PLANT != 4) { if (b.xw && !records_ran && !init_rollout) hipLaunchKernelGGL((k_cand_to_xw<P, T>), dim3((unsigned)(((size_t)B * cfg.N * cfg.A + 255) / 256)), dim3(256), 0, s, b, dm, (int)B); }
             return;
@@ -452,6 +463,7 @@ struct Solver : SolverBase {
             if (gl_nis && kb_nis) {
                 const int units = (int)(B * cfg.N);
                 if (kb_nis == 16) hipLaunchKernelGGL((k_nis_kb<P, T, 16>), dim3((units + 15) / 16), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
+                else if (kb_nis == 20) hipLaunchKernelGGL((k_nis_kb<P, T, 20>), dim3((units + 19) / 20), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
                 else if (kb_nis == 64 && sizeof(T) == 4) hipLaunchKernelGGL((k_nis_kb<P, T, sizeof(T) == 4 ? 64 : 16>), dim3((units + 63) / 64), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
                 else hipLaunchKernelGGL((k_nis_kb<P, T, 32>), dim3((units + 31) / 32), dim3(64), 0, s, b, dm, cw, dt, mode, (int)B);
                 return;
@@ -508,7 +520,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp && mq_bp) ? "k_bp_mq" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1 && !maps_in_rollouts()) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
+                             (lg && cfg.M > 1 && !maps_in_rollouts()) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : (cf_records() && cfg.M > 1) ? "k_sweep_cf" : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS};
         const int part_of[6] = {-1, 0, maps_in_rollouts() ? -1 : 1, -1, 0, 1};      // (a rollout kernel that begins with the sweep is timed as it runs in production)
         HIPCHK(hipStreamSynchronize(stream));

@@ -14,7 +14,7 @@ class PddpError(RuntimeError):
 
 # pddp_kernel_selection (include/pddp.h): value names per field, in the order of the header (index + 1 = the C value; 0 / None = the library's choice)
 KERNEL_NAMES = {"bp": ("mx", "lg", "coop", "wide"), "fp": ("tl", "lg", "coop", "tl2", "tl4"), "sweep": ("alpha", "st", "wg", "maps"), "ls": ("many", "wg"), "ab": ("full",),
-                "cf": ("ts", "coop"), "cf_bp": ("ts", "coop", "gl", "gl32", "cl", "mq"), "cf_fp": ("ts", "coop", "cf"), "cf_nis": ("ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64")}
+                "cf": ("ts", "coop"), "cf_bp": ("ts", "coop", "gl", "gl32", "cl", "mq"), "cf_fp": ("ts", "coop", "cf"), "cf_nis": ("ts", "coop", "gl", "gl8", "kb16", "kb32", "kb64", "kb20")}
 
 
 class PddpKernelSelection(C.Structure):
@@ -100,6 +100,24 @@ def algorithmic_bytes_per_kernel(n, m, N, A, M, s):
 
 def library_path():
     return os.path.join(os.path.dirname(_HERE), "lib", "libpddp.so")
+
+
+def build_id(lib_path=None):
+    """What a set of profile counters has to be bound to (VERDICT r5 task 7): `sources` = sha256 over the library's device / host sources (csrc/*.hip, csrc/*.hpp,
+    include/pddp.h, the Makefile's flags) in the tree this module runs from, `library` = sha256 of the shared object itself.  tools/make_traffic_json.py and
+    tools/make_rows_traffic.py store both next to the counters; bench.py attaches counter traffic to a run only when `sources` matches the tree it is running from."""
+    import glob
+    import hashlib
+    pkg = os.path.dirname(_HERE)
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.hpp")) + glob.glob(os.path.join(pkg, "csrc", "*.h")))
+    files += [os.path.join(os.path.dirname(pkg), "include", "pddp.h"), os.path.join(pkg, "Makefile")]
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(b"\0")
+        h.update(open(f, "rb").read())
+    path = lib_path or library_path()
+    lib = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None
+    return {"sources": h.hexdigest()[:16], "library": lib}
 
 
 _LIBS = {}

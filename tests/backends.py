@@ -16,7 +16,10 @@ HOSTSIM = os.path.join(ROOT, "tests", "hostsim", "libpddp_hostsim.so")
 
 
 def hostsim_path():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "-s"])
+    if os.environ.get("PDDP_HOSTSIM_SAN") == "1":          # the AddressSanitizer / UBSan build of the test tool (tools/sanitizers.sh; the suite then runs with libasan preloaded)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "-s", "-j8", "SAN=1"])
+        return os.path.join(ROOT, "tests", "hostsim", "libpddp_hostsim_san.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "-s", "-j8"])
     return HOSTSIM
 
 

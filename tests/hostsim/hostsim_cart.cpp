@@ -1,0 +1,4 @@
+// TEST TOOL -- NOT PRODUCT CODE.  libpddp_hostsim.so: the host emulation of plant `cart` (hostsim_impl.hpp).
+#include "hostsim_impl.hpp"
+
+Base* hostsim_make_cart(const pddp_config& c) { return mk_plant<CartPlant>(c); }

@@ -34,9 +34,12 @@ class OraResult(C.Structure):
 
 
 def build(force=False, variant="strict"):
-    so = os.path.join(ORACLE_DIR, "liboracle.so" if variant == "strict" else "liboracle_fma.so")
+    # PDDP_ORACLE_SAN=1: the strict oracle from its AddressSanitizer / UBSan build (make -C oracle SAN=1 -> liboracle_san.so; the suite then runs with libasan preloaded:
+    # tools/sanitizers.sh, profiles/r06_sanitizers.log)
+    san = variant == "strict" and os.environ.get("PDDP_ORACLE_SAN") == "1"
+    so = os.path.join(ORACLE_DIR, "liboracle_san.so" if san else "liboracle.so" if variant == "strict" else "liboracle_fma.so")
     if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "all"])
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "all"] + (["SAN=1"] if san else []))
     return so
 
 

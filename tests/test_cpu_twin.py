@@ -12,7 +12,7 @@ import pyddp
 from oracle_binding import Oracle, default_cfg, example_inputs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "parallel-ddp_amd", "lib", "libpddp_cpu.so")
+LIB = os.environ.get("PDDP_CPU_LIB") or os.path.join(ROOT, "parallel-ddp_amd", "lib", "libpddp_cpu.so")      # (PDDP_CPU_LIB: the ThreadSanitizer build, tools/sanitizers.sh)
 
 
 class CpuBuffers(C.Structure):

@@ -10,6 +10,12 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _build_hostsim_once():
+    """the ranks load the host emulation through backends.hostsim_path(), which runs make: bring the library up to date HERE, before several ranks race to rebuild it"""
+    from backends import hostsim_path
+    hostsim_path()
+
 WORKER = r'''
 import os, sys, json
 import numpy as np
@@ -49,6 +55,7 @@ shard.finalize(ctx)
 def test_world_size_2_gloo_matches_single_process(tmp_path):
     out = tmp_path / "res.json"
     script = tmp_path / "worker.py"
+    _build_hostsim_once()
     script.write_text(WORKER % dict(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -115,6 +122,7 @@ shard.finalize(ctx)
 def test_world_size_4_gloo_uneven_batch_is_rejected_and_an_even_one_gathers_in_global_order(tmp_path):
     out = tmp_path / "res4.json"
     script = tmp_path / "worker4.py"
+    _build_hostsim_once()
     script.write_text(WORKER4 % dict(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
@@ -124,6 +132,66 @@ def test_world_size_4_gloo_uneven_batch_is_rejected_and_an_even_one_gathers_in_g
     costs = np.asarray(res["costs"])
     assert costs.shape == (8, 2) and res["best"][0] == int(np.argmin(costs[:, 1]))
     assert len(set(np.round(costs[:, 0], 3))) == 8              # eight different problems, each reported once
+
+
+WORKER8 = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, os.path.join(%(root)r, "parallel-ddp_amd")); sys.path.insert(0, %(root)r)
+import pyddp, bench
+from pyddp import shard
+from backends import hostsim_path
+ctx = shard.init_from_env(8, backend="gloo")
+assert ctx.world == 8
+kw = %(kw)r
+total, N = 64, kw["N"]
+x_all, u_all, g_all = bench.ee_inputs(N, np.random.default_rng(77), total)          # bench.py --workload config3: the 64 rollouts of BASELINE configs[3]
+path = hostsim_path()
+mk = lambda batch: pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=batch, **kw), _lib_path=path)
+mine = shard.owned_problems(total, ctx.rank, 8)
+assert mine == list(range(ctx.rank, total, 8)) and len(mine) == 8
+res = shard.solve_sharded(ctx, mk, list(x_all), list(u_all), list(g_all), poll_every=2)
+sl = mk(8)
+sl.load(x_all[mine], u_all[mine], g_all[mine])
+sl.iterate(1); sl.sync()
+table = shard.allgather_cost_table(ctx, sl.get("J"), 8, kw["A"])
+assert table.shape == (total, kw["A"]) and np.array_equal(table[ctx.rank::8], sl.get("J").reshape(-1, kw["A"]).astype(np.float64))
+if ctx.rank == 0:
+    json.dump(dict(costs=res["costs"].tolist(), best=res["best"], sweeps=res["sweeps"], table=table.tolist()), open(sys.argv[1], "w"))
+shard.finalize(ctx)
+'''
+
+
+def test_world_size_8_gloo_the_split_of_baseline_config3(tmp_path):
+    """BASELINE configs[3] as the first 8-GPU run will shard it (bench.py --workload config3 --gpus 8; VERDICT r5 task 9): 64 Kuka MPC rollouts with the end-effector cost,
+    rank g owns {r : r % 8 == g}, 8 per rank, no data-path collective; the exit poll (all-reduce), the cost all-gather and the per-iteration [64 x A] cost table in GLOBAL problem
+    order -- eight gloo processes on the CPU (the per-rank solver is the host emulation of the kernels) against ONE process solving all 64."""
+    kw = dict(N=32, M=4, A=4, ee_cost=1, wafr_urdf=1, mpc_mode=1, tol_cost=1e-5, total_time=0.5, ignore_max_rho_exit=0, max_iter=4)      # (a shorter horizon and fewer step sizes than the bench: eight emulated ranks share this machine's cores)
+    out = tmp_path / "res8.json"
+    script = tmp_path / "worker8.py"
+    _build_hostsim_once()
+    script.write_text(WORKER8 % dict(root=ROOT, kw=kw))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                           "--master-port", "29618", str(script), str(out)], env=env, timeout=1500)
+    import json
+    res = json.load(open(out))
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    import bench
+    import pyddp
+    from backends import hostsim_path
+    x_all, u_all, g_all = bench.ee_inputs(kw["N"], np.random.default_rng(77), 64)
+    path = hostsim_path()
+    s = pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=64, **kw), _lib_path=path)
+    one = s.solve(x_all, u_all, g_all)
+    J0 = one["Jout"][:, 0]; Jf = one["Jout"][np.arange(64), one["iters"]]
+    costs = np.asarray(res["costs"])
+    assert costs.shape == (64, 2)
+    assert np.array_equal(costs[:, 0].astype(np.float32), J0) and np.array_equal(costs[:, 1].astype(np.float32), Jf)       # global problem order, bit for bit the single-process batch
+    assert res["best"][0] == int(np.argmin(Jf)) and res["sweeps"] % 2 == 0
+    s2 = pyddp.Solver(pyddp.default_config(4, _lib_path=path, batch=64, **kw), _lib_path=path)
+    s2.load(x_all, u_all, g_all); s2.iterate(1); s2.sync()
+    assert np.array_equal(np.asarray(res["table"]), s2.get("J").reshape(64, kw["A"]).astype(np.float64))
 
 
 @pytest.mark.gpu

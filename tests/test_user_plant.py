@@ -27,9 +27,18 @@ def build_user(extra=""):
 
 
 def build_hostsim_variant(defs, out):
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f'-DPDDP_USER_PLANT_HEADER="{POLICY}"', "-I" + os.path.join(PKG, "csrc")] + defs + \
-          ["-o", out, os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")]
-    subprocess.check_call(cmd)
+    # (the host emulation is one translation unit per plant since round 6: tests/hostsim/hostsim_*.cpp; the arm's double half is hostsim_arm.cpp compiled a second time)
+    hs = os.path.join(ROOT, "tests", "hostsim")
+    flags = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas", f'-DPDDP_USER_PLANT_HEADER="{POLICY}"', "-I" + os.path.join(PKG, "csrc")] + defs
+    objdir = out + ".objs"
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for unit, extra in (("hostsim", []), ("hostsim_pend", []), ("hostsim_cart", []), ("hostsim_quad", []), ("hostsim_arm", []), ("hostsim_arm", ["-DPDDP_HOSTSIM_ARM_HALF=1"]), ("hostsim_user", [])):
+        obj = os.path.join(objdir, unit + ("64" if extra else "") + ".o")
+        objs.append(obj)
+        procs.append(subprocess.Popen(["g++"] + flags + extra + ["-c", "-o", obj, os.path.join(hs, unit + ".cpp")]))
+    assert all(p_.wait() == 0 for p_ in procs)
+    subprocess.check_call(["g++", "-shared", "-o", out] + objs)
     return out
 
 

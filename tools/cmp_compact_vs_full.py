@@ -7,7 +7,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, pyddp
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tests'))
-import backends as _backends; _backends.install_env_selection()      # PDDP_BP / PDDP_FP / ... -> pddp_config.kernels (the library reads no environment)
+import sys as _s, os as _o; _s.path.insert(0, _o.path.dirname(_o.path.abspath(__file__))); import _sel; _sel.install()      # PDDP_BP / PDDP_FP / ... on this tool's command line -> pddp_config.kernels (tools/_sel.py; the library reads no environment)
 from oracle_binding import example_inputs
 SHAPES = [(32, 4), (32, 1), (64, 4), (128, 1), (128, 8), (256, 4), (128, 4)]
 def run(lib, env, batch, N, M, iters):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two checks of a handle's phase kernels on fixed inputs:
   * repeat every phase and compare the outputs bit for bit between repetitions (races);
-  * run every phase again with each compute unit's LDS filled with NaNs beforehand (PDDP_POISON_LDS, pddp_api.hip run_phase) and compare with the clean
+  * run every phase again with each compute unit's LDS filled with NaNs beforehand (PDDP_POISON_LDS, solver_impl.hpp run_phase) and compare with the clean
     run: a kernel that reads LDS it has not written itself shows up as NaNs or changed values (what is in LDS when a kernel starts belongs to whichever
     kernel ran on that compute unit before -- results that depend on it differ from process to process).
 usage: tools/determinism_check.py [reps] [batch] [ee|joint|cart|quad]   (env PDDP_BP / PDDP_FP / PDDP_CF_* select the kernel family; COLD=1: no warm-up sweeps)"""
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import pyddp
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tests'))
-import backends as _backends; _backends.install_env_selection()      # PDDP_BP / PDDP_FP / ... -> pddp_config.kernels (the library reads no environment)
+import sys as _s, os as _o; _s.path.insert(0, _o.path.dirname(_o.path.abspath(__file__))); import _sel; _sel.install()      # PDDP_BP / PDDP_FP / ... on this tool's command line -> pddp_config.kernels (tools/_sel.py; the library reads no environment)
 from backends import make_solver
 from oracle_binding import example_inputs
 from test_fp32_bar import EE_KW, KUKA, ee_start

@@ -4,9 +4,9 @@ import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "parallel-ddp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
-import backends as _backends; _backends.install_env_selection()
+import sys as _s, os as _o; _s.path.insert(0, _o.path.dirname(_o.path.abspath(__file__))); import _sel; _sel.install()      # PDDP_BP / PDDP_FP / ... on this tool's command line -> pddp_config.kernels (tools/_sel.py; the library reads no environment)
 import test_fp32_bar as t
-env = {"PDDP_BP": "mx", "PDDP_FP": "tl"} if len(sys.argv) > 1 and sys.argv[1] == "large" else {}
+env = dict(bp="mx", fp="tl") if len(sys.argv) > 1 and sys.argv[1] == "large" else {}
 rows, fails, ints_ok, names = t.run_bar_ee("hip", dict(t.EE_KW), env, 10, True)
 print("kernels", list(names), "ints_ok", ints_ok, "rows", len(rows), "fails", len(fails))
 c = collections.Counter((it, ph.split("[")[0], nm, "nan" if np.isnan(ek) else "num") for it, ph, nm, ek, eo, ok in fails)

@@ -6,7 +6,7 @@ asm = "/tmp/isa/pddp.s"
 os.makedirs("/tmp/isa", exist_ok=True)
 if "--no-build" not in sys.argv:
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value",
-                    "--cuda-device-only", "-S", "-o", asm, "csrc/pddp_api.hip"], cwd=pkg, capture_output=True)
+                    "--cuda-device-only", "-S", "-o", asm, "csrc/pddp_plant_" + (sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("pend", "cart", "quad", "arm") else "arm") + ".hip"], cwd=pkg, capture_output=True)
 pat = re.compile(sys.argv[1])
 lines = open(asm).read().splitlines()
 starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN4pddp\S*:", l)]

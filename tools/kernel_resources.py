@@ -4,7 +4,7 @@ usage: tools/kernel_resources.py [regex on the demangled-ish name]"""
 import os, re, subprocess, sys
 pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parallel-ddp_amd")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result", "-Wno-unused-value",
-       "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", "csrc/pddp_api.hip"]
+       "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", "csrc/pddp_plant_" + (sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("pend", "cart", "quad", "arm") else "arm") + ".hip"]
 out = subprocess.run(cmd, cwd=pkg, capture_output=True, text=True).stderr
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
 cur = {}

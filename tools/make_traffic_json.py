@@ -3,7 +3,7 @@
 usage: tools/make_traffic_json.py <tag> <profiles subdir> <batch> [handle options: "library defaults" | "lean"]
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the factor 2 on FETCH_SIZE is the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md "HBM": rocprofv3 tallies 128-byte read requests as 64 bytes)."""
-import collections, csv, glob, json, os, statistics, sys
+import collections, csv, glob, json, os, statistics, subprocess, sys
 tag, sub, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
 handle_options = sys.argv[4] if len(sys.argv) > 4 else "library defaults"     # "lean" for passes taken with bench.py --lean-ctg
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,21 @@ for f in sorted(glob.glob(src + "/*/run_counter_collection.csv")):
             d[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kern = sorted({k for k, _ in d})
 m = lambda k, c: statistics.mean(d[(k, c)]) if (k, c) in d else None
-out = {"batch": batch, "handle_options": handle_options, "source": f"profiles/{sub} (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of `python bench.py --no-cpu-baseline --no-latency --no-convergence --no-lean-row --steps 20`)", "kernels": {}}
+# the build these counters belong to: the pass writes the identity of the tree / library it profiled on the GPU box (tools/pmc_pass.sh -> build_id.json); it is stored
+# here together with the commit the working tree stood at, and bench.py attaches the traffic to a run only when the sources of the tree it runs from are the same
+sys.path.insert(0, os.path.join(root, "parallel-ddp_amd"))
+import pyddp  # noqa: E402
+bid_file = os.path.join(src, "build_id.json")
+build = json.load(open(bid_file)) if os.path.exists(bid_file) else pyddp.build_id()
+here = pyddp.build_id()
+if build.get("sources") != here["sources"]:
+    print(f"WARNING: the counters were taken on sources {build.get('sources')}, this tree is {here['sources']}: bench.py will report them as stale", file=sys.stderr)
+try:
+    build["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    build["git_dirty"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "parallel-ddp_amd/csrc", "include", "parallel-ddp_amd/Makefile"], text=True).strip())
+except Exception:      # noqa: BLE001
+    build["git_head"] = None
+out = {"batch": batch, "handle_options": handle_options, "build": build, "source": f"profiles/{sub} (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of `python bench.py --no-cpu-baseline --no-latency --no-convergence --no-lean-row --steps 20`)", "kernels": {}}
 lines = ["# Counter passes (rocprofv3 --pmc, kernel-trace only) of the bench sweep, per kernel, averages per launch", "",
          "| kernel | HBM read MB (2 x FETCH_SIZE) | HBM write MB | VALU instr / wave | MFMA instr / wave | VALU-active share of wave time | waiting on memory (s_waitcnt) | issue stalls | MFMA pipe busy share |",
          "|---|---|---|---|---|---|---|---|---|"]

@@ -5,6 +5,7 @@ TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() { d=$1; shift; timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc "$@" -d $OUT/$d -o run -- python $ROOT/bench.py --no-cpu-baseline --no-latency --no-convergence --no-lean-row --steps 20 $BARGS > $OUT/$d.log 2>&1; }
 BARGS="$*"
+python -c "import sys, json; sys.path.insert(0, '$ROOT/parallel-ddp_amd'); import pyddp; json.dump(pyddp.build_id(), open('$OUT/build_id.json', 'w'))"      # what the counters belong to
 run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 run b SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM
 run c FETCH_SIZE

@@ -4,6 +4,7 @@
 # -> gpurun_out/rows_<tag>/{kernel_stats.csv, counters.txt, rows.json}
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/rows_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+python -c "import sys, json; sys.path.insert(0, '$ROOT/parallel-ddp_amd'); import pyddp; json.dump(pyddp.build_id(), open('$OUT/build_id.json', 'w'))"      # what the counters belong to
 timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python $ROOT/bench.py --rows > $OUT/rows.log 2>&1
 cp $OUT/trace/run_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null; rm -rf $OUT/trace
 grep "^{" $OUT/rows.log | tail -1 > $OUT/rows.json

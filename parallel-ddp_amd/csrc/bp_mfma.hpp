@@ -308,6 +308,42 @@ __device__ __forceinline__ void mx_gj_pivot(T& R0, T& R1, int g, int c4, int g64
     R1 = (g == go && (PV & 1)) ? q : n1;
 }
 
+// Gauss-Jordan on [Huu | I] with one COLUMN per lane (PDDP_MX_GJ == 4): C[a] = entry (a, this lane's column); the pivot column sits in lane mx_pi(pv) of lane group 0.
+template <typename T, int NUc, int PV>
+__device__ __forceinline__ void mx_gj_column_pivot(T (&C)[NUc]) {
+    using X = Mx<T>;
+    T s[NUc];
+#pragma unroll
+    for (int a = 0; a < NUc; a++) s[a] = X::readlane(C[a], mx_pi<T>(PV));
+    const T rp = X::recip(s[PV]);
+    const T q = C[PV] * rp;
+#pragma unroll
+    for (int a = 0; a < NUc; a++) C[a] = (a == PV) ? q : X::fma(-s[a], q, C[a]);
+}
+// the same pivot with the pivot column taken through DPP row broadcasts (PDDP_MX_GJ == 5): every 16-lane row holds a complete copy of the columns, so lane mx_pi(pv) OF THE
+// LANE'S OWN ROW has the pivot column -- the pivot by one broadcast move, the six updates as v_fmac_f32_dpp with the broadcast folded in; no v_readlane, no scalar hazards
+template <typename T, int NUc, int PV>
+__device__ __forceinline__ void mx_gj_column_pivot_dpp(T (&C)[NUc]) {
+    using X = Mx<T>;
+    const T piv = X::template row_bcast<mx_pi<T>(PV)>(C[PV]);
+    const T rp = X::recip(piv);
+    const T q = C[PV] * rp;
+#pragma unroll
+    for (int a = 0; a < NUc; a++) { if (a != PV) C[a] = X::template fnma_row_bcast<mx_pi<T>(PV)>(C[a], q); }
+    C[PV] = q;
+}
+template <typename T, int NUc>
+__device__ __forceinline__ void mx_gj_columns(T (&C)[NUc]) {
+    static_assert(NUc == 7, "the arm's seven controls");
+    if constexpr (PDDP_MX_GJ == 5) {
+        mx_gj_column_pivot_dpp<T, NUc, 0>(C); mx_gj_column_pivot_dpp<T, NUc, 1>(C); mx_gj_column_pivot_dpp<T, NUc, 2>(C); mx_gj_column_pivot_dpp<T, NUc, 3>(C);
+        mx_gj_column_pivot_dpp<T, NUc, 4>(C); mx_gj_column_pivot_dpp<T, NUc, 5>(C); mx_gj_column_pivot_dpp<T, NUc, 6>(C);
+        return;
+    }
+    mx_gj_column_pivot<T, NUc, 0>(C); mx_gj_column_pivot<T, NUc, 1>(C); mx_gj_column_pivot<T, NUc, 2>(C); mx_gj_column_pivot<T, NUc, 3>(C);
+    mx_gj_column_pivot<T, NUc, 4>(C); mx_gj_column_pivot<T, NUc, 5>(C); mx_gj_column_pivot<T, NUc, 6>(C);
+}
+
 // the read-only operands of one knot as they come from memory
 template <typename T, bool FS, bool DIAGH>
 struct MxKnotIn {
@@ -714,10 +750,30 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             R0 = left ? Huu[0] : (e == u0 ? T(1) : T(0));
             R1 = left ? Huu[1] : ((e == u0 + 1 && u0 + 1 < NU) ? T(1) : T(0));
         }
+        if constexpr (PDDP_MX_GJ == 4 || PDDP_MX_GJ == 5) {
+            // Round 6: the same elimination with every lane holding a whole COLUMN of [Huu | I] (seven registers; the four lane groups carry identical copies).  Huu goes through
+            // the inverse's LDS area once (the tile's rows 2g, 2g + 1 -> rows of that area), a lane reads its column back, and a pivot is seven v_readlane of the pivot column
+            // (wave-uniform: they travel as scalar operands), one reciprocal, one multiply, six multiply-subtracts -- no LDS round trip per pivot.  Measured with the pivots'
+            // exchanges removed (profiles/r06_bp_mfma.md): the seven dependent ds_bpermute rounds are a quarter of the launch and of one problem's backward pass.  Per element
+            // the operations are the distributed form's: R[a] -= R[a][pv] * (R[pv] * (1 / R[pv][pv])), the pivot row becomes the scaled row -- the same bits.
+            if (cr < 2) { ldsI[wa] = Huu[0]; if (u0 + 1 < NU) ldsI[wa + 16] = Huu[1]; }
+            wsync();
+            T Cc[NU];
+#pragma unroll
+            for (int a = 0; a < NU; a++) { const T v = ldsI[a * 16 + c]; Cc[a] = (cr < 2) ? v : (e == a ? T(1) : T(0)); }
+            wsync();
+            mx_gj_columns<T, NU>(Cc);
+            if (g == 0 && cr >= 2 && e < NU) {
+#pragma unroll
+                for (int a = 0; a < NU; a++) ldsI[a * 16 + c - X::q_of(0, 2)] = Cc[a];      // column e of the inverse: entry (a, e) at [a * 16 + mx_pi(e)]
+            }
+            wsync();
+        } else {
         mx_gj_pivot<T, 0>(R0, R1, g, c4, g64); mx_gj_pivot<T, 1>(R0, R1, g, c4, g64); mx_gj_pivot<T, 2>(R0, R1, g, c4, g64); mx_gj_pivot<T, 3>(R0, R1, g, c4, g64);
         mx_gj_pivot<T, 4>(R0, R1, g, c4, g64); mx_gj_pivot<T, 5>(R0, R1, g, c4, g64); mx_gj_pivot<T, 6>(R0, R1, g, c4, g64);
         if (cr >= 2 && e < NU) { ldsI[wa - X::q_of(0, 2)] = R0; ldsI[wa + 16 - X::q_of(0, 2)] = R1; }   // identity column e sits two registers along: tile column mx_pi(e)
         wsync();
+        }
         mx4 InvT = zero;                                                                          // [b = 2g + r][a = control of this lane] = Huu^-1(a, b)
         if (cu) { InvT[0] = ldsI[ra]; InvT[1] = ldsI[ra + X::q_of(0, 1)]; }
         wsync();

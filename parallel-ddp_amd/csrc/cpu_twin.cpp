@@ -90,7 +90,9 @@ int run_cpu(const pddp_config& c, const pddp_cpu_buffers& B, T* x0, T* u0, const
         P::load_model(w, s.plant, &model);
         FpArgs<T> a{}; a.x = x; a.u = u; a.d = d; a.xcur = xp; a.ucur = up; a.dcur = dp; a.KT = KT; a.du = du; a.ApBK = ApBK; a.Bdu = Bdu; a.alpha = al; a.dt = dt;
         a.segx = segx.data(); a.dnorm = dnorm.data();
-        for (int b = 0; b < M; b++) for (int i = 0; i < NX; i++) segx[(size_t)NX * b + i] = x[(size_t)NX * b * dm.NB + i];   // the sweep left the start states in x
+        // the sweep left the start states of segments 1 .. M - 1 in x.  Segment 0 starts from the current trajectory (forward_sim_segment never reads segx[0..NX)) and its
+        // thread WRITES x[0..NX) while the others copy: reading knot 0 here was a data race (ThreadSanitizer, round 6: profiles/r06_sanitizers.log) -- on a value nobody used
+        for (int b = 1; b < M; b++) for (int i = 0; i < NX; i++) segx[(size_t)NX * b + i] = x[(size_t)NX * b * dm.NB + i];
         const int r = reps_of(tid, FSIM_T, M);
         for (int i = 0; i < r; i++) forward_sim_segment<P, INTEG, T>(w, s, dm, a, tid + i * FSIM_T, cw, xGoal, nullptr);
     };

@@ -368,6 +368,9 @@ __device__ __forceinline__ void cf_integrator_step(T* xn, const T* x, const T* u
         }
     }
 }
+#ifndef PDDP_SWEEPCF_PIN
+#define PDDP_SWEEPCF_PIN 1     // columns of the map whose reads may be in flight together in k_sweep_cf's product loop (1: every column's products pinned behind its reads)
+#endif
 // PART 0: the linear sweep alone (k_sweep_cf), PART 1: the rollouts alone (k_fp_cf).  Until round 5 one kernel ran both loops; the register allocation of the two together
 // is what kept it at two waves per SIMD -- asked for three or four, the compiler spilled inside the SWEEP loop (the rollout loop fits 128 registers) -- so they are two
 // launches now, each with its own occupancy; the sweep leaves the segments' start states in the candidates' records, where the rollouts read them as before.
@@ -440,7 +443,7 @@ __device__ __forceinline__ void fp_cf_body(FpCfStage<P, T, A>* stage, T (*goal_s
                     PDDP_UNROLL for (int q = 0; q < NX / W; q++) { const MV m = col[q]; PDDP_UNROLL for (int e = 0; e < W; e++) val[q * W + e] += m[e] * dxs; }
                     // (the sums are only used behind the next LDS stores, in another basic block: the optimiser SINKS all 288 operations there and leaves the reads here --
                     // an empty statement that "uses" the partial sums keeps every column's products next to its reads)
-                    PDDP_UNROLL for (int r = 0; r < NX; r++) asm volatile("" : "+v"(val[r]));
+                    if (i % PDDP_SWEEPCF_PIN == PDDP_SWEEPCF_PIN - 1) { PDDP_UNROLL for (int r = 0; r < NX; r++) asm volatile("" : "+v"(val[r])); }
                 } else {
                     PDDP_UNROLL for (int r = 0; r < NX; r++) val[r] += sc.sw.M[grp][r + NX * i] * dxs;
                 }

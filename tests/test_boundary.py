@@ -189,6 +189,18 @@ def test_reference_views_after_a_solve(dtype):
         assert np.abs(F[k].T - ref).max() <= tol * max(1.0, np.abs(ref).max()), k
         assert np.abs(Bd[k] - Bmat @ du[k]).max() <= tol * max(1.0, np.abs(Bmat @ du[k]).max()), k
     assert np.abs(F[: N - 1]).max() > 0.5
+    if dtype == np.float64:
+        # ... and against the ORACLE at the exit: the reference's d_ApBK / d_Bdu hold the LAST backward pass's computeFSVars output -- its loop breaks before
+        # nextIterationSetupGPU (DDPWrappers.cuh:104-113) -- which is what the oracle's stepped GPU-semantics loop recorded in its last iteration
+        from gpusem_steps import gpusem_iterations
+        from oracle_binding import Oracle, default_cfg
+        o = Oracle(default_cfg(4, cores=1, spawn_threads=0, N=N, M=M, A=A, wafr_urdf=1, tol_cost=0.0, total_time=0.5, max_iter=12), np.float64)
+        with np.errstate(all="ignore"):
+            last = list(gpusem_iterations(o, x0, u0, xg, 12))[-1]
+        assert last.iter == int(out["iters"][0])
+        cnt = (N - 1) * n * n
+        assert np.abs(F.ravel()[:cnt] - last.ApBK[:cnt]).max() <= 1e-8 * np.abs(last.ApBK[:cnt]).max()
+        assert np.abs(Bd.ravel()[: (N - 1) * n] - last.Bdu[: (N - 1) * n]).max() <= 1e-8 * max(np.abs(last.Bdu[: (N - 1) * n]).max(), 1e-300)
     s.refresh_reference_views()
     xs = s.get("xs").reshape(A, N, n); us = s.get("us").reshape(A, N, m); ds = s.get("ds").reshape(A, N, n)
     for a in range(A):

@@ -90,8 +90,8 @@ def design_bytes_per_problem(kernel, N, M, A, n, m, keep_ctg=True, elem=4):
     (bytes, accounting) or None for a kernel without a statement.  The ratio of the counter traffic to this figure is the kernel's wasted traffic (VERDICT r5 task 5)."""
     nm = n + m
     if kernel.startswith("k_bp_mfma"):
-        per_knot = (n // 2) * 2 * nm * elem + nm * elem + n * m * elem + m * elem + ((n * n + n) * elem if keep_ctg else 0)      # compact [A B] 588 + g 84 | K 392 + du 28 | [P | p] 840
-        return per_knot * (N - M), f"{per_knot} B per knot (compact [A B] {n // 2 * 2 * nm * elem} + g {nm * elem} read; K {n * m * elem} + du {m * elem}" + (f" + [P | p] {(n * n + n) * elem}" if keep_ctg else "") + f" written) x {N - M} knots"
+        per_knot = (n // 2) * nm * elem + nm * elem + n * m * elem + m * elem + ((n * n + n) * elem if keep_ctg else 0)      # compact [A B] 588 + g 84 | K 392 + du 28 | [P | p] 840
+        return per_knot * (N - M), f"{per_knot} B per knot (compact [A B] {n // 2 * nm * elem} + g {nm * elem} read; K {n * m * elem} + du {m * elem}" + (f" + [P | p] {(n * n + n) * elem}" if keep_ctg else "") + f" written) x {N - M} knots"
     if kernel.startswith("k_fp_tl"):
         rd = (N - 1) * (n * m + m + m) * elem + N * n * elem + A * (M - 1) * n * elem + n * elem      # gains, feed-forward, current controls (N - 1 knots), current states, the candidates' segment start states, goal
         wr = N * A * (nm + 1) * elem + 2 * A * M * elem + A * (M - 1) * n * elem                     # 22-float records of every candidate and knot, partial cost / defect sums, boundary defects

@@ -250,9 +250,10 @@ __global__ __launch_bounds__(64) void k_fp_ts(Buffers<T> b, Dims dm, CostWeights
 //     acknowledgements as well -- one write round trip on every step's critical path.
 // Here the wavefront = 64 / A problems x A step sizes fetches each knot's operands ONCE, coalesced, ONE STEP AHEAD of their use (issued before the step's arithmetic,
 // parked in registers, written to a double-buffered LDS stage after it), and the lanes read them back as broadcasts; the step's stores come last, so that what the
-// next step waits for is a load that was issued a whole step earlier.  Two loops as before: the linear sweep (forward_sweep, fp.hpp) for the segments' start states,
-// which go to the candidate's x like the reference's and are read back from there, then the rollouts (forward_sim_segment).  Per thread the arithmetic is that of
-// those two functions, operation by operation.  No barriers: a one-wave block, LDS operations of a wave retire in order (wsync).
+// next step waits for is a load that was issued a whole step earlier.  Two loops as before -- since round 6 two LAUNCHES (fp_cf_body PART 0 / 1: k_sweep_cf, k_fp_cf) --:
+// the linear sweep (forward_sweep, fp.hpp) for the segments' start states, which go to the candidates' records and are read back from there, then the rollouts
+// (forward_sim_segment).  Per thread the arithmetic is that of those two functions, operation by operation.  No barriers: a one-wave block, LDS operations of a wave
+// retire in order (wsync).
 template <typename P, typename T, int A>
 struct FpCfStage {
     static constexpr int PW = 64 / A, NX = P::NX, NU = P::NU;

@@ -16,9 +16,9 @@ ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:log_path=/tmp/pddp_asan UBSAN_OPTION
   timeout 3000 python -m pytest tests -q -m "not gpu" -p no:cacheprovider -k "pins or hostsim or fixtures_direct or lanegroup or phase_parity or solver_parity" 2>&1 | tail -6
 echo "reports: $(ls /tmp/pddp_asan* /tmp/pddp_ubsan* 2>/dev/null | wc -l) file(s)"
 for f in /tmp/pddp_asan* /tmp/pddp_ubsan*; do [ -f "$f" ] && { echo "--- $f"; head -40 "$f"; }; done
-echo "## TSan: runiLQR_CPU / runiLQR_CPU2 (thread per phase) through the C ABI of libpddp_cpu"
+echo "## TSan: runiLQR_CPU / runiLQR_CPU2 (thread per phase) through the C ABI of libpddp_cpu (the symbol / C99-header test is left out: it only spawns gcc, which hangs with libtsan preloaded)"
 TSAN_OPTIONS=halt_on_error=0:log_path=/tmp/pddp_tsan:report_signal_unsafe=0 LD_PRELOAD="$TSAN" PDDP_CPU_LIB=$ROOT/parallel-ddp_amd/lib/libpddp_cpu_tsan.so \
-  timeout 3000 python -m pytest tests/test_cpu_twin.py -q -p no:cacheprovider -k "${TSAN_K:-float64 or parallel_line_search or fewer_cores}" 2>&1 | tail -6
+  timeout 3000 python -m pytest tests/test_cpu_twin.py -q -p no:cacheprovider -k "${TSAN_K:-not exports_every_declared_symbol}" 2>&1 | tail -6
 echo "reports: $(ls /tmp/pddp_tsan* 2>/dev/null | wc -l) file(s)"
 for f in /tmp/pddp_tsan*; do [ -f "$f" ] && { echo "--- $f"; head -60 "$f"; }; done
 } 2>&1 | tee $LOG

@@ -50,8 +50,14 @@
 #ifndef PDDP_MX_STAGE_K
 #define PDDP_MX_STAGE_K 0    // prefetching variants: the gains K | du of a knot leave through LDS as 16-byte pieces (four store instructions of 16 / 8 / 16 / 12 bytes per lane) instead of
 #endif                       // four 4-byte stores per lane 56 bytes apart.  Measured slower (round 5, profiles/r05_bp_exchange.md: +40 ... +65 us -- the extra LDS round trip sits on the knot's chain): off.
+                             // 2 (round 6): the same pieces ONE KNOT LATE -- parked at the end of the knot, read with the next knot's operands, stored behind its prefetch (off the chain):
+                             // same bits, +25 ... +60 us, and the counters see the same bytes either way -- L2 merges the 4-byte stores (profiles/r06_bp_mfma.md section 4)
 #ifndef PDDP_MX_DMA_MASK
 #define PDDP_MX_DMA_MASK 0   // 1: the operand prefetch requests exactly each run's dwords (exec narrowed per run; measurement knob of round 5)
+#endif
+#ifndef PDDP_MX_ORDER
+#define PDDP_MX_ORDER 0      // 1 (compact [A B] instantiations, crossbar pivots): W_u and Huu FIRST, then the pivots with the products that do not need the inverse (W_x, Hxx, Hux, Hxu')
+                             // issued between a pivot's exchange and its update -- same operations, same bits, another order; measured: no gain (round 6, profiles/r06_bp_mfma.md section 3)
 #endif
 #ifndef PDDP_MX_GJ
 #define PDDP_MX_GJ 0         // exchanges of the distributed Gauss-Jordan inversion: 0 = through the LDS crossbar (ds_bpermute, rounds 3-5: the product); measured alternatives of
@@ -344,6 +350,30 @@ __device__ __forceinline__ void mx_gj_columns(T (&C)[NUc]) {
     mx_gj_column_pivot<T, NUc, 4>(C); mx_gj_column_pivot<T, NUc, 5>(C); mx_gj_column_pivot<T, NUc, 6>(C);
 }
 
+// The crossbar pivot in two halves (PDDP_MX_ORDER): issue = the pivot through v_readlane, the pivot row and the group's two pivot-column entries through ds_bpermute, the
+// reciprocal; finish = wait for the lanes and update the group's two rows.  Matrix instructions placed between the two run while the exchange is in flight.
+template <typename T> struct MxGjFlight { T prow, col0, col1, rp; };
+template <typename T, int PV>
+__device__ __forceinline__ void mx_gj_issue(MxGjFlight<T>& f, const T& R0, const T& R1, int c4, int g64) {
+    using X = Mx<T>;
+    constexpr int go = PV >> 1;
+    const T src = (PV & 1) ? R1 : R0;
+    const T piv = X::readlane(src, 16 * go + mx_pi<T>(PV));
+    f.prow = X::template from_lane_off<64 * go>(src, c4);
+    f.col0 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R0, g64); f.col1 = X::template from_lane_off<4 * mx_pi<T>(PV)>(R1, g64);
+    f.rp = X::recip(piv);
+}
+template <typename T, int PV>
+__device__ __forceinline__ void mx_gj_finish(MxGjFlight<T>& f, T& R0, T& R1, int g) {
+    using X = Mx<T>;
+    constexpr int go = PV >> 1;
+    X::lanes_arrived(f.prow, f.col0, f.col1, f.rp);
+    const T q = f.prow * f.rp;
+    const T n0 = X::fma(-f.col0, q, R0), n1 = X::fma(-f.col1, q, R1);
+    R0 = (g == go && !(PV & 1)) ? q : n0;
+    R1 = (g == go && (PV & 1)) ? q : n1;
+}
+
 // the read-only operands of one knot as they come from memory
 template <typename T, bool FS, bool DIAGH>
 struct MxKnotIn {
@@ -530,6 +560,15 @@ __device__ __forceinline__ void mx_lds_knot(MxKnotIn<float, FS, true>& k, unsign
 // HQQ (with DIAGH): the end-effector cost -- the running knots' Hessian is diag(hq1 x 7, hq2 x 7, hr x 7) (nominal-state and control weights) plus the dense 7 x 7 position
 // block Jee' Jee of b.Hc (the thread-lane setup kernel's compact output, fp_tl.hpp arm_tl_nis_cost_ee; its diagonal already carries hq1): one two-element load per lane and
 // knot into the position rows (registers 0, 1) of the position columns -- 196 bytes per knot instead of the 1764-byte reference-layout block.
+// The gains of one knot, staged in memory order (K(b, kx) at 14 b + kx: 392 contiguous bytes of KT; du(b) at 100 + b), as 16-byte pieces: lanes 0..23 one piece of K each,
+// lane 24 its last 8 bytes, lanes 25, 26 the 16 + 12 bytes of du -- FOUR store instructions (kMxGainStores).
+__device__ __forceinline__ void mx_store_gain_pieces(const mx_u4& w, __amdgpu_buffer_rsrc_t rKT, __amdgpu_buffer_rsrc_t rdu, int lane, unsigned knot) {
+    const unsigned soK = knot * (unsigned)(14 * 7 * 4), sod = knot * (unsigned)(7 * 4);
+    if (lane < 24) __builtin_amdgcn_raw_buffer_store_b128(w, rKT, 16u * (unsigned)lane, soK, 0);
+    else if (lane == 24) { mx_u2 h; h[0] = w[0]; h[1] = w[1]; __builtin_amdgcn_raw_buffer_store_b64(h, rKT, 384u, soK, 0); }
+    else if (lane == 25) __builtin_amdgcn_raw_buffer_store_b128(w, rdu, 0u, sod, 0);
+    else if (lane == 26) { mx_u3 t; t[0] = w[0]; t[1] = w[1]; t[2] = w[2]; __builtin_amdgcn_raw_buffer_store_b96(t, rdu, 16u, sod, 0); }
+}
 constexpr int kMxGainStores = 4, kMxCtgStores = 3;                    // store instructions per knot of the prefetching (compact [A B], float) variants: K rows 2g, 2g + 1 and du(2g), du(2g + 1) | [P | p] as 16-byte pieces
 constexpr int kMxKeepP = 1, kMxFuseSweep = 2, kMxLds = 400, kMxDmaFloats = 2 * 5 * 64 + 256 + 112;     // (float handles: two operand buffers of five 64-dword regions + the staging areas of [P | p] and of [K | du])
 template <typename T, bool FS, bool DIAGH, bool CAB, bool FUSE, bool HQQ = false>
@@ -662,6 +701,9 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
                 // every slot written the chain then also sat out the acknowledgements of three gain stores per knot.)  tests/test_isa_invariants.py holds the emitted
                 // loop to these counts: a store merged, split or added by a compiler or an edit fails the CPU suite instead of racing the LDS reads.
                 if (PDDP_MX_EXP == 3 || iter == iterCount) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if PDDP_MX_STAGE_K == 2                                              // (the block's first knot issued no gain stores behind its prefetch: they leave one knot late)
+                else if (iter == iterCount - 1) { if (keepP) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMxCtgStores) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 #ifdef PDDP_MX_CTG_WAIT                                               // (measurement variant: -DPDDP_MX_CTG_WAIT=4 is round 4's count)
                 else if (keepP) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PDDP_MX_CTG_WAIT) : "memory");
 #else
@@ -674,7 +716,14 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
                     const lptr pH = (lptr)(size_t)(aH + (unsigned)par * (unsigned)(4 * kMxDmaBuf));
                     hq0 = pH[0]; hq1v = pH[1];
                 }
+#if PDDP_MX_STAGE_K == 2
+                mx_u4 gpiece = {0u, 0u, 0u, 0u};                       // the previous knot's gains, staged in memory order at the end of its body: read with this knot's operands
+                if (iter != iterCount) gpiece = *reinterpret_cast<const mx_u4*>(const_cast<float*>(dmaLds) + 2 * kMxDmaBuf + 256 + 4 * (lane < 27 ? lane : 26));
+#endif
                 if (iter > 0) dma_issue(ks - 1, par ^ 1);
+#if PDDP_MX_STAGE_K == 2
+                if (iter != iterCount) mx_store_gain_pieces(gpiece, rKT, rdu, lane, (unsigned)(ks + 1));
+#endif
                 par ^= 1;
             }
         } else if constexpr (CAB) {
@@ -707,7 +756,50 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         // Compact [A B]: the position rows of A are [I  dt I], so their share of P'A is the position ROWS of P read as columns -- W(i, kx) gets P(kx, i) for a position
         // column kx, dt P(kx - 7, i) for a velocity column: one nonzero term per element, the bits instructions 0, 1 would have produced.  The transposition goes through
         // the wave's LDS area (one 8-byte-pair write, one 16-byte read per lane: the LDS pipe, not the float32 lanes the matrix instructions occupy).
-        mx4 W0;
+        constexpr bool REORDER = PDDP_MX_ORDER && CAB && PDDP_MX_GJ == 0 && PDDP_MX_EXP == 0;
+        mx4 W0, W1, Hxx, Hux, HxuT, Huu; mx4 W0a;
+        T R0, R1;
+        const int e = 2 * cg + cr - 2;                                // identity column of this lane (cr >= 2)
+        const int c4 = 4 * c, g64 = 64 * g;                           // ds_bpermute addresses: source lane x 4 bytes = these + a constant per pivot
+        if constexpr (REORDER) {
+            // both transpositions first (they need P and W_u only), so that nothing between the pivots waits on the LDS queue behind an exchange
+            ldsP[wa] = Pa[0]; ldsP[wa + 16] = Pa[1];
+            wsync();
+            mx4 lowP;
+#pragma unroll
+            for (int r = 0; r < 4; r++) lowP[r] = fpos * ldsP[ra + X::q_of(0, r)];
+            wsync();
+            W1 = mx_mfma_hi<T>(Pa, k.B1, zero);
+            W1[2] += rho * k.B1[2]; W1[3] += rho * k.B1[3];
+            ldsW[wa] = W1[0]; ldsW[wa + 16] = W1[1];
+            wsync();
+            const mx4 lowW = {fpos * ldsW[ra], fpos * ldsW[ra + X::q_of(0, 1)], T(0), T(0)};
+            wsync();
+            Huu = mx_mfma_hi<T>(k.B1, W1, zero) + CUU;
+            {
+                const bool left = cr < 2;
+                R0 = left ? Huu[0] : (e == u0 ? T(1) : T(0));
+                R1 = left ? Huu[1] : ((e == u0 + 1 && u0 + 1 < NU) ? T(1) : T(0));
+            }
+            MxGjFlight<T> fl;
+            mx_gj_issue<T, 0>(fl, R0, R1, c4, g64); __builtin_amdgcn_sched_barrier(0);
+            W0 = mx_mfma_hi<T>(Pa, k.A0, lowP);
+            W0a = c14 ? Pa : W0;
+            __builtin_amdgcn_sched_barrier(0);
+            mx_gj_finish<T, 0>(fl, R0, R1, g); mx_gj_issue<T, 1>(fl, R0, R1, c4, g64); __builtin_amdgcn_sched_barrier(0);
+            { const mx4 HxxLow = {W0a[0], W0a[1], dt * W0a[0], dt * W0a[1]}; Hxx = mx_mfma_hi<T>(k.A0, W0a, HxxLow) + CXX; }
+            __builtin_amdgcn_sched_barrier(0);
+            mx_gj_finish<T, 1>(fl, R0, R1, g); mx_gj_issue<T, 2>(fl, R0, R1, c4, g64); __builtin_amdgcn_sched_barrier(0);
+            Hux = mx_mfma_hi<T>(k.B1, W0a, zero) + CUX;
+            __builtin_amdgcn_sched_barrier(0);
+            mx_gj_finish<T, 2>(fl, R0, R1, g); mx_gj_issue<T, 3>(fl, R0, R1, c4, g64); __builtin_amdgcn_sched_barrier(0);
+            HxuT = mx_mfma_hi<T>(W1, k.A0, lowW) + CXU;
+            __builtin_amdgcn_sched_barrier(0);
+            mx_gj_finish<T, 3>(fl, R0, R1, g);
+            mx_gj_pivot<T, 4>(R0, R1, g, c4, g64); mx_gj_pivot<T, 5>(R0, R1, g, c4, g64); mx_gj_pivot<T, 6>(R0, R1, g, c4, g64);
+            if (cr >= 2 && e < NU) { ldsI[wa - X::q_of(0, 2)] = R0; ldsI[wa + 16 - X::q_of(0, 2)] = R1; }
+            wsync();
+        } else {
         if constexpr (CAB) {
             ldsP[wa] = Pa[0]; ldsP[wa + 16] = Pa[1];
             wsync();
@@ -717,17 +809,17 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             wsync();
             W0 = mx_mfma_hi<T>(Pa, k.A0, low);
         } else W0 = mx_mfma4<T>(Pa, k.A0, zero);
-        mx4 W1 = CAB ? mx_mfma_hi<T>(Pa, k.B1, zero) : mx_mfma4<T>(Pa, k.B1, zero);               // (compact [A B] = Euler step: the position rows of B are exact zeros)
+        W1 = CAB ? mx_mfma_hi<T>(Pa, k.B1, zero) : mx_mfma4<T>(Pa, k.B1, zero);               // (compact [A B] = Euler step: the position rows of B are exact zeros)
         if (CAB) { W1[2] += rho * k.B1[2]; W1[3] += rho * k.B1[3]; } else W1 = W1 + rho * k.B1;
-        const mx4 W0a = c14 ? Pa : W0;                                                            // vector column := p
+        W0a = c14 ? Pa : W0;                                                            // vector column := p
         // ---- H blocks (:66-93): products first, cost added after, like the reference
         // Hxx(kx, ky) | g_x.  Compact [A B]: the position rows of A are [I  dt I], so their share of A'W is W's position rows themselves (output position rows)
         // and dt x the same registers (output velocity rows: state 7 + s sits two registers above state s in the same lane) -- what instructions 0, 1 would have
         // produced, bit for bit (one nonzero term per element); instructions 2, 3 add the velocity rows
         const mx4 HxxLow = {W0a[0], W0a[1], dt * W0a[0], dt * W0a[1]};
-        const mx4 Hxx = (CAB ? mx_mfma_hi<T>(k.A0, W0a, HxxLow) : mx_mfma4<T>(k.A0, W0a, zero)) + CXX;
-        const mx4 Hux = (CAB ? mx_mfma_hi<T>(k.B1, W0a, zero) : mx_mfma4<T>(k.B1, W0a, zero)) + CUX;                                    // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
-        mx4 HxuT;                                                                                 // Hxu(kx, b) as [b][kx]   (with rho)
+        Hxx = (CAB ? mx_mfma_hi<T>(k.A0, W0a, HxxLow) : mx_mfma4<T>(k.A0, W0a, zero)) + CXX;
+        Hux = (CAB ? mx_mfma_hi<T>(k.B1, W0a, zero) : mx_mfma4<T>(k.B1, W0a, zero)) + CUX;                                    // Hux(b, kx)  | g_u      (no rho: the block K is computed from)
+                                                                                      // Hxu(kx, b) as [b][kx]   (with rho)
         if constexpr (CAB) {                                          // the position rows' share of W_u'A: W_u(kx, b) / dt W_u(kx - 7, b), transposed through LDS as above
             ldsW[wa] = W1[0]; ldsW[wa + 16] = W1[1];                  // (lanes without a control hold zeros)
             wsync();
@@ -735,16 +827,13 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             wsync();
             HxuT = mx_mfma_hi<T>(W1, k.A0, low) + CXU;
         } else HxuT = mx_mfma4<T>(W1, k.A0, zero) + CXU;
-        const mx4 Huu = (CAB ? mx_mfma_hi<T>(k.B1, W1, zero) : mx_mfma4<T>(k.B1, W1, zero)) + CUU;                                     // Huu(a, b)               (with rho)
+        Huu = (CAB ? mx_mfma_hi<T>(k.B1, W1, zero) : mx_mfma4<T>(k.B1, W1, zero)) + CUU;                                     // Huu(a, b)               (with rho)
         // ---- Huu^-1: unpivoted Gauss-Jordan on [Huu | I] (invHuu :192-204, invertMatrix cudaUtils.h:236-292).  The rows stay where the matrix core left them:
         //      lane group g owns rows 2g, 2g + 1 (R0, R1); lane mx_pi(j) of a group keeps column j of Huu, the lane two registers further along the column order
         //      (q_of(j >> 1, (j & 1) + 2)) column j of the identity part.  Per pivot
         //      the pivot row and a group's own two pivot-column entries travel through ds_bpermute (LDS crossbar: not the float32 lanes the matrix instructions
         //      need), the pivot itself through v_readlane; every group then updates its two rows -- 8 vector instructions per pivot instead of 18 with all seven
         //      rows replicated in every lane.  Same operations per element as before: R[a] -= R[a][pv] * (R[pv] / R[pv][pv]).
-        T R0, R1;
-        const int e = 2 * cg + cr - 2;                                // identity column of this lane (cr >= 2)
-        const int c4 = 4 * c, g64 = 64 * g;                           // ds_bpermute addresses: source lane x 4 bytes = these + a constant per pivot
         {
             const bool left = cr < 2;
             R0 = left ? Huu[0] : (e == u0 ? T(1) : T(0));
@@ -774,6 +863,7 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         if (cr >= 2 && e < NU) { ldsI[wa - X::q_of(0, 2)] = R0; ldsI[wa + 16 - X::q_of(0, 2)] = R1; }   // identity column e sits two registers along: tile column mx_pi(e)
         wsync();
         }
+        }
         mx4 InvT = zero;                                                                          // [b = 2g + r][a = control of this lane] = Huu^-1(a, b)
         if (cu) { InvT[0] = ldsI[ra]; InvT[1] = ldsI[ra + X::q_of(0, 1)]; }
         wsync();
@@ -783,7 +873,15 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
             // (buffer stores: the lane's offset is loop-invariant, the knot's a scalar -- kMxGainStores = FOUR store instructions per knot, which the prefetch's s_waitcnt counts on)
             constexpr unsigned E = (unsigned)sizeof(T);
             const unsigned soK = (unsigned)ks * (unsigned)(NX * NU) * E, sod = (unsigned)ks * (unsigned)NU * E;
-            if constexpr (DMA && PDDP_MX_STAGE_K) {
+            if constexpr (DMA && PDDP_MX_STAGE_K == 2) {
+                // one knot late: the gains are parked in memory order now (two LDS writes per lane, nothing waits for them) and leave at the top of the NEXT knot, read with
+                // its operands and stored behind its prefetch -- the same FOUR store instructions per knot in the same place of the order the wait counts on, the LDS trip
+                // off the chain (VERDICT r5 task 5)
+                float* stgK = const_cast<float*>(dmaLds) + 2 * kMxDmaBuf + 256;
+                if (cx) { stgK[u0 * NX + sc] = Kp[0]; if (u0 + 1 < NU) stgK[(u0 + 1) * NX + sc] = Kp[1]; }
+                else if (c14) { stgK[100 + u0] = Kp[0]; if (u0 + 1 < NU) stgK[100 + u0 + 1] = Kp[1]; }
+                wsync();
+            } else if constexpr (DMA && PDDP_MX_STAGE_K) {
                 // K (7 rows of 14: 392 contiguous bytes of KT) and du (28 bytes) staged in memory order -- K(b, kx) at 14 b + kx, du(b) at 100 + b -- and written as 16-byte
                 // pieces: lanes 0..23 one piece of K each, lane 24 its last 8 bytes, lanes 25, 26 the 16 + 12 bytes of du.  FOUR store instructions, like the per-lane form
                 // (kMxGainStores: the prefetch's wait counts them), a quarter of the memory transactions.
@@ -864,6 +962,14 @@ __device__ void arm_mx_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, int
         }
         KTk -= NX * NU; duk -= NU; Fk -= SZP; Bduk -= NX; Pk -= SZP; pk -= NX;
     }
+#if PDDP_MX_STAGE_K == 2
+    if constexpr (DMA) {
+        if (iterCount >= 0) {                                         // the last knot's gains
+            const mx_u4 gpiece = *reinterpret_cast<const mx_u4*>(const_cast<float*>(dmaLds) + 2 * kMxDmaBuf + 256 + 4 * (lane < 27 ? lane : 26));
+            mx_store_gain_pieces(gpiece, rKT, rdu, lane, (unsigned)(ks + 1));
+        }
+    }
+#endif
     if (FUSE && fuse) {                                               // Psi' of this segment, row-major [16][16]
         T* o = b.segmap + ((size_t)pb * dm.M + blk) * 256;
 #pragma unroll

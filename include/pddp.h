@@ -37,7 +37,8 @@ typedef struct pddp_solver* pddp_handle;
 typedef struct pddp_kernel_selection {
     int bp;       /* arm, backward pass:        1 mx (matrix cores)  2 lg (8-lane groups)  3 coop (one wave per block)  4 wide (one workgroup per block)             */
     int fp;       /* arm, rollouts + setup:     1 tl (thread lanes)  2 lg  3 coop  4 tl2 (two-wave split, few problems)  5 tl4 (four-wave pipeline, few problems)   */
-    int sweep;    /* arm, linear forward sweep: 1 alpha (lane group per candidate)  2 st (two sequences)  3 wg (workgroup per problem): no fusion into bp;  4 maps: fused, applied by k_sweep_maps even where the rollout kernel would apply the maps itself */
+    int sweep;    /* arm, linear forward sweep: 1 alpha (lane group per candidate)  2 st (two sequences)  3 wg (workgroup per problem): no fusion into bp;  4 maps: fused, applied by k_sweep_maps even where the rollout kernel would apply the maps itself.
+                     12-state plants on the matrix-core backward pass with the record rollouts (cf_bp mq + cf_fp cf, M > 1): 0 / 4 the backward pass composes the maps, 1..3 it writes A - B K | B du and k_sweep_cf sweeps knot by knot */
     int ls;       /* line search:               1 many (thread per problem)  2 wg (wave per problem)                                                                */
     int ab;       /* arm, layout of [A B]:      1 full (reference layout instead of the compact one)                                                                */
     int cf;       /* closed-form plants, every phase: 1 ts (thread-serial)  2 coop                                                                                   */
@@ -274,8 +275,9 @@ int pddp_set_state(pddp_handle h, const pddp_state* in /* [batch] */);
 #define PDDP_PHASE_BP_COOP   6   /* the wave-cooperative backward pass (all plants); for the KUKA arm PDDP_PHASE_BP is the lane-group
                                     kernel and this one exists so that tests can require the two to agree bit for bit */
 #define PDDP_PHASE_BP_FUSED  7   /* handles whose production sweep composes the forward sweep's per-segment maps inside the matrix-core backward pass
-                                    (KUKA arm, M > 1): that backward pass -- every output of PDDP_PHASE_BP except A - B K / B du, plus the maps */
-#define PDDP_PHASE_SWEEP_FUSED 8 /* ... and the kernel that finishes forwardSweepKern from those maps: every candidate's segment start states -> xs */
+                                    (KUKA arm; the quadrotor's k_bp_mq; M > 1): that backward pass -- every output of PDDP_PHASE_BP except A - B K / B du, plus the maps */
+#define PDDP_PHASE_SWEEP_FUSED 8 /* ... and the kernel that finishes forwardSweepKern from those maps: every candidate's segment start states -> xs (arm) /
+                                    -> the state part of the candidates' records of the boundary knots, array "xw" [problem][knot][step size][n + m] (12-state plants) */
 #define PDDP_PHASE_ROLLOUT   9   /* forwardSimKern + costKern + defectKern WITHOUT the sweep: every candidate's segments start from the states that stand in
                                     "xs" at their first knots (fpHelpers.cuh:225-301 teacher-forced from stored start states, e.g. the reference's own)      */
 int pddp_run_phase(pddp_handle h, int phase);

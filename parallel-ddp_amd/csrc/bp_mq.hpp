@@ -74,8 +74,14 @@ template <> struct MqMem<double> {
 // One (problem, block of knots).  FS: M > 1 (write A - B K, B du for the forward sweep).  DIAGH: the running knots' cost Hessian is diag(P::weight) (the closed-form cost
 // files; taken from the weights, H is not read) -- otherwise the four blocks of H_k are read (a Hessian overridden through pddp_set_array("H"), plug-in costs, and the
 // executed-reference fixtures of tests/test_fixtures_direct.py, whose H is dense).  Returns through b.err[block]: 1 = Huu not invertible with a positive determinant.
-template <typename P, typename T, bool FS, bool DIAGH>
+// FUSE (with FS; round 6): the block composes its segment's forward-sweep map instead of writing A - B K | B du of every knot -- Psi <- Psi G_k with
+// G_k = [A - B K, B du; 0, 1] (13 x 13: the tile's spare row / column (lane group 3, register 3 | the vector column) is the homogeneous coordinate), FOUR more matrix
+// instructions per knot against 624 of the knot's ~2400 bytes of memory traffic and the whole per-knot linear sweep (k_sweep_cf: it read those bytes back);
+// Psi' goes to b.segmap[problem][block] and k_sweep_maps_cf (kernels.hpp) finishes.  The last block's segment has no boundary behind it: it composes nothing.
+// Same mathematics as bp_mfma.hpp's kMxFuseSweep (the arm's production path since round 3); A - B K | B du stay available through pddp_refresh_reference_views.
+template <typename P, typename T, bool FS, bool DIAGH, bool FUSE = false>
 __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const CostWeights<T>& cw, int pb, int blk) {
+    static_assert(!FUSE || FS, "segment maps exist with M > 1 only");
     static_assert(P::NX == 12 && P::NU == 4, "matrix-core backward pass of the 12-state / 4-control plants");
     using X = Mx<T>;
     using mx4 = mx4t<T>;
@@ -149,6 +155,13 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
         wsync();
     }
     T dJ0 = T(0), dJ1 = T(0);                                                // lanes (g, vector column): control g's partial sums of the expected reduction
+    const bool fuse = FUSE && blk < dm.M - 1;
+    mx4 PsiT = zero;                                                         // Psi'(i, j) = Psi(j, i): starts as the identity of the 13 x 13 augmented map
+    if (FUSE) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) PsiT[r] = (cx && 3 * g + r == sc) ? T(1) : T(0);
+        PsiT[3] = (cv && g == 3) ? T(1) : T(0);
+    }
     // A knot's operands as they come from memory: this lane's three elements of its column of [A B], B(sc, g), g_x, g_u (and, read from H_k, its column's pieces).
     // PDDP_MQ_PREFETCH: requested ONE KNOT AHEAD -- the loads of knot k - 1 are in flight while knot k's products run (the compiler cannot hoist them itself past the
     // knot's stores); without it every knot begins with a round trip to memory that only the other resident waves hide.
@@ -230,11 +243,17 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
         // T1(kx, b) = sum_a K(a, kx) Huu(a, b) - Hxu(kx, b) as [b][kx]; its vector column is Huu' du
         const mx4 T1t = mq_controls<T>(Huu, Kp, zero) - HxuT;
         dJ0 += Kp[3] * Hux[3]; dJ1 += Kp[3] * T1t[3];                        // (only the vector-column lanes' sums are used: computeExpRed :317-334)
-        if (FS) {                                                            // A - B K | B du  (computeFSVars :281-312)
+        if (FS && (!FUSE || fuse)) {                                         // A - B K | B du  (computeFSVars :281-312)
             const mx4 BT = {T(0), T(0), T(0), cx ? bt : T(0)};               // [b][kx] = B(kx, b)
             const mx4 BK = mq_controls<T>(BT, Kp, zero);
-            const mx4 Gt = cv ? BK : AB - BK;                                 // (stored from the state-column lanes and the vector column only)
-            store_pair(stgF, mF, mBd, ks, Gt);
+            if constexpr (!FUSE) {
+                const mx4 Gt = cv ? BK : AB - BK;                             // (stored from the state-column lanes and the vector column only)
+                store_pair(stgF, mF, mBd, ks, Gt);
+            } else {
+                mx4 Gt = cx ? AB - BK : cv ? BK : zero;                       // the control columns are not part of the map
+                Gt[3] = (cv && g == 3) ? T(1) : T(0);                         // G(12, 12) = 1: the homogeneous coordinate
+                PsiT = mq_controls<T>(Gt, PsiT, mq_states<T>(Gt, PsiT, zero));
+            }
         }
         if (iter != 0 || blk != 0) {                                         // new cost-to-go (computeCTG :225-276): P(kx, ky) | p(kx); the one in front of knot 0 is never used (:396)
             mx4 val = mq_controls<T>(T1t, Kp, zero);
@@ -243,6 +262,15 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
             Pn[3] = T(0);                                                    // (the control / padding rows carry by-products: keep the tile clean)
             store_ctg(ks - 1, Pn);
             Pa = Pn;
+        }
+    }
+    if (FUSE && fuse) {                                                      // Psi' of this segment: o[c * 16 + l] = Psi(l, c), c = 12 the affine part
+        T* o = b.segmap + ((size_t)pb * dm.M + blk) * 256;
+        if (cx || cv) {
+            const int j = cx ? sc : NX;
+#pragma unroll
+            for (int r = 0; r < 3; r++) o[(3 * g + r) * 16 + j] = PsiT[r];
+            if (g == 3) o[NX * 16 + j] = PsiT[3];
         }
     }
     // dJexp[2 blk], [2 blk + 1]: the four per-control partial sums in order (the vector column's lanes 15, 31, 47, 63 for float; the same lanes by g for double)

@@ -824,13 +824,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 #ifndef PDDP_MQ_WAVES
 #define PDDP_MQ_WAVES 6      // resident waves per SIMD the float kernel is compiled for (measured: tools/quad_bp_ab.py, profiles/r05_quad_mfma.md)
 #endif
-template <typename P, typename T, bool DIAGH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? PDDP_MQ_WAVES : 3, sizeof(T) == 4 ? PDDP_MQ_WAVES : 3))) void k_bp_mq(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch) {
+#ifndef PDDP_MQ_FUSE_WAVES
+#define PDDP_MQ_FUSE_WAVES 5 // ... and the instantiations that compose the sweep maps (four more live registers: at six waves they spill 44-52 bytes)
+#endif
+template <typename P, typename T, bool DIAGH, bool FUSE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (FUSE ? PDDP_MQ_FUSE_WAVES : PDDP_MQ_WAVES) : 3, sizeof(T) == 4 ? (FUSE ? PDDP_MQ_FUSE_WAVES : PDDP_MQ_WAVES) : 3))) void k_bp_mq(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch) {
     __shared__ __attribute__((aligned(16))) T lds[kMqLds];
     const int inst = blockIdx.x;
     if (inst >= batch * dm.M) return;
-    if (dm.M > 1) mq_bp_block<P, T, true, DIAGH>(lds, b, dm, cw, inst / dm.M, inst % dm.M);
+    if (dm.M > 1) mq_bp_block<P, T, true, DIAGH, FUSE>(lds, b, dm, cw, inst / dm.M, inst % dm.M);
     else mq_bp_block<P, T, false, DIAGH>(lds, b, dm, cw, inst / dm.M, inst % dm.M);
+}
+
+// k_sweep_maps_cf: grid ceil(B / 4), block 64 -- 16 lanes per problem, lane l < NX owns entry l.  The forward sweep from the per-segment maps k_bp_mq<.., FUSE> composed:
+// the sweep x_{k+1} = xcur_{k+1} + (A - B K)_k (x_k - xcur_k) - alpha (B du)_k + [boundary] d_k (forward_sweep, fp.hpp; forwardSweepKern fpHelpers.cuh:19-63) is
+// e = t - alpha s with s <- Phi s + gamma (gamma = the map's affine column), t <- Phi t + d_boundary over the segments; at every boundary the start state of every
+// candidate goes to its RECORD of the boundary knot, where k_fp_cf reads it (what k_sweep_cf did knot by knot).  The closed-form twin of k_sweep_maps (pddp_mx.hip).
+template <typename P, typename T>
+__global__ __launch_bounds__(64) void k_sweep_maps_cf(Buffers<T> b, Dims dm, int batch) {
+    constexpr int NX = P::NX, REC = P::NX + P::NU;
+    static_assert(NX < 16, "one 16-lane row per problem, the map a 16 x 16 tile");
+    const int lane = threadIdx.x & 63, l = lane & 15, li = l < NX ? l : NX - 1;
+    const int pb_raw = blockIdx.x * 4 + (lane >> 4), pb = pb_raw < batch ? pb_raw : batch - 1;
+    const bool live = pb_raw < batch && fp_active<T>(b, dm, pb);
+    const int N = dm.N, NBk = dm.NB;
+    const T* xcur = b.xb + ((size_t)pb * 2 + b.state[pb].cur) * N * NX;
+    const T* dcur = b.dcur + (size_t)pb * N * NX;
+    T es = T(0), et = T(0);
+    for (int sgm = 0; sgm < dm.M - 1; sgm++) {
+        const T* o = b.segmap + ((size_t)pb * dm.M + sgm) * 256;                   // Psi(l, c) at [c * 16 + l]
+        const int k = (sgm + 1) * NBk - 1;
+        T ns = o[NX * 16 + li], nt = dcur[(size_t)k * NX + li];
+#pragma unroll
+        for (int cc = 0; cc < NX; cc++) {
+            const T ph = o[cc * 16 + li];
+            ns += ph * __shfl(es, cc, 16); nt += ph * __shfl(et, cc, 16);
+        }
+        es = ns; et = nt;
+        if (live && l < NX) {
+            const T base = xcur[(size_t)(k + 1) * NX + l];
+            for (int a = 0; a < dm.A; a++) b.xw[(((size_t)pb * N + k + 1) * dm.A + a) * REC + l] = base + (et - b.alpha[a] * es);
+        }
+    }
 }
 
 // API view of the compact end-effector Hessian block (Buffers::Hc): H_k of every running knot in the reference layout = Jee' Jee (+ Qx on its diagonal, already in the

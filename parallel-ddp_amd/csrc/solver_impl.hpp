@@ -136,6 +136,7 @@ struct Solver : SolverBase {
     bool gl_bp32 = false, gl_nis8 = false;
     bool cl_bp = false;                                  // 12 states + 4 controls: 16 lanes per block of knots, lane = column (k_bp_cl, bp_cl.hpp) instead of k_bp_gl; PDDP_CF_BP = cl | gl | gl32
     bool mq_bp = false;                                  // 12 states + 4 controls on the matrix cores (k_bp_mq, bp_mq.hpp): where k_bp_cl was the choice, for the plant's own diagonal cost Hessian; kernels.cf_bp = mq | cl
+    bool mq_fused = false;                               // k_bp_mq composes the segments' forward-sweep maps itself (bp_mq.hpp FUSE) and k_sweep_maps_cf finishes: no A - B K / B du traffic, no per-knot sweep; kernels.sweep = st: k_sweep_cf
     bool cf_fp_staged = false;                           // thread-serial rollouts with the knot's operands staged through LDS once per wavefront (k_fp_cf: 16 step sizes, 12-state plants); PDDP_CF_FP = cf | ts
     int kb_nis = 0;                                      // knots per wavefront of the knot-batched setup kernel (k_nis_kb: scalar plug-ins, RK3); 0 = k_nis_gl.  PDDP_CF_NIS = kb16 | kb32 | kb64
     bool gl_bp = false, gl_nis = false;                  // 16 lanes per unit (k_bp_gl / k_nis_gl): the 12-state plants with the device full; PDDP_CF_BP / _NIS = gl
@@ -232,6 +233,10 @@ struct Solver : SolverBase {
             const bool col = (m == "cl" || m == "mq") && P::NX == 12 && P::NU == 4;
             gl_bp = P::PLANT != 4 && (m == "gl" || m == "gl32" || col) && P::NX + P::NU <= 16; gl_bp32 = m == "gl32"; cl_bp = gl_bp && col; mq_bp = cl_bp && m == "mq";
         }
+        // the matrix-core backward pass of the 12-state plants with the record rollouts behind it: fused sweep maps by default (round 6: profiles/r06_quad.md)
+        if constexpr (P::PLANT != 4 && P::NX == 12 && P::NU == 4 && P::kScalarPlugin) {
+            mq_fused = gl_bp && cl_bp && mq_bp && !cf_bp && cf_fp && cf_fp_staged && c.M > 1 && (!ksel_sweep(cfg) || std::string(ksel_sweep(cfg)) == "maps");
+        }
         if (P::PLANT == 4 && sizeof(T) == 4) {        // float handles of the arm: measured crossover (profiles/r02b_sweep_wg.txt): the staged workgroup sweep up to 512 problems
             sweep_kind = (c.batch <= 512 && c.N / c.M <= 96) ? 2 : 1;      // (a segment has to fit the 96-knot staging area of k_sweep_wg)
             if (const char* v = ksel_sweep(cfg)) sweep_kind = std::string(v) == "alpha" ? 0 : std::string(v) == "st" ? 1 : std::string(v) == "wg" ? 2 : sweep_kind;
@@ -286,6 +291,7 @@ struct Solver : SolverBase {
         if constexpr (P::PLANT != 4) { if (cf_fp_staged) { b.xw_rec = P::NX + P::NU; if ((rc = alloc("xw", &b.xw, B * N * A * b.xw_rec))) return rc; } }   // records of the staged closed-form rollouts (k_fp_cf)
         if constexpr (P::PLANT == 4) { if (fp_path == kFpTl) { b.xw_rec = 22; if ((rc = alloc("xw", &b.xw, B * N * A * b.xw_rec))) return rc; } }   // knot-major candidate states (fp_tl.hpp)
         if constexpr (P::PLANT == 4) { if (sweep_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; } }
+        if (mq_fused) { if ((rc = alloc("segmap", &b.segmap, B * M * 256))) return rc; }
         if constexpr (P::PLANT == 4) {
             const char* abenv = ksel_ab(cfg);             // PDDP_AB=full: keep the reference layout (comparison runs)
             const bool full_h = c.ee_cost && c.use_limits;         // end-effector cost with USE_LIMITS_FLAG: the whole diagonal of H moves with the trajectory -> reference-layout H and [A B]
@@ -362,6 +368,12 @@ struct Solver : SolverBase {
     // forward pass: the arm runs on lane groups (fp_lg.hpp), the closed-form plants on the wave-cooperative kernel
     // part: -1 everything; 0 only the linear sweep kernel (when the path has a separate one); 1 only the rollout kernel (per-kernel timing; kernels that sweep
     // themselves still do); 2 the rollouts WITHOUT any sweep, from the start states in xs (PDDP_PHASE_ROLLOUT)
+    bool launch_sweep_maps_cf(hipStream_t s) {                // the record rollouts' sweep from the maps the fused matrix-core backward pass left (false: not this handle's path)
+        if constexpr (P::PLANT != 4 && P::NX == 12 && P::NU == 4) {
+            if (mq_fused) { hipLaunchKernelGGL((k_sweep_maps_cf<P, T>), dim3((cfg.batch + 3) / 4), dim3(64), 0, s, b, dm, (int)cfg.batch); return true; }
+        }
+        return false;
+    }
     void launch_fp(hipStream_t s, int init_rollout, int store_candidates = 0, int part = -1) {
         const unsigned B = cfg.batch;
         bool lane_groups = false;
@@ -369,19 +381,20 @@ struct Solver : SolverBase {
         if (!lane_groups) {
             bool serial = false, records_ran = false;
             if constexpr (P::PLANT != 4) {      // (the arm has its own families: no thread-serial instantiation of its cooperative bodies)
+                if (phase_fused_sweep && part == 0) { launch_sweep_maps_cf(s); return; }      // PDDP_PHASE_SWEEP_FUSED: the candidates' segment start states land in their records (xw)
                 const bool records = cf_fp && cf_fp_staged && !init_rollout && part != 2 && !store_candidates;      // (the phase hook wants the reference's candidate-major arrays: k_fp_ts, then k_cand_to_xw)
                 if (records) cand_stale = true;
                 // two launches: the linear sweep (segment start states -> the candidates' records), then the rollouts (kernels.hpp fp_cf_body); part 0 / 1 = only the one / the other
                 if constexpr (P::kScalarPlugin && (64 / 16) * P::NX <= 64) {
                     if (records && cfg.A == 16) {
-                        if (part != 1 && cfg.M > 1) hipLaunchKernelGGL((k_sweep_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B);
+                        if (part != 1 && cfg.M > 1) { if (!launch_sweep_maps_cf(s)) hipLaunchKernelGGL((k_sweep_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B); }
                         if (part != 0) hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 16>), dim3((B + 3) / 4), dim3(64), 0, s, b, dm, cw, dt, (int)B);
                         return;
                     }
                 }
                 if constexpr (P::kScalarPlugin && (64 / 8) * P::NX <= 64) {
                     if (records && cfg.A == 8) {
-                        if (part != 1 && cfg.M > 1) hipLaunchKernelGGL((k_sweep_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B);
+                        if (part != 1 && cfg.M > 1) { if (!launch_sweep_maps_cf(s)) hipLaunchKernelGGL((k_sweep_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B); }
                         if (part != 0) hipLaunchKernelGGL((k_fp_cf<P, INTEG, T, 8>), dim3((B + 7) / 8), dim3(64), 0, s, b, dm, cw, dt, (int)B);
                         return;
                     }
@@ -493,7 +506,11 @@ struct Solver : SolverBase {
                 if constexpr (P::PLANT != 4) { if (cf_bp) { hipLaunchKernelGGL((k_bp_ts<P, T>), dim3((B * cfg.M + 63) / 64), dim3(64), 0, s, b, dm, (int)B); serial = true; } }
                 if constexpr (P::PLANT != 4 && P::NX == 12 && P::NU == 4) {
                     if (!serial && gl_bp && cl_bp && mq_bp) {
-                        if (!P::kPluginCost && !h_overridden) hipLaunchKernelGGL((k_bp_mq<P, T, true>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);      // the plant's own diagonal cost Hessian: not read
+                        const bool fu = mq_fused && (!store_candidates || phase_fused_sweep);      // (the phase hook's backward pass writes A - B K / B du: its sweep is teacher-forced from them)
+                        const bool dh = !P::kPluginCost && !h_overridden;   // the plant's own diagonal cost Hessian: not read
+                        if (dh && fu) hipLaunchKernelGGL((k_bp_mq<P, T, true, true>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);
+                        else if (dh) hipLaunchKernelGGL((k_bp_mq<P, T, true>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);
+                        else if (fu) hipLaunchKernelGGL((k_bp_mq<P, T, false, true>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);
                         else hipLaunchKernelGGL((k_bp_mq<P, T, false>), dim3(B * cfg.M), dim3(64), 0, s, b, dm, cw, (int)B);
                         serial = true;
                     }
@@ -520,7 +537,7 @@ struct Solver : SolverBase {
     int time_kernels(int sweeps, float* ms, char* names, int name_stride) override {
         const bool arm = (P::PLANT == 4), tl = arm && fp_path == kFpTl, lg = arm && !fp_coop;
         const char* nm[6] = {bp_mfma ? "k_bp_mfma" : (arm && bp_lane_groups) ? "k_bp_lg" : cf_bp ? "k_bp_ts" : (gl_bp && cl_bp && mq_bp) ? "k_bp_mq" : (gl_bp && cl_bp) ? "k_bp_cl" : gl_bp ? "k_bp_gl" : bp_wide ? "k_bp_wide" : "k_bp",
-                             (lg && cfg.M > 1 && !maps_in_rollouts()) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : (cf_records() && cfg.M > 1) ? "k_sweep_cf" : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
+                             (lg && cfg.M > 1 && !maps_in_rollouts()) ? (sweep_fused ? "k_sweep_maps" : sweep_kind == 2 ? "k_sweep_wg" : sweep_kind == 1 ? "k_sweep_st" : "k_sweep_lg") : (cf_records() && cfg.M > 1) ? (mq_fused ? "k_sweep_maps" : "k_sweep_cf") : "", tl ? "k_fp_tl" : (lg && fp_split) ? (fp_two_wave ? "k_fp_tl2" : "k_fp_tl4") : lg ? "k_fp_lg" : (cf_fp && cf_fp_staged) ? "k_fp_cf" : cf_fp ? "k_fp_ts" : "k_fp", ls_in_rollouts() ? "" : ls_many ? "k_ls_many" : "k_ls", "", tl ? "k_nis_tl" : (lg && fp_split && cfg.batch <= kNisTl7MaxBatch) ? "k_nis_tl7" : lg ? "k_nis_lg" : cf_nis ? "k_nis_ts" : (gl_nis && kb_nis) ? "k_nis_kb" : gl_nis ? "k_nis_gl" : "k_nis"};
         static const int phase_of[6] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS, PDDP_PHASE_NIS};
         const int part_of[6] = {-1, 0, maps_in_rollouts() ? -1 : 1, -1, 0, 1};      // (a rollout kernel that begins with the sweep is timed as it runs in production)
         HIPCHK(hipStreamSynchronize(stream));
@@ -561,7 +578,7 @@ struct Solver : SolverBase {
     }
     int iterate(int sweeps) override {
         if (bp_mfma && !keep_all_ctg()) lean_ctg_ran = true;
-        if (sweep_fused && sweeps > 0) fs_vars_stale = true;
+        if ((sweep_fused || mq_fused) && sweeps > 0) fs_vars_stale = true;
         if (cf_fp && cf_fp_staged && sweeps > 0) cand_stale = true;      // (here, not only in launch_fp: a hipGraph REPLAY runs the rollouts without passing through the launch function)
         if (cfg.use_graph) {
             if (!graph || graph_mode != bench_mode + 2 * sp.max_iter) {
@@ -589,7 +606,7 @@ struct Solver : SolverBase {
     std::vector<hipEvent_t> trace_ev;
     int iterate_traced(int sweeps, double* phase_ms, int first_sweep, int stride) override {
         const size_t need = 6 * (size_t)sweeps;
-        if (sweep_fused && sweeps > 0) fs_vars_stale = true;
+        if ((sweep_fused || mq_fused) && sweeps > 0) fs_vars_stale = true;
         if (cf_fp && cf_fp_staged && sweeps > 0) cand_stale = true;
         while (trace_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); trace_ev.push_back(e); }
         static const int phase_of[5] = {PDDP_PHASE_BP, PDDP_PHASE_FP, PDDP_PHASE_FP, PDDP_PHASE_LS, PDDP_PHASE_NIS};
@@ -829,7 +846,7 @@ struct Solver : SolverBase {
         else if (phase == PDDP_PHASE_BP_FUSED || phase == PDDP_PHASE_SWEEP_FUSED) {
             // the production sweep path under teacher forcing: the matrix-core backward pass composes the segment maps (and writes every cost-to-go slot, not
             // A - B K / B du); then k_sweep_maps alone -- the candidates' segment start states land in xs
-            if (!sweep_fused) return fail(PDDP_EINVAL, "PDDP_PHASE_BP_FUSED / _SWEEP_FUSED: this handle's selection has no fused sweep (KUKA arm, matrix-core backward pass, M > 1, no PDDP_SWEEP override)");
+            if (!sweep_fused && !mq_fused) return fail(PDDP_EINVAL, "PDDP_PHASE_BP_FUSED / _SWEEP_FUSED: this handle's selection has no fused sweep (matrix-core backward pass -- the KUKA arm's, or the 12-state plants' with the record rollouts --, M > 1, no kernels.sweep override)");
             phase_fused_sweep = true;
             if (phase == PDDP_PHASE_BP_FUSED) launch_sweep(stream, PDDP_PHASE_BP, 1);
             else launch_fp(stream, 0, 1, 0);

@@ -94,7 +94,9 @@ def test_closed_form_plants_switch_to_thread_serial_kernels_with_the_device_full
     quad = dict(N=64, M=4, A=8, integrator=3, total_time=4.0, tol_cost=0.0, max_iter=20)      # 12 states: rollouts thread-serial, setup on 16-lane groups, backward pass cooperative (32-lane groups from 8192 blocks of knots)
     assert kernels(3, 1024, **quad) == ["k_bp", "k_fp_ts", "k_ls", "k_nis_kb"]               # RK3: the knot-batched setup (lane = knot for the scalar gradients, lane = column of [A B] after)
     assert kernels(3, 2048, **quad) == ["k_bp_mq", "k_fp_ts", "k_ls_many", "k_nis_kb"]          # backward pass: the matrix cores, one wavefront per block of knots (round 5; until then k_bp_cl: 16 lanes per block of knots, lane = column (8 step sizes of a 12-state plant: 8 problems x 12 states do not fit one fetch per lane, the staged rollouts take 16)
-    assert kernels(3, 2048, **dict(quad, A=16)) == ["k_bp_mq", "k_sweep_cf", "k_fp_cf", "k_ls_many", "k_nis_kb"]      # (round 6: the linear sweep and the rollouts are two launches)
+    assert kernels(3, 2048, **dict(quad, A=16)) == ["k_bp_mq", "k_sweep_maps", "k_fp_cf", "k_ls_many", "k_nis_kb"]      # (round 6: the matrix-core backward pass composes the segments' sweep maps, k_sweep_maps_cf finishes)
+    assert kernels(3, 2048, dict(sweep="st"), **dict(quad, A=16)) == ["k_bp_mq", "k_sweep_cf", "k_fp_cf", "k_ls_many", "k_nis_kb"]      # kernels.sweep = st: A - B K | B du of every knot + the per-knot sweep
+    assert kernels(3, 2048, dict(cf_bp="cl"), **dict(quad, A=16))[:2] == ["k_bp_cl", "k_sweep_cf"]                         # (only the matrix-core kernel composes maps)
     assert kernels(3, 2048, **dict(quad, integrator=1)) == ["k_bp_mq", "k_fp_ts", "k_ls_many", "k_nis_gl"]
     assert kernels(3, 2048, dict(cf_bp="gl32"), **quad)[0] == "k_bp_gl"
     assert kernels(3, 2048, dict(cf_nis="gl"), **quad)[-1] == "k_nis_gl"

@@ -540,7 +540,7 @@ def row_roofline(per_kernel_ms, plant, dtype):
                 "per_kernel": {nm: {"ms": round(ms, 5)} for nm, ms in per_kernel_ms.items()}}
     per = {}
     for nm, ms in per_kernel_ms.items():
-        recs = tab["kernels"].get(f"{nm}|{plant}|{dtype}")
+        recs = tab["kernels"].get(f"{nm}|{plant}|{dtype}") or tab["kernels"].get(f"{nm}_cf|{plant}|{dtype}")      # (pddp_time_kernels reports the closed-form plants' k_sweep_maps_cf as k_sweep_maps)
         if not recs or not ms:
             continue
         r = max(recs, key=lambda q: q["grid"])                          # the row with the device full is the largest launch of that kernel in the pass

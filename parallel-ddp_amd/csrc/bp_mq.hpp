@@ -8,10 +8,11 @@
 //     register r < 3 of lane group g  <->  state 3 g + r          register 3 of lane group g  <->  control g (control-row tiles) / the vector column's row (unused)
 //     column c = (cg, cr) likewise: cr < 3 a state column, cr = 3 the control cg (control-column tiles B, W_u, Huu) or, for (3, 3), the VECTOR column of the state-column
 //     tiles (p next to P, g_x next to Hxx, du next to K ...)
-// so a sum over the 12 states is instructions r = 0, 1, 2 and a sum over the 4 controls is instruction r = 3 ALONE: 17 matrix instructions per knot (four state
-// contractions x 3 -- P'[A | B] on ONE tile, then all four blocks of the Hessian from [A B]' W and its transpose, and the vector column; the first cut issued one
-// contraction per block, 23 in all: same sums, same bits, tools/quad_mq_equal.py --, K, K'Huu, B K, and two for the new cost-to-go) where the lane-per-column kernel
-// issues ~1250 vector instructions.  A knot's operands are requested one knot ahead (PDDP_MQ_PREFETCH).  Only the 4 x 4 inverse runs on the
+// so a sum over the 12 states is instructions r = 0, 1, 2 and a sum over the 4 controls is instruction r = 3 ALONE: 11 matrix instructions per knot (two state
+// contractions x 3 -- P'[A | B] on ONE tile and [A B]'W, which holds all four blocks of the Hessian: Hxu and the vector column [A B]'p are read out of those two tiles
+// through LDS transpositions (round 6, PDDP_MQ_LDS_T; until then two more contractions, 17 in all; the first cut issued one contraction per block, 23: same sums,
+// same bits every time, tools/quad_mq_equal.py / quad_equal.py) --, K, K'Huu, B K, and two for the new cost-to-go; + 4 for the segment's sweep map, FUSE) where the
+// lane-per-column kernel issues ~1250 vector instructions.  A knot's operands are requested one knot ahead (PDDP_MQ_PREFETCH).  Only the 4 x 4 inverse runs on the
 // vector ALU (16 cofactors, one per lane, through 48 words of LDS -- the operations and their order are bp_cl_block's, i.e. the reference's).
 // Float results agree with the oracle within the float32 bar (tests/test_fp32_bar.py), not bit for bit: sums over the state index run in the matrix core's order.
 // The cost Hessian of the running knots is taken as diag(P::weight) where it is the plant's own (closed-form cost files); a Hessian overridden through the API and plug-in
@@ -36,8 +37,13 @@ template <typename T> __device__ __forceinline__ mx4t<T> mq_controls(const mx4t<
 #define PDDP_MQ_STAGE 0       // 1: float handles send [P | p] and [A - B K | B du] of a knot through LDS in memory order as 16-byte pieces -- built, same bits, measured SLOWER (round 6,
                               // profiles/r06_quad.md: 2.11 -> 2.24 ms mean of four alternating handles each); the product keeps the dwordx3 stores in tile order
 #endif
+#ifndef PDDP_MQ_LDS_T
+#define PDDP_MQ_LDS_T 1       // Hxu' and the vector column [A B]'p are read out of products the knot forms anyway -- row (vector column) of W = [P | p]'[A | B] and the control columns
+                              // of [A B]'W -- through two LDS transpositions instead of two more three-instruction products (W'[A B], [A B]'V): 21 -> 15 matrix instructions per knot
+                              // with the maps, the same sums in the same order, the same bits (tools/quad_equal.py); 0: the products (round 5's second cut)
+#endif
 constexpr int kMqStage = 160;                  // one staged pair: a 12 x 12 block (144) + its 12-vector right behind it, padded to whole 16-byte pieces
-constexpr int kMqLds = 64 + 2 * kMqStage;      // elements per wave: Huu 16 | cofactors 16 | inverse 16 | boundary p 16 | staging [P | p] | staging [A - B K | B du]
+constexpr int kMqLds = 64 + 2 * kMqStage + 64; // elements per wave: Huu 16 | cofactors 16 | inverse 16 | boundary p 16 | staging [P | p] | staging [A - B K | B du] | [A B]'p 16 | Hxu 48
 
 // Per-knot memory operations of the loop.  float: BUFFER instructions -- a wave-uniform resource per array, the knot's position a scalar byte offset, the lane's share a
 // loop-invariant 32-bit vector offset (no 64-bit vector address arithmetic per access: as in bp_mfma.hpp, that arithmetic was a third of the first cut's vector
@@ -206,13 +212,31 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
         //   Hm  = [A B]' Wr:  rows = columns of [A B]; state rows: Hxx(kx, ky) in the state columns; control rows: Hux(b, kx) (state columns: no rho) | Huu(b, a) (with rho)
         //   HmT = Wr' [A B]:  control rows: Hxu(kx, b) as [b][kx] (with rho)
         //   Hv  = [A B]' V:   vector column: A'p (state rows) and B'p (control rows)
-        const mx4 Hm = mq_states<T>(AB, Wr, zero), HmT = mq_states<T>(Wr, AB, zero), Hv = mq_states<T>(AB, V, zero);
+        mx4 Hm, Hv = zero; T hxu = T(0);
+        if constexpr (PDDP_MQ_LDS_T) {
+            // W's row of the vector column IS p'[A | B] (the rho term above touches the state rows only): Hv(j) = sum_s [A B](s, j) p(s), the products and their order those of
+            // [A B]'V.  It sits in lane group 3's register 3, one column per lane; the vector-column lanes want it as rows: through LDS.  Likewise Hxu(kx, b) =
+            // sum_s A(s, kx) W(s, control b) is entry (kx, control column b) of Hm = [A B]'W -- the sum W'[A B] forms for its entry (b, kx), multiplication commuted.
+            T* ldsV = lds + 64 + 2 * kMqStage; T* ldsX = ldsV + 16;
+            if (g == 3) ldsV[cx ? sc : NX + cg] = Wr[3];
+            Hm = mq_states<T>(AB, Wr, zero);
+            if (cu) { ldsX[cg * NX + 3 * g] = Hm[0]; ldsX[cg * NX + 3 * g + 1] = Hm[1]; ldsX[cg * NX + 3 * g + 2] = Hm[2]; }
+            wsync();
+            if (cv) { Hv[0] = ldsV[3 * g]; Hv[1] = ldsV[3 * g + 1]; Hv[2] = ldsV[3 * g + 2]; Hv[3] = ldsV[NX + g]; }
+            if (cx) hxu = ldsX[g * NX + sc];
+            wsync();
+        } else {
+            Hm = mq_states<T>(AB, Wr, zero);
+            const mx4 HmT = mq_states<T>(Wr, AB, zero);
+            Hv = mq_states<T>(AB, V, zero);
+            hxu = HmT[3];
+        }
         mx4 Hxx, Hux = CUX, HxuT = CXU, Huu = CUU;
 #pragma unroll
         for (int r = 0; r < 3; r++) Hxx[r] = (cx ? Hm[r] : cv ? Hv[r] : T(0)) + CXX[r];          // Hxx(kx, ky) | g_x
         Hxx[3] = T(0);
         Hux[3] = (cx ? Hm[3] : cv ? Hv[3] : T(0)) + CUX[3];                                       // Hux(b, kx)  | g_u     (no rho)
-        HxuT[3] = (cx ? HmT[3] : T(0)) + CXU[3];                                                  // Hxu(kx, b) as [b][kx]  (with rho)
+        HxuT[3] = (cx ? hxu : T(0)) + CXU[3];                                                     // Hxu(kx, b) as [b][kx]  (with rho)
         Huu[3] = (cu ? Hm[3] : T(0)) + CUU[3];                                                    // Huu(a, b)              (with rho)
         // ---- Huu^-1: 4 x 4 adjugate with a det > 0 test (invHuu_dim4 :132-188; the operations of bp_cl_block): A2[row + 4 col]
         if (cu) ldsU[g + 4 * cg] = Huu[3];

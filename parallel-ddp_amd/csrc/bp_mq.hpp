@@ -33,6 +33,10 @@ template <typename T> __device__ __forceinline__ mx4t<T> mq_controls(const mx4t<
 #ifndef PDDP_MQ_PREFETCH
 #define PDDP_MQ_PREFETCH 1    // a knot's operands requested one knot ahead (measured: tools/quad_bp_ab.py, profiles/r05_quad_mfma.md)
 #endif
+#ifndef PDDP_MQ_FUSE_PREFETCH
+#define PDDP_MQ_FUSE_PREFETCH 0   // ... for the instantiations that compose the sweep maps: without the eight prefetch registers they fit SIX waves per SIMD (78 registers, no scratch) --
+                                  // 1.71-1.75 ms against 1.79-1.81 with the prefetch at five waves; [A B] alone ahead (2) spills at six: 2.06-2.20 (profiles/r06_quad.md)
+#endif
 #ifndef PDDP_MQ_STAGE
 #define PDDP_MQ_STAGE 0       // 1: float handles send [P | p] and [A - B K | B du] of a knot through LDS in memory order as 16-byte pieces -- built, same bits, measured SLOWER (round 6,
                               // profiles/r06_quad.md: 2.11 -> 2.24 ms mean of four alternating handles each); the product keeps the dwordx3 stores in tile order
@@ -172,11 +176,13 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
     // PDDP_MQ_PREFETCH: requested ONE KNOT AHEAD -- the loads of knot k - 1 are in flight while knot k's products run (the compiler cannot hoist them itself past the
     // knot's stores); without it every knot begins with a round trip to memory that only the other resident waves hide.
     struct Ops { T v[3], bt, gx[3], gu, hc[3], hu, hxu; };
+    constexpr int PF = FUSE ? PDDP_MQ_FUSE_PREFETCH : PDDP_MQ_PREFETCH;    // 1: everything one knot ahead; 2: [A B] one knot ahead, the gradient at the knot; 0: nothing ahead
+    auto fetch_g = [&](int k, Ops& o) { const unsigned sG = (unsigned)k * NM; mG.ld3(o.gx, oG3, sG); o.gu = mG.ld1(oGu, sG); };
     auto fetch = [&](int k, Ops& o) {
-        const unsigned sAB = (unsigned)k * SZAB, sG = (unsigned)k * NM;      // (wave-uniform element offsets of the knot)
+        const unsigned sAB = (unsigned)k * SZAB;                             // (wave-uniform element offsets of the knot)
         mAB.ld3(o.v, oCol, sAB);
         o.bt = FS ? mAB.ld1(oBt, sAB) : T(0);                                // B(sc, g)   (state-column lanes)
-        mG.ld3(o.gx, oG3, sG); o.gu = mG.ld1(oGu, sG);
+        if (PF != 2) fetch_g(k, o);
         if (!DIAGH) {                                                        // Hcost(kx, ky) | Hcost(12 + b, kx) | Hcost(kx, 12 + b) | Hcost(12 + a, 12 + b): column-major H_k
             const unsigned sH = (unsigned)k * SZH;
             mH.ld3(o.hc, oHcol + oG3, sH);                                   // this lane's column of H_k
@@ -184,11 +190,11 @@ __device__ void mq_bp_block(T* lds, const Buffers<T>& b, const Dims& dm, const C
         }
     };
     Ops nxt;
-    if (PDDP_MQ_PREFETCH && iterCount >= 0) fetch(ks, nxt);
+    if (PF && iterCount >= 0) fetch(ks, nxt);
     for (int iter = iterCount; iter >= 0; iter--, ks--) {
         // ---- operands: A(3g + r, sc) | B(3g + r, control cg) | B(sc, control g) | g_x, g_u in the vector column
         Ops o;
-        if (PDDP_MQ_PREFETCH) { o = nxt; if (iter > 0) fetch(ks - 1, nxt); } else fetch(ks, o);
+        if (PF) { o = nxt; if (PF == 2) fetch_g(ks, o); if (iter > 0) fetch(ks - 1, nxt); } else fetch(ks, o);
         // ONE tile holds [A | B]: A(3g + r, sc) in the state columns, B(3g + r, control cg) in the control columns (column 15 is control 3 here -- the vector
         // column of the state-column tiles is kept in a tile of its own, V, below)
         mx4 AB = {o.v[0], o.v[1], o.v[2], T(0)}, CXX = zero;

@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 #define PDDP_MQ_WAVES 6      // resident waves per SIMD the float kernel is compiled for (measured: tools/quad_bp_ab.py, profiles/r05_quad_mfma.md)
 #endif
 #ifndef PDDP_MQ_FUSE_WAVES
-#define PDDP_MQ_FUSE_WAVES 5 // ... and the instantiations that compose the sweep maps (four more live registers: at six waves they spill 44-52 bytes)
+#define PDDP_MQ_FUSE_WAVES 6 // ... and the instantiations that compose the sweep maps (four more live registers: six waves without the operand prefetch, PDDP_MQ_FUSE_PREFETCH in bp_mq.hpp)
 #endif
 template <typename P, typename T, bool DIAGH, bool FUSE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (FUSE ? PDDP_MQ_FUSE_WAVES : PDDP_MQ_WAVES) : 3, sizeof(T) == 4 ? (FUSE ? PDDP_MQ_FUSE_WAVES : PDDP_MQ_WAVES) : 3))) void k_bp_mq(Buffers<T> b, Dims dm, CostWeights<T> cw, int batch) {

@@ -127,6 +127,9 @@ extern "C" int pddp_set_array(pddp_handle h, const char* name, const void* host,
     // the first write into "H" of a handle that keeps the compact end-effector position block: bring the reference-layout array up to date FIRST (a partial write
     // then lands on the current values, and the caller's data is not overwritten by the expansion afterwards)
     if (std::strcmp(name, "H") == 0 && !s->h_overridden && (rc = s->h_view())) return rc;
+    // A - B K / B du of a handle whose production sweeps compose maps instead of writing them: materialise both from the last sweep FIRST (the one that is not being
+    // written must not stay stale, and the phase hook's rollouts must not rebuild over the caller's data afterwards)
+    if ((std::strcmp(name, "ApBK") == 0 || std::strcmp(name, "Bdu") == 0) && s->fs_vars_stale && (rc = s->reference_views(1))) return rc;
     const bool cand = std::strcmp(name, "xs") == 0 || std::strcmp(name, "us") == 0;
     if (cand && s->cand_stale && (rc = s->cand_view(0))) return rc;                          // (the other of the two arrays must hold the records' values before both go back)
     HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));

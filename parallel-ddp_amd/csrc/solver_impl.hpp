@@ -840,6 +840,8 @@ struct Solver : SolverBase {
         }
         if (phase >= 0 && phase <= 3) {
             if (phase == PDDP_PHASE_BP) fs_vars_stale = false;     // (the hook's backward pass writes A - B K / B du itself)
+            // the hook's rollouts sweep from A - B K / B du: after production sweeps that composed maps instead of writing them, rebuild them from [A B], K, du first
+            if (phase == PDDP_PHASE_FP && fs_vars_stale && cfg.M > 1) { int rc = reference_views(1); if (rc) return rc; }
             launch_sweep(stream, phase, 1);                         // teacher-forcing hook: the forward pass also stores every candidate trajectory
             if (phase == PDDP_PHASE_FP) hipLaunchKernelGGL((k_reduce_parts<T>), dim3((B + 63) / 64), dim3(64), 0, stream, b, dm, (int)B);   // J / dmax readable right after the phase
         }

@@ -243,6 +243,33 @@ def test_float32_fused_sweep_maps_against_the_per_knot_sweep_at_the_bench_geomet
     s.close()
 
 
+def test_the_rollout_hook_after_fused_production_sweeps_sweeps_from_rebuilt_operands():
+    """Production sweeps of this selection write no A - B K | B du.  pddp_run_phase(PDDP_PHASE_FP), whose rollouts sweep from those arrays, must rebuild them from the last
+    sweep's [A B], K, du first -- the same bits as with an explicit pddp_refresh_reference_views before it -- and a caller's own pddp_set_array("ApBK") in between must survive."""
+    kw = dict(QUAD, max_iter=12)
+    N, A, n = kw["N"], kw["A"], 12
+    x0, u0, xg = example_inputs(3, N, np.float32, noise=np.random.default_rng(3).normal(0, 0.002, (N, n)))
+    got = []
+    for explicit in (0, 1, 2):
+        s = make_solver("hip", 3, dtype=0, batch=1, use_graph=1, kernels=PINNED, **kw)
+        assert kernel_names(s) == BENCHED
+        s.load(x0, u0, xg); s.iterate(3); s.sync()
+        if explicit == 1:
+            s.refresh_reference_views()
+        if explicit == 2:
+            F = s.get("ApBK").copy(); F *= np.float32(0.5)                       # a caller's own operands
+            s.set("ApBK", F)
+        s.run_phase(pyddp.PHASE_FP)
+        xs = s.get("xs").reshape(A, N, n).copy()
+        got.append(xs)
+        if explicit == 2:
+            assert np.array_equal(s.get("ApBK"), F)
+        s.close()
+    assert np.isfinite(got[0][0]).all() and np.abs(got[0][0]).max() > 0
+    assert np.array_equal(got[0], got[1], equal_nan=True)
+    assert not np.array_equal(got[0], got[2], equal_nan=True), "the caller's A - B K did not reach the sweep"
+
+
 @pytest.mark.parametrize("dtype", [1, 0], ids=["float64", "float32"])
 def test_whole_sweeps_at_the_bench_geometry_equal_single_problem_solves_and_follow_the_oracle(dtype):
     iters = 8

@@ -9,7 +9,10 @@ import pytest
 from backends import BACKENDS, make_solver
 from oracle_binding import OracleMpc, default_cfg, example_inputs
 
-RNG = np.random.default_rng(42)
+def _rng(*key):
+    """A generator per test (and parameter set): the inputs of a test must not depend on which tests ran before it in the process (pytest -k / -n / -m gpu select
+    different subsets; until round 6 one module-level generator made every test's data a function of the run's selection and order)."""
+    return np.random.default_rng([42, *[int(k) for k in key]])
 
 
 def close(a, b, tol=1e-6):
@@ -24,6 +27,7 @@ def close(a, b, tol=1e-6):
     (2, dict(N=32, M=2, A=8, integrator=3, total_time=2.0, tol_cost=1e-5, max_iter=8), 1),
 ])
 def test_receding_horizon_sequence(backend, plant, kw, full):
+    RNG = _rng(1, plant, full)
     dtype = np.float64
     N = kw["N"]
     s = make_solver(backend, plant, dtype=1, **kw)
@@ -67,6 +71,7 @@ def test_receding_horizon_sequence(backend, plant, kw, full):
 def test_mpc_batch_rollouts_are_independent(backend):
     """64-rollout shape of BASELINE configs[3], scaled down: a batch of MPC problems with different measured states and shifts gives,
     problem by problem, exactly what separate single-problem handles give."""
+    RNG = _rng(2)
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, mpc_mode=1, total_time=0.5, tol_cost=1e-5, max_iter=5)
     B = 3
     xs, us, gs = [], [], []
@@ -92,6 +97,7 @@ def test_mpc_batch_rollouts_are_independent(backend):
 def test_mpc_batch_with_a_per_call_iteration_limit_keeps_the_trace_rows(backend):
     """A per-call max_iter below config.max_iter must not move the rows of Jout / alphaOut: their stride is fixed at allocation
     (config.max_iter + 2).  Batch of 3 against single-problem handles, trace rows and iteration counts compared."""
+    RNG = _rng(3)
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, mpc_mode=1, total_time=0.5, tol_cost=1e-5, max_iter=8)
     B = 3
     xs, us, gs = [], [], []
@@ -119,6 +125,7 @@ def test_plain_solve_then_polled_mpc_solves_on_one_handle():
     """runiLQR_GPU followed by the MPC loop on the same handle (the canonical flow): the status polls of the plain solve allocate the pinned state
     buffer BEFORE the first pddp_mpc_solve grows its staging area, and an MPC call with max_iter > poll_every polls again.  Polled and un-polled
     calls must give the same bits."""
+    RNG = _rng(4)
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, total_time=0.5, tol_cost=0.0, max_iter=8)
     x0, u0, xg = example_inputs(4, 32, np.float32, noise=RNG.normal(0, 0.001, (32, 14)))
     res = []
@@ -143,6 +150,7 @@ def test_warm_started_mpc_after_a_plain_solve_shifts_the_whole_cost_to_go():
     """A handle WITHOUT mpc_mode runs a plain solve on the matrix-core backward pass, then a warm-started MPC call (shift > 0, clear_vars = 0): the shift moves
     interior cost-to-go slots into the block boundaries (MPCHelpers.cuh:602-655), so the plain solve must have written them.  float64, against the lane-group
     family (which the receding-horizon tests above hold against the oracle): identical step-size indices, J / x to 1e-6."""
+    RNG = _rng(5)
     import os
     kw = dict(N=32, M=4, A=8, wafr_urdf=1, total_time=0.5, tol_cost=0.0, max_iter=6)
     x0, u0, xg = example_inputs(4, 32, np.float64, noise=RNG.normal(0, 0.001, (32, 14)))
